@@ -1,0 +1,161 @@
+/* sdfkit_hip.h -- C ABI of libsdfkit_hip.so, the MI355X (gfx950) implementation of
+ * SdfKit's hot path  Voxels.SampleSdf -> [Voxels.ClipToBounds] -> MarchingCubes.CreateMesh.
+ *
+ * The reference (praeclarum/SdfKit, 100 % managed C#) has no FFI boundary of its own;
+ * these entry points are what a `[DllImport("sdfkit_hip")]` shim behind the reference's
+ * public Sdf / Voxels / MarchingCubes / Mesh API binds.  Each entry
+ * point cites the reference interface it replaces (file:line relative to the reference).
+ *
+ * Conventions: plain pointers and sizes only; every function returns an sdfk_status
+ * (0 = OK) and records a thread-local message readable with sdfk_last_error(); the
+ * library never retains caller (host) pointers after a call returns; volumes are
+ * [nx][ny][nz] row-major (z fastest) exactly like C# `float[nx,ny,nz]` /
+ * `Vector3[nx,ny,nz]` (Voxels.cs:8-9).  There is NO CPU fallback: without a HIP device
+ * every compute entry point fails with SDFK_ERR_NO_DEVICE.
+ */
+#ifndef SDFKIT_HIP_H
+#define SDFKIT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFK_ABI_VERSION 1
+
+typedef enum sdfk_status {
+    SDFK_OK = 0,
+    SDFK_ERR_INVALID = 1,    /* bad argument */
+    SDFK_ERR_NO_DEVICE = 2,  /* no HIP device / sdfk_init not called */
+    SDFK_ERR_HIP = 3,        /* a HIP runtime call failed */
+    SDFK_ERR_COMPILE = 4,    /* hiprtc failed on a generated SDF kernel */
+    SDFK_ERR_NOMEM = 5,
+    SDFK_ERR_UNSUPPORTED = 6
+} sdfk_status;
+
+/* ---- SDF programs ----------------------------------------------------------
+ * Replaces the `Sdf` delegate (Sdf.cs:8) for SDFs that can run on the GPU: the shim
+ * lowers an SdfExpr tree (SdfExpr.cs:16-212) or a tagged Sdfs.* factory (Sdf.cs:118-215)
+ * to a flat SSA list of scalar float32 operations.  Value id = instruction index.
+ * sdfk_program_create JIT-compiles it with hiprtc into a grid-sampling kernel -- the
+ * counterpart of SdfExprCompiler.Compile (SdfExpr.cs:225-273).  All arithmetic is IEEE
+ * binary32, one rounding per op, no FMA contraction. */
+typedef enum sdfk_opcode {
+    SDFK_OP_CONST = 0,   /* imm */
+    SDFK_OP_X = 1, SDFK_OP_Y = 2, SDFK_OP_Z = 3,   /* sample point (Voxels.cs:104-106) */
+    SDFK_OP_ADD = 4, SDFK_OP_SUB = 5, SDFK_OP_MUL = 6, SDFK_OP_DIV = 7,  /* a ? b */
+    SDFK_OP_NEG = 8, SDFK_OP_ABS = 9, SDFK_OP_SQRT = 10, SDFK_OP_FLOOR = 11, /* f(a) */
+    SDFK_OP_MIN_SEL = 12, /* (a < b) ? a : b   -- Vector3.Min component */
+    SDFK_OP_MAX_SEL = 13, /* (a > b) ? a : b   -- Vector3.Max component */
+    SDFK_OP_MIN_IEEE = 14,/* Math.Min / MathF.Min (IEEE 754:2019 minimum) */
+    SDFK_OP_MAX_IEEE = 15,/* Math.Max / MathF.Max (IEEE 754:2019 maximum) */
+    SDFK_OP_SEL_LT = 16   /* (a < b) ? c : d   -- SdfExprs.Union (SdfExpr.cs:63-66) */
+} sdfk_opcode;
+
+typedef struct sdfk_op {
+    int32_t opcode;
+    int32_t a, b, c, d;  /* operand value ids (unused = -1) */
+    float imm;
+} sdfk_op;
+
+typedef struct sdfk_program sdfk_program;
+typedef struct sdfk_volume sdfk_volume;
+typedef struct sdfk_mesh sdfk_mesh;
+typedef struct sdfk_march_job sdfk_march_job;
+
+/* ---- lifetime -------------------------------------------------------------- */
+int sdfk_abi_version(void);
+/* Select HIP device `device` (ordinal) and create the library stream. Idempotent. */
+int sdfk_init(int device);
+void sdfk_shutdown(void);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int sdfk_set_stream(void* hip_stream);
+int sdfk_synchronize(void);
+const char* sdfk_last_error(void);
+
+/* out_rgbw = value ids of (colour.X, colour.Y, colour.Z, distance W) -- the Vector4 the
+ * delegate writes (Sdf.cs:8).  writes_color = 0 for delegates that only assign `.W`
+ * (Sdfs.Sphere/Box/Plane, Sdf.cs:134,153,211): colour stays (0,0,0) (Voxels.cs:88-92). */
+int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
+                        int32_t writes_color, sdfk_program** out);
+/* Generate + hiprtc-compile for gfx950 without loading (needs no device): a lowering
+ * check the shim can run at build time. */
+int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color);
+const char* sdfk_program_source(const sdfk_program* p);
+void sdfk_program_destroy(sdfk_program* p);
+
+/* ---- Voxels (Voxels.cs:6-65) ------------------------------------------------
+ * Device-resident `Values` (+ `Colors` when with_colors != 0).  A *slab* volume holds the
+ * voxel planes [z0, z0+nz_local) of a global nx*ny*nz_global grid (multi-GPU Z sharding);
+ * sdfk_volume_create is the slab z0 = 0, nz_local = nz. */
+int sdfk_volume_create(int32_t nx, int32_t ny, int32_t nz, const float min[3], const float max[3],
+                       int32_t with_colors, sdfk_volume** out);
+int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global, const float min[3],
+                            const float max[3], int32_t z0, int32_t nz_local,
+                            int32_t with_colors, sdfk_volume** out);
+/* host <-> device copies of Voxels.Values / Voxels.Colors (colors may be NULL) */
+int sdfk_volume_upload(sdfk_volume* v, const float* values, const float* colors3);
+int sdfk_volume_download(const sdfk_volume* v, float* values, float* colors3);
+int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void** colors3);
+void sdfk_volume_free(sdfk_volume* v);
+
+/* Voxels.SampleSdf(Sdf, batchSize, maxDegreeOfParallelism) (Voxels.cs:72-125): evaluates
+ * the program at every cell centre and stores W -> Values, XYZ -> Colors.  batchSize and
+ * maxDegreeOfParallelism have no GPU meaning and are not part of the ABI.
+ * clip_to_bounds != 0 fuses Voxels.ClipToBounds (SdfEx.ToVoxels, Sdf.cs:49-57). */
+int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds);
+/* Voxels.ClipToBounds (Voxels.cs:133-167) on an existing volume. */
+int sdfk_volume_clip_to_bounds(sdfk_volume* v);
+
+/* ---- MarchingCubes.CreateMesh (MarchingCubes.cs:39-92) ----------------------
+ * One-shot forms.  The mesh is left on the device; query with sdfk_mesh_*. */
+int sdfk_march(const sdfk_volume* v, float iso_value, int32_t step, sdfk_mesh** out);
+/* Host-array form: `values`/`colors3` are the managed Voxels.Values / Voxels.Colors arrays
+ * pinned by the shim for the duration of the call (colors3 may be NULL = zeros). */
+int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32_t ny, int32_t nz,
+                    const float min[3], const float max[3], float iso_value, int32_t step,
+                    sdfk_mesh** out);
+/* SdfEx.ToMesh (Sdf.cs:59-63): sample (+clip) and mesh without leaving the device. */
+int sdfk_sample_march(const sdfk_program* p, const float min[3], const float max[3],
+                      int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds,
+                      float iso_value, int32_t step, sdfk_mesh** out);
+
+/* Two-phase form for Z-slab sharding (one process per GPU).  `v` is a slab whose planes
+ * cover the cell layers [layer_begin, layer_end) (global layer indices) plus context:
+ * two planes below layer_begin (unless that reaches plane 0) and one plane above
+ * layer_end (unless that reaches the last plane).  begin: classify + count, returns the
+ * numbers of vertices and triangle indices this slab owns.  finish: emit, with
+ * `vertex_base` = sum of the vertex counts of all lower slabs (exchanged by the caller,
+ * e.g. with an RCCL all-gather), so that indices are global and the concatenation of the
+ * slab meshes in rank order equals the single-device mesh. step must be 1. */
+int sdfk_march_begin(const sdfk_volume* v, float iso_value, int32_t layer_begin, int32_t layer_end,
+                     sdfk_march_job** job, int64_t* n_vertices, int64_t* n_indices);
+int sdfk_march_finish(sdfk_march_job* job, int64_t vertex_base, sdfk_mesh** out);
+void sdfk_march_job_free(sdfk_march_job* job);
+
+/* ---- Mesh (Mesh.cs:8-64) ----------------------------------------------------
+ * Vertices/Colors/Normals: 3 floats each per vertex; Triangles: int32 indices
+ * (Mesh.cs:10-13).  Vertices/Normals are already transformed to world space
+ * (MarchingCubes.cs:85-90, Mesh.cs:47-64). */
+int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices);
+int sdfk_mesh_bounds(const sdfk_mesh* m, float min[3], float max[3]);      /* Mesh.Measure */
+int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* colors3, float* normals3,
+                   int32_t* triangles);                                      /* any may be NULL */
+int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, void** normals3,
+                          void** triangles);
+/* diagnostics: number of active cells, and of case-13 cells with no tiling
+ * ("Impossible case 13?", MarchingCubes.cs:365) seen while meshing */
+int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case13_cells);
+void sdfk_mesh_free(sdfk_mesh* m);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------
+ * When enabled, every kernel launch is bracketed by hipEvents on the launch stream. */
+int sdfk_profile_enable(int32_t on);
+int sdfk_profile_reset(void);
+/* number of distinct kernels recorded; fills name/total milliseconds/launch count */
+int sdfk_profile_count(void);
+int sdfk_profile_get(int32_t i, const char** name, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFKIT_HIP_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of libsdfkit_hip.so (include/sdfkit_hip.h).
+
+There is no fallback of any kind: if the shared library is missing it is built with
+hipcc; if that fails, or if no gfx950 device is present when a compute entry point is
+used, an exception is raised.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+_inited_device = None
+
+
+class SdfKitNativeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"sdfkit_hip status {status}: {message}")
+        self.status = status
+
+
+class Op(C.Structure):
+    """struct sdfk_op"""
+    _fields_ = [("opcode", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32),
+                ("d", C.c_int32), ("imm", C.c_float)]
+
+
+# every symbol declared in include/sdfkit_hip.h: name -> (restype, argtypes)
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_fp, _vpp = C.POINTER(C.c_float), C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "sdfk_abi_version": (C.c_int, []),
+    "sdfk_init": (C.c_int, [C.c_int]),
+    "sdfk_shutdown": (None, []),
+    "sdfk_set_stream": (C.c_int, [_vp]),
+    "sdfk_synchronize": (C.c_int, []),
+    "sdfk_last_error": (C.c_char_p, []),
+    "sdfk_program_create": (C.c_int, [C.POINTER(Op), _i32, C.POINTER(_i32), _i32, _vpp]),
+    "sdfk_program_check": (C.c_int, [C.POINTER(Op), _i32, C.POINTER(_i32), _i32]),
+    "sdfk_program_source": (C.c_char_p, [_vp]),
+    "sdfk_program_destroy": (None, [_vp]),
+    "sdfk_volume_create": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _i32, _vpp]),
+    "sdfk_volume_create_slab": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _i32, _i32, _i32, _vpp]),
+    "sdfk_volume_upload": (C.c_int, [_vp, _vp, _vp]),
+    "sdfk_volume_download": (C.c_int, [_vp, _vp, _vp]),
+    "sdfk_volume_device_ptrs": (C.c_int, [_vp, _vpp, _vpp]),
+    "sdfk_volume_free": (None, [_vp]),
+    "sdfk_sample": (C.c_int, [_vp, _vp, _i32]),
+    "sdfk_volume_clip_to_bounds": (C.c_int, [_vp]),
+    "sdfk_march": (C.c_int, [_vp, _f, _i32, _vpp]),
+    "sdfk_march_host": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _fp, _fp, _f, _i32, _vpp]),
+    "sdfk_sample_march": (C.c_int, [_vp, _fp, _fp, _i32, _i32, _i32, _i32, _f, _i32, _vpp]),
+    "sdfk_march_begin": (C.c_int, [_vp, _f, _i32, _i32, _vpp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sdfk_march_finish": (C.c_int, [_vp, _i64, _vpp]),
+    "sdfk_march_job_free": (None, [_vp]),
+    "sdfk_mesh_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sdfk_mesh_bounds": (C.c_int, [_vp, _fp, _fp]),
+    "sdfk_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sdfk_mesh_device_ptrs": (C.c_int, [_vp, _vpp, _vpp, _vpp, _vpp]),
+    "sdfk_mesh_stats": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sdfk_mesh_free": (None, [_vp]),
+    "sdfk_profile_enable": (C.c_int, [_i32]),
+    "sdfk_profile_reset": (C.c_int, []),
+    "sdfk_profile_count": (C.c_int, []),
+    "sdfk_profile_get": (C.c_int, [_i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+
+def library_path():
+    return os.path.join(_HERE, "libsdfkit_hip.so")
+
+
+def lib():
+    """Load (building if needed) the shared library.  Raises if it cannot be produced."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path) or _build.needs_build():
+            try:
+                _build.build()
+            except Exception as e:  # no silent fallback
+                if not os.path.exists(path):
+                    raise RuntimeError(f"libsdfkit_hip.so is missing and could not be built with hipcc: {e}") from e
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise SdfKitNativeError(status, lib().sdfk_last_error().decode("utf-8", "replace"))
+
+
+def init(device=None):
+    """sdfk_init on `device` (default: LOCAL_RANK or 0).  Raises without a gfx950 GPU."""
+    global _inited_device
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _inited_device is None:
+        check(lib().sdfk_init(device))
+        _inited_device = device
+    elif _inited_device != device:
+        raise RuntimeError(f"sdfkit_hip already initialised on device {_inited_device}")
+    return _inited_device
+
+
+def shutdown():
+    global _inited_device
+    if _lib is not None:
+        _lib.sdfk_shutdown()
+    _inited_device = None
+
+
+def f3(v):
+    import numpy as np
+    return (C.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+def profile_snapshot():
+    """{kernel name: (total_ms, launches)} recorded since the last reset."""
+    L = lib()
+    out = {}
+    for i in range(L.sdfk_profile_count()):
+        name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+        check(L.sdfk_profile_get(i, C.byref(name), C.byref(ms), C.byref(n)))
+        out[name.value.decode()] = (ms.value, n.value)
+    return out

@@ -1,0 +1,230 @@
+// mc_device.h -- device-side Lewiner marching-cubes decisions and vertex math for gfx950.
+//
+// Everything here is per-cell arithmetic on the eight corner values of one cube, in
+// double precision exactly like the reference (Cell.cs:74,191-208: float voxels are
+// widened, the iso value is subtracted in double).  The translation unit is compiled
+// with -ffp-contract=off: `A*C - B*D` must round as two multiplies and a subtract.
+//
+// Corner order v0..v7 (Luts.cs:30-52): v0=(x,y,z) v1=(x+1,y,z) v2=(x+1,y+1,z) v3=(x,y+1,z),
+// v4..v7 the same at z+1.  "Bit order" index = dz*4+dy*2+dx (Cell.cs:318-319).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mc_luts.h"
+
+namespace sdfk {
+
+__constant__ int8_t c_lut[MCLUT_BLOB_SIZE] = {MCLUT_BLOB_VALUES};
+
+#define MC_L1(name, i) (c_lut[MCLUT_OFF_##name + (i)])
+#define MC_L2(name, i, j) (c_lut[MCLUT_OFF_##name + (i) * MCLUT_DIM1_##name + (j)])
+#define MC_ROW2(name, i) (MCLUT_OFF_##name + (i) * MCLUT_DIM1_##name)
+#define MC_ROW3(name, i, j) (MCLUT_OFF_##name + ((i) * MCLUT_DIM1_##name + (j)) * MCLUT_DIM2_##name)
+
+// MarchingCubes.cs:37 and Cell.cs:63: a DOUBLE literal, not C's FLT_EPSILON.
+#define MC_EPS 0.0000001
+
+struct Tiling {
+    int lut_off;  // start of the triangle row in c_lut, -1 when nothing is emitted
+    int nt;       // triangles
+    int index;    // 8-bit corner sign word (Cell.cs:220-229)
+};
+
+// MarchingCubes.cs:376-407
+__device__ __forceinline__ bool mc_test_face(const double* v, int face)
+{
+    const int af = face < 0 ? -face : face;
+    double A = 0, B = 0, C = 0, D = 0;
+    switch (af) {
+    case 1: A = v[0]; B = v[4]; C = v[5]; D = v[1]; break;
+    case 2: A = v[1]; B = v[5]; C = v[6]; D = v[2]; break;
+    case 3: A = v[2]; B = v[6]; C = v[7]; D = v[3]; break;
+    case 4: A = v[3]; B = v[7]; C = v[4]; D = v[0]; break;
+    case 5: A = v[0]; B = v[3]; C = v[2]; D = v[1]; break;
+    case 6: A = v[4]; B = v[7]; C = v[6]; D = v[5]; break;
+    default: break;
+    }
+    const double acbd = A * C - B * D;
+    if (acbd > -MC_EPS && acbd < MC_EPS) return face >= 0;
+    return (double)face * A * acbd >= 0;
+}
+
+// Reference-edge lerp table of MarchingCubes.cs:440-511:
+// t = v[a]/(v[a]-v[b]+eps); Bt = v[B0]+(v[B1]-v[B0])*t; Ct, Dt likewise.
+__constant__ int8_t c_interior_edges[12][8] = {
+    {0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7},
+    {3, 0, 2, 1, 6, 5, 7, 4}, {4, 5, 7, 6, 3, 2, 0, 1}, {5, 6, 4, 7, 0, 3, 1, 2},
+    {6, 7, 5, 4, 1, 0, 2, 3}, {7, 4, 6, 5, 2, 1, 3, 0}, {0, 4, 3, 7, 2, 6, 1, 5},
+    {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
+
+// MarchingCubes.cs:412-546
+__device__ __noinline__ bool mc_test_internal(const double* v, int cas, int config, int subconfig, int s)
+{
+    double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
+    if (cas == 4 || cas == 10) {
+        const double a = (v[4] - v[0]) * (v[6] - v[2]) - (v[7] - v[3]) * (v[5] - v[1]);
+        const double b = v[2] * (v[4] - v[0]) + v[0] * (v[6] - v[2]) - v[1] * (v[7] - v[3]) - v[3] * (v[5] - v[1]);
+        t = -b / (2 * a + MC_EPS);
+        if (t < 0 || t > 1) return s > 0;
+        At = v[0] + (v[4] - v[0]) * t;
+        Bt = v[3] + (v[7] - v[3]) * t;
+        Ct = v[2] + (v[6] - v[2]) * t;
+        Dt = v[1] + (v[5] - v[1]) * t;
+    } else {
+        int edge;
+        if (cas == 6) edge = MC_L2(test6, config, 2);
+        else if (cas == 7) edge = MC_L2(test7, config, 4);
+        else if (cas == 12) edge = MC_L2(test12, config, 3);
+        else edge = c_lut[MC_ROW3(tiling13_5_1, config, subconfig)];
+        if (edge >= 0 && edge < 12) {
+            const int8_t* e = c_interior_edges[edge];
+            t = v[e[0]] / (v[e[0]] - v[e[1]] + MC_EPS);
+            At = 0;
+            Bt = v[e[2]] + (v[e[3]] - v[e[2]]) * t;
+            Ct = v[e[4]] + (v[e[5]] - v[e[4]]) * t;
+            Dt = v[e[6]] + (v[e[7]] - v[e[6]]) * t;
+        }
+    }
+    int test = 0;
+    if (At >= 0) test += 1;
+    if (Bt >= 0) test += 2;
+    if (Ct >= 0) test += 4;
+    if (Dt >= 0) test += 8;
+    switch (test) {  // MarchingCubes.cs:526-545
+    case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 12: return s > 0;
+    case 5: if (At * Ct - Bt * Dt < MC_EPS) return s > 0; break;
+    case 10: if (At * Ct - Bt * Dt >= MC_EPS) return s > 0; break;
+    default: return s < 0;  // 7, 11, 13, 14, 15
+    }
+    return s < 0;
+}
+
+// The 33-case dispatcher of MarchingCubes.cs:94-371 as a pure function of the corners.
+__device__ __noinline__ Tiling mc_resolve(const double* v)
+{
+    Tiling r;
+    int index = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) index |= (v[k] > 0.0) ? (1 << k) : 0;
+    r.index = index;
+    r.lut_off = -1;
+    r.nt = 0;
+    const int cas = MC_L2(cases, index, 0);
+    const int cfg = MC_L2(cases, index, 1);
+    int sub = 0;
+    switch (cas) {
+    case 1: r.lut_off = MC_ROW2(tiling1, cfg); r.nt = 1; break;
+    case 2: r.lut_off = MC_ROW2(tiling2, cfg); r.nt = 2; break;
+    case 3:
+        if (mc_test_face(v, MC_L1(test3, cfg))) { r.lut_off = MC_ROW2(tiling3_2, cfg); r.nt = 4; }
+        else { r.lut_off = MC_ROW2(tiling3_1, cfg); r.nt = 2; }
+        break;
+    case 4:
+        if (mc_test_internal(v, cas, cfg, 0, MC_L1(test4, cfg))) { r.lut_off = MC_ROW2(tiling4_1, cfg); r.nt = 2; }
+        else { r.lut_off = MC_ROW2(tiling4_2, cfg); r.nt = 6; }
+        break;
+    case 5: r.lut_off = MC_ROW2(tiling5, cfg); r.nt = 3; break;
+    case 6:
+        if (mc_test_face(v, MC_L2(test6, cfg, 0))) { r.lut_off = MC_ROW2(tiling6_2, cfg); r.nt = 5; }
+        else if (mc_test_internal(v, cas, cfg, 0, MC_L2(test6, cfg, 1))) { r.lut_off = MC_ROW2(tiling6_1_1, cfg); r.nt = 3; }
+        else { r.lut_off = MC_ROW2(tiling6_1_2, cfg); r.nt = 9; }
+        break;
+    case 7:
+        if (mc_test_face(v, MC_L2(test7, cfg, 0))) sub += 1;
+        if (mc_test_face(v, MC_L2(test7, cfg, 1))) sub += 2;
+        if (mc_test_face(v, MC_L2(test7, cfg, 2))) sub += 4;
+        switch (sub) {
+        case 0: r.lut_off = MC_ROW2(tiling7_1, cfg); r.nt = 3; break;
+        case 1: r.lut_off = MC_ROW3(tiling7_2, cfg, 0); r.nt = 5; break;
+        case 2: r.lut_off = MC_ROW3(tiling7_2, cfg, 1); r.nt = 5; break;
+        case 3: r.lut_off = MC_ROW3(tiling7_3, cfg, 0); r.nt = 9; break;
+        case 4: r.lut_off = MC_ROW3(tiling7_2, cfg, 2); r.nt = 5; break;
+        case 5: r.lut_off = MC_ROW3(tiling7_3, cfg, 1); r.nt = 9; break;
+        case 6: r.lut_off = MC_ROW3(tiling7_3, cfg, 2); r.nt = 9; break;
+        default:
+            if (mc_test_internal(v, cas, cfg, sub, MC_L2(test7, cfg, 3))) { r.lut_off = MC_ROW2(tiling7_4_2, cfg); r.nt = 9; }
+            else { r.lut_off = MC_ROW2(tiling7_4_1, cfg); r.nt = 5; }
+            break;
+        }
+        break;
+    case 8: r.lut_off = MC_ROW2(tiling8, cfg); r.nt = 2; break;
+    case 9: r.lut_off = MC_ROW2(tiling9, cfg); r.nt = 4; break;
+    case 10:
+        if (mc_test_face(v, MC_L2(test10, cfg, 0))) {
+            if (mc_test_face(v, MC_L2(test10, cfg, 1))) { r.lut_off = MC_ROW2(tiling10_1_1_, cfg); r.nt = 4; }
+            else { r.lut_off = MC_ROW2(tiling10_2, cfg); r.nt = 8; }
+        } else {
+            if (mc_test_face(v, MC_L2(test10, cfg, 1))) { r.lut_off = MC_ROW2(tiling10_2_, cfg); r.nt = 8; }
+            else if (mc_test_internal(v, cas, cfg, 0, MC_L2(test10, cfg, 2))) { r.lut_off = MC_ROW2(tiling10_1_1, cfg); r.nt = 4; }
+            else { r.lut_off = MC_ROW2(tiling10_1_2, cfg); r.nt = 8; }
+        }
+        break;
+    case 11: r.lut_off = MC_ROW2(tiling11, cfg); r.nt = 4; break;
+    case 12:
+        if (mc_test_face(v, MC_L2(test12, cfg, 0))) {
+            if (mc_test_face(v, MC_L2(test12, cfg, 1))) { r.lut_off = MC_ROW2(tiling12_1_1_, cfg); r.nt = 4; }
+            else { r.lut_off = MC_ROW2(tiling12_2, cfg); r.nt = 8; }
+        } else {
+            if (mc_test_face(v, MC_L2(test12, cfg, 1))) { r.lut_off = MC_ROW2(tiling12_2_, cfg); r.nt = 8; }
+            else if (mc_test_internal(v, cas, cfg, 0, MC_L2(test12, cfg, 2))) { r.lut_off = MC_ROW2(tiling12_1_1, cfg); r.nt = 4; }
+            else { r.lut_off = MC_ROW2(tiling12_1_2, cfg); r.nt = 8; }
+        }
+        break;
+    case 13: {
+#pragma unroll 1
+        for (int k = 0; k < 6; k++)
+            if (mc_test_face(v, MC_L2(test13, cfg, k))) sub += 1 << k;
+        sub = MC_L1(subconfig13, sub);
+        if (sub == 0) { r.lut_off = MC_ROW2(tiling13_1, cfg); r.nt = 4; }
+        else if (sub >= 1 && sub <= 6) { r.lut_off = MC_ROW3(tiling13_2, cfg, sub - 1); r.nt = 6; }
+        else if (sub >= 7 && sub <= 18) { r.lut_off = MC_ROW3(tiling13_3, cfg, sub - 7); r.nt = 10; }
+        else if (sub >= 19 && sub <= 22) { r.lut_off = MC_ROW3(tiling13_4, cfg, sub - 19); r.nt = 12; }
+        else if (sub >= 23 && sub <= 26) {
+            const int s5 = sub - 23;
+            if (mc_test_internal(v, cas, cfg, s5, MC_L2(test13, cfg, 6))) { r.lut_off = MC_ROW3(tiling13_5_1, cfg, s5); r.nt = 6; }
+            else { r.lut_off = MC_ROW3(tiling13_5_2, cfg, s5); r.nt = 10; }
+        }
+        else if (sub >= 27 && sub <= 38) { r.lut_off = MC_ROW3(tiling13_3_, cfg, sub - 27); r.nt = 10; }
+        else if (sub >= 39 && sub <= 44) { r.lut_off = MC_ROW3(tiling13_2_, cfg, sub - 39); r.nt = 6; }
+        else if (sub == 45) { r.lut_off = MC_ROW2(tiling13_1_, cfg); r.nt = 4; }
+        // else: "Impossible case 13?" (MarchingCubes.cs:365) -- the cell emits nothing
+        break;
+    }
+    case 14: r.lut_off = MC_ROW2(tiling14, cfg); r.nt = 4; break;
+    default: break;
+    }
+    return r;
+}
+
+// ---- edge geometry ----------------------------------------------------------
+// Edge e of a cell lies on a grid edge with direction dir (0=X,1=Y,2=Z; 3 = the cell's
+// centre vertex) based at voxel (x+ox, y+oy, z+oz) -- the face-layer slot j of
+// Cell.cs:371-441.
+__constant__ int8_t c_edge_dir[13] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2, 3};
+__constant__ int8_t c_edge_ox[13] = {0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0};
+__constant__ int8_t c_edge_oy[13] = {0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0};
+__constant__ int8_t c_edge_oz[13] = {0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+// The (up to) four cells around a grid edge in sweep order (z outer, y, x inner) as
+// offsets from the base voxel, and the id the edge has inside each of them.
+__constant__ int8_t c_share_dx[3][4] = {{0, 0, 0, 0}, {-1, 0, -1, 0}, {-1, 0, -1, 0}};
+__constant__ int8_t c_share_dy[3][4] = {{-1, 0, -1, 0}, {0, 0, 0, 0}, {-1, -1, 0, 0}};
+__constant__ int8_t c_share_dz[3][4] = {{-1, -1, 0, 0}, {-1, -1, 0, 0}, {0, 0, 0, 0}};
+__constant__ int8_t c_share_edge[3][4] = {{6, 4, 2, 0}, {5, 7, 1, 3}, {10, 11, 9, 8}};
+
+// Corner k (v0..v7 order) -> voxel offsets.
+__constant__ int8_t c_corner_dx[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+__constant__ int8_t c_corner_dy[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+__constant__ int8_t c_corner_dz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+// bit-order index -> corner number (Cell.cs:453-460: vv[2]=v3, vv[3]=v2, vv[6]=v7, vv[7]=v6)
+__constant__ int8_t c_bit_to_corner[8] = {0, 1, 3, 2, 4, 5, 7, 6};
+
+// Corner gradients of Cell.cs:491-498, component j of corner k (corner order):
+// vg[k][j] = v[c_grad_a[k][j]] - v[c_grad_b[k][j]].
+__constant__ int8_t c_grad_a[8][3] = {{0, 0, 0}, {0, 1, 1}, {3, 1, 2}, {3, 0, 3}, {4, 4, 0}, {4, 5, 1}, {7, 5, 2}, {7, 4, 3}};
+__constant__ int8_t c_grad_b[8][3] = {{1, 3, 4}, {1, 2, 5}, {2, 2, 6}, {2, 3, 7}, {5, 7, 4}, {5, 6, 5}, {6, 6, 6}, {6, 7, 7}};
+__device__ __forceinline__ double mc_corner_gradient(const double* v, int k, int j)
+{
+    return v[c_grad_a[k][j]] - v[c_grad_b[k][j]];
+}
+
+}  // namespace sdfk

@@ -1,0 +1,192 @@
+// sample_codegen.h -- lowers an SDF program (flat SSA list of float32 ops, see
+// include/sdfkit_hip.h) to HIP source for hiprtc.  This is the GPU counterpart of the
+// reference's SdfExprCompiler (SdfExpr.cs:225-273), which wraps a per-point expression
+// in a batch loop and JIT-compiles it; here the "batch loop" is the grid-sampling kernel
+// of Voxels.SampleSdf (Voxels.cs:72-125) with ClipToBounds (Voxels.cs:133-167) fused in.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/sdfkit_hip.h"
+
+#define SDFK_STR_(...) #__VA_ARGS__
+#define SDFK_STR(...) SDFK_STR_(__VA_ARGS__)
+// One definition, used both by the host (below) and pasted into the generated source.
+#define SDFK_SAMPLE_ARGS_BODY                                                                   \
+    float* values; float* colors; float mx, my, mz, dx, dy, dz; int nx, ny, nz; int z0, nz_global; \
+    int clip; float outside; int nzu; int row_stride;
+
+struct SampleArgs { SDFK_SAMPLE_ARGS_BODY };
+
+namespace sdfk {
+
+static const char* const kSamplePrelude =
+    "struct SampleArgs { " SDFK_STR(SDFK_SAMPLE_ARGS_BODY) " };\n"
+    R"SRC(
+// Math.Max / MathF.Max and Math.Min / MathF.Min: IEEE 754:2019 maximum / minimum
+__device__ __forceinline__ float sdfk_max_ieee(float a, float b)
+{
+    if (a != b) { if (!(a != a)) return b < a ? a : b; return a; }
+    return __builtin_signbitf(b) ? a : b;
+}
+__device__ __forceinline__ float sdfk_min_ieee(float a, float b)
+{
+    if (a != b) { if (!(a != a)) return a < b ? a : b; return a; }
+    return __builtin_signbitf(a) ? a : b;
+}
+)SRC";
+
+static const char* const kSampleKernels = R"SRC(
+// Voxels.SampleSdf (Voxels.cs:72-125): sample point of voxel (ix,iy,iz) is
+//   p = (min + 0.5*D) + (float)i * D   per axis (Voxels.cs:81,104-106),
+// value -> Values[ix,iy,iz] (z fastest), colour -> Colors[ix,iy,iz].
+// blockDim = (TZ, TR): TZ lanes walk z (4 voxels each, one 16-byte store), TR rows per
+// workgroup; rows (ix*ny+iy) are contiguous in memory so a wave stores >= 1 KiB contiguous.
+extern "C" __global__ __launch_bounds__(256) void sdfk_sample_vec4(SampleArgs A)
+{
+    const int tz = blockDim.x, tr = blockDim.y;
+    long row = (long)blockIdx.x * tr + threadIdx.y;
+    const long nrows = (long)A.nx * A.ny;
+    if (row >= nrows) return;
+    int ix = (int)(row / A.ny), iy = (int)(row % A.ny);
+    const int sq = A.row_stride / A.ny, sr = A.row_stride % A.ny;
+    for (; row < nrows; row += A.row_stride) {
+        const float px = A.mx + (float)ix * A.dx;
+        const float py = A.my + (float)iy * A.dy;
+        const bool edge_xy = (ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1);
+        float* vrow = A.values + row * A.nz;
+        for (int u = threadIdx.x; u < A.nzu; u += tz) {
+            const int z = 4 * u;
+            float w[4], r[4], g[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int zg = A.z0 + z + k;
+                const float pz = A.mz + (float)zg * A.dz;
+                sdf_eval(px, py, pz, r[k], g[k], b[k], w[k]);
+                if (A.clip && (edge_xy || zg == 0 || zg == A.nz_global - 1)) w[k] = A.outside;
+            }
+            *reinterpret_cast<float4*>(vrow + z) = make_float4(w[0], w[1], w[2], w[3]);
+            if (A.colors) {
+                float4* c = reinterpret_cast<float4*>(A.colors + (row * A.nz + z) * 3);
+                c[0] = make_float4(r[0], g[0], b[0], r[1]);
+                c[1] = make_float4(g[1], b[1], r[2], g[2]);
+                c[2] = make_float4(b[2], r[3], g[3], b[3]);
+            }
+        }
+        ix += sq; iy += sr;
+        if (iy >= A.ny) { iy -= A.ny; ix++; }
+    }
+}
+
+// same, one voxel per lane-iteration (nz not a multiple of 4)
+extern "C" __global__ __launch_bounds__(256) void sdfk_sample_scalar(SampleArgs A)
+{
+    const int tz = blockDim.x, tr = blockDim.y;
+    long row = (long)blockIdx.x * tr + threadIdx.y;
+    const long nrows = (long)A.nx * A.ny;
+    if (row >= nrows) return;
+    int ix = (int)(row / A.ny), iy = (int)(row % A.ny);
+    const int sq = A.row_stride / A.ny, sr = A.row_stride % A.ny;
+    for (; row < nrows; row += A.row_stride) {
+        const float px = A.mx + (float)ix * A.dx;
+        const float py = A.my + (float)iy * A.dy;
+        const bool edge_xy = (ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1);
+        for (int z = threadIdx.x; z < A.nzu; z += tz) {
+            const int zg = A.z0 + z;
+            const float pz = A.mz + (float)zg * A.dz;
+            float w, r, g, b;
+            sdf_eval(px, py, pz, r, g, b, w);
+            if (A.clip && (edge_xy || zg == 0 || zg == A.nz_global - 1)) w = A.outside;
+            const long o = row * A.nz + z;
+            A.values[o] = w;
+            if (A.colors) { A.colors[o * 3] = r; A.colors[o * 3 + 1] = g; A.colors[o * 3 + 2] = b; }
+        }
+        ix += sq; iy += sr;
+        if (iy >= A.ny) { iy -= A.ny; ix++; }
+    }
+}
+)SRC";
+
+inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t out_rgbw[4], int writes_color,
+                                   std::string& src, std::string& err)
+{
+    char buf[256];
+    if (n_ops > (1 << 20)) { err = "program too long"; return false; }
+    std::string body;
+    body.reserve((size_t)n_ops * 48);
+    for (int i = 0; i < n_ops; i++) {
+        const sdfk_op& o = ops[i];
+        auto arg = [&](int32_t id, const char* which) -> bool {
+            if (id < 0 || id >= i) {
+                snprintf(buf, sizeof buf, "op %d: operand %s = %d does not name an earlier value", i, which, id);
+                err = buf;
+                return false;
+            }
+            return true;
+        };
+        int arity = 0;
+        const char* fmt = nullptr;
+        switch (o.opcode) {
+        case SDFK_OP_CONST: {
+            uint32_t bits;
+            memcpy(&bits, &o.imm, 4);
+            snprintf(buf, sizeof buf, "    const float v%d = __uint_as_float(0x%08xu);\n", i, bits);
+            body += buf;
+            continue;
+        }
+        case SDFK_OP_X: snprintf(buf, sizeof buf, "    const float v%d = X;\n", i); body += buf; continue;
+        case SDFK_OP_Y: snprintf(buf, sizeof buf, "    const float v%d = Y;\n", i); body += buf; continue;
+        case SDFK_OP_Z: snprintf(buf, sizeof buf, "    const float v%d = Z;\n", i); body += buf; continue;
+        case SDFK_OP_ADD: arity = 2; fmt = "v%d + v%d"; break;
+        case SDFK_OP_SUB: arity = 2; fmt = "v%d - v%d"; break;
+        case SDFK_OP_MUL: arity = 2; fmt = "v%d * v%d"; break;
+        case SDFK_OP_DIV: arity = 2; fmt = "v%d / v%d"; break;
+        case SDFK_OP_NEG: arity = 1; fmt = "-v%d"; break;
+        case SDFK_OP_ABS: arity = 1; fmt = "__builtin_fabsf(v%d)"; break;
+        case SDFK_OP_SQRT: arity = 1; fmt = "__builtin_sqrtf(v%d)"; break;
+        case SDFK_OP_FLOOR: arity = 1; fmt = "__builtin_floorf(v%d)"; break;
+        case SDFK_OP_MIN_SEL: arity = 3; fmt = "(v%d < v%d) ? v%d : v%d"; break;
+        case SDFK_OP_MAX_SEL: arity = 3; fmt = "(v%d > v%d) ? v%d : v%d"; break;
+        case SDFK_OP_MIN_IEEE: arity = 2; fmt = "sdfk_min_ieee(v%d, v%d)"; break;
+        case SDFK_OP_MAX_IEEE: arity = 2; fmt = "sdfk_max_ieee(v%d, v%d)"; break;
+        case SDFK_OP_SEL_LT: arity = 4; fmt = "(v%d < v%d) ? v%d : v%d"; break;
+        default:
+            snprintf(buf, sizeof buf, "op %d: unknown opcode %d", i, o.opcode);
+            err = buf;
+            return false;
+        }
+        if (arity >= 1 && !arg(o.a, "a")) return false;
+        if (arity >= 2 && !arg(o.b, "b")) return false;
+        if (arity >= 4 && (!arg(o.c, "c") || !arg(o.d, "d"))) return false;
+        char ex[160];
+        if (arity == 1) snprintf(ex, sizeof ex, fmt, o.a);
+        else if (arity == 2) snprintf(ex, sizeof ex, fmt, o.a, o.b);
+        else if (arity == 3) snprintf(ex, sizeof ex, fmt, o.a, o.b, o.a, o.b);  // compare-select on (a,b)
+        else snprintf(ex, sizeof ex, fmt, o.a, o.b, o.c, o.d);
+        snprintf(buf, sizeof buf, "    const float v%d = %s;\n", i, ex);
+        body += buf;
+    }
+    for (int k = 0; k < 4; k++) {
+        if (k < 3 && !writes_color) continue;
+        if (out_rgbw[k] < 0 || out_rgbw[k] >= n_ops) { err = "output id out of range"; return false; }
+    }
+    src.clear();
+    src += kSamplePrelude;
+    src += "__device__ __forceinline__ void sdf_eval(float X, float Y, float Z, float& R, float& G, float& B, float& W)\n{\n";
+    src += body;
+    if (writes_color) {
+        snprintf(buf, sizeof buf, "    R = v%d; G = v%d; B = v%d;\n", out_rgbw[0], out_rgbw[1], out_rgbw[2]);
+        src += buf;
+    } else {
+        // delegates that only assign .W leave colour at the zeroed scratch value (Voxels.cs:88-92)
+        src += "    R = 0.0f; G = 0.0f; B = 0.0f;\n";
+    }
+    snprintf(buf, sizeof buf, "    W = v%d;\n}\n", out_rgbw[3]);
+    src += buf;
+    src += kSampleKernels;
+    return true;
+}
+
+}  // namespace sdfk

@@ -1,0 +1,940 @@
+// sdfkit_hip.hip -- C ABI (include/sdfkit_hip.h) and host-side driver of libsdfkit_hip.so.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ... -lhiprtc
+// (see sdfkit_amd/build.py).  gfx950 only; there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfkit_hip.h"
+#include "mc_kernels.hip"
+#include "sample_codegen.h"
+
+using namespace sdfk;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string t_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    t_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(SDFK_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// context: device, stream, caching device allocator, profiling events
+// ---------------------------------------------------------------------------
+namespace {
+
+struct ProfSpan { int name_id; hipEvent_t a, b; };
+
+struct Context {
+    bool inited = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::multimap<size_t, void*> free_blocks;   // caching allocator: size class -> block
+    std::map<void*, size_t> live_blocks;
+    // profiling
+    bool prof_on = false;
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_ms;
+    std::vector<int64_t> prof_n;
+    std::vector<ProfSpan> prof_pending;
+    std::vector<hipEvent_t> prof_event_pool;
+    // pinned host scratch for counter read-back
+    McCounters* h_counters = nullptr;
+    float* h_bounds = nullptr;
+};
+
+Context g;
+std::recursive_mutex g_mu;
+
+size_t size_class(size_t n)
+{
+    size_t c = 256;
+    while (c < n) c = (c < (size_t(1) << 26)) ? c * 2 : c + (size_t(1) << 26);  // pow2 up to 64 MiB, then 64 MiB steps
+    return c;
+}
+
+int dev_alloc(void** p, size_t n)
+{
+    if (n == 0) n = 1;
+    const size_t c = size_class(n);
+    auto it = g.free_blocks.find(c);
+    if (it != g.free_blocks.end()) {
+        *p = it->second;
+        g.free_blocks.erase(it);
+        g.live_blocks[*p] = c;
+        return SDFK_OK;
+    }
+    hipError_t e = hipMalloc(p, c);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        for (auto& kv : g.free_blocks) (void)hipFree(kv.second);
+        g.free_blocks.clear();
+        e = hipMalloc(p, c);
+        if (e != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", c, hipGetErrorString(e));
+    }
+    g.live_blocks[*p] = c;
+    return SDFK_OK;
+}
+
+void dev_free(void* p)
+{
+    if (!p) return;
+    auto it = g.live_blocks.find(p);
+    if (it == g.live_blocks.end()) return;
+    g.free_blocks.emplace(it->second, p);
+    g.live_blocks.erase(it);
+}
+
+int prof_name_id(const char* name)
+{
+    for (size_t i = 0; i < g.prof_names.size(); i++)
+        if (g.prof_names[i] == name) return (int)i;
+    g.prof_names.push_back(name);
+    g.prof_ms.push_back(0.0);
+    g.prof_n.push_back(0);
+    return (int)g.prof_names.size() - 1;
+}
+
+hipEvent_t prof_event()
+{
+    if (!g.prof_event_pool.empty()) {
+        hipEvent_t e = g.prof_event_pool.back();
+        g.prof_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_drain()
+{
+    for (auto& s : g.prof_pending) {
+        (void)hipEventSynchronize(s.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            g.prof_ms[s.name_id] += ms;
+            g.prof_n[s.name_id] += 1;
+        }
+        g.prof_event_pool.push_back(s.a);
+        g.prof_event_pool.push_back(s.b);
+    }
+    g.prof_pending.clear();
+}
+
+struct ProfScope {
+    ProfSpan s;
+    bool on;
+    explicit ProfScope(const char* name) : on(g.prof_on)
+    {
+        if (on) {
+            s.name_id = prof_name_id(name);
+            s.a = prof_event();
+            s.b = prof_event();
+            (void)hipEventRecord(s.a, g.stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (on) {
+            (void)hipEventRecord(s.b, g.stream);
+            g.prof_pending.push_back(s);
+            if (g.prof_pending.size() > 4096) prof_drain();
+        }
+    }
+};
+
+int require_init()
+{
+    if (!g.inited) return fail(SDFK_ERR_NO_DEVICE, "sdfk_init() has not been called or no HIP device is available");
+    return SDFK_OK;
+}
+
+int grid_for(size_t work_items, int per_block = 256, int max_blocks = 256 * 8)
+{
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// opaque objects
+// ---------------------------------------------------------------------------
+struct sdfk_program {
+    std::string source;
+    hipModule_t module = nullptr;
+    hipFunction_t fn_vec4 = nullptr;
+    hipFunction_t fn_scalar = nullptr;
+    int writes_color = 0;
+};
+
+struct sdfk_volume {
+    int nx = 0, ny = 0, nz = 0;       // local dims (nz = planes held)
+    int nz_global = 0, z0 = 0;
+    float gmin[3], gmax[3];
+    float* values = nullptr;
+    float* colors = nullptr;          // nullptr: colours are all zero
+    size_t nvox() const { return (size_t)nx * ny * nz; }
+};
+
+struct sdfk_mesh {
+    int64_t nv = 0, ni = 0;
+    float* vertices = nullptr;
+    float* colors = nullptr;
+    float* normals = nullptr;
+    int32_t* triangles = nullptr;
+    float* bounds = nullptr;  // device float[6]
+    float h_min[3] = {0, 0, 0}, h_max[3] = {0, 0, 0};
+    bool bounds_valid = false;
+    int64_t n_active = 0, n_case13 = 0;
+};
+
+struct sdfk_march_job {
+    McParams P;
+    McCounters c;
+    // everything below is owned by the job
+    std::vector<void*> owned;
+    sdfk_volume* sub = nullptr;    // subsampled copy for step > 1
+    int gnx, gny, gnz;             // global voxel dims for Mesh.Transform
+    float gmin[3], gmax[3];
+    bool finished = false;
+};
+
+// ---------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------
+extern "C" int sdfk_abi_version(void) { return SDFK_ABI_VERSION; }
+
+extern "C" const char* sdfk_last_error(void) { return t_err.c_str(); }
+
+extern "C" int sdfk_init(int device)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (g.inited) {
+        if (device != g.device) return fail(SDFK_ERR_INVALID, "already initialised on device %d", g.device);
+        return SDFK_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(SDFK_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(SDFK_ERR_INVALID, "device %d out of range (%d devices)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SDFK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
+    g.stream = g.own_stream;
+    HIPCHK(hipHostMalloc((void**)&g.h_counters, sizeof(McCounters)));
+    HIPCHK(hipHostMalloc((void**)&g.h_bounds, 6 * sizeof(float)));
+    g.device = device;
+    g.inited = true;
+    return SDFK_OK;
+}
+
+extern "C" void sdfk_shutdown(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!g.inited) return;
+    (void)hipStreamSynchronize(g.stream);
+    prof_drain();
+    for (auto e : g.prof_event_pool) (void)hipEventDestroy(e);
+    g.prof_event_pool.clear();
+    for (auto& kv : g.free_blocks) (void)hipFree(kv.second);
+    g.free_blocks.clear();
+    for (auto& kv : g.live_blocks) (void)hipFree(kv.first);
+    g.live_blocks.clear();
+    if (g.h_counters) (void)hipHostFree(g.h_counters);
+    if (g.h_bounds) (void)hipHostFree(g.h_bounds);
+    g.h_counters = nullptr;
+    g.h_bounds = nullptr;
+    if (g.own_stream) (void)hipStreamDestroy(g.own_stream);
+    g.own_stream = nullptr;
+    g.stream = nullptr;
+    g.inited = false;
+}
+
+extern "C" int sdfk_set_stream(void* hip_stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (int r = require_init()) return r;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.stream = hip_stream ? (hipStream_t)hip_stream : g.own_stream;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_synchronize(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (int r = require_init()) return r;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return SDFK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// programs (JIT, counterpart of SdfExprCompiler.Compile, SdfExpr.cs:225-273)
+// ---------------------------------------------------------------------------
+static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
+                           std::string& src, std::vector<char>& code)
+{
+    std::string err;
+    if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err))
+        return fail(SDFK_ERR_INVALID, "SDF program: %s", err.c_str());
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_sample.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(SDFK_ERR_COMPILE, "hiprtcCreateProgram failed");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
+    hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(SDFK_ERR_COMPILE, "hiprtc: %s\n%s", hiprtcGetErrorString(rc), log.c_str());
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color)
+{
+    if (!ops || !out_rgbw || n_ops <= 0) return fail(SDFK_ERR_INVALID, "sdfk_program_check: null/empty argument");
+    std::string src;
+    std::vector<char> code;
+    return compile_program(ops, n_ops, out_rgbw, writes_color, src, code);
+}
+
+extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
+                                   int32_t writes_color, sdfk_program** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!out || !ops || !out_rgbw || n_ops <= 0) return fail(SDFK_ERR_INVALID, "sdfk_program_create: null/empty argument");
+    *out = nullptr;
+    if (int r = require_init()) return r;
+    std::string src;
+    std::vector<char> code;
+    if (int r = compile_program(ops, n_ops, out_rgbw, writes_color, src, code)) return r;
+    sdfk_program* p = new sdfk_program();
+    p->source = src;
+    p->writes_color = writes_color;
+    hipError_t e = hipModuleLoadData(&p->module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_vec4, p->module, "sdfk_sample_vec4");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_scalar, p->module, "sdfk_sample_scalar");
+    if (e != hipSuccess) {
+        if (p->module) (void)hipModuleUnload(p->module);
+        delete p;
+        return fail(SDFK_ERR_HIP, "loading JIT module: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return SDFK_OK;
+}
+
+extern "C" const char* sdfk_program_source(const sdfk_program* p) { return p ? p->source.c_str() : ""; }
+
+extern "C" void sdfk_program_destroy(sdfk_program* p)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p) return;
+    if (g.inited) (void)hipStreamSynchronize(g.stream);
+    if (p->module) (void)hipModuleUnload(p->module);
+    delete p;
+}
+
+// ---------------------------------------------------------------------------
+// volumes
+// ---------------------------------------------------------------------------
+extern "C" int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global, const float min[3],
+                                       const float max[3], int32_t z0, int32_t nz_local,
+                                       int32_t with_colors, sdfk_volume** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!out || !min || !max) return fail(SDFK_ERR_INVALID, "sdfk_volume_create: null argument");
+    *out = nullptr;
+    if (nx < 1 || ny < 1 || nz_global < 1 || nz_local < 1 || z0 < 0 || z0 + nz_local > nz_global)
+        return fail(SDFK_ERR_INVALID, "sdfk_volume_create: bad dimensions %dx%dx%d (slab z0=%d nz=%d)", nx, ny, nz_global, z0, nz_local);
+    if ((int64_t)nx * ny * nz_global >= (int64_t(1) << 31))
+        return fail(SDFK_ERR_INVALID, "grid exceeds the reference's int32 linear index (Voxels.cs:82)");
+    if (int r = require_init()) return r;
+    sdfk_volume* v = new sdfk_volume();
+    v->nx = nx; v->ny = ny; v->nz = nz_local; v->nz_global = nz_global; v->z0 = z0;
+    memcpy(v->gmin, min, sizeof v->gmin);
+    memcpy(v->gmax, max, sizeof v->gmax);
+    int r = dev_alloc((void**)&v->values, v->nvox() * sizeof(float));
+    if (!r && with_colors) r = dev_alloc((void**)&v->colors, v->nvox() * 3 * sizeof(float));
+    if (r) { dev_free(v->values); delete v; return r; }
+    *out = v;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_volume_create(int32_t nx, int32_t ny, int32_t nz, const float min[3], const float max[3],
+                                  int32_t with_colors, sdfk_volume** out)
+{
+    return sdfk_volume_create_slab(nx, ny, nz, min, max, 0, nz, with_colors, out);
+}
+
+extern "C" void sdfk_volume_free(sdfk_volume* v)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!v) return;
+    if (g.inited) (void)hipStreamSynchronize(g.stream);
+    dev_free(v->values);
+    dev_free(v->colors);
+    delete v;
+}
+
+extern "C" int sdfk_volume_upload(sdfk_volume* v, const float* values, const float* colors3)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!v || !values) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: null argument");
+    if (int r = require_init()) return r;
+    if (colors3 && !v->colors) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: volume was created without colours");
+    HIPCHK(hipMemcpyAsync(v->values, values, v->nvox() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    if (colors3) HIPCHK(hipMemcpyAsync(v->colors, colors3, v->nvox() * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));  // the caller's arrays are not retained
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_volume_download(const sdfk_volume* v, float* values, float* colors3)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!v) return fail(SDFK_ERR_INVALID, "sdfk_volume_download: null volume");
+    if (int r = require_init()) return r;
+    if (values) HIPCHK(hipMemcpyAsync(values, v->values, v->nvox() * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+    if (colors3) {
+        if (v->colors) HIPCHK(hipMemcpyAsync(colors3, v->colors, v->nvox() * 3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+        else memset(colors3, 0, v->nvox() * 3 * sizeof(float));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void** colors3)
+{
+    if (!v) return fail(SDFK_ERR_INVALID, "null volume");
+    if (values) *values = v->values;
+    if (colors3) *colors3 = v->colors;
+    return SDFK_OK;
+}
+
+// Voxels.cs:32-34,81,139: cell size, first cell centre and ClipToBounds value, in float
+static void grid_constants(const sdfk_volume* v, float d[3], float m[3], float* outside)
+{
+    const int n[3] = {v->nx, v->ny, v->nz_global};
+    for (int k = 0; k < 3; k++) {
+        d[k] = n[k] >= 1 ? (v->gmax[k] - v->gmin[k]) / (float)n[k] : 0.0f;
+        const float h = 0.5f * d[k];
+        m[k] = v->gmin[k] + h;
+    }
+    *outside = (v->gmax[0] - v->gmin[0]) / (float)v->nx;
+}
+
+extern "C" int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !v) return fail(SDFK_ERR_INVALID, "sdfk_sample: null argument");
+    if (int r = require_init()) return r;
+    SampleArgs A;
+    memset(&A, 0, sizeof A);
+    float d[3], m[3], outside;
+    grid_constants(v, d, m, &outside);
+    A.values = v->values;
+    A.colors = v->colors;
+    A.mx = m[0]; A.my = m[1]; A.mz = m[2];
+    A.dx = d[0]; A.dy = d[1]; A.dz = d[2];
+    A.nx = v->nx; A.ny = v->ny; A.nz = v->nz;
+    A.z0 = v->z0; A.nz_global = v->nz_global;
+    A.clip = clip_to_bounds ? 1 : 0;
+    A.outside = outside;
+    const bool vec = (v->nz % 4) == 0;
+    const int nzu = vec ? v->nz / 4 : v->nz;      // work units along z per row
+    int tz = 1;
+    while (tz < nzu && tz < 256) tz *= 2;
+    const int tr = 256 / tz;
+    const long nrows = (long)v->nx * v->ny;
+    long nblk = (nrows + tr - 1) / tr;
+    const long maxblk = 256L * 16;
+    if (nblk > maxblk) nblk = maxblk;
+    A.nzu = nzu;
+    A.row_stride = (int)(nblk * tr);
+    void* params[] = {&A};
+    ProfScope ps(vec ? "sdfk_sample_vec4" : "sdfk_sample_scalar");
+    HIPCHK(hipModuleLaunchKernel(vec ? p->fn_vec4 : p->fn_scalar, (unsigned)nblk, 1, 1, (unsigned)tz, (unsigned)tr, 1, 0, g.stream, params, nullptr));
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_volume_clip_to_bounds(sdfk_volume* v)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!v) return fail(SDFK_ERR_INVALID, "null volume");
+    if (int r = require_init()) return r;
+    float d[3], m[3], outside;
+    grid_constants(v, d, m, &outside);
+    ProfScope ps("k_clip");
+    hipLaunchKernelGGL(k_clip, dim3(grid_for(v->nvox())), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->z0, v->nz_global, outside);
+    HIPCHK(hipGetLastError());
+    return SDFK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// marching cubes driver
+// ---------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+int job_alloc(sdfk_march_job* j, T** p, size_t count)
+{
+    void* q = nullptr;
+    if (int r = dev_alloc(&q, count * sizeof(T))) return r;
+    j->owned.push_back(q);
+    *p = (T*)q;
+    return SDFK_OK;
+}
+
+void job_release(sdfk_march_job* j)
+{
+    for (void* p : j->owned) dev_free(p);
+    j->owned.clear();
+    if (j->sub) {
+        dev_free(j->sub->values);
+        dev_free(j->sub->colors);
+        delete j->sub;
+        j->sub = nullptr;
+    }
+}
+
+int launch_classify(sdfk_march_job* j, bool redo_bits)
+{
+    McParams& P = j->P;
+    HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(McCounters), g.stream));
+    if (redo_bits) {
+        ProfScope ps("k_signbits");
+        if (P.nz % 4 == 0) {
+            const int wx = P.nxw >= 8 ? 8 : (P.nxw >= 4 ? 4 : (P.nxw >= 2 ? 2 : 1));
+            const dim3 grid((P.nz + 63) / 64, P.ny, (P.nxw + wx - 1) / wx);
+            switch (wx) {
+            case 8: hipLaunchKernelGGL(k_signbits_tile<8>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            case 4: hipLaunchKernelGGL(k_signbits_tile<4>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            case 2: hipLaunchKernelGGL(k_signbits_tile<2>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            default: hipLaunchKernelGGL(k_signbits_tile<1>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            }
+        } else {
+            const dim3 grid((P.nz + 63) / 64, P.ny, P.nxw);
+            hipLaunchKernelGGL(k_signbits_generic, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps("k_segments");
+        hipLaunchKernelGGL(k_segments, dim3((P.nseg + 255) / 256), dim3(256), 0, g.stream, P);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps("k_resolve");
+        hipLaunchKernelGGL(k_resolve, dim3(256 * 8), dim3(256), 0, g.stream, P);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps("k_segsum");
+        hipLaunchKernelGGL(k_segsum, dim3(256 * 8), dim3(256), 0, g.stream, P);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps("k_scan");
+        hipLaunchKernelGGL(k_scan_reduce, dim3(P.nscanblk), dim3(256), 0, g.stream, P);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, g.stream, P);
+        hipLaunchKernelGGL(k_scan_final, dim3(P.nscanblk), dim3(256), 0, g.stream, P);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(g.h_counters, P.counters, sizeof(McCounters), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    j->c = *g.h_counters;
+    return SDFK_OK;
+}
+
+// The job works on `v` (or on a subsampled copy when step > 1).
+int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end,
+                     sdfk_march_job** out, int64_t* n_vertices, int64_t* n_indices)
+{
+    *out = nullptr;
+    if (step < 1) return fail(SDFK_ERR_INVALID, "step must be >= 1");
+    const bool slab = (v->z0 != 0 || v->nz != v->nz_global);
+    if (step != 1 && (slab || layer_begin != 0)) return fail(SDFK_ERR_UNSUPPORTED, "slab meshing supports step == 1 only");
+    sdfk_march_job* j = new sdfk_march_job();
+    j->gnx = v->nx; j->gny = v->ny; j->gnz = v->nz_global;
+    memcpy(j->gmin, v->gmin, sizeof j->gmin);
+    memcpy(j->gmax, v->gmax, sizeof j->gmax);
+    const sdfk_volume* w = v;
+    if (step > 1) {
+        // MarchingCubes.cs:49-80 touches only voxels at multiples of step
+        sdfk_volume* s = new sdfk_volume(*v);
+        s->nx = (v->nx - 1) / step + 1; s->ny = (v->ny - 1) / step + 1; s->nz = (v->nz - 1) / step + 1;
+        s->nz_global = s->nz;
+        s->values = nullptr; s->colors = nullptr;
+        j->sub = s;
+        int r = dev_alloc((void**)&s->values, s->nvox() * sizeof(float));
+        if (!r && v->colors) r = dev_alloc((void**)&s->colors, s->nvox() * 3 * sizeof(float));
+        if (r) { job_release(j); delete j; return r; }
+        ProfScope ps("k_subsample");
+        hipLaunchKernelGGL(k_subsample, dim3(grid_for(s->nvox())), dim3(256), 0, g.stream, v->values, v->colors,
+                           s->values, s->colors, v->nx, v->ny, v->nz, s->nx, s->ny, s->nz, step);
+        w = s;
+        layer_end = s->nz - 1;
+    }
+    McParams& P = j->P;
+    memset(&P, 0, sizeof P);
+    P.values = w->values; P.colors = w->colors;
+    P.nx = w->nx; P.ny = w->ny; P.nz = w->nz;
+    P.ncx = w->nx - 1; P.ncy = w->ny - 1; P.ncz = w->nz - 1;
+    P.nxw = (w->nx + 63) / 64;
+    P.z0 = w->z0;
+    P.iso = iso;
+    P.step = step;
+    const int ncz_global = w->nz_global - 1;
+    if (layer_begin < 0 || layer_end > std::max(ncz_global, 0) || layer_begin > layer_end) {
+        job_release(j); delete j;
+        return fail(SDFK_ERR_INVALID, "layer range [%d,%d) outside [0,%d)", layer_begin, layer_end, ncz_global);
+    }
+    P.lay_emit_begin = layer_begin - w->z0;
+    P.lay_emit_end = layer_end - w->z0;
+    P.lay_count_begin = layer_begin > 0 ? P.lay_emit_begin - 1 : P.lay_emit_begin;
+    const bool empty = (P.ncx <= 0 || P.ncy <= 0 || P.ncz <= 0 || layer_begin == layer_end);
+    if (!empty) {
+        // context planes the slab must hold (see sdfkit_hip.h)
+        const int need_lo = std::max(layer_begin - 2, 0), need_hi = std::min(layer_end + 2, w->nz_global);
+        if (w->z0 > need_lo || w->z0 + w->nz < need_hi) {
+            job_release(j); delete j;
+            return fail(SDFK_ERR_INVALID, "slab planes [%d,%d) do not cover the context [%d,%d) of layers [%d,%d)",
+                        w->z0, w->z0 + w->nz, need_lo, need_hi, layer_begin, layer_end);
+        }
+    }
+    memset(&j->c, 0, sizeof j->c);
+    if (empty) {
+        P.nseg = 0;
+        *out = j;
+        if (n_vertices) *n_vertices = 0;
+        if (n_indices) *n_indices = 0;
+        return SDFK_OK;
+    }
+    P.nseg = (uint32_t)((size_t)P.ncz * P.ncy * P.nxw);
+    P.nscanblk = (P.nseg + SCAN_TILE - 1) / SCAN_TILE;
+    const size_t nvox = (size_t)P.nx * P.ny * P.nz;
+    const size_t ncell = (size_t)P.ncx * P.ncy * P.ncz;
+    size_t cap = std::max<size_t>(ncell / 12, 1u << 16);
+    cap = std::min(cap, ncell);
+    int r = 0;
+    r = r ? r : job_alloc(j, &P.bits, (size_t)P.nz * P.ny * P.nxw + 1);
+    r = r ? r : job_alloc(j, &P.segpack, P.nseg);
+    r = r ? r : job_alloc(j, &P.segprefix, P.nseg);
+    r = r ? r : job_alloc(j, &P.blocksum, P.nscanblk);
+    r = r ? r : job_alloc(j, &P.emap, nvox * 4);
+    r = r ? r : job_alloc(j, &P.counters, 1);
+    size_t act_idx = 0;
+    auto alloc_records = [&](size_t c) -> int {
+        int rr = 0;
+        rr = rr ? rr : job_alloc(j, &P.act, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_info, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_own, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
+        P.cap_active = (uint32_t)c;
+        return rr;
+    };
+    act_idx = j->owned.size();
+    r = r ? r : alloc_records(cap);
+    if (r) { job_release(j); delete j; return r; }
+    r = launch_classify(j, true);
+    if (!r && j->c.n_active > P.cap_active) {
+        // active-cell list too small: grow to the exact need and redo from K2a
+        for (size_t k = act_idx; k < j->owned.size(); k++) dev_free(j->owned[k]);
+        j->owned.resize(act_idx);
+        r = alloc_records(j->c.n_active);
+        r = r ? r : launch_classify(j, false);
+    }
+    if (r) { job_release(j); delete j; return r; }
+    if (n_vertices) *n_vertices = (int64_t)j->c.total_v - (int64_t)j->c.nghost;
+    if (n_indices) *n_indices = (int64_t)j->c.total_t * 3;
+    *out = j;
+    return SDFK_OK;
+}
+
+int march_finish_impl(sdfk_march_job* j, int64_t vertex_base, sdfk_mesh** out)
+{
+    *out = nullptr;
+    if (j->finished) return fail(SDFK_ERR_INVALID, "march job already finished");
+    sdfk_mesh* m = new sdfk_mesh();
+    m->nv = (int64_t)j->c.total_v - (int64_t)j->c.nghost;
+    m->ni = (int64_t)j->c.total_t * 3;
+    m->n_active = j->c.n_active;
+    m->n_case13 = j->c.n_dead;
+    if (vertex_base + m->nv >= (int64_t(1) << 31)) { delete m; return fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])"); }
+    int r = 0;
+    r = r ? r : dev_alloc((void**)&m->vertices, (size_t)std::max<int64_t>(m->nv, 1) * 3 * sizeof(float));
+    r = r ? r : dev_alloc((void**)&m->colors, (size_t)std::max<int64_t>(m->nv, 1) * 3 * sizeof(float));
+    r = r ? r : dev_alloc((void**)&m->normals, (size_t)std::max<int64_t>(m->nv, 1) * 3 * sizeof(float));
+    r = r ? r : dev_alloc((void**)&m->triangles, (size_t)std::max<int64_t>(m->ni, 1) * sizeof(int32_t));
+    r = r ? r : dev_alloc((void**)&m->bounds, 6 * sizeof(float));
+    if (r) { sdfk_mesh_free(m); return r; }
+    j->finished = true;
+    if (j->P.nseg == 0 || j->c.n_active == 0) {
+        m->bounds_valid = true;  // Mesh.Measure leaves Min/Max at zero for an empty mesh (Mesh.cs:32)
+        *out = m;
+        return SDFK_OK;
+    }
+    McMeshOut M;
+    memset(&M, 0, sizeof M);
+    M.vertices = m->vertices; M.colors = m->colors; M.normals = m->normals; M.triangles = m->triangles;
+    M.cap_vertices = (uint32_t)m->nv;
+    M.cap_indices = (size_t)m->ni;
+    M.vertex_base = vertex_base;
+    // MarchingCubes.cs:85-90 (row-vector T*S*T) and Mesh.cs:49-55, all float32
+    const int nn[3] = {j->gnx, j->gny, j->gnz};
+    for (int k = 0; k < 3; k++) {
+        const float size = j->gmax[k] - j->gmin[k];
+        const float sum = j->gmin[k] + j->gmax[k];
+        const float center = sum * 0.5f;
+        const float t1 = (float)(-(nn[k] - 1)) / 2.0f;
+        M.sc[k] = size / (float)(nn[k] - 1);
+        const float ts = t1 * M.sc[k];
+        M.tr[k] = ts + center;
+    }
+    {
+        const float yz = M.sc[1] * M.sc[2], xz = M.sc[0] * M.sc[2], xy = M.sc[0] * M.sc[1];
+        const float det = M.sc[0] * yz;
+        const float inv_det = 1.0f / det;
+        M.inv[0] = yz * inv_det; M.inv[1] = xz * inv_det; M.inv[2] = xy * inv_det;
+    }
+    const int vgrid = grid_for(j->c.n_active, 256, 256 * 8);
+    if (int rr = job_alloc(j, &M.bounds_partial, (size_t)vgrid * 6)) { sdfk_mesh_free(m); return rr; }
+    {
+        ProfScope ps("k_vertices");
+        hipLaunchKernelGGL(k_vertices, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
+        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(256), 0, g.stream, (const float*)M.bounds_partial, vgrid, m->bounds);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps("k_triangles");
+        hipLaunchKernelGGL(k_triangles, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
+        HIPCHK(hipGetLastError());
+    }
+    *out = m;
+    return SDFK_OK;
+}
+
+}  // namespace
+
+extern "C" int sdfk_march_begin(const sdfk_volume* v, float iso_value, int32_t layer_begin, int32_t layer_end,
+                                sdfk_march_job** job, int64_t* n_vertices, int64_t* n_indices)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!v || !job) return fail(SDFK_ERR_INVALID, "sdfk_march_begin: null argument");
+    if (int r = require_init()) return r;
+    return march_begin_impl(v, iso_value, 1, layer_begin, layer_end, job, n_vertices, n_indices);
+}
+
+extern "C" int sdfk_march_finish(sdfk_march_job* job, int64_t vertex_base, sdfk_mesh** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!job || !out) return fail(SDFK_ERR_INVALID, "sdfk_march_finish: null argument");
+    if (int r = require_init()) return r;
+    return march_finish_impl(job, vertex_base, out);
+}
+
+extern "C" void sdfk_march_job_free(sdfk_march_job* job)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!job) return;
+    if (g.inited) (void)hipStreamSynchronize(g.stream);
+    job_release(job);
+    delete job;
+}
+
+extern "C" int sdfk_march(const sdfk_volume* v, float iso_value, int32_t step, sdfk_mesh** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!v || !out) return fail(SDFK_ERR_INVALID, "sdfk_march: null argument");
+    *out = nullptr;
+    if (int r = require_init()) return r;
+    if (v->z0 != 0 || v->nz != v->nz_global) return fail(SDFK_ERR_INVALID, "sdfk_march needs a whole volume; use sdfk_march_begin/finish for slabs");
+    sdfk_march_job* j = nullptr;
+    int r = march_begin_impl(v, iso_value, step, 0, std::max(v->nz_global - 1, 0), &j, nullptr, nullptr);
+    if (r) return r;
+    r = march_finish_impl(j, 0, out);
+    // the emit kernels read job buffers: release them only after the stream has drained
+    if (!r && j->P.nseg) r = (hipStreamSynchronize(g.stream) == hipSuccess) ? SDFK_OK : fail(SDFK_ERR_HIP, "stream sync failed");
+    job_release(j);
+    delete j;
+    return r;
+}
+
+extern "C" int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32_t ny, int32_t nz,
+                               const float min[3], const float max[3], float iso_value, int32_t step,
+                               sdfk_mesh** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!values || !out) return fail(SDFK_ERR_INVALID, "sdfk_march_host: null argument");
+    sdfk_volume* v = nullptr;
+    int r = sdfk_volume_create(nx, ny, nz, min, max, colors3 ? 1 : 0, &v);
+    if (r) return r;
+    r = sdfk_volume_upload(v, values, colors3);
+    if (!r) r = sdfk_march(v, iso_value, step, out);
+    sdfk_volume_free(v);
+    return r;
+}
+
+extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], const float max[3],
+                                 int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds,
+                                 float iso_value, int32_t step, sdfk_mesh** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !out) return fail(SDFK_ERR_INVALID, "sdfk_sample_march: null argument");
+    sdfk_volume* v = nullptr;
+    int r = sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
+    if (r) return r;
+    r = sdfk_sample(p, v, clip_to_bounds);
+    if (!r) r = sdfk_march(v, iso_value, step, out);
+    sdfk_volume_free(v);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// meshes
+// ---------------------------------------------------------------------------
+extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices)
+{
+    if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (n_vertices) *n_vertices = m->nv;
+    if (n_indices) *n_indices = m->ni;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case13_cells)
+{
+    if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (n_active_cells) *n_active_cells = m->n_active;
+    if (n_case13_cells) *n_case13_cells = m->n_case13;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_mesh_bounds(const sdfk_mesh* mc, float min[3], float max[3])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    sdfk_mesh* m = const_cast<sdfk_mesh*>(mc);
+    if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (int r = require_init()) return r;
+    if (!m->bounds_valid) {
+        HIPCHK(hipMemcpyAsync(g.h_bounds, m->bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        if (m->nv > 0) { memcpy(m->h_min, g.h_bounds, 12); memcpy(m->h_max, g.h_bounds + 3, 12); }
+        m->bounds_valid = true;
+    }
+    if (min) memcpy(min, m->h_min, 12);
+    if (max) memcpy(max, m->h_max, 12);
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* colors3, float* normals3, int32_t* triangles)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (int r = require_init()) return r;
+    const size_t vb = (size_t)m->nv * 3 * sizeof(float);
+    if (vertices3 && vb) HIPCHK(hipMemcpyAsync(vertices3, m->vertices, vb, hipMemcpyDeviceToHost, g.stream));
+    if (colors3 && vb) HIPCHK(hipMemcpyAsync(colors3, m->colors, vb, hipMemcpyDeviceToHost, g.stream));
+    if (normals3 && vb) HIPCHK(hipMemcpyAsync(normals3, m->normals, vb, hipMemcpyDeviceToHost, g.stream));
+    if (triangles && m->ni) HIPCHK(hipMemcpyAsync(triangles, m->triangles, (size_t)m->ni * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, void** normals3, void** triangles)
+{
+    if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (vertices3) *vertices3 = m->vertices;
+    if (colors3) *colors3 = m->colors;
+    if (normals3) *normals3 = m->normals;
+    if (triangles) *triangles = m->triangles;
+    return SDFK_OK;
+}
+
+extern "C" void sdfk_mesh_free(sdfk_mesh* m)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!m) return;
+    if (g.inited) (void)hipStreamSynchronize(g.stream);
+    dev_free(m->vertices);
+    dev_free(m->colors);
+    dev_free(m->normals);
+    dev_free(m->triangles);
+    dev_free(m->bounds);
+    delete m;
+}
+
+// ---------------------------------------------------------------------------
+// measurement hooks
+// ---------------------------------------------------------------------------
+extern "C" int sdfk_profile_enable(int32_t on)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (int r = require_init()) return r;
+    if (!on) prof_drain();
+    g.prof_on = on != 0;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_profile_reset(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    prof_drain();
+    std::fill(g.prof_ms.begin(), g.prof_ms.end(), 0.0);
+    std::fill(g.prof_n.begin(), g.prof_n.end(), 0);
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_profile_count(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    prof_drain();
+    return (int)g.prof_names.size();
+}
+
+extern "C" int sdfk_profile_get(int32_t i, const char** name, double* total_ms, int64_t* launches)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    prof_drain();
+    if (i < 0 || i >= (int)g.prof_names.size()) return fail(SDFK_ERR_INVALID, "profile index out of range");
+    if (name) *name = g.prof_names[i].c_str();
+    if (total_ms) *total_ms = g.prof_ms[i];
+    if (launches) *launches = g.prof_n[i];
+    return SDFK_OK;
+}

@@ -1,0 +1,276 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the
+same inputs.  Bars (BASELINE.json north_star): sampled values bit-exact; cell case indices
+and triangle topology bit-exact; vertex positions within 1e-5 abs (we additionally record
+whether they are bit-exact); normals/colours within 1e-5 (unpinned by the reference)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdfkit_amd import MarchingCubes, Sdfs, Voxels
+from sdfkit_amd import _native as N
+from tests import scenes as S
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 1e-5      # north_star: "within 1e-5 abs on interpolated vertex positions"
+ATTR_TOL = 1e-5
+
+
+def assert_mesh_equal(m, o, exact=True):
+    """m: sdfkit_amd.Mesh (GPU), o: OracleMesh."""
+    assert len(m.Vertices) == len(o.vertices), (len(m.Vertices), len(o.vertices))
+    assert len(m.Triangles) == len(o.triangles)
+    assert np.array_equal(m.Triangles, o.triangles), "triangle topology differs"
+    if len(o.vertices) == 0:
+        return
+    dv = np.abs(m.Vertices.astype(np.float64) - o.vertices.astype(np.float64))
+    assert np.nanmax(dv) <= POS_TOL, f"vertex positions differ by {np.nanmax(dv)}"
+    dc = np.abs(m.Colors.astype(np.float64) - o.colors.astype(np.float64))
+    assert np.nanmax(dc) <= ATTR_TOL, f"colours differ by {np.nanmax(dc)}"
+    nan_m, nan_o = np.isnan(m.Normals), np.isnan(o.normals)
+    assert np.array_equal(nan_m, nan_o)
+    dn = np.abs(np.nan_to_num(m.Normals).astype(np.float64) - np.nan_to_num(o.normals).astype(np.float64))
+    assert dn.max() <= ATTR_TOL, f"normals differ by {dn.max()}"
+    if exact:  # stronger than the bar: the double-precision cell math is reproduced exactly
+        assert np.array_equal(m.Vertices, o.vertices)
+        assert np.array_equal(m.Colors, o.colors)
+        assert np.array_equal(m.Normals, o.normals, equal_nan=True)
+    assert np.array_equal(m.Min, o.min) and np.array_equal(m.Max, o.max)
+
+
+# ---------------------------------------------------------------------------
+# sampling (Voxels.SampleSdf + ClipToBounds)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(S.CATALOGUE))
+@pytest.mark.parametrize("dims,clip", [((32, 32, 32), False), ((17, 23, 29), True), ((40, 12, 36), True)])
+def test_sample_bit_exact(gpu, name, dims, clip):
+    scene, sdf = S.CATALOGUE[name]()
+    mn, mx = [-2.8125, -2.5, -2.25], [2.8125, 2.75, 2.5]
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    if clip:
+        O.clip_to_bounds(ov, mn, mx)
+    v = sdf.ToVoxels(mn, mx, *dims, clipToBounds=clip)
+    assert np.array_equal(v.Values, ov), f"{name}: values differ (max {np.abs(v.Values - ov).max()})"
+    assert np.array_equal(v.Colors, oc), f"{name}: colours differ"
+    assert (v.NX, v.NY, v.NZ) == dims
+    assert np.array_equal(np.array([v.DX, v.DY, v.DZ]), O.cell_size(mn, mx, *dims))
+
+
+def test_sample_instance_then_clip(gpu):
+    scene, sdf = S.sphere_w(2.0)
+    v = Voxels.SampleSdf(sdf, [-1] * 3, [1] * 3, 10, 10, 10)
+    ov, _ = O.sample(scene, [-1] * 3, [1] * 3, 10, 10, 10)
+    assert np.array_equal(v.Values, ov)
+    v.ClipToBounds()
+    O.clip_to_bounds(ov, [-1] * 3, [1] * 3)
+    assert np.array_equal(v.Values, ov)
+
+
+def test_sqrt_div_correctly_rounded(gpu):
+    """the JIT kernel's sqrt and divide must be correctly rounded."""
+    from sdfkit_amd import Sdf, Vec4, MathF
+    sdf = Sdf(lambda p: Vec4(MathF.Sqrt(abs(p.x * p.y)), p.x / p.z, p.y / (p.z * p.z), MathF.Sqrt(p.z)), True)
+    mn, mx = [0.001, 0.37, 1e-3], [977.0, 1.63, 3.0]
+    v = sdf.ToVoxels(mn, mx, 64, 64, 256, clipToBounds=False)
+    x = np.array([O.sample_position(mn, mx, 64, 64, 256, i)[0] for i in range(64)], np.float32)
+    y = np.array([O.sample_position(mn, mx, 64, 64, 256, i * 64)[1] for i in range(64)], np.float32)
+    z = np.array([O.sample_position(mn, mx, 64, 64, 256, i * 64 * 64)[2] for i in range(256)], np.float32)
+    X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
+    assert np.array_equal(v.Values, np.sqrt(Z))
+    assert np.array_equal(v.Colors[..., 0], np.sqrt(np.abs(X * Y)))
+    assert np.array_equal(v.Colors[..., 1], X / Z)
+    assert np.array_equal(v.Colors[..., 2], Y / (Z * Z))
+
+
+# ---------------------------------------------------------------------------
+# marching cubes on the reference's own test scenes (golden counts + full oracle parity)
+# ---------------------------------------------------------------------------
+GOLDEN = [  # (name, scene, min, max, n, clip, expected vertex count), SURVEY.md 8c
+    ("ColoredSpheres", S.colored_spheres, [-3] * 3, [3] * 3, 32, False, 104),
+    ("Sphere5", lambda: S.sphere_w(1.0), [-1.5] * 3, [1.5] * 3, 5, False, 54),
+    ("Sphere10", lambda: S.sphere_w(2.0), [-2.5] * 3, [2.5] * 3, 10, False, 312),
+    ("UnclippedSphere10", lambda: S.sphere_w(2.0), [-1] * 3, [1] * 3, 10, False, 0),
+    ("ClippedSphere10", lambda: S.sphere_w(2.0), [-1] * 3, [1] * 3, 10, True, 384),
+    ("Box10", lambda: S.box_w(2.0), [-2.5] * 3, [2.5] * 3, 10, False, 384),
+    ("Cylinder50", lambda: S.cylinder(1, 3), [-1.5, -3.5, -1.5], [1.5, 3.5, 1.5], 50, False, 7456),
+    ("Sphere128", lambda: S.sphere_w(3.0), [-3.1] * 3, [3.1] * 3, 128, False, 72240),
+    ("CreateMeshSphere", lambda: S.sphere_w(0.5), [-1] * 3, [1] * 3, 32, True, 1248),
+    ("SolidSphere", lambda: S.solid_sphere(0.5), [-1] * 3, [1] * 3, 32, True, 1248),
+    ("C1_Sphere64", lambda: S.sphere_w(1.0), [-1.5] * 3, [1.5] * 3, 64, False, 8616),
+]
+
+
+@pytest.mark.parametrize("case", GOLDEN, ids=[g[0] for g in GOLDEN])
+def test_golden_scene(gpu, case):
+    name, mk, mn, mx, n, clip, expect = case
+    scene, sdf = mk()
+    ov, oc = O.sample(scene, mn, mx, n, n, n)
+    if clip:
+        O.clip_to_bounds(ov, mn, mx)
+    om = O.march(ov, oc, mn, mx)
+    assert len(om.vertices) == expect
+    # two-stage path: Voxels.SampleSdf -> (ClipToBounds) -> MarchingCubes.CreateMesh
+    vol = Voxels.SampleSdf(sdf, mn, mx, n, n, n)
+    if clip:
+        vol.ClipToBounds()
+    got = []
+    m = MarchingCubes.CreateMesh(vol, 0.0, 1, got.append)
+    assert len(m.Vertices) == expect
+    assert_mesh_equal(m, om)
+    assert m.ActiveCells == len(om.cells)
+    if n > 2:
+        assert all(0.0 <= f <= 1.0 for f in got) and min(got) < 1e-6 and 1 - max(got) < 1e-6
+    # fused path: SdfEx.ToMesh
+    m2 = sdf.ToMesh(mn, mx, n, n, n, clipToBounds=clip)
+    assert_mesh_equal(m2, om)
+
+
+@pytest.mark.parametrize("name", ["readme_repeat_xy", "union8", "repeat_xz_box", "sdf_with_color", "repeat_xy_plain"])
+def test_coloured_scenes(gpu, name):
+    scene, sdf = S.CATALOGUE[name]()
+    mn, mx, n = [-2.8125] * 3, [2.8125] * 3, (48, 40, 52)
+    ov, oc = O.sample(scene, mn, mx, *n)
+    O.clip_to_bounds(ov, mn, mx)
+    om = O.march(ov, oc, mn, mx)
+    assert len(om.vertices) > 0
+    m = sdf.ToMesh(mn, mx, *n)
+    assert_mesh_equal(m, om)
+
+
+# ---------------------------------------------------------------------------
+# host-array path and the ambiguous / centre-vertex tilings (random volumes)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(8))
+def test_random_volume_all_cases(gpu, seed):
+    """17^3 uniform(-1,1): hits all 14 cases, the face/interior tests, centre vertices
+    (oracle-only pin: no reference test reaches these)."""
+    rng = np.random.default_rng(seed)
+    shape = (17, 17, 17) if seed < 4 else (9 + seed, 21, 14)
+    v = rng.uniform(-1, 1, shape).astype(np.float32)
+    c = rng.uniform(0, 1, shape + (3,)).astype(np.float32)
+    mn, mx = [-1, -2, -3], [1.5, 2.5, 3.5]
+    om = O.march(v, c, mn, mx)
+    assert len(np.unique(om.cells[:, 1])) > 200  # most of the 254 active sign words occur
+    m = MarchingCubes.CreateMesh(Voxels(v, c, mn, mx))
+    assert_mesh_equal(m, om)
+    assert m.ImpossibleCase13Cells == om.impossible13
+
+
+@pytest.mark.parametrize("iso,step", [(0.25, 1), (-0.3, 1), (0.0, 2), (0.1, 3), (0.0, 5)])
+def test_iso_and_step(gpu, iso, step):
+    rng = np.random.default_rng(100 + step)
+    v = rng.uniform(-1, 1, (26, 19, 23)).astype(np.float32)
+    c = rng.uniform(0, 1, (26, 19, 23, 3)).astype(np.float32)
+    mn, mx = [-1] * 3, [1] * 3
+    om = O.march(v, c, mn, mx, iso, step)
+    m = MarchingCubes.CreateMesh(Voxels(v, c, mn, mx), iso, step)
+    assert_mesh_equal(m, om)
+    scene, sdf = S.sphere_w(1.0)
+    ov, oc = O.sample(scene, [-1.5] * 3, [1.5] * 3, 40, 40, 40)
+    om = O.march(ov, oc, [-1.5] * 3, [1.5] * 3, iso, step)
+    m = sdf.ToMesh([-1.5] * 3, [1.5] * 3, 40, 40, 40, clipToBounds=False, isoValue=iso, step=step)
+    assert_mesh_equal(m, om)
+
+
+def test_impossible_case13_cells(gpu):
+    """A +-1 checkerboard makes every cell a case-13 cell whose six face tests are all
+    degenerate (|AC-BD| < eps): exercises the 'Impossible case 13?' branch and the vertex
+    creation rule when earlier cells of the sweep emit nothing."""
+    i, j, k = np.meshgrid(np.arange(7), np.arange(6), np.arange(9), indexing="ij")
+    v = np.where((i + j + k) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    rng = np.random.default_rng(7)
+    # perturb some voxels so that dead and live case-13 cells are mixed
+    mask = rng.uniform(size=v.shape) < 0.35
+    v[mask] *= rng.uniform(0.2, 3.0, size=mask.sum()).astype(np.float32)
+    om = O.march(v, None, [-1] * 3, [1] * 3)
+    m = MarchingCubes.CreateMesh(Voxels(v, None, [-1] * 3, [1] * 3))
+    assert om.impossible13 > 0
+    assert m.ImpossibleCase13Cells == om.impossible13
+    assert_mesh_equal(m, om)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (2, 2, 2), (1, 5, 5), (5, 1, 5), (5, 5, 1), (2, 3, 65), (65, 2, 3), (3, 70, 2), (130, 3, 4)])
+def test_degenerate_and_ragged_shapes(gpu, shape):
+    rng = np.random.default_rng(sum(shape))
+    v = rng.uniform(-1, 1, shape).astype(np.float32)
+    om = O.march(v, None, [-1] * 3, [1] * 3)
+    m = MarchingCubes.CreateMesh(Voxels(v, None, [-1] * 3, [1] * 3))
+    assert_mesh_equal(m, om)
+
+
+def test_empty_and_full_volumes(gpu):
+    for fill in (1.0, -1.0, 0.0):
+        v = np.full((12, 12, 12), fill, np.float32)
+        m = MarchingCubes.CreateMesh(Voxels(v, None, [-1] * 3, [1] * 3))
+        assert len(m.Vertices) == 0 and len(m.Triangles) == 0
+
+
+def test_nan_and_inf_voxels(gpu):
+    rng = np.random.default_rng(3)
+    v = rng.uniform(-1, 1, (12, 13, 16)).astype(np.float32)
+    v[3, 4, 5] = np.inf
+    v[7, 7, 7] = -np.inf
+    om = O.march(v, None, [-1] * 3, [1] * 3)
+    m = MarchingCubes.CreateMesh(Voxels(v, None, [-1] * 3, [1] * 3))
+    assert_mesh_equal(m, om, exact=False)
+    assert np.array_equal(m.Triangles, om.triangles)
+
+
+# ---------------------------------------------------------------------------
+# full-size properties (BASELINE configs C2 / C3): size-independent invariants
+# ---------------------------------------------------------------------------
+def _sign_change_edges(v, iso=0.0):
+    s = v > iso
+    return int((s[1:] != s[:-1]).sum() + (s[:, 1:] != s[:, :-1]).sum() + (s[:, :, 1:] != s[:, :, :-1]).sum())
+
+
+def test_c2_sphere_256(gpu):
+    scene, sdf = S.sphere_w(1.0)
+    vol = Voxels.SampleSdf(sdf, [-1.5] * 3, [1.5] * 3, 256, 256, 256)
+    m = vol.ToMesh()
+    assert len(m.Vertices) == 137232  # sign-changing edges at 256^3
+    assert len(m.Vertices) == _sign_change_edges(vol.Values)
+    t = m.Triangles.reshape(-1, 3)
+    # closed 2-manifold: every undirected edge is shared by exactly two triangles, Euler = 2
+    e = np.sort(np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    assert np.all(cnt == 2)
+    assert len(m.Vertices) - len(cnt) + len(t) == 2
+    # vertices numbered in order of first reference (serial sweep property)
+    first = np.full(len(m.Vertices), len(m.Triangles), np.int64)
+    np.minimum.at(first, m.Triangles, np.arange(len(m.Triangles)))
+    assert np.all(np.diff(first) > 0)
+    # all vertices within half a cell of the unit sphere, normals point outwards
+    r = np.linalg.norm(m.Vertices.astype(np.float64), axis=1)
+    assert np.abs(r - 1.0).max() < 3.0 / 256
+    assert np.all(np.einsum("ij,ij->i", m.Normals, m.Vertices) > 0.9 * r)
+    assert np.abs(np.linalg.norm(m.Normals.astype(np.float64), axis=1) - 1).max() < 1e-6
+    assert np.abs(m.Center).max() <= 1e-6
+    # oracle parity at this size too (about 1 s of CPU)
+    ov, oc = O.sample(scene, [-1.5] * 3, [1.5] * 3, 256, 256, 256)
+    assert np.array_equal(vol.Values, ov)
+    om = O.march(ov, oc, [-1.5] * 3, [1.5] * 3)
+    assert_mesh_equal(m, om)
+
+
+def test_c3_repeat_xy_512_properties(gpu):
+    scene, sdf = S.readme_repeat_xy()
+    mn, mx = [-2.8125] * 3, [2.8125] * 3
+    vol = sdf.ToVoxels(mn, mx, 512, 512, 512)
+    m = vol.ToMesh()
+    vals = vol.Values
+    assert len(m.Vertices) == _sign_change_edges(vals)
+    t = m.Triangles
+    assert t.min() == 0 and t.max() == len(m.Vertices) - 1
+    first = np.full(len(m.Vertices), len(t), np.int64)
+    np.minimum.at(first, t, np.arange(len(t)))
+    assert np.all(np.diff(first) > 0)
+    # spot-check the volume against the oracle on a thin x-slab (full 512^3 on CPU is slow)
+    ov, oc = O.sample(scene, mn, mx, 512, 512, 512, threads=0)
+    O.clip_to_bounds(ov, mn, mx)
+    assert np.array_equal(vals, ov)
+    assert np.array_equal(vol.Colors, oc)
+    # colour blend stays inside the palette range of the scene
+    assert m.Colors.min() >= 0.9 - 3.0 / 6 - 1e-6 and m.Colors.max() <= 0.9 + 1e-6
