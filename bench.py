@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the sample -> mesh hot path on MI355X.
+
+Metric (BASELINE.json): Mvoxels/s (+ Mtris/s) of Voxels.SampleSdf -> MarchingCubes.CreateMesh
+on a synthetic 512^3 sphere SDF (`Sdfs.Sphere(1)`, bounds -1.5..1.5, no clip, iso 0) -- config
+"C3s" of BASELINE.md.  A step = one pass of the path over that grid: the JIT sampling kernel
+writes the volume to HBM, the marching-cubes pipeline reads it and leaves the indexed mesh
+(vertices, colours, normals, triangles) in HBM; inputs and outputs stay device-resident.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+N > 1: the SAME 512^3 grid is sharded by Z slab over the ranks (strong scaling), with an RCCL
+all-gather of the slab meshes (sdfkit_amd/dist.py).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+
+
+def scene_for(name):
+    from sdfkit_amd import SdfExprs, Sdfs, Vec3
+    if name == "sphere":
+        return Sdfs.Sphere(1.0), [-1.5] * 3, [1.5] * 3, False
+    if name == "repeatxy":  # BASELINE C3 (README scene), clipToBounds = true
+        sdf = SdfExprs.Sphere(0.5).RepeatXY(1.125, 1.125,
+                                            lambda i, p, d: 0.9 * Vec3.of(p.x.b, 1.0) - Vec3.Abs(i) / 6.0).ToSdf()
+        return sdf, [-2.8125] * 3, [2.8125] * 3, True
+    raise SystemExit(f"unknown scene {name}")
+
+
+def cpu_baseline(scene, n):
+    """Reference-algorithm CPU baseline: the C restatement of the reference (oracle/), sampler
+    multi-threaded over 2048-point batches on all host cores, marching cubes single-threaded
+    exactly like the reference.  Bounded sample of the same workload (smaller grid)."""
+    from oracle import oracle as O
+    s = O.Scene()
+    if scene == "sphere":
+        s.sphere_w(1.0)
+        mn, mx, clip = [-1.5] * 3, [1.5] * 3, False
+    else:
+        s.f_repeat_xy_idx(s.f_sphere(0.5), 1.125, 1.125, O.CF_README)
+        mn, mx, clip = [-2.8125] * 3, [2.8125] * 3, True
+    cores = O.hardware_threads()
+    best = None
+    tris = 0
+    for it in range(2):  # 1 warm-up + 1 timed (Perf/Program.cs:43-62 convention, bounded)
+        t0 = time.perf_counter()
+        v, c = O.sample(s, mn, mx, n, n, n, threads=cores)
+        if clip:
+            O.clip_to_bounds(v, mn, mx)
+        t1 = time.perf_counter()
+        m = O.march(v, c, mn, mx)
+        t2 = time.perf_counter()
+        best = (t2 - t0, t1 - t0, t2 - t1)
+        tris = len(m.triangles) // 3
+    return {"value": round(n ** 3 / best[0] / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": f"{n}^3 grid of the same scene, 1 warm-up + 1 timed pass "
+                      f"(sample {best[1]:.2f} s on {cores} threads, marching cubes {best[2]:.2f} s on 1 thread)",
+            "mtris_per_s": round(tris / best[0] / 1e6, 3)}
+
+
+def load_pmc_traffic(kernel, n):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), if present."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        d = json.load(open(p))
+        return d.get(f"{kernel}@{n}")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=512, help="grid edge")
+    ap.add_argument("--scene", default="sphere", choices=["sphere", "repeatxy"])
+    ap.add_argument("--cpu-n", type=int, default=256, help="grid edge of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sdfkit_amd import _native as N
+    from sdfkit_amd import dist as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    N.init(local_rank)
+    L = N.lib()
+    stream = torch.cuda.current_stream()
+    N.check(L.sdfk_set_stream(C.c_void_p(stream.cuda_stream)))
+
+    n = args.n
+    sdf, mn, mx, clip = scene_for(args.scene)
+    prog = sdf.program()
+    nv = ni = 0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        def step():
+            m = C.c_void_p()
+            N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+            a, b = C.c_int64(), C.c_int64()
+            N.check(L.sdfk_mesh_counts(m, C.byref(a), C.byref(b)))
+            L.sdfk_mesh_free(m)
+            return a.value, b.value
+    else:
+        worker = D.GpuSlabWorker(sdf, mn, mx, n, n, n, rank, world, clip, 0.0)
+        bufs = {}
+
+        def make_buffer(nbytes):
+            if nbytes not in bufs:
+                bufs[nbytes] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            return bufs[nbytes]
+
+        def step():
+            g, nvs, nis = D.sharded_step(worker, None, dev, make_buffer)
+            return sum(nvs), sum(nis)
+
+    for _ in range(args.warmup):
+        nv, ni = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nv, ni = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / args.steps * 1e3
+
+    # per-kernel durations: HIP events on the launch stream, same K steps again (events
+    # around every launch perturb the un-instrumented timing above, so they get their own pass)
+    N.check(L.sdfk_profile_reset())
+    N.check(L.sdfk_profile_enable(1))
+    for _ in range(args.steps):
+        step()
+    barrier()
+    N.check(L.sdfk_profile_enable(0))
+    prof = N.profile_snapshot()
+    kern = {k: {"avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "launches": v[1]} for k, v in prof.items() if v[1]}
+
+    if rank == 0:
+        nvox_rank = n * n * (D.slab_planes(*D.slab_layers(n - 1, world, rank), n)[1] if world > 1 else n)
+        colors = bool(sdf.writes_color)
+        # algorithmic bytes per launch: sample stores 4 B/voxel (+12 B colour),
+        # signbits loads 4 B/voxel; candidates for "dominant kernel"
+        cands = {}
+        for k in ("sdfk_sample_vec4", "sdfk_sample_scalar"):
+            if k in kern:
+                cands[k] = nvox_rank * (16 if colors else 4)
+        if "k_signbits" in kern:
+            cands["k_signbits"] = nvox_rank * 4
+        dom = max(cands, key=lambda k: kern[k]["avg_us"]) if cands else None
+        roof = None
+        if dom:
+            ach = cands[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(dom, n),
+                    "algorithmic_bytes_per_launch": cands[dom], "avg_launch_us": kern[dom]["avg_us"],
+                    "method": "hipEvent pairs around each launch on the launch stream, separate K-step pass"}
+        total_alg = n ** 3 * (32 if colors else 8) + 36 * nv + 4 * ni
+        out = {
+            "metric": "Mvoxels/s, 512^3 sphere SDF sample->mesh" if (n == 512 and args.scene == "sphere")
+                      else f"Mvoxels/s, {n}^3 {args.scene} SDF sample->mesh",
+            "value": round(n ** 3 / (dt / args.steps) / 1e6, 1),
+            "unit": "Mvoxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 (sampling) / f64 (cell math)",
+            "data": "synthetic",
+            "config": {"workload": f"{'Sdfs.Sphere(1), bounds -1.5..1.5, no clip' if args.scene == 'sphere' else 'SdfExprs.Sphere(0.5).RepeatXY(1.125,1.125,colour), bounds -2.8125..2.8125, clipToBounds'}"
+                                   f", {n}^3 voxels, iso 0, step 1; Voxels.SampleSdf -> MarchingCubes.CreateMesh, device-resident",
+                       "grid": [n, n, n], "vertices": nv, "triangles": ni // 3,
+                       "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, RCCL all-gather of slab meshes"},
+            "mtris_per_s": round(ni / 3 / (dt / args.steps) / 1e6, 2),
+            "pipeline_algorithmic_gbs": round(total_alg / (dt / args.steps) / 1e9, 1),
+            "pipeline_frac_of_hbm_peak": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels_us": kern,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        worker.close()
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

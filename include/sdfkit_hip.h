@@ -142,6 +142,10 @@ int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* colors3, float* 
                    int32_t* triangles);                                      /* any may be NULL */
 int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, void** normals3,
                           void** triangles);
+/* device-to-device copy into caller-owned device buffers (e.g. torch tensors used as RCCL
+ * all-gather inputs), asynchronous on the library stream; any pointer may be NULL */
+int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* colors3, void* normals3,
+                          void* triangles);
 /* diagnostics: number of active cells, and of case-13 cells with no tiling
  * ("Impossible case 13?", MarchingCubes.cs:365) seen while meshing */
 int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case13_cells);

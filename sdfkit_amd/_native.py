@@ -58,6 +58,7 @@ SIGNATURES = {
     "sdfk_mesh_bounds": (C.c_int, [_vp, _fp, _fp]),
     "sdfk_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sdfk_mesh_device_ptrs": (C.c_int, [_vp, _vpp, _vpp, _vpp, _vpp]),
+    "sdfk_mesh_copy_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sdfk_mesh_stats": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_mesh_free": (None, [_vp]),
     "sdfk_profile_enable": (C.c_int, [_i32]),

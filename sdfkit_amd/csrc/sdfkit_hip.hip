@@ -877,6 +877,19 @@ extern "C" int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* color
     return SDFK_OK;
 }
 
+extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* colors3, void* normals3, void* triangles)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (int r = require_init()) return r;
+    const size_t vb = (size_t)m->nv * 3 * sizeof(float);
+    if (vertices3 && vb) HIPCHK(hipMemcpyAsync(vertices3, m->vertices, vb, hipMemcpyDeviceToDevice, g.stream));
+    if (colors3 && vb) HIPCHK(hipMemcpyAsync(colors3, m->colors, vb, hipMemcpyDeviceToDevice, g.stream));
+    if (normals3 && vb) HIPCHK(hipMemcpyAsync(normals3, m->normals, vb, hipMemcpyDeviceToDevice, g.stream));
+    if (triangles && m->ni) HIPCHK(hipMemcpyAsync(triangles, m->triangles, (size_t)m->ni * sizeof(int32_t), hipMemcpyDeviceToDevice, g.stream));
+    return SDFK_OK;
+}
+
 extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, void** normals3, void** triangles)
 {
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");

@@ -1,0 +1,204 @@
+"""Z-slab sharding of the sample -> mesh path over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  The
+reference has no distributed path at all; this is new design:
+
+* Rank r owns the contiguous CELL layers [lb, le) of the serial z sweep
+  (MarchingCubes.cs:53-82), so the global vertex/triangle order is the concatenation of
+  the slabs in rank order.
+* Sampling is a pure function of the voxel index (Voxels.cs:99-108), so no halo is
+  EXCHANGED: each rank samples its own planes plus context planes [lb-2, le+2).
+  The two planes below let it recount which vertices the layer lb-1 creates (they are
+  referenced by layer lb) including the "earlier cell emits nothing" corner case; the plane
+  above feeds the normals of vertices on its top face.
+* Exchange #1 (tiny): all-gather of (vertex count, index count); exclusive prefix = global
+  vertex base of each slab.  Triangle indices are emitted already rebased.
+* Exchange #2: one padded all-gather of the packed slab meshes [bounds | V | C | N | T].
+
+The compute backend is a "slab worker" with begin()/finish(); GpuSlabWorker is the product
+one (C ABI, HIP).  The exchange code only touches torch tensors, so it is exercised on CPU
+with the gloo backend in tests/ (with a worker built from fixtures).
+"""
+import ctypes as C
+
+import numpy as np
+
+HEADER_BYTES = 32  # 6 float32 bounds + 2 pad
+
+
+def slab_layers(n_layers, world, rank):
+    """Balanced contiguous split of `n_layers` cell layers: returns [lb, le)."""
+    base, rem = divmod(max(n_layers, 0), world)
+    lb = rank * base + min(rank, rem)
+    return lb, lb + base + (1 if rank < rem else 0)
+
+
+def slab_planes(lb, le, nz):
+    """Voxel planes [z0, z0+n) a slab must hold for layers [lb, le) (include/sdfkit_hip.h)."""
+    z0 = max(lb - 2, 0)
+    z1 = min(le + 2, nz)
+    return z0, z1 - z0
+
+
+def exclusive_prefix(counts):
+    out, acc = [], 0
+    for c in counts:
+        out.append(acc)
+        acc += int(c)
+    return out, acc
+
+
+class GpuSlabWorker:
+    """Product worker: samples and meshes one Z slab on this process's GPU."""
+
+    def __init__(self, sdf, mn, mx, nx, ny, nz, rank, world, clip_to_bounds=True, iso=0.0):
+        from . import _native as N
+        self.N = N
+        N.init()
+        self.sdf, self.mn, self.mx = sdf, mn, mx
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.clip, self.iso = clip_to_bounds, iso
+        self.lb, self.le = slab_layers(nz - 1, world, rank)
+        self.z0, self.nzl = slab_planes(self.lb, self.le, nz)
+        self.vol = C.c_void_p()
+        N.check(N.lib().sdfk_volume_create_slab(nx, ny, nz, N.f3(mn), N.f3(mx), self.z0, max(self.nzl, 1),
+                                                1 if sdf.writes_color else 0, C.byref(self.vol)))
+        self.prog = sdf.program()
+        self.job = None
+        self.mesh = None
+
+    def begin(self):
+        N = self.N
+        self.release()
+        N.check(N.lib().sdfk_sample(self.prog, self.vol, 1 if self.clip else 0))
+        job, nv, ni = C.c_void_p(), C.c_int64(), C.c_int64()
+        N.check(N.lib().sdfk_march_begin(self.vol, C.c_float(self.iso), self.lb, self.le, C.byref(job),
+                                         C.byref(nv), C.byref(ni)))
+        self.job = job
+        return nv.value, ni.value
+
+    def finish(self, vertex_base):
+        N = self.N
+        m = C.c_void_p()
+        N.check(N.lib().sdfk_march_finish(self.job, vertex_base, C.byref(m)))
+        self.mesh = m
+        return m
+
+    def pack_into(self, buf, nv, ni):
+        """Pack [bounds | V | C | N | T] of the finished slab mesh into the uint8 torch
+        tensor `buf` (on this GPU), device to device."""
+        N = self.N
+        mn, mx = (C.c_float * 3)(), (C.c_float * 3)()
+        N.check(N.lib().sdfk_mesh_bounds(self.mesh, mn, mx))
+        import torch
+        hdr = torch.tensor(list(mn) + list(mx) + [0.0, 0.0], dtype=torch.float32)
+        buf[:HEADER_BYTES].copy_(hdr.view(torch.uint8).to(buf.device, non_blocking=True))
+        p = buf.data_ptr() + HEADER_BYTES
+        vb = nv * 12
+        N.check(N.lib().sdfk_mesh_copy_device(self.mesh, p, p + vb, p + 2 * vb, p + 3 * vb))
+
+    def release(self):
+        N = self.N
+        if self.mesh is not None:
+            N.lib().sdfk_mesh_free(self.mesh)
+            self.mesh = None
+        if self.job is not None:
+            N.lib().sdfk_march_job_free(self.job)
+            self.job = None
+
+    def close(self):
+        self.release()
+        if self.vol is not None:
+            self.N.lib().sdfk_volume_free(self.vol)
+            self.vol = None
+
+
+def payload_bytes(nv, ni):
+    return HEADER_BYTES + 36 * int(nv) + 4 * int(ni)
+
+
+def exchange_counts(nv, ni, group=None, device="cpu"):
+    """All-gather of (nv, ni).  Returns (list of nv, list of ni)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([nv, ni], dtype=torch.int64, device=device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    host = torch.stack(out).cpu().numpy()
+    return [int(x) for x in host[:, 0]], [int(x) for x in host[:, 1]]
+
+
+def gather_payloads(buf, group=None):
+    """One padded all-gather of the packed slab meshes.  `buf`: uint8 tensor, same length
+    on every rank.  Returns a [world, len] uint8 tensor."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out.view(-1), buf, group=group)
+    else:
+        parts = [out[r] for r in range(world)]
+        dist.all_gather(parts, buf, group=group)
+    return out
+
+
+def unpack(gathered, nvs, nis):
+    """Concatenate slab payloads in rank order -> (V, C, N, T, min, max) numpy arrays."""
+    g = gathered.cpu().numpy()
+    V, Cc, Nn, T, mins, maxs = [], [], [], [], [], []
+    for r, (nv, ni) in enumerate(zip(nvs, nis)):
+        row = g[r]
+        hdr = row[:HEADER_BYTES].view(np.float32)
+        o = HEADER_BYTES
+        vb = nv * 12
+        V.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
+        Cc.append(row[o + vb:o + 2 * vb].view(np.float32).reshape(-1, 3))
+        Nn.append(row[o + 2 * vb:o + 3 * vb].view(np.float32).reshape(-1, 3))
+        T.append(row[o + 3 * vb:o + 3 * vb + 4 * ni].view(np.int32))
+        if nv > 0:
+            mins.append(hdr[0:3])
+            maxs.append(hdr[3:6])
+    mn = np.min(np.stack(mins), axis=0) if mins else np.zeros(3, np.float32)
+    mx = np.max(np.stack(maxs), axis=0) if maxs else np.zeros(3, np.float32)
+    return (np.concatenate(V), np.concatenate(Cc), np.concatenate(Nn), np.concatenate(T),
+            mn.astype(np.float32), mx.astype(np.float32))
+
+
+def sharded_step(worker, group=None, device="cpu", make_buffer=None):
+    """One sample -> mesh pass of this rank's slab plus the two exchanges.  Returns
+    (gathered uint8 [world, L], nvs, nis).  `make_buffer(nbytes)` returns the uint8 send
+    buffer (on `device`); the worker packs its slab mesh into it."""
+    import torch
+    nv, ni = worker.begin()
+    nvs, nis = exchange_counts(nv, ni, group, device)
+    bases, _ = exclusive_prefix(nvs)
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    worker.finish(bases[rank])
+    nbytes = max(payload_bytes(a, b) for a, b in zip(nvs, nis))
+    nbytes = (nbytes + 255) // 256 * 256
+    buf = make_buffer(nbytes) if make_buffer else torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    worker.pack_into(buf, nv, ni)
+    return gather_payloads(buf, group), nvs, nis
+
+
+def sharded_to_mesh(sdf, mn, mx, nx, ny, nz, clip_to_bounds=True, iso=0.0, group=None):
+    """SdfEx.ToMesh over all ranks of `group` (one GPU each); every rank returns the full Mesh."""
+    import torch
+    import torch.distributed as dist
+    from . import _native as N
+    from .api import Mesh
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    N.init(torch.cuda.current_device())
+    N.check(N.lib().sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    w = GpuSlabWorker(sdf, mn, mx, nx, ny, nz, rank, world, clip_to_bounds, iso)
+    try:
+        gathered, nvs, nis = sharded_step(w, group, dev)
+        torch.cuda.current_stream().synchronize()
+        V, Cc, Nn, T, bmin, bmax = unpack(gathered, nvs, nis)
+    finally:
+        w.close()
+    return Mesh(V, Cc, Nn, T, bmin, bmax)

@@ -174,20 +174,42 @@ def test_iso_and_step(gpu, iso, step):
     assert_mesh_equal(m, om)
 
 
+# Corner values (v0..v7) of a case-13 cell whose face tests come out (1,0,1,0,0,0): face 1
+# is degenerate (|v0*v5 - v4*v1| = 3e-8 < 1e-7 -> true), face 3 is true, faces 2,4,5,6 false;
+# Luts.subconfig13[5] = -1, i.e. "Marching Cubes: Impossible case 13?" (MarchingCubes.cs:365).
+DEAD13 = np.array([1e-4, -2e-4, 1.5, -1.0, -2e-4, 1e-4, -1.0, 1.5], np.float32)
+CORNER = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+
+
+def plant_dead_cells(v, cells, flip=()):
+    for n, (x, y, z) in enumerate(cells):
+        sgn = -1.0 if n in flip else 1.0   # flipped: sign word 0x5A instead of 0xA5
+        for k, (dx, dy, dz) in enumerate(CORNER):
+            v[x + dx, y + dy, z + dz] = sgn * DEAD13[k]
+    return v
+
+
 def test_impossible_case13_cells(gpu):
-    """A +-1 checkerboard makes every cell a case-13 cell whose six face tests are all
-    degenerate (|AC-BD| < eps): exercises the 'Impossible case 13?' branch and the vertex
-    creation rule when earlier cells of the sweep emit nothing."""
-    i, j, k = np.meshgrid(np.arange(7), np.arange(6), np.arange(9), indexing="ij")
-    v = np.where((i + j + k) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    """Cells that resolve to no tiling emit nothing, so vertices on their edges are created
+    by LATER cells of the sweep (or never): exercises the vertex-creation rule when an
+    earlier cell is dead, at the volume corner, in the interior and on the far faces."""
+    assert O.resolve_tiling(DEAD13.astype(np.float64))[1:] == (-1, 0)
     rng = np.random.default_rng(7)
-    # perturb some voxels so that dead and live case-13 cells are mixed
-    mask = rng.uniform(size=v.shape) < 0.35
-    v[mask] *= rng.uniform(0.2, 3.0, size=mask.sum()).astype(np.float32)
-    om = O.march(v, None, [-1] * 3, [1] * 3)
-    m = MarchingCubes.CreateMesh(Voxels(v, None, [-1] * 3, [1] * 3))
-    assert om.impossible13 > 0
+    v = rng.uniform(-1, 1, (14, 12, 13)).astype(np.float32)
+    c = rng.uniform(0, 1, v.shape + (3,)).astype(np.float32)
+    cells = [(0, 0, 0), (5, 5, 5), (12, 10, 11), (0, 6, 3), (8, 0, 9), (3, 3, 0), (9, 7, 2), (2, 9, 8)]
+    plant_dead_cells(v, cells, flip=(1, 4))
+    om = O.march(v, c, [-1] * 3, [1] * 3)
+    assert om.impossible13 >= 6
+    m = MarchingCubes.CreateMesh(Voxels(v, c, [-1] * 3, [1] * 3))
     assert m.ImpossibleCase13Cells == om.impossible13
+    assert_mesh_equal(m, om)
+    # a volume made only of dead cells and empty space
+    w = np.full((6, 6, 6), -1.0, np.float32)
+    plant_dead_cells(w, [(2, 2, 2)])
+    om = O.march(w, None, [-1] * 3, [1] * 3)
+    m = MarchingCubes.CreateMesh(Voxels(w, None, [-1] * 3, [1] * 3))
+    assert om.impossible13 == 1
     assert_mesh_equal(m, om)
 
 
@@ -274,3 +296,67 @@ def test_c3_repeat_xy_512_properties(gpu):
     assert np.array_equal(vol.Colors, oc)
     # colour blend stays inside the palette range of the scene
     assert m.Colors.min() >= 0.9 - 3.0 / 6 - 1e-6 and m.Colors.max() <= 0.9 + 1e-6
+
+
+# ---------------------------------------------------------------------------
+# Z-slab sharding: slabs meshed one after another on this GPU must concatenate to exactly
+# the single-volume mesh (what the 8-GPU path relies on; sdfkit_amd/dist.py)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+@pytest.mark.parametrize("scene_name,dims", [("readme_repeat_xy", (40, 36, 44)), ("union8", (33, 30, 26))])
+def test_slab_concatenation_equals_whole(gpu, world, scene_name, dims):
+    from sdfkit_amd import dist as D
+    scene, sdf = S.CATALOGUE[scene_name]()
+    mn, mx = [-2.8125] * 3, [2.8125] * 3
+    whole = sdf.ToMesh(mn, mx, *dims)
+    workers = [D.GpuSlabWorker(sdf, mn, mx, *dims, r, world, True, 0.0) for r in range(world)]
+    try:
+        counts = [w.begin() for w in workers]
+        bases, total = D.exclusive_prefix([c[0] for c in counts])
+        assert total == len(whole.Vertices)
+        V, Cc, Nn, T, mins, maxs = [], [], [], [], [], []
+        for w, (nv, ni), base in zip(workers, counts, bases):
+            h = w.finish(base)
+            v = np.empty((nv, 3), np.float32); c = np.empty((nv, 3), np.float32)
+            n = np.empty((nv, 3), np.float32); t = np.empty((ni,), np.int32)
+            N.check(N.lib().sdfk_mesh_copy(h, v.ctypes.data, c.ctypes.data, n.ctypes.data, t.ctypes.data))
+            V.append(v); Cc.append(c); Nn.append(n); T.append(t)
+    finally:
+        for w in workers:
+            w.close()
+    assert np.array_equal(np.concatenate(T), whole.Triangles)
+    assert np.array_equal(np.concatenate(V), whole.Vertices)
+    assert np.array_equal(np.concatenate(Cc), whole.Colors)
+    assert np.array_equal(np.concatenate(Nn), whole.Normals, equal_nan=True)
+
+
+def test_slab_with_dead_cells_at_the_seam(gpu):
+    """'Impossible 13' cells right below / at a slab seam: the lower slab's last layer and the
+    upper slab's recount of it must agree on who creates the seam vertices."""
+    rng = np.random.default_rng(11)
+    v = rng.uniform(-1, 1, (10, 9, 16)).astype(np.float32)
+    plant_dead_cells(v, [(2, 2, 6), (5, 4, 7), (7, 1, 5), (1, 6, 8), (4, 4, 3)])
+    mn, mx = [-1] * 3, [1] * 3
+    om = O.march(v, None, mn, mx)
+    assert om.impossible13 >= 4
+    L = N.lib()
+    world = 2
+    from sdfkit_amd import dist as D
+    got_t, got_v, base = [], [], 0
+    for r in range(world):
+        lb, le = D.slab_layers(15, world, r)   # seam at layer 8 (rank 0: [0,8), rank 1: [8,15))
+        z0, nzl = D.slab_planes(lb, le, 16)
+        vol = C.c_void_p()
+        N.check(L.sdfk_volume_create_slab(10, 9, 16, N.f3(mn), N.f3(mx), z0, nzl, 0, C.byref(vol)))
+        sub = np.ascontiguousarray(v[:, :, z0:z0 + nzl])
+        N.check(L.sdfk_volume_upload(vol, sub.ctypes.data, None))
+        job, nv, ni = C.c_void_p(), C.c_int64(), C.c_int64()
+        N.check(L.sdfk_march_begin(vol, C.c_float(0.0), lb, le, C.byref(job), C.byref(nv), C.byref(ni)))
+        m = C.c_void_p()
+        N.check(L.sdfk_march_finish(job, base, C.byref(m)))
+        vv = np.empty((nv.value, 3), np.float32); tt = np.empty((ni.value,), np.int32)
+        N.check(L.sdfk_mesh_copy(m, vv.ctypes.data, None, None, tt.ctypes.data))
+        got_v.append(vv); got_t.append(tt); base += nv.value
+        L.sdfk_mesh_free(m); L.sdfk_march_job_free(job); L.sdfk_volume_free(vol)
+    assert np.array_equal(np.concatenate(got_t), om.triangles)
+    assert np.array_equal(np.concatenate(got_v), om.vertices)
