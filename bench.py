@@ -178,9 +178,9 @@ def main():
         # algorithmic bytes per launch: sample stores 4 B/voxel (+12 B colour),
         # signbits loads 4 B/voxel; candidates for "dominant kernel"
         cands = {}
-        for k in ("sdfk_sample_vec4", "sdfk_sample_scalar"):
-            if k in kern:
-                cands[k] = nvox_rank * (16 if colors else 4)
+        for k in ("sdfk_sample_bits", "sdfk_sample_scalar"):
+            if k in kern:  # stores: 4 B/voxel distance (+12 B colour) + 1/8 B/voxel sign bits
+                cands[k] = nvox_rank * (16 if colors else 4) + nvox_rank // 8
         if "k_signbits" in kern:
             cands["k_signbits"] = nvox_rank * 4
         dom = max(cands, key=lambda k: kern[k]["avg_us"]) if cands else None

@@ -30,8 +30,24 @@ struct Tiling {
     int index;    // 8-bit corner sign word (Cell.cs:220-229)
 };
 
+// Corner accessors.  The Lewiner tables index the eight corners with run-time indices; a
+// per-thread register array indexed that way is demoted to scratch memory by the compiler,
+// so kernels keep each thread's corners in its own LDS column instead (conflict-free:
+// consecutive lanes -> consecutive banks) and hand the decision functions an accessor.
+struct CornersLds {          // float voxels in LDS, [corner][thread] with `stride` threads
+    const float* p;
+    int stride;
+    double iso;
+    __device__ __forceinline__ double operator[](int k) const { return (double)p[k * stride] - iso; }
+};
+struct CornersPtr {          // plain array of iso-subtracted doubles
+    const double* p;
+    __device__ __forceinline__ double operator[](int k) const { return p[k]; }
+};
+
 // MarchingCubes.cs:376-407
-__device__ __forceinline__ bool mc_test_face(const double* v, int face)
+template <class V>
+__device__ __forceinline__ bool mc_test_face(const V& v, int face)
 {
     const int af = face < 0 ? -face : face;
     double A = 0, B = 0, C = 0, D = 0;
@@ -58,7 +74,8 @@ __constant__ int8_t c_interior_edges[12][8] = {
     {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
 
 // MarchingCubes.cs:412-546
-__device__ __noinline__ bool mc_test_internal(const double* v, int cas, int config, int subconfig, int s)
+template <class V>
+__device__ __forceinline__ bool mc_test_internal(const V& v, int cas, int config, int subconfig, int s)
 {
     double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
     if (cas == 4 || cas == 10) {
@@ -100,7 +117,8 @@ __device__ __noinline__ bool mc_test_internal(const double* v, int cas, int conf
 }
 
 // The 33-case dispatcher of MarchingCubes.cs:94-371 as a pure function of the corners.
-__device__ __noinline__ Tiling mc_resolve(const double* v)
+template <class V>
+__device__ __forceinline__ Tiling mc_resolve(const V& v)
 {
     Tiling r;
     int index = 0;
@@ -222,7 +240,8 @@ __constant__ int8_t c_bit_to_corner[8] = {0, 1, 3, 2, 4, 5, 7, 6};
 // vg[k][j] = v[c_grad_a[k][j]] - v[c_grad_b[k][j]].
 __constant__ int8_t c_grad_a[8][3] = {{0, 0, 0}, {0, 1, 1}, {3, 1, 2}, {3, 0, 3}, {4, 4, 0}, {4, 5, 1}, {7, 5, 2}, {7, 4, 3}};
 __constant__ int8_t c_grad_b[8][3] = {{1, 3, 4}, {1, 2, 5}, {2, 2, 6}, {2, 3, 7}, {5, 7, 4}, {5, 6, 5}, {6, 6, 6}, {6, 7, 7}};
-__device__ __forceinline__ double mc_corner_gradient(const double* v, int k, int j)
+template <class V>
+__device__ __forceinline__ double mc_corner_gradient(const V& v, int k, int j)
 {
     return v[c_grad_a[k][j]] - v[c_grad_b[k][j]];
 }

@@ -101,42 +101,59 @@ __global__ __launch_bounds__(256) void k_signbits_generic(const float* __restric
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t shr1_in(uint64_t w, uint64_t next) { return (w >> 1) | (next << 63); }
 
+constexpr int SEG_PER_THREAD = 8;                    // segments handled by one lane
+constexpr int SEG_PER_BLOCK = 256 * SEG_PER_THREAD;  // one returning atomic per 2048 segments
+
+__device__ __forceinline__ uint64_t segment_active_mask(const McParams& P, uint32_t s, uint64_t& m13)
+{
+    const uint32_t xw = s % P.nxw;
+    const uint32_t t = s / P.nxw;
+    const uint32_t y = t % P.ncy;
+    const uint32_t z = t / P.ncy;
+    m13 = 0;
+    if ((int)z < P.lay_count_begin || (int)z >= P.lay_emit_end) return 0;
+    const uint64_t* r00 = P.bits + ((size_t)z * P.ny + y) * P.nxw + xw;  // (y  , z  )
+    const uint64_t* r01 = r00 + P.nxw;                                     // (y+1, z  )
+    const uint64_t* r10 = r00 + (size_t)P.ny * P.nxw;                      // (y  , z+1)
+    const uint64_t* r11 = r10 + P.nxw;                                     // (y+1, z+1)
+    const bool more = (xw + 1 < (uint32_t)P.nxw);
+    const uint64_t a = r00[0], b = r01[0], c = r10[0], d = r11[0];
+    const uint64_t as = shr1_in(a, more ? r00[1] : 0), bs = shr1_in(b, more ? r01[1] : 0);
+    const uint64_t cs = shr1_in(c, more ? r10[1] : 0), ds = shr1_in(d, more ? r11[1] : 0);
+    // cells of this word: x = 64*xw + bit, valid while x < ncx
+    const int rem = P.ncx - (int)xw * 64;
+    const uint64_t valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    const uint64_t all1 = a & as & b & bs & c & cs & d & ds;
+    const uint64_t any1 = a | as | b | bs | c | cs | d | ds;
+    // corner sign words 0xA5 / 0x5A (case 13): v0=a v1=as v2=bs v3=b v4=c v5=cs v6=ds v7=d
+    const uint64_t pa5 = a & bs & cs & d & ~as & ~b & ~c & ~ds;
+    const uint64_t p5a = ~a & ~bs & ~cs & ~d & as & b & c & ds;
+    m13 = (pa5 | p5a) & valid;
+    return (any1 & ~all1) & valid;
+}
+
 __global__ __launch_bounds__(256) void k_segments(McParams P)
 {
     __shared__ uint32_t s_wave_tot[4];
     __shared__ uint32_t s_base;
     const uint32_t nseg = P.nseg;
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    uint64_t active = 0;
-    if (s < nseg) {
-        const uint32_t xw = s % P.nxw;
-        const uint32_t t = s / P.nxw;
-        const uint32_t y = t % P.ncy;
-        const uint32_t z = t / P.ncy;
-        if ((int)z >= P.lay_count_begin && (int)z < P.lay_emit_end) {
-            const uint64_t* r00 = P.bits + ((size_t)z * P.ny + y) * P.nxw + xw;  // (y  , z  )
-            const uint64_t* r01 = r00 + P.nxw;                                     // (y+1, z  )
-            const uint64_t* r10 = r00 + (size_t)P.ny * P.nxw;                      // (y  , z+1)
-            const uint64_t* r11 = r10 + P.nxw;                                     // (y+1, z+1)
-            const bool more = (xw + 1 < (uint32_t)P.nxw);
-            const uint64_t a = r00[0], b = r01[0], c = r10[0], d = r11[0];
-            const uint64_t as = shr1_in(a, more ? r00[1] : 0), bs = shr1_in(b, more ? r01[1] : 0);
-            const uint64_t cs = shr1_in(c, more ? r10[1] : 0), ds = shr1_in(d, more ? r11[1] : 0);
-            // cells of this word: x = 64*xw + bit, valid while x < ncx
-            const int rem = P.ncx - (int)xw * 64;
-            const uint64_t valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-            const uint64_t all1 = a & as & b & bs & c & cs & d & ds;
-            const uint64_t any1 = a | as | b | bs | c | cs | d | ds;
-            active = (any1 & ~all1) & valid;
-            // corner sign words 0xA5 / 0x5A (case 13): v0=a v1=as v2=bs v3=b v4=c v5=cs v6=ds v7=d
-            const uint64_t pa5 = a & bs & cs & d & ~as & ~b & ~c & ~ds;
-            const uint64_t p5a = ~a & ~bs & ~cs & ~d & as & b & c & ds;
-            if ((pa5 | p5a) & valid) atomicAdd(&P.counters->n_case13, (uint32_t)__popcll((pa5 | p5a) & valid));
+    const uint32_t chunk = blockIdx.x * (uint32_t)SEG_PER_BLOCK;
+    uint64_t active[SEG_PER_THREAD];
+    uint32_t cnt = 0, n13 = 0;
+#pragma unroll
+    for (int i = 0; i < SEG_PER_THREAD; i++) {
+        const uint32_t s = chunk + (uint32_t)i * 256u + threadIdx.x;   // coalesced across lanes
+        active[i] = 0;
+        if (s < nseg) {
+            uint64_t m13;
+            active[i] = segment_active_mask(P, s, m13);
+            n13 += (uint32_t)__popcll(m13);
+            P.segpack[s] = 0;
         }
-        P.segpack[s] = 0;
+        cnt += (uint32_t)__popcll(active[i]);
     }
-    // wave-level exclusive prefix of popcounts, one atomic per workgroup
-    const uint32_t cnt = (uint32_t)__popcll(active);
+    if (n13) atomicAdd(&P.counters->n_case13, n13);
+    // exclusive prefix of the per-lane counts; ONE returning atomic per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = cnt;
 #pragma unroll
@@ -154,12 +171,16 @@ __global__ __launch_bounds__(256) void k_segments(McParams P)
     if (cnt) {
         uint32_t pos = s_base + (incl - cnt);
         for (int w = 0; w < wave; w++) pos += s_wave_tot[w];
-        uint64_t m = active;
-        while (m) {
-            const int bit = __builtin_ctzll(m);
-            m &= m - 1;
-            if (pos < P.cap_active) P.act[pos] = (s << 6) | (uint32_t)bit;
-            pos++;
+#pragma unroll
+        for (int i = 0; i < SEG_PER_THREAD; i++) {
+            const uint32_t s = chunk + (uint32_t)i * 256u + threadIdx.x;
+            uint64_t m = active[i];
+            while (m) {   // the cells of one segment stay contiguous and in x order
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                if (pos < P.cap_active) P.act[pos] = (s << 6) | (uint32_t)bit;
+                pos++;
+            }
         }
     }
 }
@@ -177,15 +198,15 @@ __device__ __forceinline__ void decode_cell(const McParams& P, uint32_t id, int&
     x = (int)(xw * 64 + (id & 63));
 }
 
-__device__ __forceinline__ void load_corners(const McParams& P, int x, int y, int z, double* v)
+// the 8 corner voxels of cell (x,y,z) into this thread's LDS column ([corner][thread])
+__device__ __forceinline__ void stage_corners(const McParams& P, int x, int y, int z, float* col, int stride)
 {
     const size_t sx = (size_t)P.ny * P.nz, sy = (size_t)P.nz;
     const float* p = P.values + (size_t)x * sx + (size_t)y * sy + z;
-    const double iso = (double)P.iso;
-    v[0] = (double)p[0] - iso;           v[4] = (double)p[1] - iso;
-    v[1] = (double)p[sx] - iso;          v[5] = (double)p[sx + 1] - iso;
-    v[3] = (double)p[sy] - iso;          v[7] = (double)p[sy + 1] - iso;
-    v[2] = (double)p[sx + sy] - iso;     v[6] = (double)p[sx + sy + 1] - iso;
+    const float a0 = p[0], a4 = p[1], a1 = p[sx], a5 = p[sx + 1];
+    const float a3 = p[sy], a7 = p[sy + 1], a2 = p[sx + sy], a6 = p[sx + sy + 1];
+    col[0] = a0; col[stride] = a1; col[2 * stride] = a2; col[3 * stride] = a3;
+    col[4 * stride] = a4; col[5 * stride] = a5; col[6 * stride] = a6; col[7 * stride] = a7;
 }
 
 __device__ __forceinline__ bool cell_in_range(const McParams& P, int x, int y, int z)
@@ -196,10 +217,18 @@ __device__ __forceinline__ bool cell_in_range(const McParams& P, int x, int y, i
 }
 
 // "Impossible case 13" cells emit nothing and therefore never create or reference a vertex.
-__device__ __noinline__ bool cell_is_dead(const McParams& P, int x, int y, int z)
+// `col` is the calling thread's LDS column ([corner][256 threads]); its content is replaced.
+// (takes the few fields it needs by value: a reference to the kernel-argument block would
+// force a scratch copy of it at this out-of-line call)
+__device__ __noinline__ bool cell_is_dead(const float* values, int ny, int nz, float iso, int x, int y, int z, float* col)
 {
-    double v[8];
-    load_corners(P, x, y, z, v);
+    {
+        const size_t sx = (size_t)ny * nz, sy = (size_t)nz;
+        const float* p = values + (size_t)x * sx + (size_t)y * sy + z;
+        col[0] = p[0]; col[256] = p[sx]; col[2 * 256] = p[sx + sy]; col[3 * 256] = p[sy];
+        col[4 * 256] = p[1]; col[5 * 256] = p[sx + 1]; col[6 * 256] = p[sx + sy + 1]; col[7 * 256] = p[sy + 1];
+    }
+    const CornersLds v{col, 256, (double)iso};
     int index = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) index |= (v[k] > 0.0) ? (1 << k) : 0;
@@ -211,10 +240,8 @@ __device__ __noinline__ bool cell_is_dead(const McParams& P, int x, int y, int z
 // Does an earlier cell of the sweep (one that is alive) share edge e of cell (x,y,z)?
 // Predecessor sets derived from Cell.cs:371-441 (which cells map to the same face-layer
 // slot) and the sweep order of MarchingCubes.cs:53-80.
-__device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, int e, int x, int y, int z, bool check_dead)
-{
-    // up to three predecessors per edge, offsets (dx,dy,dz)
-    const int8_t PD[12][3][3] = {
+// up to three predecessors per edge, offsets (dx,dy,dz); 9 = none
+__constant__ int8_t c_pred[12][3][3] = {
         {{0, -1, -1}, {0, 0, -1}, {0, -1, 0}},   // e0
         {{0, 0, -1}, {1, 0, -1}, {9, 9, 9}},     // e1
         {{0, 0, -1}, {0, 1, -1}, {9, 9, 9}},     // e2
@@ -227,10 +254,13 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, int
         {{0, -1, 0}, {1, -1, 0}, {9, 9, 9}},     // e9
         {{9, 9, 9}, {9, 9, 9}, {9, 9, 9}},       // e10
         {{-1, 0, 0}, {9, 9, 9}, {9, 9, 9}}};     // e11
+
+__device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, int e, int x, int y, int z, bool check_dead, float* col)
+{
     for (int k = 0; k < 3; k++) {
-        const int dx = PD[e][k][0];
+        const int dx = c_pred[e][k][0];
         if (dx == 9) break;
-        const int px = x + dx, py = y + PD[e][k][1], pz = z + PD[e][k][2];
+        const int px = x + dx, py = y + c_pred[e][k][1], pz = z + c_pred[e][k][2];
         if (px < 0 || py < 0 || px >= P.ncx || py >= P.ncy) continue;
         if (pz < 0) {
             // below the slab: exists globally iff this is not global layer 0; assumed alive
@@ -239,7 +269,7 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, int
             continue;
         }
         if (pz >= P.ncz) continue;
-        if (!check_dead || !cell_is_dead(P, px, py, pz)) return true;
+        if (!check_dead || !cell_is_dead(P.values, P.ny, P.nz, P.iso, px, py, pz, col)) return true;
     }
     return false;
 }
@@ -249,14 +279,16 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, int
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(McParams P)
 {
+    __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const bool check_dead = P.counters->n_case13 != 0;
+    float* col = s_v + threadIdx.x;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         int x, y, z;
         uint32_t seg;
         decode_cell(P, P.act[i], x, y, z, seg);
-        double v[8];
-        load_corners(P, x, y, z, v);
+        stage_corners(P, x, y, z, col, 256);
+        const CornersLds v{col, 256, (double)P.iso};
         const Tiling t = mc_resolve(v);
         uint32_t info = 0;
         uint64_t own = 0;
@@ -267,7 +299,7 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
                 const int e = c_lut[t.lut_off + k];
                 if (seen & (1u << e)) continue;
                 seen |= 1u << e;
-                const bool mine = (e == 12) || !edge_has_live_predecessor(P, e, x, y, z, check_dead);
+                const bool mine = (e == 12) || !edge_has_live_predecessor(P, e, x, y, z, check_dead, col);
                 if (mine) {
                     own |= (uint64_t)e << (4 * nown);
                     nown++;
@@ -434,9 +466,10 @@ __device__ __forceinline__ void load_corner_color(const McParams& P, int x, int 
     c[0] = P.colors[o * 3]; c[1] = P.colors[o * 3 + 1]; c[2] = P.colors[o * 3 + 2];
 }
 
-// Accumulate into n[] what cell (cx,cy,cz) with corners v adds for its edge `es`, in the
-// order of Cell.cs:332-333/355-356: once per occurrence in the LUT row, corner 1 then 2.
-__device__ __forceinline__ void add_cell_edge_gradients(const double* v, int lut_off, int nt, int es, float* n)
+// Accumulate into n[] what a cell with corners v adds for its edge `es`, in the order of
+// Cell.cs:332-333/355-356: once per occurrence in the LUT row, corner 1 then corner 2.
+template <class V>
+__device__ __forceinline__ void add_cell_edge_gradients(const V& v, int lut_off, int nt, int es, float* n)
 {
     int occ = 0;
     for (int k = 0; k < 3 * nt; k++) occ += (c_lut[lut_off + k] == es) ? 1 : 0;
@@ -448,6 +481,7 @@ __device__ __forceinline__ void add_cell_edge_gradients(const double* v, int lut
     float g1[3], g2[3];
     // NB: Cell.cs:157-158 indexes the corner-ordered gradient table with the BIT-order
     // index (inherited quirk); reproduced: gradient of "corner i1", not of corner bit_to_corner[i1].
+#pragma unroll
     for (int j = 0; j < 3; j++) {
         g1[j] = (float)(mc_corner_gradient(v, i1, j) * w1);
         g2[j] = (float)(mc_corner_gradient(v, i2, j) * w2);
@@ -458,73 +492,123 @@ __device__ __forceinline__ void add_cell_edge_gradients(const double* v, int lut
     }
 }
 
+// Workgroup-level re-balancing: a chunk of 256 records owns a variable number of output
+// items each (created vertices / triangle indices).  An exclusive prefix in LDS plus a
+// binary search turns "one thread per record" into "one thread per output item".
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* s_pre /*[257]*/, uint32_t* s_wave /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(incl, o);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - v;
+    for (int w = 0; w < wave; w++) pre += s_wave[w];
+    s_pre[threadIdx.x] = pre;
+    if (threadIdx.x == 255) s_pre[256] = pre + v;
+    __syncthreads();
+    return s_pre[256];
+}
+
+__device__ __forceinline__ int find_owner_256(const uint32_t* s_pre, uint32_t j)
+{
+    int lo = 0, hi = 255;   // largest r with s_pre[r] <= j
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_pre[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
+    __shared__ float s_c[4 * 8 * 256];   // corners of the <=4 cells around the edge: [cell][corner][thread]
+    __shared__ uint32_t s_pre[257];
+    __shared__ uint32_t s_wave[4];
     __shared__ float s_red[6][4];
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
+    const double iso = (double)P.iso;
+    const double stp = (double)P.step;
     float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t info = P.rec_info[i];
-        const int nown = (int)((info >> 18) & 15u);
-        if (!nown) continue;
-        int x, y, z;
-        uint32_t seg;
-        decode_cell(P, P.act[i], x, y, z, seg);
-        const uint32_t vbase = P.segprefix[seg].x + (P.rec_pre[i] & 0xffffu);
-        const bool emit = (z >= P.lay_emit_begin);
-        const uint64_t own = P.rec_own[i];
-        const int lut_off = (int)(info & 0x3fffu);
-        // nt as stored is zeroed for non-emitting layers; the row length is needed for normals
-        double v[8];
-        load_corners(P, x, y, z, v);
-        int nt_row = (int)((info >> 14) & 15u);
-        const double stp = (double)P.step;
-        for (int r = 0; r < nown; r++) {
-            const int e = (int)((own >> (4 * r)) & 15u);
-            const uint32_t vi = vbase + (uint32_t)r;
+    float* col = s_c + threadIdx.x;
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t irec = base + threadIdx.x;
+        const uint32_t my_nown = (irec < n) ? ((P.rec_info[irec] >> 18) & 15u) : 0u;
+        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);
+        for (uint32_t j = threadIdx.x; j < total; j += 256u) {
+            const int rr = find_owner_256(s_pre, j);
+            const uint32_t i = base + (uint32_t)rr;
+            const int r = (int)(j - s_pre[rr]);
+            const uint32_t info = P.rec_info[i];
+            int x, y, z;
+            uint32_t seg;
+            decode_cell(P, P.act[i], x, y, z, seg);
+            const uint32_t vi = P.segprefix[seg].x + (P.rec_pre[i] & 0xffffu) + (uint32_t)r;
+            const int e = (int)((P.rec_own[i] >> (4 * r)) & 15u);
             const int dir = c_edge_dir[e];
             const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
             P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx] = vi;
-            if (!emit) continue;
+            if (z < P.lay_emit_begin) continue;   // context layer: only its vertex ids are needed
             const uint32_t out = vi - nghost;
             if (out >= M.cap_vertices) { P.counters->overflow = 1u; continue; }
-            float pos[3], col[3], nrm[3] = {0.0f, 0.0f, 0.0f};
+            const int lut_off = (int)(info & 0x3fffu);
+            const int nt_row = (int)((info >> 14) & 15u);
+            float pos[3], colr[3], nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
             if (e == 12) {
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
-                double w[8], fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0;
-                for (int k = 0; k < 8; k++) w[k] = 1.0 / (MC_EPS + fabs(v[k]));
+                stage_corners(P, x, y, z, col, 256);
+                const CornersLds v{col, 256, iso};
+                double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
+                float fc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    fx += (double)c_corner_dx[k] * w[k];
-                    fy += (double)c_corner_dy[k] * w[k];
-                    fz += (double)c_corner_dz[k] * w[k];
-                    ff += w[k];
-                }
-                float fc[3] = {0, 0, 0};
-                for (int k = 0; k < 8; k++) {
+                    const double wk = 1.0 / (MC_EPS + fabs(v[k]));
+                    fx += (double)((k == 1 || k == 2 || k == 5 || k == 6) ? 1 : 0) * wk;
+                    fy += (double)((k == 2 || k == 3 || k == 6 || k == 7) ? 1 : 0) * wk;
+                    fz += (double)(k >= 4 ? 1 : 0) * wk;
+                    ff += wk;
                     float ck[3];
                     load_corner_color(P, x, y, z, k, ck);
-                    const float wk = (float)w[k];
-                    if (k == 0) { fc[0] = ck[0] * wk; fc[1] = ck[1] * wk; fc[2] = ck[2] * wk; }
-                    else { fc[0] = fc[0] + ck[0] * wk; fc[1] = fc[1] + ck[1] * wk; fc[2] = fc[2] + ck[2] * wk; }
+                    const float wf = (float)wk;
+                    if (k == 0) { fc[0] = ck[0] * wf; fc[1] = ck[1] * wf; fc[2] = ck[2] * wf; }
+                    else { fc[0] = fc[0] + ck[0] * wf; fc[1] = fc[1] + ck[1] * wf; fc[2] = fc[2] + ck[2] * wf; }
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++) {
+                        const double term = wk * mc_corner_gradient(v, k, jj);
+                        gsum[jj] = (k == 0) ? term : gsum[jj] + term;
+                    }
                 }
                 pos[0] = (float)((double)xs + stp * fx / ff);
                 pos[1] = (float)((double)ys + stp * fy / ff);
                 pos[2] = (float)((double)zs + stp * fz / ff);
-                for (int j = 0; j < 3; j++) col[j] = (float)((double)fc[j] / ff);
-                float g[3];
-                for (int j = 0; j < 3; j++) {
-                    double sacc = w[0] * mc_corner_gradient(v, 0, j);
-                    for (int k = 1; k < 8; k++) sacc = sacc + w[k] * mc_corner_gradient(v, k, j);
-                    g[j] = (float)sacc;
-                }
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) colr[jj] = (float)((double)fc[jj] / ff);
+                const float g0 = (float)gsum[0], g1 = (float)gsum[1], g2 = (float)gsum[2];
                 int occ = 0;
                 for (int k = 0; k < 3 * nt_row; k++) occ += (c_lut[lut_off + k] == 12) ? 1 : 0;
-                for (int o = 0; o < occ; o++) { nrm[0] = nrm[0] + g[0]; nrm[1] = nrm[1] + g[1]; nrm[2] = nrm[2] + g[2]; }
+                for (int o = 0; o < occ; o++) { nrm[0] = nrm[0] + g0; nrm[1] = nrm[1] + g1; nrm[2] = nrm[2] + g2; }
             } else {
+                // stage the corners of every in-range cell around this grid edge (sweep order)
+                int own_s = 0;
+                unsigned okmask = 0;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int cx = gx + c_share_dx[dir][s], cy = gy + c_share_dy[dir][s], cz = gz + c_share_dz[dir][s];
+                    const bool ok = cell_in_range(P, cx, cy, cz);
+                    okmask |= ok ? (1u << s) : 0u;
+                    if (cx == x && cy == y && cz == z) own_s = s;
+                    if (ok) stage_corners(P, cx, cy, cz, col + s * (8 * 256), 256);
+                }
                 // Cell.AddFaceFromEdgeIndex, Cell.cs:314-350 (creator-cell frame)
+                const CornersLds v{col + own_s * (8 * 256), 256, iso};
                 const int dx1 = MC_L2(edgesrelx, e, 0), dx2 = MC_L2(edgesrelx, e, 1);
                 const int dy1 = MC_L2(edgesrely, e, 0), dy2 = MC_L2(edgesrely, e, 1);
                 const int dz1 = MC_L2(edgesrelz, e, 0), dz2 = MC_L2(edgesrelz, e, 1);
@@ -541,23 +625,24 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 pos[0] = (float)((double)xs + stp * fx / ff);
                 pos[1] = (float)((double)ys + stp * fy / ff);
                 pos[2] = (float)((double)zs + stp * fz / ff);
-                for (int j = 0; j < 3; j++) {
-                    const float cj = ca[j] * w1f + cb[j] * w2f;
-                    col[j] = (float)((double)cj / ff);
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) {
+                    const float cj = ca[jj] * w1f + cb[jj] * w2f;
+                    colr[jj] = (float)((double)cj / ff);
                 }
-                // normal: gather over the cells around this grid edge, in sweep order
+                // normal: gather over the cells around the edge, in sweep order
+#pragma unroll 1
                 for (int s = 0; s < 4; s++) {
-                    const int cx = gx + c_share_dx[dir][s], cy = gy + c_share_dy[dir][s], cz = gz + c_share_dz[dir][s];
-                    if (!cell_in_range(P, cx, cy, cz)) continue;
+                    if (!((okmask >> s) & 1u)) continue;
+                    const CornersLds vs{col + s * (8 * 256), 256, iso};
                     const int es = c_share_edge[dir][s];
-                    if (cx == x && cy == y && cz == z) {
-                        add_cell_edge_gradients(v, lut_off, nt_row, es, nrm);
-                    } else {
-                        double vs[8];
-                        load_corners(P, cx, cy, cz, vs);
+                    int lo = lut_off, nts = nt_row;
+                    if (s != own_s) {
                         const Tiling ts = mc_resolve(vs);
-                        if (ts.nt > 0) add_cell_edge_gradients(vs, ts.lut_off, ts.nt, es, nrm);
+                        lo = ts.lut_off;
+                        nts = ts.nt;
                     }
+                    if (nts > 0) add_cell_edge_gradients(vs, lo, nts, es, nrm);
                 }
             }
             // Cell.NegativeNormals (Cell.cs:97-109), then Mesh.Transform (Mesh.cs:47-64)
@@ -572,7 +657,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             float* oc = M.colors + (size_t)out * 3;
             float* on = M.normals + (size_t)out * 3;
             ov[0] = px; ov[1] = py; ov[2] = pz;
-            oc[0] = col[0]; oc[1] = col[1]; oc[2] = col[2];
+            oc[0] = colr[0]; oc[1] = colr[1]; oc[2] = colr[2];
             on[0] = t0 / tl; on[1] = t1 / tl; on[2] = t2 / tl;
             if (M.grid_vertices) {
                 float* og = M.grid_vertices + (size_t)out * 3;
@@ -581,16 +666,22 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             bmin[0] = fminf(bmin[0], px); bmin[1] = fminf(bmin[1], py); bmin[2] = fminf(bmin[2], pz);
             bmax[0] = fmaxf(bmax[0], px); bmax[1] = fmaxf(bmax[1], py); bmax[2] = fmaxf(bmax[2], pz);
         }
+        __syncthreads();   // s_pre is rewritten by the next chunk
     }
     // per-workgroup AABB partials (Mesh.Measure, Mesh.cs:30-45), reduced by k_bounds
     float r[6] = {bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2]};
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
         for (int j = 0; j < 3; j++) r[j] = fminf(r[j], __shfl_down(r[j], o));
+#pragma unroll
         for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], __shfl_down(r[j], o));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) for (int j = 0; j < 6; j++) s_red[j][wave] = r[j];
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) s_red[j][wave] = r[j];
+    }
     __syncthreads();
     if (threadIdx.x < 6) {
         const int j = threadIdx.x;
@@ -629,27 +720,32 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partia
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 {
+    __shared__ uint32_t s_pre[257];
+    __shared__ uint32_t s_wave[4];
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t info = P.rec_info[i];
-        const int nt = (int)((info >> 14) & 15u);
-        if (!nt) continue;
-        int x, y, z;
-        uint32_t seg;
-        decode_cell(P, P.act[i], x, y, z, seg);
-        const uint32_t tb = P.segprefix[seg].y + (P.rec_pre[i] >> 16);
-        const int lut_off = (int)(info & 0x3fffu);
-        const size_t o0 = (size_t)tb * 3;
-        if (o0 + (size_t)nt * 3 > M.cap_indices) { P.counters->overflow = 1u; continue; }
-        for (int k = 0; k < 3 * nt; k++) {
-            const int e = c_lut[lut_off + k];
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t irec = base + threadIdx.x;
+        const uint32_t my_ni = (irec < n) ? 3u * ((P.rec_info[irec] >> 14) & 15u) : 0u;
+        const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
+        for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
+            const int rr = find_owner_256(s_pre, j);
+            const uint32_t i = base + (uint32_t)rr;
+            const uint32_t k = j - s_pre[rr];
+            const uint32_t info = P.rec_info[i];
+            int x, y, z;
+            uint32_t seg;
+            decode_cell(P, P.act[i], x, y, z, seg);
+            const size_t o = ((size_t)P.segprefix[seg].y + (P.rec_pre[i] >> 16)) * 3 + k;
+            if (o >= M.cap_indices) { P.counters->overflow = 1u; continue; }
+            const int e = c_lut[(info & 0x3fffu) + k];
             const int dir = c_edge_dir[e];
             const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
             const uint32_t vi = P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx];
-            M.triangles[o0 + k] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
+            M.triangles[o] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
         }
+        __syncthreads();
     }
 }
 

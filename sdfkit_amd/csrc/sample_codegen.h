@@ -16,7 +16,7 @@
 // One definition, used both by the host (below) and pasted into the generated source.
 #define SDFK_SAMPLE_ARGS_BODY                                                                   \
     float* values; float* colors; float mx, my, mz, dx, dy, dz; int nx, ny, nz; int z0, nz_global; \
-    int clip; float outside; int nzu; int row_stride;
+    int clip; float outside; int nzu; int row_stride; unsigned long long* bits; int nxw; float iso;
 
 struct SampleArgs { SDFK_SAMPLE_ARGS_BODY };
 
@@ -77,6 +77,68 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_sample_vec4(SampleArgs A)
         }
         ix += sq; iy += sr;
         if (iy >= A.ny) { iy -= A.ny; ix++; }
+    }
+}
+
+// Fused form (nz % 4 == 0): sampling AND the marching-cubes sign bits in one pass over the
+// grid.  A workgroup owns 64 x-rows x 256 z of one y: lane = 4 consecutive z (one 16-byte
+// store, 1 KiB contiguous per wave instruction), each wave walks 16 rows.  The 4 sign bits
+// (value > iso) of every lane go to LDS; then, with lane = x, four __ballot()s per LDS column
+// produce the 64-bit X-words bits[z][y][xw] the marching-cubes classifier reads -- the
+// volume itself is never re-read densely.
+extern "C" __global__ __launch_bounds__(256) void sdfk_sample_bits(SampleArgs A)
+{
+    constexpr int PITCH = 68;   // 17 dwords: lane = x reads hit 32 distinct banks
+    __shared__ unsigned char nib[64 * PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int zc = blockIdx.x * 256;
+    const int iy = blockIdx.y;
+    const int xw = blockIdx.z;
+    const int z = zc + 4 * lane;
+    const bool zok = z < A.nz;
+    const float py = A.my + (float)iy * A.dy;
+    const bool edge_y = (iy == 0) | (iy == A.ny - 1);
+    float pz[4];
+    bool edge_z[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int zg = A.z0 + z + k;
+        pz[k] = A.mz + (float)zg * A.dz;
+        edge_z[k] = (zg == 0) | (zg == A.nz_global - 1);
+    }
+    for (int r = wave; r < 64; r += 4) {
+        const int ix = xw * 64 + r;
+        unsigned n = 0;
+        if (ix < A.nx && zok) {
+            const float px = A.mx + (float)ix * A.dx;
+            const bool edge_xy = edge_y | (ix == 0) | (ix == A.nx - 1);
+            float w[4], cr[4], cg[4], cb[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sdf_eval(px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
+                if (A.clip && (edge_xy || edge_z[k])) w[k] = A.outside;
+            }
+            const long o = ((long)ix * A.ny + iy) * A.nz + z;
+            *reinterpret_cast<float4*>(A.values + o) = make_float4(w[0], w[1], w[2], w[3]);
+            if (A.colors) {
+                float4* c = reinterpret_cast<float4*>(A.colors + o * 3);
+                c[0] = make_float4(cr[0], cg[0], cb[0], cr[1]);
+                c[1] = make_float4(cg[1], cb[1], cr[2], cg[2]);
+                c[2] = make_float4(cb[2], cr[3], cg[3], cb[3]);
+            }
+            n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
+        }
+        nib[r * PITCH + lane] = (unsigned char)n;
+    }
+    __syncthreads();
+    for (int q = wave; q < 64; q += 4) {
+        const unsigned n = nib[lane * PITCH + q];
+        const unsigned long long b0 = __ballot(n & 1u), b1 = __ballot(n & 2u), b2 = __ballot(n & 4u), b3 = __ballot(n & 8u);
+        const int zq = zc + 4 * q;
+        if (lane < 4 && zq < A.nz) {
+            const unsigned long long wd = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+            A.bits[((long)(zq + lane) * A.ny + iy) * A.nxw + xw] = wd;
+        }
     }
 }
 

@@ -191,6 +191,7 @@ struct sdfk_program {
     std::string source;
     hipModule_t module = nullptr;
     hipFunction_t fn_vec4 = nullptr;
+    hipFunction_t fn_bits = nullptr;
     hipFunction_t fn_scalar = nullptr;
     int writes_color = 0;
 };
@@ -201,7 +202,14 @@ struct sdfk_volume {
     float gmin[3], gmax[3];
     float* values = nullptr;
     float* colors = nullptr;          // nullptr: colours are all zero
+    // sign bits (value > bits_iso) packed along X, written by the fused sampling kernel;
+    // valid until Values change (upload / ClipToBounds)
+    uint64_t* bits = nullptr;
+    float bits_iso = 0.0f;
+    bool bits_valid = false;
     size_t nvox() const { return (size_t)nx * ny * nz; }
+    int nxw() const { return (nx + 63) / 64; }
+    size_t nbitwords() const { return (size_t)nz * ny * nxw() + 1; }
 };
 
 struct sdfk_mesh {
@@ -352,6 +360,7 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     hipError_t e = hipModuleLoadData(&p->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_vec4, p->module, "sdfk_sample_vec4");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_scalar, p->module, "sdfk_sample_scalar");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
     if (e != hipSuccess) {
         if (p->module) (void)hipModuleUnload(p->module);
         delete p;
@@ -411,6 +420,7 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
     if (g.inited) (void)hipStreamSynchronize(g.stream);
     dev_free(v->values);
     dev_free(v->colors);
+    dev_free(v->bits);
     delete v;
 }
 
@@ -420,6 +430,7 @@ extern "C" int sdfk_volume_upload(sdfk_volume* v, const float* values, const flo
     if (!v || !values) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: null argument");
     if (int r = require_init()) return r;
     if (colors3 && !v->colors) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: volume was created without colours");
+    v->bits_valid = false;
     HIPCHK(hipMemcpyAsync(v->values, values, v->nvox() * sizeof(float), hipMemcpyHostToDevice, g.stream));
     if (colors3) HIPCHK(hipMemcpyAsync(v->colors, colors3, v->nvox() * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));  // the caller's arrays are not retained
@@ -460,11 +471,8 @@ static void grid_constants(const sdfk_volume* v, float d[3], float m[3], float* 
     *outside = (v->gmax[0] - v->gmin[0]) / (float)v->nx;
 }
 
-extern "C" int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds)
+static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, float iso_hint)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!p || !v) return fail(SDFK_ERR_INVALID, "sdfk_sample: null argument");
-    if (int r = require_init()) return r;
     SampleArgs A;
     memset(&A, 0, sizeof A);
     float d[3], m[3], outside;
@@ -477,8 +485,25 @@ extern "C" int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_t
     A.z0 = v->z0; A.nz_global = v->nz_global;
     A.clip = clip_to_bounds ? 1 : 0;
     A.outside = outside;
-    const bool vec = (v->nz % 4) == 0;
-    const int nzu = vec ? v->nz / 4 : v->nz;      // work units along z per row
+    v->bits_valid = false;
+    void* params[] = {&A};
+    if ((v->nz % 4) == 0) {
+        // fused sampling + sign bits (iso known or guessed 0): marching cubes then skips its
+        // dense pass over the volume
+        if (!v->bits) {
+            if (int r = dev_alloc((void**)&v->bits, v->nbitwords() * sizeof(uint64_t))) return r;
+        }
+        A.bits = (unsigned long long*)v->bits;
+        A.nxw = v->nxw();
+        A.iso = iso_hint;
+        ProfScope ps("sdfk_sample_bits");
+        HIPCHK(hipModuleLaunchKernel(p->fn_bits, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny, (unsigned)v->nxw(),
+                                     256, 1, 1, 0, g.stream, params, nullptr));
+        v->bits_iso = iso_hint;
+        v->bits_valid = true;
+        return SDFK_OK;
+    }
+    const int nzu = v->nz;      // one voxel per lane-iteration
     int tz = 1;
     while (tz < nzu && tz < 256) tz *= 2;
     const int tr = 256 / tz;
@@ -488,10 +513,17 @@ extern "C" int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_t
     if (nblk > maxblk) nblk = maxblk;
     A.nzu = nzu;
     A.row_stride = (int)(nblk * tr);
-    void* params[] = {&A};
-    ProfScope ps(vec ? "sdfk_sample_vec4" : "sdfk_sample_scalar");
-    HIPCHK(hipModuleLaunchKernel(vec ? p->fn_vec4 : p->fn_scalar, (unsigned)nblk, 1, 1, (unsigned)tz, (unsigned)tr, 1, 0, g.stream, params, nullptr));
+    ProfScope ps("sdfk_sample_scalar");
+    HIPCHK(hipModuleLaunchKernel(p->fn_scalar, (unsigned)nblk, 1, 1, (unsigned)tz, (unsigned)tr, 1, 0, g.stream, params, nullptr));
     return SDFK_OK;
+}
+
+extern "C" int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !v) return fail(SDFK_ERR_INVALID, "sdfk_sample: null argument");
+    if (int r = require_init()) return r;
+    return sample_impl(p, v, clip_to_bounds, 0.0f);
 }
 
 extern "C" int sdfk_volume_clip_to_bounds(sdfk_volume* v)
@@ -501,6 +533,7 @@ extern "C" int sdfk_volume_clip_to_bounds(sdfk_volume* v)
     if (int r = require_init()) return r;
     float d[3], m[3], outside;
     grid_constants(v, d, m, &outside);
+    v->bits_valid = false;
     ProfScope ps("k_clip");
     hipLaunchKernelGGL(k_clip, dim3(grid_for(v->nvox())), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->z0, v->nz_global, outside);
     HIPCHK(hipGetLastError());
@@ -557,7 +590,7 @@ int launch_classify(sdfk_march_job* j, bool redo_bits)
     }
     {
         ProfScope ps("k_segments");
-        hipLaunchKernelGGL(k_segments, dim3((P.nseg + 255) / 256), dim3(256), 0, g.stream, P);
+        hipLaunchKernelGGL(k_segments, dim3((P.nseg + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     {
@@ -654,7 +687,9 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     size_t cap = std::max<size_t>(ncell / 12, 1u << 16);
     cap = std::min(cap, ncell);
     int r = 0;
-    r = r ? r : job_alloc(j, &P.bits, (size_t)P.nz * P.ny * P.nxw + 1);
+    const bool have_bits = (step == 1 && v->bits && v->bits_valid && v->bits_iso == iso);
+    if (have_bits) P.bits = v->bits;   // written by the fused sampling kernel; owned by the volume
+    else r = r ? r : job_alloc(j, &P.bits, (size_t)P.nz * P.ny * P.nxw + 1);
     r = r ? r : job_alloc(j, &P.segpack, P.nseg);
     r = r ? r : job_alloc(j, &P.segprefix, P.nseg);
     r = r ? r : job_alloc(j, &P.blocksum, P.nscanblk);
@@ -673,7 +708,7 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     act_idx = j->owned.size();
     r = r ? r : alloc_records(cap);
     if (r) { job_release(j); delete j; return r; }
-    r = launch_classify(j, true);
+    r = launch_classify(j, !have_bits);
     if (!r && j->c.n_active > P.cap_active) {
         // active-cell list too small: grow to the exact need and redo from K2a
         for (size_t k = act_idx; k < j->owned.size(); k++) dev_free(j->owned[k]);
@@ -821,7 +856,8 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     sdfk_volume* v = nullptr;
     int r = sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
     if (r) return r;
-    r = sdfk_sample(p, v, clip_to_bounds);
+    r = require_init();
+    if (!r) r = sample_impl(p, v, clip_to_bounds, step == 1 ? iso_value : 0.0f);
     if (!r) r = sdfk_march(v, iso_value, step, out);
     sdfk_volume_free(v);
     return r;
