@@ -14,10 +14,22 @@
 
 namespace sdfk {
 
-__constant__ int8_t c_lut[MCLUT_BLOB_SIZE] = {MCLUT_BLOB_VALUES};
+// The packed table blob lives in __constant__ memory; kernels copy it into LDS once per
+// workgroup (13.5 KB) because the per-cell decisions are chains of dependent table reads
+// with run-time (divergent) indices -- LDS latency instead of vector-cache latency.
+__constant__ __attribute__((aligned(16))) int8_t c_lut[MCLUT_BLOB_SIZE] = {MCLUT_BLOB_VALUES};
+static_assert(MCLUT_BLOB_SIZE % 4 == 0, "blob is copied to LDS in dwords");
 
-#define MC_L1(name, i) (c_lut[MCLUT_OFF_##name + (i)])
-#define MC_L2(name, i, j) (c_lut[MCLUT_OFF_##name + (i) * MCLUT_DIM1_##name + (j)])
+__device__ __forceinline__ void mc_load_lut_to_lds(int8_t* s_lut)
+{
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(c_lut);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_lut);
+    for (int i = threadIdx.x; i < MCLUT_BLOB_SIZE / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+// every function below takes `lut` = base of the blob (LDS or constant)
+#define MC_L1(name, i) (lut[MCLUT_OFF_##name + (i)])
+#define MC_L2(name, i, j) (lut[MCLUT_OFF_##name + (i) * MCLUT_DIM1_##name + (j)])
 #define MC_ROW2(name, i) (MCLUT_OFF_##name + (i) * MCLUT_DIM1_##name)
 #define MC_ROW3(name, i, j) (MCLUT_OFF_##name + ((i) * MCLUT_DIM1_##name + (j)) * MCLUT_DIM2_##name)
 
@@ -75,7 +87,7 @@ __constant__ int8_t c_interior_edges[12][8] = {
 
 // MarchingCubes.cs:412-546
 template <class V>
-__device__ __forceinline__ bool mc_test_internal(const V& v, int cas, int config, int subconfig, int s)
+__device__ __forceinline__ bool mc_test_internal(const int8_t* lut, const V& v, int cas, int config, int subconfig, int s)
 {
     double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
     if (cas == 4 || cas == 10) {
@@ -92,7 +104,7 @@ __device__ __forceinline__ bool mc_test_internal(const V& v, int cas, int config
         if (cas == 6) edge = MC_L2(test6, config, 2);
         else if (cas == 7) edge = MC_L2(test7, config, 4);
         else if (cas == 12) edge = MC_L2(test12, config, 3);
-        else edge = c_lut[MC_ROW3(tiling13_5_1, config, subconfig)];
+        else edge = lut[MC_ROW3(tiling13_5_1, config, subconfig)];
         if (edge >= 0 && edge < 12) {
             const int8_t* e = c_interior_edges[edge];
             t = v[e[0]] / (v[e[0]] - v[e[1]] + MC_EPS);
@@ -118,7 +130,7 @@ __device__ __forceinline__ bool mc_test_internal(const V& v, int cas, int config
 
 // The 33-case dispatcher of MarchingCubes.cs:94-371 as a pure function of the corners.
 template <class V>
-__device__ __forceinline__ Tiling mc_resolve(const V& v)
+__device__ __forceinline__ Tiling mc_resolve(const int8_t* lut, const V& v)
 {
     Tiling r;
     int index = 0;
@@ -138,13 +150,13 @@ __device__ __forceinline__ Tiling mc_resolve(const V& v)
         else { r.lut_off = MC_ROW2(tiling3_1, cfg); r.nt = 2; }
         break;
     case 4:
-        if (mc_test_internal(v, cas, cfg, 0, MC_L1(test4, cfg))) { r.lut_off = MC_ROW2(tiling4_1, cfg); r.nt = 2; }
+        if (mc_test_internal(lut, v, cas, cfg, 0, MC_L1(test4, cfg))) { r.lut_off = MC_ROW2(tiling4_1, cfg); r.nt = 2; }
         else { r.lut_off = MC_ROW2(tiling4_2, cfg); r.nt = 6; }
         break;
     case 5: r.lut_off = MC_ROW2(tiling5, cfg); r.nt = 3; break;
     case 6:
         if (mc_test_face(v, MC_L2(test6, cfg, 0))) { r.lut_off = MC_ROW2(tiling6_2, cfg); r.nt = 5; }
-        else if (mc_test_internal(v, cas, cfg, 0, MC_L2(test6, cfg, 1))) { r.lut_off = MC_ROW2(tiling6_1_1, cfg); r.nt = 3; }
+        else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test6, cfg, 1))) { r.lut_off = MC_ROW2(tiling6_1_1, cfg); r.nt = 3; }
         else { r.lut_off = MC_ROW2(tiling6_1_2, cfg); r.nt = 9; }
         break;
     case 7:
@@ -160,7 +172,7 @@ __device__ __forceinline__ Tiling mc_resolve(const V& v)
         case 5: r.lut_off = MC_ROW3(tiling7_3, cfg, 1); r.nt = 9; break;
         case 6: r.lut_off = MC_ROW3(tiling7_3, cfg, 2); r.nt = 9; break;
         default:
-            if (mc_test_internal(v, cas, cfg, sub, MC_L2(test7, cfg, 3))) { r.lut_off = MC_ROW2(tiling7_4_2, cfg); r.nt = 9; }
+            if (mc_test_internal(lut, v, cas, cfg, sub, MC_L2(test7, cfg, 3))) { r.lut_off = MC_ROW2(tiling7_4_2, cfg); r.nt = 9; }
             else { r.lut_off = MC_ROW2(tiling7_4_1, cfg); r.nt = 5; }
             break;
         }
@@ -173,7 +185,7 @@ __device__ __forceinline__ Tiling mc_resolve(const V& v)
             else { r.lut_off = MC_ROW2(tiling10_2, cfg); r.nt = 8; }
         } else {
             if (mc_test_face(v, MC_L2(test10, cfg, 1))) { r.lut_off = MC_ROW2(tiling10_2_, cfg); r.nt = 8; }
-            else if (mc_test_internal(v, cas, cfg, 0, MC_L2(test10, cfg, 2))) { r.lut_off = MC_ROW2(tiling10_1_1, cfg); r.nt = 4; }
+            else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test10, cfg, 2))) { r.lut_off = MC_ROW2(tiling10_1_1, cfg); r.nt = 4; }
             else { r.lut_off = MC_ROW2(tiling10_1_2, cfg); r.nt = 8; }
         }
         break;
@@ -184,7 +196,7 @@ __device__ __forceinline__ Tiling mc_resolve(const V& v)
             else { r.lut_off = MC_ROW2(tiling12_2, cfg); r.nt = 8; }
         } else {
             if (mc_test_face(v, MC_L2(test12, cfg, 1))) { r.lut_off = MC_ROW2(tiling12_2_, cfg); r.nt = 8; }
-            else if (mc_test_internal(v, cas, cfg, 0, MC_L2(test12, cfg, 2))) { r.lut_off = MC_ROW2(tiling12_1_1, cfg); r.nt = 4; }
+            else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test12, cfg, 2))) { r.lut_off = MC_ROW2(tiling12_1_1, cfg); r.nt = 4; }
             else { r.lut_off = MC_ROW2(tiling12_1_2, cfg); r.nt = 8; }
         }
         break;
@@ -199,7 +211,7 @@ __device__ __forceinline__ Tiling mc_resolve(const V& v)
         else if (sub >= 19 && sub <= 22) { r.lut_off = MC_ROW3(tiling13_4, cfg, sub - 19); r.nt = 12; }
         else if (sub >= 23 && sub <= 26) {
             const int s5 = sub - 23;
-            if (mc_test_internal(v, cas, cfg, s5, MC_L2(test13, cfg, 6))) { r.lut_off = MC_ROW3(tiling13_5_1, cfg, s5); r.nt = 6; }
+            if (mc_test_internal(lut, v, cas, cfg, s5, MC_L2(test13, cfg, 6))) { r.lut_off = MC_ROW3(tiling13_5_1, cfg, s5); r.nt = 6; }
             else { r.lut_off = MC_ROW3(tiling13_5_2, cfg, s5); r.nt = 10; }
         }
         else if (sub >= 27 && sub <= 38) { r.lut_off = MC_ROW3(tiling13_3_, cfg, sub - 27); r.nt = 10; }

@@ -4,25 +4,27 @@
 // output order (vertex numbering, triangle order, float32 normal accumulation order)
 // depends on that sweep.  This pipeline reproduces the same output in parallel:
 //
-//   K1 signbits   volume[x][y][z] (z fastest)  ->  1 bit per voxel, packed along X:
-//                 bits[z][y][xw], bit b = (value(64*xw+b, y, z) > iso).  The only dense
-//                 pass over the volume: 4 B/voxel read, 1/8 B/voxel written.
-//   K2a segments  one thread per 64-cell X-run ("segment", = 64 consecutive cells of the
-//                 serial sweep): bit-parallel test "8 corners not all equal", wave
-//                 ballot/prefix-sum compaction of the active cells into a list.
-//   K2b resolve   one thread per active cell: gathers the 8 corners, runs the 33-case
-//                 dispatcher, decides which edge vertices the cell CREATES in the serial
-//                 sweep (it is the first cell of the sweep that touches that grid edge).
-//   K2c segsum    per-segment ordered prefix of created-vertex / triangle counts.
-//   K3  scan      exclusive scan of the per-segment counts in serial-sweep order.
-//   K4  vertices  creator cells write position / colour / normal at the vertex's serial
-//                 index; the normal is a gather over the <=4 cells around the edge in
-//                 sweep order (bit-exact float32 accumulation order, no atomics).
-//   K5  triangles every active cell writes its triangle indices at its serial offset,
-//                 reading vertex ids from a sparse per-grid-edge map written by K4.
+//   K1  signbits  volume[x][y][z] (z fastest) -> 1 bit per voxel packed along X:
+//                 bits[z][y][xw], bit b = (value(64*xw+b, y, z) > iso).  The only dense pass
+//                 over the volume (4 B/voxel read).  Skipped when the fused sampling kernel
+//                 (sample_codegen.h, sdfk_sample_bits) already produced the bits.
+//   K2  compact   persistent workgroups walk the 64-cell X-runs of the sweep in order;
+//                 "8 corners not all equal" is 64-bit-parallel on the sign words; popcounts
+//                 are scanned in the workgroup (wave shuffles) and across workgroups with a
+//                 decoupled look-back chain, so the active-cell list comes out in EXACT
+//                 serial-sweep order without sorting and without atomics.
+//   K3  resolve   one lane per active cell: gathers the 8 corners into its LDS column, runs
+//                 the 33-case dispatcher, decides which vertices the cell CREATES in the sweep
+//                 (it is the first live cell of the sweep touching that grid edge), and scans
+//                 (created vertices, triangles) with the same look-back chain -> every cell
+//                 knows its first vertex id and first triangle.
+//   K4  vertices  one lane per created vertex: position/colour in the creator's frame, normal
+//                 as a gather over the <=4 cells around the edge in sweep order (bit-exact
+//                 float32 accumulation order, no atomics).
+//   K5  triangles one lane per triangle index, vertex ids from a sparse per-grid-edge map.
 //
-// LUTs live in __constant__ memory (mc_device.h).  No MFMA: nothing here is a
-// contraction.  Compile with -ffp-contract=off.
+// Lookup tables are copied from __constant__ to LDS per workgroup.  No MFMA: nothing here
+// is a contraction.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mc_device.h"
@@ -97,31 +99,99 @@ __global__ __launch_bounds__(256) void k_signbits_generic(const float* __restric
 }
 
 // ---------------------------------------------------------------------------
-// K2a: per-segment activity, compaction of active cells
+// workgroup / grid scan helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t n = __shfl_up(v, o);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exclusive prefix of v over the 256 lanes of the workgroup; *total = workgroup sum
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_wave /*[4]*/, uint64_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t incl = wave_incl_scan_u64(v);
+    __syncthreads();   // s_wave may still be read from a previous call
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t pre = incl - v;
+    for (int w = 0; w < wave; w++) pre += s_wave[w];
+    *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return pre;
+}
+
+// Decoupled look-back (single-pass chained scan) across logical blocks processed in
+// increasing order by persistent, co-resident workgroups.  One 64-bit word per logical block:
+// status in bits 63:62 (0 = not yet, 1 = aggregate of this block, 2 = inclusive prefix),
+// value in bits 61:0.  Status and value travel in ONE naturally aligned word written and read
+// with relaxed agent-scope atomics, so no other ordering is needed and no data hand-off
+// depends on workgroup placement.  Called by wave 0 (all 64 lanes); returns the exclusive
+// prefix of block b.  The spin is bounded: on give-up *failed is set.
+constexpr uint64_t ST_AGG = 1ull << 62, ST_PRE = 2ull << 62, ST_MASK = 3ull << 62;
+
+__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* state, int b, uint64_t total, uint32_t* failed)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane == 0)
+        __hip_atomic_store(&state[b], (b == 0 ? ST_PRE : ST_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b == 0) return 0;
+    uint64_t excl = 0;
+    int pos = b - 1;
+    for (;;) {
+        const int idx = pos - lane;
+        uint64_t w = ST_PRE;   // before block 0: prefix 0
+        int spins = 0;
+        for (;;) {
+            if (idx >= 0) w = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any((w & ST_MASK) == 0)) break;
+            if (++spins > (1 << 24)) { *failed = 2u; return excl; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const uint64_t pm = __ballot((w & ST_MASK) == ST_PRE);
+        if (pm) {
+            const int first = __builtin_ctzll(pm);   // nearest predecessor holding a full prefix
+            excl += wave_sum_u64(lane <= first ? (w & ~ST_MASK) : 0ull);
+            break;
+        }
+        excl += wave_sum_u64(w & ~ST_MASK);
+        pos -= 64;
+    }
+    if (lane == 0)
+        __hip_atomic_store(&state[b], ST_PRE | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+// ---------------------------------------------------------------------------
+// K2: ordered compaction of active cells
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t shr1_in(uint64_t w, uint64_t next) { return (w >> 1) | (next << 63); }
 
-constexpr int SEG_PER_THREAD = 8;                    // segments handled by one lane
-constexpr int SEG_PER_BLOCK = 256 * SEG_PER_THREAD;  // one returning atomic per 2048 segments
-
-__device__ __forceinline__ uint64_t segment_active_mask(const McParams& P, uint32_t s, uint64_t& m13)
+// activity of the 64 cells x = 64*xw .. 64*xw+63 of row (y_l, z) from the staged sign words
+__device__ __forceinline__ uint64_t segment_mask(const uint64_t* lo, const uint64_t* hi, int nxw, int ncx,
+                                                 int y_l, int xw, uint64_t& m13)
 {
-    const uint32_t xw = s % P.nxw;
-    const uint32_t t = s / P.nxw;
-    const uint32_t y = t % P.ncy;
-    const uint32_t z = t / P.ncy;
-    m13 = 0;
-    if ((int)z < P.lay_count_begin || (int)z >= P.lay_emit_end) return 0;
-    const uint64_t* r00 = P.bits + ((size_t)z * P.ny + y) * P.nxw + xw;  // (y  , z  )
-    const uint64_t* r01 = r00 + P.nxw;                                     // (y+1, z  )
-    const uint64_t* r10 = r00 + (size_t)P.ny * P.nxw;                      // (y  , z+1)
-    const uint64_t* r11 = r10 + P.nxw;                                     // (y+1, z+1)
-    const bool more = (xw + 1 < (uint32_t)P.nxw);
+    const uint64_t* r00 = lo + y_l * nxw + xw;   // (y  , z  )
+    const uint64_t* r01 = r00 + nxw;             // (y+1, z  )
+    const uint64_t* r10 = hi + y_l * nxw + xw;   // (y  , z+1)
+    const uint64_t* r11 = r10 + nxw;             // (y+1, z+1)
+    const bool more = xw + 1 < nxw;
     const uint64_t a = r00[0], b = r01[0], c = r10[0], d = r11[0];
     const uint64_t as = shr1_in(a, more ? r00[1] : 0), bs = shr1_in(b, more ? r01[1] : 0);
     const uint64_t cs = shr1_in(c, more ? r10[1] : 0), ds = shr1_in(d, more ? r11[1] : 0);
-    // cells of this word: x = 64*xw + bit, valid while x < ncx
-    const int rem = P.ncx - (int)xw * 64;
+    const int rem = ncx - xw * 64;   // cells of this word: x = 64*xw + bit, valid while x < ncx
     const uint64_t valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
     const uint64_t all1 = a & as & b & bs & c & cs & d & ds;
     const uint64_t any1 = a | as | b | bs | c | cs | d | ds;
@@ -132,54 +202,71 @@ __device__ __forceinline__ uint64_t segment_active_mask(const McParams& P, uint3
     return (any1 & ~all1) & valid;
 }
 
-__global__ __launch_bounds__(256) void k_segments(McParams P)
+// Logical block b = (layer z, chunk of `yb` cell rows); logical order == sweep order.
+// Dynamic LDS: two planes of (yb+1) rows x nxw sign words.
+__global__ __launch_bounds__(256) void k_compact(McParams P)
 {
-    __shared__ uint32_t s_wave_tot[4];
-    __shared__ uint32_t s_base;
-    const uint32_t nseg = P.nseg;
-    const uint32_t chunk = blockIdx.x * (uint32_t)SEG_PER_BLOCK;
-    uint64_t active[SEG_PER_THREAD];
-    uint32_t cnt = 0, n13 = 0;
-#pragma unroll
-    for (int i = 0; i < SEG_PER_THREAD; i++) {
-        const uint32_t s = chunk + (uint32_t)i * 256u + threadIdx.x;   // coalesced across lanes
-        active[i] = 0;
-        if (s < nseg) {
-            uint64_t m13;
-            active[i] = segment_active_mask(P, s, m13);
-            n13 += (uint32_t)__popcll(m13);
-            P.segpack[s] = 0;
-        }
-        cnt += (uint32_t)__popcll(active[i]);
-    }
-    if (n13) atomicAdd(&P.counters->n_case13, n13);
-    // exclusive prefix of the per-lane counts; ONE returning atomic per workgroup
+    extern __shared__ uint64_t s_bits[];
+    __shared__ uint64_t s_wave[4];
+    __shared__ uint64_t s_excl;
+    const int plane = (P.yb + 1) * P.nxw;
+    const int nlog = (P.lay_list_end - P.lay_count_begin) * P.nyc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t n = __shfl_up(incl, o);
-        if (lane >= o) incl += n;
-    }
-    if (lane == 63) s_wave_tot[wave] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-        s_base = tot ? atomicAdd(&P.counters->n_active, tot) : 0u;
-    }
-    __syncthreads();
-    if (cnt) {
-        uint32_t pos = s_base + (incl - cnt);
-        for (int w = 0; w < wave; w++) pos += s_wave_tot[w];
-#pragma unroll
-        for (int i = 0; i < SEG_PER_THREAD; i++) {
-            const uint32_t s = chunk + (uint32_t)i * 256u + threadIdx.x;
-            uint64_t m = active[i];
-            while (m) {   // the cells of one segment stay contiguous and in x order
-                const int bit = __builtin_ctzll(m);
-                m &= m - 1;
-                if (pos < P.cap_active) P.act[pos] = (s << 6) | (uint32_t)bit;
-                pos++;
+    for (int b = blockIdx.x; b < nlog; b += gridDim.x) {
+        const int z = P.lay_count_begin + b / P.nyc;
+        const int y0 = (b % P.nyc) * P.yb;
+        const int rows = min(P.yb, P.ncy - y0);
+        const int nwords = (rows + 1) * P.nxw;
+        const uint64_t* g0 = P.bits + ((size_t)z * P.ny + y0) * P.nxw;
+        const uint64_t* g1 = g0 + (size_t)P.ny * P.nxw;
+        __syncthreads();   // previous iteration is done with s_bits
+        for (int i = threadIdx.x; i < nwords; i += 256) {
+            s_bits[i] = g0[i];
+            s_bits[plane + i] = g1[i];
+        }
+        __syncthreads();
+        // each lane owns `per` CONSECUTIVE segments, so lane order == sweep order
+        const int nsegs = rows * P.nxw;
+        const int per = (nsegs + 255) >> 8;
+        const int sb = min((int)threadIdx.x * per, nsegs), se = min(sb + per, nsegs);
+        uint32_t cnt = 0, n13 = 0;
+        {
+            int y_l = sb / P.nxw, xw = sb % P.nxw;
+            for (int s = sb; s < se; s++) {
+                uint64_t m13;
+                cnt += (uint32_t)__popcll(segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13));
+                n13 += (uint32_t)__popcll(m13);
+                if (++xw == P.nxw) { xw = 0; y_l++; }
+            }
+        }
+        if (n13) atomicAdd(&P.counters->n_case13, n13);
+        uint64_t total;
+        const uint64_t pre = block_excl_scan_u64(cnt, s_wave, &total);
+        if (wave == 0) {
+            const uint64_t ex = lookback_exclusive(P.state_a, b, total, &P.counters->overflow);
+            if (lane == 0) {
+                s_excl = ex;
+                if (b == nlog - 1) P.counters->n_active = (uint32_t)(ex + total);
+            }
+        }
+        __syncthreads();
+        if (cnt) {
+            uint32_t pos = (uint32_t)(s_excl + pre);
+            int y_l = sb / P.nxw, xw = sb % P.nxw;
+            for (int s = sb; s < se; s++) {
+                uint64_t m13;
+                uint64_t m = segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13);
+                const uint32_t yz = (uint32_t)(y0 + y_l) << 16;
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (pos < P.cap_active) {
+                        P.rec_xy[pos] = (uint32_t)(xw * 64 + bit) | yz;
+                        P.rec_z[pos] = (uint32_t)z;
+                    }
+                    pos++;
+                }
+                if (++xw == P.nxw) { xw = 0; y_l++; }
             }
         }
     }
@@ -188,21 +275,11 @@ __global__ __launch_bounds__(256) void k_segments(McParams P)
 // ---------------------------------------------------------------------------
 // shared helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void decode_cell(const McParams& P, uint32_t id, int& x, int& y, int& z, uint32_t& seg)
-{
-    seg = id >> 6;
-    const uint32_t xw = seg % P.nxw;
-    const uint32_t t = seg / P.nxw;
-    y = (int)(t % P.ncy);
-    z = (int)(t / P.ncy);
-    x = (int)(xw * 64 + (id & 63));
-}
-
 // the 8 corner voxels of cell (x,y,z) into this thread's LDS column ([corner][thread])
-__device__ __forceinline__ void stage_corners(const McParams& P, int x, int y, int z, float* col, int stride)
+__device__ __forceinline__ void stage_corners(const float* values, int ny, int nz, int x, int y, int z, float* col, int stride)
 {
-    const size_t sx = (size_t)P.ny * P.nz, sy = (size_t)P.nz;
-    const float* p = P.values + (size_t)x * sx + (size_t)y * sy + z;
+    const size_t sx = (size_t)ny * nz, sy = (size_t)nz;
+    const float* p = values + (size_t)x * sx + (size_t)y * sy + z;
     const float a0 = p[0], a4 = p[1], a1 = p[sx], a5 = p[sx + 1];
     const float a3 = p[sy], a7 = p[sy + 1], a2 = p[sx + sy], a6 = p[sx + sy + 1];
     col[0] = a0; col[stride] = a1; col[2 * stride] = a2; col[3 * stride] = a3;
@@ -220,42 +297,38 @@ __device__ __forceinline__ bool cell_in_range(const McParams& P, int x, int y, i
 // `col` is the calling thread's LDS column ([corner][256 threads]); its content is replaced.
 // (takes the few fields it needs by value: a reference to the kernel-argument block would
 // force a scratch copy of it at this out-of-line call)
-__device__ __noinline__ bool cell_is_dead(const float* values, int ny, int nz, float iso, int x, int y, int z, float* col)
+__device__ __noinline__ bool cell_is_dead(const int8_t* lut, const float* values, int ny, int nz, float iso,
+                                          int x, int y, int z, float* col)
 {
-    {
-        const size_t sx = (size_t)ny * nz, sy = (size_t)nz;
-        const float* p = values + (size_t)x * sx + (size_t)y * sy + z;
-        col[0] = p[0]; col[256] = p[sx]; col[2 * 256] = p[sx + sy]; col[3 * 256] = p[sy];
-        col[4 * 256] = p[1]; col[5 * 256] = p[sx + 1]; col[6 * 256] = p[sx + sy + 1]; col[7 * 256] = p[sy + 1];
-    }
+    stage_corners(values, ny, nz, x, y, z, col, 256);
     const CornersLds v{col, 256, (double)iso};
     int index = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) index |= (v[k] > 0.0) ? (1 << k) : 0;
     if (index != 0xA5 && index != 0x5A) return false;
-    const Tiling t = mc_resolve(v);
+    const Tiling t = mc_resolve(lut, v);
     return t.nt == 0;
 }
 
-// Does an earlier cell of the sweep (one that is alive) share edge e of cell (x,y,z)?
-// Predecessor sets derived from Cell.cs:371-441 (which cells map to the same face-layer
-// slot) and the sweep order of MarchingCubes.cs:53-80.
-// up to three predecessors per edge, offsets (dx,dy,dz); 9 = none
+// Does an earlier LIVE cell of the sweep share edge e of cell (x,y,z)?  Predecessor sets
+// derived from Cell.cs:371-441 (which cells map to the same face-layer slot) and the sweep
+// order of MarchingCubes.cs:53-80.  Up to three predecessors per edge, offsets (dx,dy,dz); 9 = none.
 __constant__ int8_t c_pred[12][3][3] = {
-        {{0, -1, -1}, {0, 0, -1}, {0, -1, 0}},   // e0
-        {{0, 0, -1}, {1, 0, -1}, {9, 9, 9}},     // e1
-        {{0, 0, -1}, {0, 1, -1}, {9, 9, 9}},     // e2
-        {{-1, 0, -1}, {0, 0, -1}, {-1, 0, 0}},   // e3
-        {{0, -1, 0}, {9, 9, 9}, {9, 9, 9}},      // e4
-        {{9, 9, 9}, {9, 9, 9}, {9, 9, 9}},       // e5
-        {{9, 9, 9}, {9, 9, 9}, {9, 9, 9}},       // e6
-        {{-1, 0, 0}, {9, 9, 9}, {9, 9, 9}},      // e7
-        {{-1, -1, 0}, {0, -1, 0}, {-1, 0, 0}},   // e8
-        {{0, -1, 0}, {1, -1, 0}, {9, 9, 9}},     // e9
-        {{9, 9, 9}, {9, 9, 9}, {9, 9, 9}},       // e10
-        {{-1, 0, 0}, {9, 9, 9}, {9, 9, 9}}};     // e11
+    {{0, -1, -1}, {0, 0, -1}, {0, -1, 0}},   // e0
+    {{0, 0, -1}, {1, 0, -1}, {9, 9, 9}},     // e1
+    {{0, 0, -1}, {0, 1, -1}, {9, 9, 9}},     // e2
+    {{-1, 0, -1}, {0, 0, -1}, {-1, 0, 0}},   // e3
+    {{0, -1, 0}, {9, 9, 9}, {9, 9, 9}},      // e4
+    {{9, 9, 9}, {9, 9, 9}, {9, 9, 9}},       // e5
+    {{9, 9, 9}, {9, 9, 9}, {9, 9, 9}},       // e6
+    {{-1, 0, 0}, {9, 9, 9}, {9, 9, 9}},      // e7
+    {{-1, -1, 0}, {0, -1, 0}, {-1, 0, 0}},   // e8
+    {{0, -1, 0}, {1, -1, 0}, {9, 9, 9}},     // e9
+    {{9, 9, 9}, {9, 9, 9}, {9, 9, 9}},       // e10
+    {{-1, 0, 0}, {9, 9, 9}, {9, 9, 9}}};     // e11
 
-__device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, int e, int x, int y, int z, bool check_dead, float* col)
+__device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, const int8_t* lut, int e, int x, int y,
+                                                          int z, bool check_dead, float* col)
 {
     for (int k = 0; k < 3; k++) {
         const int dx = c_pred[e][k][0];
@@ -269,232 +342,100 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, int
             continue;
         }
         if (pz >= P.ncz) continue;
-        if (!check_dead || !cell_is_dead(P.values, P.ny, P.nz, P.iso, px, py, pz, col)) return true;
+        if (!check_dead || !cell_is_dead(lut, P.values, P.ny, P.nz, P.iso, px, py, pz, col)) return true;
     }
     return false;
 }
 
 // ---------------------------------------------------------------------------
-// K2b: resolve tilings and vertex creation per active cell
+// K3: resolve tilings + vertex creation + ordered scan of (vertices, triangles)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(McParams P)
 {
     __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
+    __shared__ uint64_t s_wave[4];
+    __shared__ uint64_t s_excl;
+    mc_load_lut_to_lds(s_lut);
+    __syncthreads();
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const bool check_dead = P.counters->n_case13 != 0;
+    const size_t nvox = (size_t)P.nx * P.ny * P.nz;
+    const int nchunks = (int)((n + 255u) >> 8);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* col = s_v + threadIdx.x;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        int x, y, z;
-        uint32_t seg;
-        decode_cell(P, P.act[i], x, y, z, seg);
-        stage_corners(P, x, y, z, col, 256);
-        const CornersLds v{col, 256, (double)P.iso};
-        const Tiling t = mc_resolve(v);
-        uint32_t info = 0;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint32_t i = (uint32_t)c * 256u + threadIdx.x;
+        uint32_t info = 0, nown = 0, nt_emit = 0;
         uint64_t own = 0;
-        if (t.nt > 0) {
-            uint32_t seen = 0;
-            int nown = 0;
-            for (int k = 0; k < 3 * t.nt; k++) {
-                const int e = c_lut[t.lut_off + k];
-                if (seen & (1u << e)) continue;
-                seen |= 1u << e;
-                const bool mine = (e == 12) || !edge_has_live_predecessor(P, e, x, y, z, check_dead, col);
-                if (mine) {
-                    own |= (uint64_t)e << (4 * nown);
-                    nown++;
+        int x = 0, y = 0, z = 0;
+        if (i < n) {
+            const uint32_t xy = P.rec_xy[i];
+            x = (int)(xy & 0xffffu); y = (int)(xy >> 16); z = (int)P.rec_z[i];
+            stage_corners(P.values, P.ny, P.nz, x, y, z, col, 256);
+            const CornersLds v{col, 256, (double)P.iso};
+            const Tiling t = mc_resolve(s_lut, v);
+            const bool counted = z < P.lay_emit_end;     // the layer above is context only
+            const bool emit = counted && z >= P.lay_emit_begin;
+            if (t.nt > 0) {
+                if (counted) {
+                    uint32_t seen = 0;
+                    for (int k = 0; k < 3 * t.nt; k++) {
+                        const int e = s_lut[t.lut_off + k];
+                        if (seen & (1u << e)) continue;
+                        seen |= 1u << e;
+                        const bool mine = (e == 12) || !edge_has_live_predecessor(P, s_lut, e, x, y, z, check_dead, col);
+                        if (mine) {
+                            own |= (uint64_t)e << (4 * nown);
+                            nown++;
+                        }
+                    }
+                }
+                nt_emit = emit ? (uint32_t)t.nt : 0u;
+                info = (uint32_t)t.lut_off | (nt_emit << 14) | (nown << 18);
+                // every classified cell publishes its tiling: K4 reads it for the normals
+                P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = (uint32_t)t.lut_off | ((uint32_t)t.nt << 14);
+            } else {
+                P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = 0u;
+                if (emit && (t.index == 0xA5 || t.index == 0x5A)) atomicAdd(&P.counters->n_dead, 1u);
+            }
+            if (emit) atomicAdd(&P.counters->n_emit_cells, 1u);
+        }
+        // ordered scan: (created vertices, triangles) packed as v << 31 | t
+        const uint64_t pair = ((uint64_t)nown << 31) | nt_emit;
+        uint64_t total;
+        const uint64_t pre = block_excl_scan_u64(pair, s_wave, &total);
+        if (wave == 0) {
+            const uint64_t ex = lookback_exclusive(P.state_b, c, total, &P.counters->overflow);
+            if (lane == 0) {
+                s_excl = ex;
+                if (c == nchunks - 1) {
+                    P.counters->total_v = (uint32_t)((ex + total) >> 31);
+                    P.counters->total_t = (uint32_t)((ex + total) & 0x7fffffffull);
                 }
             }
-            const bool emit = (z >= P.lay_emit_begin);
-            info = (uint32_t)t.lut_off | ((uint32_t)(emit ? t.nt : 0) << 14) | ((uint32_t)nown << 18);
-        } else if (t.index == 0xA5 || t.index == 0x5A) {
-            atomicAdd(&P.counters->n_dead, 1u);
         }
-        P.rec_info[i] = info;
-        P.rec_own[i] = own;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K2c: ordered within-segment prefix + segment totals
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_segsum(McParams P)
-{
-    const uint32_t n = min(P.counters->n_active, P.cap_active);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t seg = P.act[i] >> 6;
-        if (i > 0 && (P.act[i - 1] >> 6) == seg) continue;  // not the first cell of its segment
-        uint32_t vs = 0, ts = 0;
-        for (uint32_t j = i; j < n && (P.act[j] >> 6) == seg; j++) {
-            const uint32_t info = P.rec_info[j];
-            P.rec_pre[j] = vs | (ts << 16);
-            vs += (info >> 18) & 15u;
-            ts += (info >> 14) & 15u;
-        }
-        P.segpack[seg] = vs | (ts << 16);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K3: exclusive scan of segpack (serial-sweep order) -> segprefix
-// ---------------------------------------------------------------------------
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
-
-__device__ __forceinline__ uint2 block_reduce_add(uint2 v, uint2* smem)
-{
-    // wave reduce
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        v.x += __shfl_down(v.x, o);
-        v.y += __shfl_down(v.y, o);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) smem[wave] = v;
-    __syncthreads();
-    uint2 r = make_uint2(0, 0);
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { r.x += smem[w].x; r.y += smem[w].y; }
-    __syncthreads();
-    return r;
-}
-
-__global__ __launch_bounds__(256) void k_scan_reduce(McParams P)
-{
-    __shared__ uint2 sm[4];
-    const uint32_t base = blockIdx.x * SCAN_TILE;
-    uint2 acc = make_uint2(0, 0);
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        const uint32_t i = base + k * 256 + threadIdx.x;
-        if (i < P.nseg) {
-            const uint32_t p = P.segpack[i];
-            acc.x += p & 0xffffu;
-            acc.y += p >> 16;
-        }
-    }
-    const uint2 tot = block_reduce_add(acc, sm);
-    if (threadIdx.x == 0) P.blocksum[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_blocks(McParams P)
-{
-    // single workgroup: exclusive scan of blocksum[0..nblk) in place, totals to counters
-    __shared__ uint2 sm[16];
-    __shared__ uint2 s_carry;
-    if (threadIdx.x == 0) s_carry = make_uint2(0, 0);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < P.nscanblk; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        uint2 v = (i < P.nscanblk) ? P.blocksum[i] : make_uint2(0, 0);
-        uint2 incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t ax = __shfl_up(incl.x, o), ay = __shfl_up(incl.y, o);
-            if (lane >= o) { incl.x += ax; incl.y += ay; }
-        }
-        if (lane == 63) sm[wave] = incl;
         __syncthreads();
-        uint2 wpre = make_uint2(0, 0), all = make_uint2(0, 0);
-        for (int w = 0; w < 16; w++) {
-            if (w < wave) { wpre.x += sm[w].x; wpre.y += sm[w].y; }
-            all.x += sm[w].x; all.y += sm[w].y;
+        if (i < n) {
+            const uint64_t basep = s_excl + pre;
+            const uint32_t vb = (uint32_t)(basep >> 31), tb = (uint32_t)(basep & 0x7fffffffull);
+            P.rec_info[i] = info;
+            P.rec_own[i] = own;
+            P.rec_base[i] = make_uint2(vb, tb);
+            // first cell of the emitted layers: everything numbered before it is "ghost"
+            if (z >= P.lay_emit_begin && (i == 0 || (int)P.rec_z[i - 1] < P.lay_emit_begin)) {
+                P.counters->nghost = vb;
+                P.counters->nghost_set = 1u;
+            }
         }
-        const uint2 carry = s_carry;
-        if (i < P.nscanblk)
-            P.blocksum[i] = make_uint2(carry.x + wpre.x + incl.x - v.x, carry.y + wpre.y + incl.y - v.y);
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = make_uint2(carry.x + all.x, carry.y + all.y);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        P.counters->total_v = s_carry.x;
-        P.counters->total_t = s_carry.y;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_scan_final(McParams P)
-{
-    __shared__ uint2 sm[4];
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint2 item[SCAN_ITEMS];
-    uint2 acc = make_uint2(0, 0);
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        const uint32_t i = base + k;
-        uint32_t p = (i < P.nseg) ? P.segpack[i] : 0u;
-        item[k] = make_uint2(p & 0xffffu, p >> 16);
-        acc.x += item[k].x;
-        acc.y += item[k].y;
-    }
-    // exclusive scan of per-thread sums across the workgroup
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2 incl = acc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t ax = __shfl_up(incl.x, o), ay = __shfl_up(incl.y, o);
-        if (lane >= o) { incl.x += ax; incl.y += ay; }
-    }
-    if (lane == 63) sm[wave] = incl;
-    __syncthreads();
-    uint2 pre = P.blocksum[blockIdx.x];
-    for (int w = 0; w < wave; w++) { pre.x += sm[w].x; pre.y += sm[w].y; }
-    pre.x += incl.x - acc.x;
-    pre.y += incl.y - acc.y;
-    const uint32_t seg_emit0 = (uint32_t)P.lay_emit_begin * (uint32_t)P.ncy * (uint32_t)P.nxw;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        const uint32_t i = base + k;
-        if (i < P.nseg) {
-            P.segprefix[i] = pre;
-            if (i == seg_emit0) P.counters->nghost = pre.x;
-        }
-        pre.x += item[k].x;
-        pre.y += item[k].y;
     }
 }
 
 // ---------------------------------------------------------------------------
-// K4: vertices
+// K4 / K5 helpers: workgroup-level re-balancing.  A chunk of 256 cells owns a variable
+// number of output items each (created vertices / triangle indices).  An exclusive prefix
+// in LDS plus a binary search turns "one lane per cell" into "one lane per output item".
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float v3len(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
-
-__device__ __forceinline__ void load_corner_color(const McParams& P, int x, int y, int z, int corner, float* c)
-{
-    if (!P.colors) { c[0] = c[1] = c[2] = 0.0f; return; }
-    const size_t o = ((size_t)(x + c_corner_dx[corner]) * P.ny + (y + c_corner_dy[corner])) * P.nz + (z + c_corner_dz[corner]);
-    c[0] = P.colors[o * 3]; c[1] = P.colors[o * 3 + 1]; c[2] = P.colors[o * 3 + 2];
-}
-
-// Accumulate into n[] what a cell with corners v adds for its edge `es`, in the order of
-// Cell.cs:332-333/355-356: once per occurrence in the LUT row, corner 1 then corner 2.
-template <class V>
-__device__ __forceinline__ void add_cell_edge_gradients(const V& v, int lut_off, int nt, int es, float* n)
-{
-    int occ = 0;
-    for (int k = 0; k < 3 * nt; k++) occ += (c_lut[lut_off + k] == es) ? 1 : 0;
-    if (!occ) return;
-    const int i1 = MC_L2(edgesrelz, es, 0) * 4 + MC_L2(edgesrely, es, 0) * 2 + MC_L2(edgesrelx, es, 0);
-    const int i2 = MC_L2(edgesrelz, es, 1) * 4 + MC_L2(edgesrely, es, 1) * 2 + MC_L2(edgesrelx, es, 1);
-    const double w1 = 1.0 / (MC_EPS + fabs(v[c_bit_to_corner[i1]]));
-    const double w2 = 1.0 / (MC_EPS + fabs(v[c_bit_to_corner[i2]]));
-    float g1[3], g2[3];
-    // NB: Cell.cs:157-158 indexes the corner-ordered gradient table with the BIT-order
-    // index (inherited quirk); reproduced: gradient of "corner i1", not of corner bit_to_corner[i1].
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        g1[j] = (float)(mc_corner_gradient(v, i1, j) * w1);
-        g2[j] = (float)(mc_corner_gradient(v, i2, j) * w2);
-    }
-    for (int o = 0; o < occ; o++) {
-        n[0] = n[0] + g1[0]; n[1] = n[1] + g1[1]; n[2] = n[2] + g1[2];
-        n[0] = n[0] + g2[0]; n[1] = n[1] + g2[1]; n[2] = n[2] + g2[2];
-    }
-}
-
-// Workgroup-level re-balancing: a chunk of 256 records owns a variable number of output
-// items each (created vertices / triangle indices).  An exclusive prefix in LDS plus a
-// binary search turns "one thread per record" into "one thread per output item".
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* s_pre /*[257]*/, uint32_t* s_wave /*[4]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -504,6 +445,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
         const uint32_t n = __shfl_up(incl, o);
         if (lane >= o) incl += n;
     }
+    __syncthreads();   // previous chunk is done with s_pre / s_wave
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     uint32_t pre = incl - v;
@@ -525,14 +467,57 @@ __device__ __forceinline__ int find_owner_256(const uint32_t* s_pre, uint32_t j)
     return lo;
 }
 
+__device__ __forceinline__ float v3len(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+
+__device__ __forceinline__ void load_corner_color(const McParams& P, int x, int y, int z, int corner, float* c)
+{
+    if (!P.colors) { c[0] = c[1] = c[2] = 0.0f; return; }
+    const size_t o = ((size_t)(x + c_corner_dx[corner]) * P.ny + (y + c_corner_dy[corner])) * P.nz + (z + c_corner_dz[corner]);
+    c[0] = P.colors[o * 3]; c[1] = P.colors[o * 3 + 1]; c[2] = P.colors[o * 3 + 2];
+}
+
+// Accumulate into n[] what a cell with corners v adds for its edge `es`, in the order of
+// Cell.cs:332-333/355-356: once per occurrence in the LUT row, corner 1 then corner 2.
+template <class V>
+__device__ __forceinline__ void add_cell_edge_gradients(const int8_t* lut, const V& v, int lut_off, int nt, int es, float* n)
+{
+    int occ = 0;
+    for (int k = 0; k < 3 * nt; k++) occ += (lut[lut_off + k] == es) ? 1 : 0;
+    if (!occ) return;
+    const int i1 = MC_L2(edgesrelz, es, 0) * 4 + MC_L2(edgesrely, es, 0) * 2 + MC_L2(edgesrelx, es, 0);
+    const int i2 = MC_L2(edgesrelz, es, 1) * 4 + MC_L2(edgesrely, es, 1) * 2 + MC_L2(edgesrelx, es, 1);
+    const double w1 = 1.0 / (MC_EPS + fabs(v[c_bit_to_corner[i1]]));
+    const double w2 = 1.0 / (MC_EPS + fabs(v[c_bit_to_corner[i2]]));
+    float g1[3], g2[3];
+    // NB: Cell.cs:157-158 indexes the corner-ordered gradient table with the BIT-order
+    // index (inherited quirk); reproduced: gradient of "corner i1", not of corner bit_to_corner[i1].
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        g1[j] = (float)(mc_corner_gradient(v, i1, j) * w1);
+        g2[j] = (float)(mc_corner_gradient(v, i2, j) * w2);
+    }
+    for (int o = 0; o < occ; o++) {
+        n[0] = n[0] + g1[0]; n[1] = n[1] + g1[1]; n[2] = n[2] + g1[2];
+        n[0] = n[0] + g2[0]; n[1] = n[1] + g2[1]; n[2] = n[2] + g2[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4: vertices
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
     __shared__ float s_c[4 * 8 * 256];   // corners of the <=4 cells around the edge: [cell][corner][thread]
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_xy[256], s_z[256], s_info[256], s_vb[256];
+    __shared__ uint64_t s_own[256];
     __shared__ float s_red[6][4];
+    mc_load_lut_to_lds(s_lut);
+    const int8_t* lut = s_lut;
     const uint32_t n = min(P.counters->n_active, P.cap_active);
-    const uint32_t nghost = P.counters->nghost;
+    const uint32_t nghost = P.counters->nghost_set ? P.counters->nghost : P.counters->total_v;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     const double iso = (double)P.iso;
     const double stp = (double)P.step;
@@ -540,18 +525,25 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     float* col = s_c + threadIdx.x;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t irec = base + threadIdx.x;
-        const uint32_t my_nown = (irec < n) ? ((P.rec_info[irec] >> 18) & 15u) : 0u;
+        uint32_t my_nown = 0;
+        __syncthreads();   // previous chunk is done with the s_* record fields
+        if (irec < n) {
+            const uint32_t info = P.rec_info[irec];
+            my_nown = (info >> 18) & 15u;
+            s_xy[threadIdx.x] = P.rec_xy[irec];
+            s_z[threadIdx.x] = P.rec_z[irec];
+            s_info[threadIdx.x] = info;
+            s_vb[threadIdx.x] = P.rec_base[irec].x;
+            s_own[threadIdx.x] = P.rec_own[irec];
+        }
         const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);
-        for (uint32_t j = threadIdx.x; j < total; j += 256u) {
+        for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per created vertex
             const int rr = find_owner_256(s_pre, j);
-            const uint32_t i = base + (uint32_t)rr;
             const int r = (int)(j - s_pre[rr]);
-            const uint32_t info = P.rec_info[i];
-            int x, y, z;
-            uint32_t seg;
-            decode_cell(P, P.act[i], x, y, z, seg);
-            const uint32_t vi = P.segprefix[seg].x + (P.rec_pre[i] & 0xffffu) + (uint32_t)r;
-            const int e = (int)((P.rec_own[i] >> (4 * r)) & 15u);
+            const uint32_t info = s_info[rr];
+            const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
+            const uint32_t vi = s_vb[rr] + (uint32_t)r;
+            const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = c_edge_dir[e];
             const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
             P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx] = vi;
@@ -564,7 +556,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
             if (e == 12) {
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
-                stage_corners(P, x, y, z, col, 256);
+                stage_corners(P.values, P.ny, P.nz, x, y, z, col, 256);
                 const CornersLds v{col, 256, iso};
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
                 float fc[3] = {0.0f, 0.0f, 0.0f};
@@ -593,19 +585,25 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 for (int jj = 0; jj < 3; jj++) colr[jj] = (float)((double)fc[jj] / ff);
                 const float g0 = (float)gsum[0], g1 = (float)gsum[1], g2 = (float)gsum[2];
                 int occ = 0;
-                for (int k = 0; k < 3 * nt_row; k++) occ += (c_lut[lut_off + k] == 12) ? 1 : 0;
+                for (int k = 0; k < 3 * nt_row; k++) occ += (lut[lut_off + k] == 12) ? 1 : 0;
                 for (int o = 0; o < occ; o++) { nrm[0] = nrm[0] + g0; nrm[1] = nrm[1] + g1; nrm[2] = nrm[2] + g2; }
             } else {
-                // stage the corners of every in-range cell around this grid edge (sweep order)
+                // stage the corners, and fetch the tilings, of every in-range cell around this
+                // grid edge (sweep order); all loads are independent of each other
                 int own_s = 0;
                 unsigned okmask = 0;
+                uint32_t tinfo[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int cx = gx + c_share_dx[dir][s], cy = gy + c_share_dy[dir][s], cz = gz + c_share_dz[dir][s];
                     const bool ok = cell_in_range(P, cx, cy, cz);
                     okmask |= ok ? (1u << s) : 0u;
                     if (cx == x && cy == y && cz == z) own_s = s;
-                    if (ok) stage_corners(P, cx, cy, cz, col + s * (8 * 256), 256);
+                    tinfo[s] = 0;
+                    if (ok) {
+                        stage_corners(P.values, P.ny, P.nz, cx, cy, cz, col + s * (8 * 256), 256);
+                        tinfo[s] = P.emap[4 * nvox + ((size_t)cz * P.ny + cy) * P.nx + cx];
+                    }
                 }
                 // Cell.AddFaceFromEdgeIndex, Cell.cs:314-350 (creator-cell frame)
                 const CornersLds v{col + own_s * (8 * 256), 256, iso};
@@ -631,18 +629,12 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     colr[jj] = (float)((double)cj / ff);
                 }
                 // normal: gather over the cells around the edge, in sweep order
-#pragma unroll 1
+#pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    if (!((okmask >> s) & 1u)) continue;
+                    const int nts = (int)((tinfo[s] >> 14) & 15u);
+                    if (!((okmask >> s) & 1u) || nts == 0) continue;
                     const CornersLds vs{col + s * (8 * 256), 256, iso};
-                    const int es = c_share_edge[dir][s];
-                    int lo = lut_off, nts = nt_row;
-                    if (s != own_s) {
-                        const Tiling ts = mc_resolve(vs);
-                        lo = ts.lut_off;
-                        nts = ts.nt;
-                    }
-                    if (nts > 0) add_cell_edge_gradients(vs, lo, nts, es, nrm);
+                    add_cell_edge_gradients(lut, vs, (int)(tinfo[s] & 0x3fffu), nts, c_share_edge[dir][s], nrm);
                 }
             }
             // Cell.NegativeNormals (Cell.cs:97-109), then Mesh.Transform (Mesh.cs:47-64)
@@ -666,7 +658,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             bmin[0] = fminf(bmin[0], px); bmin[1] = fminf(bmin[1], py); bmin[2] = fminf(bmin[2], pz);
             bmax[0] = fmaxf(bmax[0], px); bmax[1] = fmaxf(bmax[1], py); bmax[2] = fmaxf(bmax[2], pz);
         }
-        __syncthreads();   // s_pre is rewritten by the next chunk
     }
     // per-workgroup AABB partials (Mesh.Measure, Mesh.cs:30-45), reduced by k_bounds
     float r[6] = {bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2]};
@@ -678,6 +669,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], __shfl_down(r[j], o));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < 6; j++) s_red[j][wave] = r[j];
@@ -696,16 +688,23 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partia
     __shared__ float s_red[6][4];
     float r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int b = threadIdx.x; b < nblk; b += 256) {
+#pragma unroll
         for (int j = 0; j < 3; j++) r[j] = fminf(r[j], partial[(size_t)b * 6 + j]);
+#pragma unroll
         for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], partial[(size_t)b * 6 + j]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
         for (int j = 0; j < 3; j++) r[j] = fminf(r[j], __shfl_down(r[j], o));
+#pragma unroll
         for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], __shfl_down(r[j], o));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) for (int j = 0; j < 6; j++) s_red[j][wave] = r[j];
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) s_red[j][wave] = r[j];
+    }
     __syncthreads();
     if (threadIdx.x < 6) {
         const int j = threadIdx.x;
@@ -720,32 +719,39 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partia
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 {
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_xy[256], s_z[256], s_lo[256], s_tb[256];
+    mc_load_lut_to_lds(s_lut);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
-    const uint32_t nghost = P.counters->nghost;
+    const uint32_t nghost = P.counters->nghost_set ? P.counters->nghost : P.counters->total_v;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t irec = base + threadIdx.x;
-        const uint32_t my_ni = (irec < n) ? 3u * ((P.rec_info[irec] >> 14) & 15u) : 0u;
+        uint32_t my_ni = 0;
+        __syncthreads();
+        if (irec < n) {
+            const uint32_t info = P.rec_info[irec];
+            my_ni = 3u * ((info >> 14) & 15u);
+            s_xy[threadIdx.x] = P.rec_xy[irec];
+            s_z[threadIdx.x] = P.rec_z[irec];
+            s_lo[threadIdx.x] = info & 0x3fffu;
+            s_tb[threadIdx.x] = P.rec_base[irec].y;
+        }
         const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
             const int rr = find_owner_256(s_pre, j);
-            const uint32_t i = base + (uint32_t)rr;
             const uint32_t k = j - s_pre[rr];
-            const uint32_t info = P.rec_info[i];
-            int x, y, z;
-            uint32_t seg;
-            decode_cell(P, P.act[i], x, y, z, seg);
-            const size_t o = ((size_t)P.segprefix[seg].y + (P.rec_pre[i] >> 16)) * 3 + k;
+            const size_t o = (size_t)s_tb[rr] * 3 + k;
             if (o >= M.cap_indices) { P.counters->overflow = 1u; continue; }
-            const int e = c_lut[(info & 0x3fffu) + k];
+            const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
+            const int e = s_lut[s_lo[rr] + k];
             const int dir = c_edge_dir[e];
             const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
             const uint32_t vi = P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx];
             M.triangles[o] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
         }
-        __syncthreads();
     }
 }
 

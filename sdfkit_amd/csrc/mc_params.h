@@ -6,14 +6,16 @@
 namespace sdfk {
 
 struct McCounters {
-    uint32_t n_active;   // active cells found by K2a (may exceed the list capacity)
-    uint32_t n_case13;   // cells whose sign word is 0xA5/0x5A (candidates for "impossible 13")
-    uint32_t n_dead;     // case-13 cells that resolved to no tiling
-    uint32_t total_v;    // vertices created in [lay_count_begin, lay_emit_end)
-    uint32_t total_t;    // triangles emitted in [lay_emit_begin, lay_emit_end)
-    uint32_t nghost;     // vertices created in [lay_count_begin, lay_emit_begin)
-    uint32_t overflow;   // an output capacity was too small
-    uint32_t pad;
+    uint32_t n_active;     // active cells listed (may exceed the list capacity)
+    uint32_t n_case13;     // cells whose sign word is 0xA5/0x5A (candidates for "impossible 13")
+    uint32_t n_dead;       // case-13 cells that resolved to no tiling, in emitted layers
+    uint32_t total_v;      // vertices created in [lay_count_begin, lay_emit_end)
+    uint32_t total_t;      // triangles emitted in [lay_emit_begin, lay_emit_end)
+    uint32_t nghost;       // vertices created below lay_emit_begin (valid when nghost_set)
+    uint32_t nghost_set;
+    uint32_t overflow;     // 1: an output capacity was too small; 2: a bounded spin gave up
+    uint32_t n_emit_cells; // active cells inside emitted layers
+    uint32_t pad[7];
 };
 
 struct McParams {
@@ -21,26 +23,27 @@ struct McParams {
     const float* colors;   // [nx][ny][nz][3] or nullptr (= zeros)
     int nx, ny, nz;        // voxel dims of this (slab) volume
     int ncx, ncy, ncz;     // cell dims = n-1
-    int nxw;               // 64-bit X words per (z,y) row
-    uint32_t nseg;         // ncz*ncy*nxw segments, serial-sweep order
+    int nxw;               // 64-bit X words per (z,y) row of the sign-bit array
     int z0;                // global z of local plane 0
-    int lay_count_begin;   // first local cell layer whose created vertices are counted
+    int lay_count_begin;   // first local cell layer whose created vertices are numbered
     int lay_emit_begin;    // first local cell layer that is emitted
     int lay_emit_end;      // one past the last emitted layer
+    int lay_list_end;      // one past the last layer that is classified (emit_end or +1)
     float iso;
     int step;              // scale of cell coordinates in vertex positions (Cell.cs:345-347)
     // workspace
-    uint64_t* bits;
-    uint32_t* segpack;     // per segment: created vertices | triangles << 16
-    uint2* segprefix;      // exclusive scan of segpack, (vertices, triangles)
-    uint2* blocksum;
-    uint32_t nscanblk;
-    uint32_t* act;         // active cells: segment << 6 | bit
+    const uint64_t* bits;  // [nz][ny][nxw]: bit b of word xw = (value(64*xw+b, y, z) > iso)
+    int yb;                // y rows per logical block of k_compact
+    int nyc;               // ceil(ncy / yb)
+    uint64_t* state_a;     // decoupled look-back state of k_compact, one word per logical block
+    uint64_t* state_b;     // ... of k_resolve, one word per 256-record chunk
+    uint32_t* rec_xy;      // active cells in serial-sweep order: x | y << 16
+    uint32_t* rec_z;       //                                     z (local layer)
     uint32_t* rec_info;    // lut_off | nt << 14 | n_created << 18
     uint64_t* rec_own;     // created edge ids, 4 bits each, creation order
-    uint32_t* rec_pre;     // within-segment prefix: vertices | triangles << 16
+    uint2* rec_base;       // (first vertex id, first triangle) of the cell in sweep order
     uint32_t cap_active;
-    uint32_t* emap;        // [4][nz][ny][nx] vertex id per grid edge (X,Y,Z) / cell centre
+    uint32_t* emap;        // [5][nz][ny][nx]: vertex id per grid edge X,Y,Z / cell centre; tiling per cell
     McCounters* counters;
 };
 

@@ -230,9 +230,11 @@ struct sdfk_march_job {
     // everything below is owned by the job
     std::vector<void*> owned;
     sdfk_volume* sub = nullptr;    // subsampled copy for step > 1
+    size_t n_state_a = 0, n_state_b = 0;
     int gnx, gny, gnz;             // global voxel dims for Mesh.Transform
     float gmin[3], gmax[3];
     bool finished = false;
+    bool empty = false;
 };
 
 // ---------------------------------------------------------------------------
@@ -395,6 +397,8 @@ extern "C" int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global
         return fail(SDFK_ERR_INVALID, "sdfk_volume_create: bad dimensions %dx%dx%d (slab z0=%d nz=%d)", nx, ny, nz_global, z0, nz_local);
     if ((int64_t)nx * ny * nz_global >= (int64_t(1) << 31))
         return fail(SDFK_ERR_INVALID, "grid exceeds the reference's int32 linear index (Voxels.cs:82)");
+    if (nx > 65535 || ny > 65535)
+        return fail(SDFK_ERR_UNSUPPORTED, "nx and ny are limited to 65535 (cell coordinates are packed in 16 bits)");
     if (int r = require_init()) return r;
     sdfk_volume* v = new sdfk_volume();
     v->nx = nx; v->ny = ny; v->nz = nz_local; v->nz_global = nz_global; v->z0 = z0;
@@ -567,52 +571,50 @@ void job_release(sdfk_march_job* j)
     }
 }
 
+constexpr int PERSISTENT_BLOCKS = 512;   // 2 workgroups of 256 per CU: all co-resident (look-back chains)
+
 int launch_classify(sdfk_march_job* j, bool redo_bits)
 {
     McParams& P = j->P;
     HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(McCounters), g.stream));
+    HIPCHK(hipMemsetAsync(P.state_a, 0, j->n_state_a * sizeof(uint64_t), g.stream));
+    HIPCHK(hipMemsetAsync(P.state_b, 0, j->n_state_b * sizeof(uint64_t), g.stream));
     if (redo_bits) {
+        uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
         if (P.nz % 4 == 0) {
             const int wx = P.nxw >= 8 ? 8 : (P.nxw >= 4 ? 4 : (P.nxw >= 2 ? 2 : 1));
             const dim3 grid((P.nz + 63) / 64, P.ny, (P.nxw + wx - 1) / wx);
             switch (wx) {
-            case 8: hipLaunchKernelGGL(k_signbits_tile<8>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
-            case 4: hipLaunchKernelGGL(k_signbits_tile<4>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
-            case 2: hipLaunchKernelGGL(k_signbits_tile<2>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
-            default: hipLaunchKernelGGL(k_signbits_tile<1>, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            case 8: hipLaunchKernelGGL(k_signbits_tile<8>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            case 4: hipLaunchKernelGGL(k_signbits_tile<4>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            case 2: hipLaunchKernelGGL(k_signbits_tile<2>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
+            default: hipLaunchKernelGGL(k_signbits_tile<1>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
             }
         } else {
             const dim3 grid((P.nz + 63) / 64, P.ny, P.nxw);
-            hipLaunchKernelGGL(k_signbits_generic, grid, dim3(256), 0, g.stream, P.values, P.bits, P.nx, P.ny, P.nz, P.nxw, P.iso);
+            hipLaunchKernelGGL(k_signbits_generic, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso);
         }
         HIPCHK(hipGetLastError());
     }
     {
-        ProfScope ps("k_segments");
-        hipLaunchKernelGGL(k_segments, dim3((P.nseg + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK), dim3(256), 0, g.stream, P);
+        ProfScope ps("k_compact");
+        const int nlog = (P.lay_list_end - P.lay_count_begin) * P.nyc;
+        const size_t lds = (size_t)2 * (P.yb + 1) * P.nxw * sizeof(uint64_t);
+        hipLaunchKernelGGL(k_compact, dim3(std::min(nlog, PERSISTENT_BLOCKS)), dim3(256), lds, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps("k_resolve");
-        hipLaunchKernelGGL(k_resolve, dim3(256 * 8), dim3(256), 0, g.stream, P);
-        HIPCHK(hipGetLastError());
-    }
-    {
-        ProfScope ps("k_segsum");
-        hipLaunchKernelGGL(k_segsum, dim3(256 * 8), dim3(256), 0, g.stream, P);
-        HIPCHK(hipGetLastError());
-    }
-    {
-        ProfScope ps("k_scan");
-        hipLaunchKernelGGL(k_scan_reduce, dim3(P.nscanblk), dim3(256), 0, g.stream, P);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, g.stream, P);
-        hipLaunchKernelGGL(k_scan_final, dim3(P.nscanblk), dim3(256), 0, g.stream, P);
+        const int nchunks = (int)((P.cap_active + 255u) / 256u);
+        hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, PERSISTENT_BLOCKS)), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(g.h_counters, P.counters, sizeof(McCounters), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     j->c = *g.h_counters;
+    if (j->c.overflow == 2u) return fail(SDFK_ERR_HIP, "marching cubes: an inter-workgroup scan chain timed out");
+    if (!j->c.nghost_set) j->c.nghost = j->c.total_v;
     return SDFK_OK;
 }
 
@@ -662,6 +664,7 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     P.lay_emit_begin = layer_begin - w->z0;
     P.lay_emit_end = layer_end - w->z0;
     P.lay_count_begin = layer_begin > 0 ? P.lay_emit_begin - 1 : P.lay_emit_begin;
+    P.lay_list_end = std::min(P.lay_emit_end + 1, P.ncz);   // the layer above feeds seam normals
     const bool empty = (P.ncx <= 0 || P.ncy <= 0 || P.ncz <= 0 || layer_begin == layer_end);
     if (!empty) {
         // context planes the slab must hold (see sdfkit_hip.h)
@@ -673,15 +676,16 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
         }
     }
     memset(&j->c, 0, sizeof j->c);
+    j->empty = empty;
     if (empty) {
-        P.nseg = 0;
         *out = j;
         if (n_vertices) *n_vertices = 0;
         if (n_indices) *n_indices = 0;
         return SDFK_OK;
     }
-    P.nseg = (uint32_t)((size_t)P.ncz * P.ncy * P.nxw);
-    P.nscanblk = (P.nseg + SCAN_TILE - 1) / SCAN_TILE;
+    // logical blocks of k_compact: `yb` cell rows of one layer, sign words staged in <= 40 KB of LDS
+    P.yb = std::max(1, std::min(128, 2560 / P.nxw - 1));
+    P.nyc = (P.ncy + P.yb - 1) / P.yb;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     const size_t ncell = (size_t)P.ncx * P.ncy * P.ncz;
     size_t cap = std::max<size_t>(ncell / 12, 1u << 16);
@@ -689,19 +693,25 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     int r = 0;
     const bool have_bits = (step == 1 && v->bits && v->bits_valid && v->bits_iso == iso);
     if (have_bits) P.bits = v->bits;   // written by the fused sampling kernel; owned by the volume
-    else r = r ? r : job_alloc(j, &P.bits, (size_t)P.nz * P.ny * P.nxw + 1);
-    r = r ? r : job_alloc(j, &P.segpack, P.nseg);
-    r = r ? r : job_alloc(j, &P.segprefix, P.nseg);
-    r = r ? r : job_alloc(j, &P.blocksum, P.nscanblk);
-    r = r ? r : job_alloc(j, &P.emap, nvox * 4);
+    else {
+        uint64_t* bits = nullptr;
+        r = r ? r : job_alloc(j, &bits, (size_t)P.nz * P.ny * P.nxw + 1);
+        P.bits = bits;
+    }
+    j->n_state_a = (size_t)(P.lay_list_end - P.lay_count_begin) * P.nyc + 1;
+    r = r ? r : job_alloc(j, &P.state_a, j->n_state_a);
+    r = r ? r : job_alloc(j, &P.emap, nvox * 5);
     r = r ? r : job_alloc(j, &P.counters, 1);
     size_t act_idx = 0;
     auto alloc_records = [&](size_t c) -> int {
         int rr = 0;
-        rr = rr ? rr : job_alloc(j, &P.act, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_xy, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_z, c);
         rr = rr ? rr : job_alloc(j, &P.rec_info, c);
         rr = rr ? rr : job_alloc(j, &P.rec_own, c);
-        rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_base, c);
+        j->n_state_b = c / 256 + 2;
+        rr = rr ? rr : job_alloc(j, &P.state_b, j->n_state_b);
         P.cap_active = (uint32_t)c;
         return rr;
     };
@@ -710,7 +720,7 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     if (r) { job_release(j); delete j; return r; }
     r = launch_classify(j, !have_bits);
     if (!r && j->c.n_active > P.cap_active) {
-        // active-cell list too small: grow to the exact need and redo from K2a
+        // active-cell list too small: grow to the exact need and redo from the compaction
         for (size_t k = act_idx; k < j->owned.size(); k++) dev_free(j->owned[k]);
         j->owned.resize(act_idx);
         r = alloc_records(j->c.n_active);
@@ -730,7 +740,7 @@ int march_finish_impl(sdfk_march_job* j, int64_t vertex_base, sdfk_mesh** out)
     sdfk_mesh* m = new sdfk_mesh();
     m->nv = (int64_t)j->c.total_v - (int64_t)j->c.nghost;
     m->ni = (int64_t)j->c.total_t * 3;
-    m->n_active = j->c.n_active;
+    m->n_active = j->c.n_emit_cells;
     m->n_case13 = j->c.n_dead;
     if (vertex_base + m->nv >= (int64_t(1) << 31)) { delete m; return fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])"); }
     int r = 0;
@@ -741,7 +751,7 @@ int march_finish_impl(sdfk_march_job* j, int64_t vertex_base, sdfk_mesh** out)
     r = r ? r : dev_alloc((void**)&m->bounds, 6 * sizeof(float));
     if (r) { sdfk_mesh_free(m); return r; }
     j->finished = true;
-    if (j->P.nseg == 0 || j->c.n_active == 0) {
+    if (j->empty || j->c.n_active == 0) {
         m->bounds_valid = true;  // Mesh.Measure leaves Min/Max at zero for an empty mesh (Mesh.cs:32)
         *out = m;
         return SDFK_OK;
@@ -826,7 +836,7 @@ extern "C" int sdfk_march(const sdfk_volume* v, float iso_value, int32_t step, s
     if (r) return r;
     r = march_finish_impl(j, 0, out);
     // the emit kernels read job buffers: release them only after the stream has drained
-    if (!r && j->P.nseg) r = (hipStreamSynchronize(g.stream) == hipSuccess) ? SDFK_OK : fail(SDFK_ERR_HIP, "stream sync failed");
+    if (!r && !j->empty) r = (hipStreamSynchronize(g.stream) == hipSuccess) ? SDFK_OK : fail(SDFK_ERR_HIP, "stream sync failed");
     job_release(j);
     delete j;
     return r;
