@@ -8,16 +8,16 @@
 //                 bits[z][y][xw], bit b = (value(64*xw+b, y, z) > iso).  The only dense pass
 //                 over the volume (4 B/voxel read).  Skipped when the fused sampling kernel
 //                 (sample_codegen.h, sdfk_sample_bits) already produced the bits.
-//   K2  compact   persistent workgroups walk the 64-cell X-runs of the sweep in order;
-//                 "8 corners not all equal" is 64-bit-parallel on the sign words; popcounts
-//                 are scanned in the workgroup (wave shuffles) and across workgroups with a
-//                 decoupled look-back chain, so the active-cell list comes out in EXACT
-//                 serial-sweep order without sorting and without atomics.
+//   K2  compact   workgroups own chunks of 64-cell X-runs in sweep order; "8 corners not all
+//                 equal" is 64-bit-parallel on the sign words.  Count pass -> one-workgroup
+//                 scan of the per-chunk counts -> write pass (wave-shuffle prefix inside the
+//                 workgroup): the active-cell list comes out in EXACT serial-sweep order
+//                 without sorting and without atomics.
 //   K3  resolve   one lane per active cell: gathers the 8 corners into its LDS column, runs
 //                 the 33-case dispatcher, decides which vertices the cell CREATES in the sweep
-//                 (it is the first live cell of the sweep touching that grid edge), and scans
-//                 (created vertices, triangles) with the same look-back chain -> every cell
-//                 knows its first vertex id and first triangle.
+//                 (it is the first live cell of the sweep touching that grid edge); per-256-cell
+//                 totals of (created vertices, triangles) are scanned by one workgroup, so
+//                 every cell's first vertex id / first triangle = chunk prefix + in-chunk prefix.
 //   K4  vertices  one lane per created vertex: position/colour in the creator's frame, normal
 //                 as a gather over the <=4 cells around the edge in sweep order (bit-exact
 //                 float32 accumulation order, no atomics).
@@ -133,47 +133,6 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_
     return pre;
 }
 
-// Decoupled look-back (single-pass chained scan) across logical blocks processed in
-// increasing order by persistent, co-resident workgroups.  One 64-bit word per logical block:
-// status in bits 63:62 (0 = not yet, 1 = aggregate of this block, 2 = inclusive prefix),
-// value in bits 61:0.  Status and value travel in ONE naturally aligned word written and read
-// with relaxed agent-scope atomics, so no other ordering is needed and no data hand-off
-// depends on workgroup placement.  Called by wave 0 (all 64 lanes); returns the exclusive
-// prefix of block b.  The spin is bounded: on give-up *failed is set.
-constexpr uint64_t ST_AGG = 1ull << 62, ST_PRE = 2ull << 62, ST_MASK = 3ull << 62;
-
-__device__ __forceinline__ uint64_t lookback_exclusive(uint64_t* state, int b, uint64_t total, uint32_t* failed)
-{
-    const int lane = threadIdx.x & 63;
-    if (lane == 0)
-        __hip_atomic_store(&state[b], (b == 0 ? ST_PRE : ST_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (b == 0) return 0;
-    uint64_t excl = 0;
-    int pos = b - 1;
-    for (;;) {
-        const int idx = pos - lane;
-        uint64_t w = ST_PRE;   // before block 0: prefix 0
-        int spins = 0;
-        for (;;) {
-            if (idx >= 0) w = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!__any((w & ST_MASK) == 0)) break;
-            if (++spins > (1 << 24)) { *failed = 2u; return excl; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const uint64_t pm = __ballot((w & ST_MASK) == ST_PRE);
-        if (pm) {
-            const int first = __builtin_ctzll(pm);   // nearest predecessor holding a full prefix
-            excl += wave_sum_u64(lane <= first ? (w & ~ST_MASK) : 0ull);
-            break;
-        }
-        excl += wave_sum_u64(w & ~ST_MASK);
-        pos -= 64;
-    }
-    if (lane == 0)
-        __hip_atomic_store(&state[b], ST_PRE | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
-
 // ---------------------------------------------------------------------------
 // K2: ordered compaction of active cells
 // ---------------------------------------------------------------------------
@@ -203,71 +162,131 @@ __device__ __forceinline__ uint64_t segment_mask(const uint64_t* lo, const uint6
 }
 
 // Logical block b = (layer z, chunk of `yb` cell rows); logical order == sweep order.
-// Dynamic LDS: two planes of (yb+1) rows x nxw sign words.
+// Dynamic LDS: two planes of (yb+1) rows x nxw sign words.  WRITE = false: count the active
+// cells of the block; WRITE = true: write them at blockpre[b] + in-block prefix.
+template <bool WRITE>
 __global__ __launch_bounds__(256) void k_compact(McParams P)
 {
     extern __shared__ uint64_t s_bits[];
     __shared__ uint64_t s_wave[4];
-    __shared__ uint64_t s_excl;
     const int plane = (P.yb + 1) * P.nxw;
-    const int nlog = (P.lay_list_end - P.lay_count_begin) * P.nyc;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = blockIdx.x; b < nlog; b += gridDim.x) {
-        const int z = P.lay_count_begin + b / P.nyc;
-        const int y0 = (b % P.nyc) * P.yb;
-        const int rows = min(P.yb, P.ncy - y0);
-        const int nwords = (rows + 1) * P.nxw;
-        const uint64_t* g0 = P.bits + ((size_t)z * P.ny + y0) * P.nxw;
-        const uint64_t* g1 = g0 + (size_t)P.ny * P.nxw;
-        __syncthreads();   // previous iteration is done with s_bits
-        for (int i = threadIdx.x; i < nwords; i += 256) {
-            s_bits[i] = g0[i];
-            s_bits[plane + i] = g1[i];
+    const int b = blockIdx.x;
+    const int z = P.lay_count_begin + b / P.nyc;
+    const int y0 = (b % P.nyc) * P.yb;
+    const int rows = min(P.yb, P.ncy - y0);
+    const int nwords = (rows + 1) * P.nxw;
+    const uint64_t* g0 = P.bits + ((size_t)z * P.ny + y0) * P.nxw;
+    const uint64_t* g1 = g0 + (size_t)P.ny * P.nxw;
+    for (int i = threadIdx.x; i < nwords; i += 256) {
+        s_bits[i] = g0[i];
+        s_bits[plane + i] = g1[i];
+    }
+    __syncthreads();
+    // each lane owns `per` CONSECUTIVE segments, so lane order == sweep order
+    const int nsegs = rows * P.nxw;
+    const int per = (nsegs + 255) >> 8;
+    const int sb = min((int)threadIdx.x * per, nsegs), se = min(sb + per, nsegs);
+    uint32_t cnt = 0, n13 = 0;
+    {
+        int y_l = sb / P.nxw, xw = sb % P.nxw;
+        for (int s = sb; s < se; s++) {
+            uint64_t m13;
+            cnt += (uint32_t)__popcll(segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13));
+            n13 += (uint32_t)__popcll(m13);
+            if (++xw == P.nxw) { xw = 0; y_l++; }
         }
-        __syncthreads();
-        // each lane owns `per` CONSECUTIVE segments, so lane order == sweep order
-        const int nsegs = rows * P.nxw;
-        const int per = (nsegs + 255) >> 8;
-        const int sb = min((int)threadIdx.x * per, nsegs), se = min(sb + per, nsegs);
-        uint32_t cnt = 0, n13 = 0;
-        {
-            int y_l = sb / P.nxw, xw = sb % P.nxw;
-            for (int s = sb; s < se; s++) {
-                uint64_t m13;
-                cnt += (uint32_t)__popcll(segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13));
-                n13 += (uint32_t)__popcll(m13);
-                if (++xw == P.nxw) { xw = 0; y_l++; }
-            }
-        }
+    }
+    uint64_t total;
+    const uint64_t pre = block_excl_scan_u64(cnt, s_wave, &total);
+    if (!WRITE) {
         if (n13) atomicAdd(&P.counters->n_case13, n13);
-        uint64_t total;
-        const uint64_t pre = block_excl_scan_u64(cnt, s_wave, &total);
-        if (wave == 0) {
-            const uint64_t ex = lookback_exclusive(P.state_a, b, total, &P.counters->overflow);
-            if (lane == 0) {
-                s_excl = ex;
-                if (b == nlog - 1) P.counters->n_active = (uint32_t)(ex + total);
-            }
-        }
-        __syncthreads();
-        if (cnt) {
-            uint32_t pos = (uint32_t)(s_excl + pre);
-            int y_l = sb / P.nxw, xw = sb % P.nxw;
-            for (int s = sb; s < se; s++) {
-                uint64_t m13;
-                uint64_t m = segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13);
-                const uint32_t yz = (uint32_t)(y0 + y_l) << 16;
-                while (m) {
-                    const int bit = __builtin_ctzll(m);
-                    m &= m - 1;
-                    if (pos < P.cap_active) {
-                        P.rec_xy[pos] = (uint32_t)(xw * 64 + bit) | yz;
-                        P.rec_z[pos] = (uint32_t)z;
-                    }
-                    pos++;
+        if (threadIdx.x == 0) P.blockcnt[b] = total;
+        return;
+    }
+    if (cnt) {
+        uint32_t pos = (uint32_t)(P.blockcnt[b] + pre);   // blockcnt now holds the exclusive prefix
+        int y_l = sb / P.nxw, xw = sb % P.nxw;
+        for (int s = sb; s < se; s++) {
+            uint64_t m13;
+            uint64_t m = segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13);
+            const uint32_t yz = (uint32_t)(y0 + y_l) << 16;
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                if (pos < P.cap_active) {
+                    P.rec_xy[pos] = (uint32_t)(xw * 64 + bit) | yz;
+                    P.rec_z[pos] = (uint32_t)z;
                 }
-                if (++xw == P.nxw) { xw = 0; y_l++; }
+                pos++;
             }
+            if (++xw == P.nxw) { xw = 0; y_l++; }
+        }
+    }
+}
+
+// One workgroup: in-place exclusive scan of data[0..n) (64-bit adds; a value may pack two
+// counters).  MODE 0: per-block active-cell counts -> n_active, n_ghost_records.
+// MODE 1: per-chunk (vertices << 31 | triangles) -> totals and nghost.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_scan1(McParams P)
+{
+    __shared__ uint64_t sm[16];
+    __shared__ uint64_t s_carry;
+    uint64_t* data = MODE == 0 ? P.blockcnt : P.chunktot;
+    uint32_t n;
+    if (MODE == 0) n = (uint32_t)((P.lay_list_end - P.lay_count_begin) * P.nyc);
+    else n = (min(P.counters->n_active, P.cap_active) + 255u) >> 8;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = (i < n) ? data[i] : 0ull;
+        const uint64_t incl = wave_incl_scan_u64(v);
+        if (lane == 63) sm[wave] = incl;
+        __syncthreads();
+        uint64_t wpre = 0, all = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) wpre += sm[w];
+            all += sm[w];
+        }
+        const uint64_t carry = s_carry;
+        if (i < n) data[i] = carry + wpre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + all;
+        __syncthreads();
+    }
+    if (MODE == 0) {
+        if (threadIdx.x == 0) {
+            const uint32_t tot = (uint32_t)s_carry;
+            P.counters->n_active = tot;
+            // cells listed below the first emitted layer (the "ghost" layer of a slab), and
+            // inside the emitted layers
+            const uint32_t gb = (uint32_t)((P.lay_emit_begin - P.lay_count_begin) * P.nyc);
+            const uint32_t ge = (uint32_t)((P.lay_emit_end - P.lay_count_begin) * P.nyc);
+            const uint32_t ng = gb == 0 ? 0u : (gb < n ? (uint32_t)data[gb] : tot);
+            P.counters->n_ghost_cells = ng;
+            P.counters->n_emit_cells = (ge < n ? (uint32_t)data[ge] : tot) - ng;
+        }
+    } else {
+        // vertices numbered before the first emitted cell: chunk prefix + in-chunk prefix
+        __shared__ uint32_t s_part[16];
+        const uint32_t nrec = min(P.counters->n_active, P.cap_active);
+        const uint32_t i0 = min(P.counters->n_ghost_cells, nrec);
+        const uint32_t c0 = i0 >> 8, r0 = i0 & 255u;
+        uint32_t part = 0;
+        if (threadIdx.x < r0) part = (P.rec_info[c0 * 256u + threadIdx.x] >> 18) & 15u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) s_part[wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t in_chunk = 0;
+            for (int w = 0; w < 16; w++) in_chunk += s_part[w];
+            const uint64_t basep = (c0 < n) ? data[c0] : s_carry;
+            P.counters->nghost = (uint32_t)(basep >> 31) + in_chunk;
+            P.counters->total_v = (uint32_t)(s_carry >> 31);
+            P.counters->total_t = (uint32_t)(s_carry & 0x7fffffffull);
         }
     }
 }
@@ -348,35 +367,33 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, con
 }
 
 // ---------------------------------------------------------------------------
-// K3: resolve tilings + vertex creation + ordered scan of (vertices, triangles)
+// K3: resolve tilings + vertex creation; per-chunk totals of (vertices, triangles)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(McParams P)
 {
     __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
     __shared__ uint64_t s_wave[4];
-    __shared__ uint64_t s_excl;
     mc_load_lut_to_lds(s_lut);
     __syncthreads();
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const bool check_dead = P.counters->n_case13 != 0;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     const int nchunks = (int)((n + 255u) >> 8);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* col = s_v + threadIdx.x;
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint32_t i = (uint32_t)c * 256u + threadIdx.x;
-        uint32_t info = 0, nown = 0, nt_emit = 0;
-        uint64_t own = 0;
-        int x = 0, y = 0, z = 0;
+        uint32_t nown = 0, nt_emit = 0;
         if (i < n) {
             const uint32_t xy = P.rec_xy[i];
-            x = (int)(xy & 0xffffu); y = (int)(xy >> 16); z = (int)P.rec_z[i];
+            const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), z = (int)P.rec_z[i];
             stage_corners(P.values, P.ny, P.nz, x, y, z, col, 256);
             const CornersLds v{col, 256, (double)P.iso};
             const Tiling t = mc_resolve(s_lut, v);
             const bool counted = z < P.lay_emit_end;     // the layer above is context only
             const bool emit = counted && z >= P.lay_emit_begin;
+            uint32_t info = 0;
+            uint64_t own = 0;
             if (t.nt > 0) {
                 if (counted) {
                     uint32_t seen = 0;
@@ -399,35 +416,13 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
                 P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = 0u;
                 if (emit && (t.index == 0xA5 || t.index == 0x5A)) atomicAdd(&P.counters->n_dead, 1u);
             }
-            if (emit) atomicAdd(&P.counters->n_emit_cells, 1u);
-        }
-        // ordered scan: (created vertices, triangles) packed as v << 31 | t
-        const uint64_t pair = ((uint64_t)nown << 31) | nt_emit;
-        uint64_t total;
-        const uint64_t pre = block_excl_scan_u64(pair, s_wave, &total);
-        if (wave == 0) {
-            const uint64_t ex = lookback_exclusive(P.state_b, c, total, &P.counters->overflow);
-            if (lane == 0) {
-                s_excl = ex;
-                if (c == nchunks - 1) {
-                    P.counters->total_v = (uint32_t)((ex + total) >> 31);
-                    P.counters->total_t = (uint32_t)((ex + total) & 0x7fffffffull);
-                }
-            }
-        }
-        __syncthreads();
-        if (i < n) {
-            const uint64_t basep = s_excl + pre;
-            const uint32_t vb = (uint32_t)(basep >> 31), tb = (uint32_t)(basep & 0x7fffffffull);
             P.rec_info[i] = info;
             P.rec_own[i] = own;
-            P.rec_base[i] = make_uint2(vb, tb);
-            // first cell of the emitted layers: everything numbered before it is "ghost"
-            if (z >= P.lay_emit_begin && (i == 0 || (int)P.rec_z[i - 1] < P.lay_emit_begin)) {
-                P.counters->nghost = vb;
-                P.counters->nghost_set = 1u;
-            }
         }
+        // (created vertices, triangles) of the chunk, packed as v << 31 | t
+        uint64_t total;
+        (void)block_excl_scan_u64(((uint64_t)nown << 31) | nt_emit, s_wave, &total);
+        if (threadIdx.x == 0) P.chunktot[c] = total;
     }
 }
 
@@ -511,13 +506,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_xy[256], s_z[256], s_info[256], s_vb[256];
+    __shared__ uint32_t s_xy[256], s_z[256], s_info[256];
     __shared__ uint64_t s_own[256];
     __shared__ float s_red[6][4];
     mc_load_lut_to_lds(s_lut);
     const int8_t* lut = s_lut;
     const uint32_t n = min(P.counters->n_active, P.cap_active);
-    const uint32_t nghost = P.counters->nghost_set ? P.counters->nghost : P.counters->total_v;
+    const uint32_t nghost = P.counters->nghost;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     const double iso = (double)P.iso;
     const double stp = (double)P.step;
@@ -533,16 +528,16 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             s_xy[threadIdx.x] = P.rec_xy[irec];
             s_z[threadIdx.x] = P.rec_z[irec];
             s_info[threadIdx.x] = info;
-            s_vb[threadIdx.x] = P.rec_base[irec].x;
             s_own[threadIdx.x] = P.rec_own[irec];
         }
         const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);
+        const uint32_t chunk_vbase = (uint32_t)(P.chunktot[base >> 8] >> 31);   // scanned by k_scan1<1>
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per created vertex
             const int rr = find_owner_256(s_pre, j);
             const int r = (int)(j - s_pre[rr]);
             const uint32_t info = s_info[rr];
             const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
-            const uint32_t vi = s_vb[rr] + (uint32_t)r;
+            const uint32_t vi = chunk_vbase + j;   // chunk prefix + in-chunk prefix: serial vertex id
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = c_edge_dir[e];
             const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
@@ -722,10 +717,10 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_xy[256], s_z[256], s_lo[256], s_tb[256];
+    __shared__ uint32_t s_xy[256], s_z[256], s_lo[256];
     mc_load_lut_to_lds(s_lut);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
-    const uint32_t nghost = P.counters->nghost_set ? P.counters->nghost : P.counters->total_v;
+    const uint32_t nghost = P.counters->nghost;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t irec = base + threadIdx.x;
@@ -737,13 +732,13 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             s_xy[threadIdx.x] = P.rec_xy[irec];
             s_z[threadIdx.x] = P.rec_z[irec];
             s_lo[threadIdx.x] = info & 0x3fffu;
-            s_tb[threadIdx.x] = P.rec_base[irec].y;
         }
         const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
+        const size_t chunk_ibase = (size_t)(P.chunktot[base >> 8] & 0x7fffffffull) * 3;
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
             const int rr = find_owner_256(s_pre, j);
             const uint32_t k = j - s_pre[rr];
-            const size_t o = (size_t)s_tb[rr] * 3 + k;
+            const size_t o = chunk_ibase + j;   // serial position of this triangle index
             if (o >= M.cap_indices) { P.counters->overflow = 1u; continue; }
             const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
             const int e = s_lut[s_lo[rr] + k];

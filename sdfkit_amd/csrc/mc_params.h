@@ -11,8 +11,8 @@ struct McCounters {
     uint32_t n_dead;       // case-13 cells that resolved to no tiling, in emitted layers
     uint32_t total_v;      // vertices created in [lay_count_begin, lay_emit_end)
     uint32_t total_t;      // triangles emitted in [lay_emit_begin, lay_emit_end)
-    uint32_t nghost;       // vertices created below lay_emit_begin (valid when nghost_set)
-    uint32_t nghost_set;
+    uint32_t nghost;       // vertices created below lay_emit_begin
+    uint32_t n_ghost_cells;// active cells listed below lay_emit_begin
     uint32_t overflow;     // 1: an output capacity was too small; 2: a bounded spin gave up
     uint32_t n_emit_cells; // active cells inside emitted layers
     uint32_t pad[7];
@@ -35,13 +35,12 @@ struct McParams {
     const uint64_t* bits;  // [nz][ny][nxw]: bit b of word xw = (value(64*xw+b, y, z) > iso)
     int yb;                // y rows per logical block of k_compact
     int nyc;               // ceil(ncy / yb)
-    uint64_t* state_a;     // decoupled look-back state of k_compact, one word per logical block
-    uint64_t* state_b;     // ... of k_resolve, one word per 256-record chunk
+    uint64_t* blockcnt;    // active cells per logical block of k_compact; exclusive prefix after k_scan1<0>
+    uint64_t* chunktot;    // (vertices << 31 | triangles) per 256-cell chunk; exclusive prefix after k_scan1<1>
     uint32_t* rec_xy;      // active cells in serial-sweep order: x | y << 16
     uint32_t* rec_z;       //                                     z (local layer)
     uint32_t* rec_info;    // lut_off | nt << 14 | n_created << 18
     uint64_t* rec_own;     // created edge ids, 4 bits each, creation order
-    uint2* rec_base;       // (first vertex id, first triangle) of the cell in sweep order
     uint32_t cap_active;
     uint32_t* emap;        // [5][nz][ny][nx]: vertex id per grid edge X,Y,Z / cell centre; tiling per cell
     McCounters* counters;

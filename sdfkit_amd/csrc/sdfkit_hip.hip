@@ -230,7 +230,6 @@ struct sdfk_march_job {
     // everything below is owned by the job
     std::vector<void*> owned;
     sdfk_volume* sub = nullptr;    // subsampled copy for step > 1
-    size_t n_state_a = 0, n_state_b = 0;
     int gnx, gny, gnz;             // global voxel dims for Mesh.Transform
     float gmin[3], gmax[3];
     bool finished = false;
@@ -571,14 +570,10 @@ void job_release(sdfk_march_job* j)
     }
 }
 
-constexpr int PERSISTENT_BLOCKS = 512;   // 2 workgroups of 256 per CU: all co-resident (look-back chains)
-
 int launch_classify(sdfk_march_job* j, bool redo_bits)
 {
     McParams& P = j->P;
     HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(McCounters), g.stream));
-    HIPCHK(hipMemsetAsync(P.state_a, 0, j->n_state_a * sizeof(uint64_t), g.stream));
-    HIPCHK(hipMemsetAsync(P.state_b, 0, j->n_state_b * sizeof(uint64_t), g.stream));
     if (redo_bits) {
         uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
@@ -601,20 +596,21 @@ int launch_classify(sdfk_march_job* j, bool redo_bits)
         ProfScope ps("k_compact");
         const int nlog = (P.lay_list_end - P.lay_count_begin) * P.nyc;
         const size_t lds = (size_t)2 * (P.yb + 1) * P.nxw * sizeof(uint64_t);
-        hipLaunchKernelGGL(k_compact, dim3(std::min(nlog, PERSISTENT_BLOCKS)), dim3(256), lds, g.stream, P);
+        hipLaunchKernelGGL(k_compact<false>, dim3(nlog), dim3(256), lds, g.stream, P);
+        hipLaunchKernelGGL(k_scan1<0>, dim3(1), dim3(1024), 0, g.stream, P);
+        hipLaunchKernelGGL(k_compact<true>, dim3(nlog), dim3(256), lds, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps("k_resolve");
         const int nchunks = (int)((P.cap_active + 255u) / 256u);
-        hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, PERSISTENT_BLOCKS)), dim3(256), 0, g.stream, P);
+        hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, 256 * 12)), dim3(256), 0, g.stream, P);
+        hipLaunchKernelGGL(k_scan1<1>, dim3(1), dim3(1024), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(g.h_counters, P.counters, sizeof(McCounters), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     j->c = *g.h_counters;
-    if (j->c.overflow == 2u) return fail(SDFK_ERR_HIP, "marching cubes: an inter-workgroup scan chain timed out");
-    if (!j->c.nghost_set) j->c.nghost = j->c.total_v;
     return SDFK_OK;
 }
 
@@ -698,8 +694,7 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
         r = r ? r : job_alloc(j, &bits, (size_t)P.nz * P.ny * P.nxw + 1);
         P.bits = bits;
     }
-    j->n_state_a = (size_t)(P.lay_list_end - P.lay_count_begin) * P.nyc + 1;
-    r = r ? r : job_alloc(j, &P.state_a, j->n_state_a);
+    r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.nyc + 1);
     r = r ? r : job_alloc(j, &P.emap, nvox * 5);
     r = r ? r : job_alloc(j, &P.counters, 1);
     size_t act_idx = 0;
@@ -709,9 +704,7 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
         rr = rr ? rr : job_alloc(j, &P.rec_z, c);
         rr = rr ? rr : job_alloc(j, &P.rec_info, c);
         rr = rr ? rr : job_alloc(j, &P.rec_own, c);
-        rr = rr ? rr : job_alloc(j, &P.rec_base, c);
-        j->n_state_b = c / 256 + 2;
-        rr = rr ? rr : job_alloc(j, &P.state_b, j->n_state_b);
+        rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
         P.cap_active = (uint32_t)c;
         return rr;
     };
