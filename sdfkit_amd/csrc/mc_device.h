@@ -17,14 +17,22 @@ namespace sdfk {
 // The packed table blob lives in __constant__ memory; kernels copy it into LDS once per
 // workgroup (13.5 KB) because the per-cell decisions are chains of dependent table reads
 // with run-time (divergent) indices -- LDS latency instead of vector-cache latency.
-__constant__ __attribute__((aligned(16))) int8_t c_lut[MCLUT_BLOB_SIZE] = {MCLUT_BLOB_VALUES};
-static_assert(MCLUT_BLOB_SIZE % 4 == 0, "blob is copied to LDS in dwords");
+constexpr int MCLUT_PADDED = (MCLUT_BLOB_SIZE + 15) & ~15;   // copied in 16-byte pieces
+__constant__ __attribute__((aligned(16))) int8_t c_lut[MCLUT_PADDED] = {MCLUT_BLOB_VALUES};
 
-__device__ __forceinline__ void mc_load_lut_to_lds(int8_t* s_lut)
+// 256-thread workgroups only.  All loads are issued before the first LDS store: a plain
+// "load; store" loop is not unrolled by the compiler and costs one L2 round trip per trip.
+__device__ __forceinline__ void mc_load_lut_to_lds(int8_t* s_lut /* MCLUT_PADDED bytes, 16-byte aligned */)
 {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(c_lut);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(s_lut);
-    for (int i = threadIdx.x; i < MCLUT_BLOB_SIZE / 4; i += blockDim.x) dst[i] = src[i];
+    constexpr int N = MCLUT_PADDED / 16;
+    static_assert(N > 768 && N <= 1024, "copy below assumes 3 full rounds + 1 partial of 256 lanes");
+    const uint4* src = reinterpret_cast<const uint4*>(c_lut);
+    uint4* dst = reinterpret_cast<uint4*>(s_lut);
+    const int t = (int)threadIdx.x;
+    const uint4 r0 = src[t], r1 = src[t + 256], r2 = src[t + 512];
+    const uint4 r3 = src[min(t + 768, N - 1)];
+    dst[t] = r0; dst[t + 256] = r1; dst[t + 512] = r2;
+    if (t + 768 < N) dst[t + 768] = r3;
 }
 
 // every function below takes `lut` = base of the blob (LDS or constant)
@@ -51,6 +59,18 @@ struct CornersLds {          // float voxels in LDS, [corner][thread] with `stri
     int stride;
     double iso;
     __device__ __forceinline__ double operator[](int k) const { return (double)p[k * stride] - iso; }
+};
+// Corners of one cell inside a 3x3x3 voxel block staged per thread in LDS
+// ([(lx*3+ly)*3+lz][256 threads]); (ox,oy,oz) = the cell's origin inside the block.
+struct CornersNbr {
+    const float* p;
+    int ox, oy, oz;
+    double iso;
+    __device__ __forceinline__ double operator[](int k) const
+    {
+        const int dx = ((k + 1) >> 1) & 1, dy = (k >> 1) & 1, dz = k >> 2;   // corner k of Luts.cs:30-52
+        return (double)p[(((ox + dx) * 3 + (oy + dy)) * 3 + (oz + dz)) * 256] - iso;
+    }
 };
 struct CornersPtr {          // plain array of iso-subtracted doubles
     const double* p;

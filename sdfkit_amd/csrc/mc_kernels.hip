@@ -177,9 +177,18 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     const int nwords = (rows + 1) * P.nxw;
     const uint64_t* g0 = P.bits + ((size_t)z * P.ny + y0) * P.nxw;
     const uint64_t* g1 = g0 + (size_t)P.ny * P.nxw;
-    for (int i = threadIdx.x; i < nwords; i += 256) {
-        s_bits[i] = g0[i];
-        s_bits[plane + i] = g1[i];
+    {   // (yb+1)*nxw <= 2560 words per plane: at most 10 per lane; all loads issued up front
+        uint64_t r0[10], r1[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int i = (int)threadIdx.x + 256 * k;
+            if (i < nwords) { r0[k] = g0[i]; r1[k] = g1[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int i = (int)threadIdx.x + 256 * k;
+            if (i < nwords) { s_bits[i] = r0[k]; s_bits[plane + i] = r1[k]; }
+        }
     }
     __syncthreads();
     // each lane owns `per` CONSECUTIVE segments, so lane order == sweep order
@@ -294,15 +303,21 @@ __global__ __launch_bounds__(1024) void k_scan1(McParams P)
 // ---------------------------------------------------------------------------
 // shared helpers
 // ---------------------------------------------------------------------------
+// 4-byte-aligned vector types: gfx950 (unaligned access mode) loads them with one instruction
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
 // the 8 corner voxels of cell (x,y,z) into this thread's LDS column ([corner][thread])
 __device__ __forceinline__ void stage_corners(const float* values, int ny, int nz, int x, int y, int z, float* col, int stride)
 {
+    // the two z-neighbours of a corner pair are adjacent in memory: four 8-byte loads
     const size_t sx = (size_t)ny * nz, sy = (size_t)nz;
     const float* p = values + (size_t)x * sx + (size_t)y * sy + z;
-    const float a0 = p[0], a4 = p[1], a1 = p[sx], a5 = p[sx + 1];
-    const float a3 = p[sy], a7 = p[sy + 1], a2 = p[sx + sy], a6 = p[sx + sy + 1];
-    col[0] = a0; col[stride] = a1; col[2 * stride] = a2; col[3 * stride] = a3;
-    col[4 * stride] = a4; col[5 * stride] = a5; col[6 * stride] = a6; col[7 * stride] = a7;
+    const f2u q0 = *reinterpret_cast<const f2u*>(p), q1 = *reinterpret_cast<const f2u*>(p + sx);
+    const f2u q3 = *reinterpret_cast<const f2u*>(p + sy), q2 = *reinterpret_cast<const f2u*>(p + sx + sy);
+    col[0] = q0.x; col[stride] = q1.x; col[2 * stride] = q2.x; col[3 * stride] = q3.x;
+    col[4 * stride] = q0.y; col[5 * stride] = q1.y; col[6 * stride] = q2.y; col[7 * stride] = q3.y;
 }
 
 __device__ __forceinline__ bool cell_in_range(const McParams& P, int x, int y, int z)
@@ -372,7 +387,7 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, con
 __global__ __launch_bounds__(256) void k_resolve(McParams P)
 {
     __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
     __shared__ uint64_t s_wave[4];
     mc_load_lut_to_lds(s_lut);
     __syncthreads();
@@ -468,7 +483,8 @@ __device__ __forceinline__ void load_corner_color(const McParams& P, int x, int 
 {
     if (!P.colors) { c[0] = c[1] = c[2] = 0.0f; return; }
     const size_t o = ((size_t)(x + c_corner_dx[corner]) * P.ny + (y + c_corner_dy[corner])) * P.nz + (z + c_corner_dz[corner]);
-    c[0] = P.colors[o * 3]; c[1] = P.colors[o * 3 + 1]; c[2] = P.colors[o * 3 + 2];
+    const f3u q = *reinterpret_cast<const f3u*>(P.colors + o * 3);
+    c[0] = q.x; c[1] = q.y; c[2] = q.z;
 }
 
 // Accumulate into n[] what a cell with corners v adds for its edge `es`, in the order of
@@ -500,10 +516,44 @@ __device__ __forceinline__ void add_cell_edge_gradients(const int8_t* lut, const
 // ---------------------------------------------------------------------------
 // K4: vertices
 // ---------------------------------------------------------------------------
+// The 3x3x3 voxel block around grid point (gx,gy,gz) -- origin (gx-1,gy-1,gz-1) -- into this
+// thread's LDS column: nine 16-byte loads (one per (x,y) row, z contiguous) instead of up
+// to 32 scattered dword loads.  Out-of-volume rows are clamped; their values are never used.
+__device__ __forceinline__ void stage_block3(const McParams& P, int gx, int gy, int gz, float* col)
+{
+    const int bz = gz - 1;
+    if (P.nz >= 4) {
+        const int zs = min(max(bz, 0), P.nz - 4);
+        const int sh = bz - zs;   // element of the float4 holding local z = 0
+        f4u q[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int x = min(max(gx - 1 + r / 3, 0), P.nx - 1), y = min(max(gy - 1 + r % 3, 0), P.ny - 1);
+            q[r] = *reinterpret_cast<const f4u*>(P.values + ((size_t)x * P.ny + y) * P.nz + zs);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+#pragma unroll
+            for (int lz = 0; lz < 3; lz++) {
+                const int e = min(max(sh + lz, 0), 3);
+                const float v = e == 0 ? q[r].x : (e == 1 ? q[r].y : (e == 2 ? q[r].z : q[r].w));
+                col[(r * 3 + lz) * 256] = v;
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < 27; r++) {
+            const int x = min(max(gx - 1 + r / 9, 0), P.nx - 1), y = min(max(gy - 1 + (r / 3) % 3, 0), P.ny - 1);
+            const int z = min(max(bz + r % 3, 0), P.nz - 1);
+            col[r * 256] = P.values[((size_t)x * P.ny + y) * P.nz + z];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
-    __shared__ float s_c[4 * 8 * 256];   // corners of the <=4 cells around the edge: [cell][corner][thread]
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
+    __shared__ float s_c[27 * 256];   // per-thread 3x3x3 voxel block: [(lx*3+ly)*3+lz][thread]
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_xy[256], s_z[256], s_info[256];
@@ -549,10 +599,12 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int nt_row = (int)((info >> 14) & 15u);
             float pos[3], colr[3], nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
+            // voxel block around the edge's base point (for the centre vertex: around the cell)
+            stage_block3(P, gx, gy, gz, col);
+            // the creator cell inside the block
+            const CornersNbr v{col, x - gx + 1, y - gy + 1, z - gz + 1, iso};
             if (e == 12) {
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
-                stage_corners(P.values, P.ny, P.nz, x, y, z, col, 256);
-                const CornersLds v{col, 256, iso};
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
                 float fc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -583,9 +635,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 for (int k = 0; k < 3 * nt_row; k++) occ += (lut[lut_off + k] == 12) ? 1 : 0;
                 for (int o = 0; o < occ; o++) { nrm[0] = nrm[0] + g0; nrm[1] = nrm[1] + g1; nrm[2] = nrm[2] + g2; }
             } else {
-                // stage the corners, and fetch the tilings, of every in-range cell around this
-                // grid edge (sweep order); all loads are independent of each other
-                int own_s = 0;
+                // tilings of the in-range cells around this grid edge (sweep order), published by K3
                 unsigned okmask = 0;
                 uint32_t tinfo[4];
 #pragma unroll
@@ -593,15 +643,10 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     const int cx = gx + c_share_dx[dir][s], cy = gy + c_share_dy[dir][s], cz = gz + c_share_dz[dir][s];
                     const bool ok = cell_in_range(P, cx, cy, cz);
                     okmask |= ok ? (1u << s) : 0u;
-                    if (cx == x && cy == y && cz == z) own_s = s;
                     tinfo[s] = 0;
-                    if (ok) {
-                        stage_corners(P.values, P.ny, P.nz, cx, cy, cz, col + s * (8 * 256), 256);
-                        tinfo[s] = P.emap[4 * nvox + ((size_t)cz * P.ny + cy) * P.nx + cx];
-                    }
+                    if (ok) tinfo[s] = P.emap[4 * nvox + ((size_t)cz * P.ny + cy) * P.nx + cx];
                 }
                 // Cell.AddFaceFromEdgeIndex, Cell.cs:314-350 (creator-cell frame)
-                const CornersLds v{col + own_s * (8 * 256), 256, iso};
                 const int dx1 = MC_L2(edgesrelx, e, 0), dx2 = MC_L2(edgesrelx, e, 1);
                 const int dy1 = MC_L2(edgesrely, e, 0), dy2 = MC_L2(edgesrely, e, 1);
                 const int dz1 = MC_L2(edgesrelz, e, 0), dz2 = MC_L2(edgesrelz, e, 1);
@@ -628,7 +673,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 for (int s = 0; s < 4; s++) {
                     const int nts = (int)((tinfo[s] >> 14) & 15u);
                     if (!((okmask >> s) & 1u) || nts == 0) continue;
-                    const CornersLds vs{col + s * (8 * 256), 256, iso};
+                    const CornersNbr vs{col, c_share_dx[dir][s] + 1, c_share_dy[dir][s] + 1, c_share_dz[dir][s] + 1, iso};
                     add_cell_edge_gradients(lut, vs, (int)(tinfo[s] & 0x3fffu), nts, c_share_edge[dir][s], nrm);
                 }
             }
@@ -714,7 +759,7 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partia
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 {
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_BLOB_SIZE];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_xy[256], s_z[256], s_lo[256];
@@ -735,17 +780,33 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
         }
         const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
         const size_t chunk_ibase = (size_t)(P.chunktot[base >> 8] & 0x7fffffffull) * 3;
-        for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
-            const int rr = find_owner_256(s_pre, j);
-            const uint32_t k = j - s_pre[rr];
-            const size_t o = chunk_ibase + j;   // serial position of this triangle index
-            if (o >= M.cap_indices) { P.counters->overflow = 1u; continue; }
-            const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
-            const int e = s_lut[s_lo[rr] + k];
-            const int dir = c_edge_dir[e];
-            const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
-            const uint32_t vi = P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx];
-            M.triangles[o] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
+        // one lane per triangle index; four independent gathers in flight per lane
+        for (uint32_t j0 = threadIdx.x; j0 < total; j0 += 1024u) {
+            uint32_t vi[4];
+            size_t o[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + 256u * u;
+                ok[u] = j < total;
+                vi[u] = 0;
+                o[u] = chunk_ibase + j;   // serial position of this triangle index
+                if (ok[u]) {
+                    const int rr = find_owner_256(s_pre, j);
+                    const uint32_t k = j - s_pre[rr];
+                    const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
+                    const int e = s_lut[s_lo[rr] + k];
+                    const int dir = c_edge_dir[e];
+                    const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
+                    vi[u] = P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!ok[u]) continue;
+                if (o[u] >= M.cap_indices) { P.counters->overflow = 1u; continue; }
+                M.triangles[o[u]] = (int32_t)((int64_t)vi[u] - (int64_t)nghost + M.vertex_base);
+            }
         }
     }
 }
