@@ -45,10 +45,18 @@ __device__ __forceinline__ void mc_load_lut_to_lds(int8_t* s_lut /* MCLUT_PADDED
 #define MC_EPS 0.0000001
 
 struct Tiling {
-    int lut_off;  // start of the triangle row in c_lut, -1 when nothing is emitted
+    int lut_off;  // start of the triangle row in the blob, -1 when nothing is emitted
+    int row;      // row id (index into c_rowocc / MCLUT_ROWOFF), valid when nt > 0
     int nt;       // triangles
     int index;    // 8-bit corner sign word (Cell.cs:220-229)
 };
+#define MC_PICK2(name, i, ntv) do { r.lut_off = MC_ROW2(name, i); r.row = MCLUT_ROWBASE_##name + (i); r.nt = (ntv); } while (0)
+#define MC_PICK3(name, i, j, ntv) do { r.lut_off = MC_ROW3(name, i, j); r.row = MCLUT_ROWBASE_##name + (i) * MCLUT_DIM1_##name + (j); r.nt = (ntv); } while (0)
+
+// Per triangle row: how often it references each vertex id 0..12 (4 bits each).  Derived
+// from the tiling tables by tools/gen_luts.py; replaces scanning the row (Cell.cs:238-265
+// visits every entry) when only the NUMBER of references to one edge is needed.
+__constant__ uint64_t c_rowocc[MCLUT_NROWS] = {MCLUT_ROWOCC_VALUES};
 
 // Corner accessors.  The Lewiner tables index the eight corners with run-time indices; a
 // per-thread register array indexed that way is demoted to scratch memory by the compiler,
@@ -158,66 +166,67 @@ __device__ __forceinline__ Tiling mc_resolve(const int8_t* lut, const V& v)
     for (int k = 0; k < 8; k++) index |= (v[k] > 0.0) ? (1 << k) : 0;
     r.index = index;
     r.lut_off = -1;
+    r.row = 0;
     r.nt = 0;
     const int cas = MC_L2(cases, index, 0);
     const int cfg = MC_L2(cases, index, 1);
     int sub = 0;
     switch (cas) {
-    case 1: r.lut_off = MC_ROW2(tiling1, cfg); r.nt = 1; break;
-    case 2: r.lut_off = MC_ROW2(tiling2, cfg); r.nt = 2; break;
+    case 1: MC_PICK2(tiling1, cfg, 1); break;
+    case 2: MC_PICK2(tiling2, cfg, 2); break;
     case 3:
-        if (mc_test_face(v, MC_L1(test3, cfg))) { r.lut_off = MC_ROW2(tiling3_2, cfg); r.nt = 4; }
-        else { r.lut_off = MC_ROW2(tiling3_1, cfg); r.nt = 2; }
+        if (mc_test_face(v, MC_L1(test3, cfg))) { MC_PICK2(tiling3_2, cfg, 4); }
+        else { MC_PICK2(tiling3_1, cfg, 2); }
         break;
     case 4:
-        if (mc_test_internal(lut, v, cas, cfg, 0, MC_L1(test4, cfg))) { r.lut_off = MC_ROW2(tiling4_1, cfg); r.nt = 2; }
-        else { r.lut_off = MC_ROW2(tiling4_2, cfg); r.nt = 6; }
+        if (mc_test_internal(lut, v, cas, cfg, 0, MC_L1(test4, cfg))) { MC_PICK2(tiling4_1, cfg, 2); }
+        else { MC_PICK2(tiling4_2, cfg, 6); }
         break;
-    case 5: r.lut_off = MC_ROW2(tiling5, cfg); r.nt = 3; break;
+    case 5: MC_PICK2(tiling5, cfg, 3); break;
     case 6:
-        if (mc_test_face(v, MC_L2(test6, cfg, 0))) { r.lut_off = MC_ROW2(tiling6_2, cfg); r.nt = 5; }
-        else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test6, cfg, 1))) { r.lut_off = MC_ROW2(tiling6_1_1, cfg); r.nt = 3; }
-        else { r.lut_off = MC_ROW2(tiling6_1_2, cfg); r.nt = 9; }
+        if (mc_test_face(v, MC_L2(test6, cfg, 0))) { MC_PICK2(tiling6_2, cfg, 5); }
+        else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test6, cfg, 1))) { MC_PICK2(tiling6_1_1, cfg, 3); }
+        else { MC_PICK2(tiling6_1_2, cfg, 9); }
         break;
     case 7:
         if (mc_test_face(v, MC_L2(test7, cfg, 0))) sub += 1;
         if (mc_test_face(v, MC_L2(test7, cfg, 1))) sub += 2;
         if (mc_test_face(v, MC_L2(test7, cfg, 2))) sub += 4;
         switch (sub) {
-        case 0: r.lut_off = MC_ROW2(tiling7_1, cfg); r.nt = 3; break;
-        case 1: r.lut_off = MC_ROW3(tiling7_2, cfg, 0); r.nt = 5; break;
-        case 2: r.lut_off = MC_ROW3(tiling7_2, cfg, 1); r.nt = 5; break;
-        case 3: r.lut_off = MC_ROW3(tiling7_3, cfg, 0); r.nt = 9; break;
-        case 4: r.lut_off = MC_ROW3(tiling7_2, cfg, 2); r.nt = 5; break;
-        case 5: r.lut_off = MC_ROW3(tiling7_3, cfg, 1); r.nt = 9; break;
-        case 6: r.lut_off = MC_ROW3(tiling7_3, cfg, 2); r.nt = 9; break;
+        case 0: MC_PICK2(tiling7_1, cfg, 3); break;
+        case 1: MC_PICK3(tiling7_2, cfg, 0, 5); break;
+        case 2: MC_PICK3(tiling7_2, cfg, 1, 5); break;
+        case 3: MC_PICK3(tiling7_3, cfg, 0, 9); break;
+        case 4: MC_PICK3(tiling7_2, cfg, 2, 5); break;
+        case 5: MC_PICK3(tiling7_3, cfg, 1, 9); break;
+        case 6: MC_PICK3(tiling7_3, cfg, 2, 9); break;
         default:
-            if (mc_test_internal(lut, v, cas, cfg, sub, MC_L2(test7, cfg, 3))) { r.lut_off = MC_ROW2(tiling7_4_2, cfg); r.nt = 9; }
-            else { r.lut_off = MC_ROW2(tiling7_4_1, cfg); r.nt = 5; }
+            if (mc_test_internal(lut, v, cas, cfg, sub, MC_L2(test7, cfg, 3))) { MC_PICK2(tiling7_4_2, cfg, 9); }
+            else { MC_PICK2(tiling7_4_1, cfg, 5); }
             break;
         }
         break;
-    case 8: r.lut_off = MC_ROW2(tiling8, cfg); r.nt = 2; break;
-    case 9: r.lut_off = MC_ROW2(tiling9, cfg); r.nt = 4; break;
+    case 8: MC_PICK2(tiling8, cfg, 2); break;
+    case 9: MC_PICK2(tiling9, cfg, 4); break;
     case 10:
         if (mc_test_face(v, MC_L2(test10, cfg, 0))) {
-            if (mc_test_face(v, MC_L2(test10, cfg, 1))) { r.lut_off = MC_ROW2(tiling10_1_1_, cfg); r.nt = 4; }
-            else { r.lut_off = MC_ROW2(tiling10_2, cfg); r.nt = 8; }
+            if (mc_test_face(v, MC_L2(test10, cfg, 1))) { MC_PICK2(tiling10_1_1_, cfg, 4); }
+            else { MC_PICK2(tiling10_2, cfg, 8); }
         } else {
-            if (mc_test_face(v, MC_L2(test10, cfg, 1))) { r.lut_off = MC_ROW2(tiling10_2_, cfg); r.nt = 8; }
-            else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test10, cfg, 2))) { r.lut_off = MC_ROW2(tiling10_1_1, cfg); r.nt = 4; }
-            else { r.lut_off = MC_ROW2(tiling10_1_2, cfg); r.nt = 8; }
+            if (mc_test_face(v, MC_L2(test10, cfg, 1))) { MC_PICK2(tiling10_2_, cfg, 8); }
+            else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test10, cfg, 2))) { MC_PICK2(tiling10_1_1, cfg, 4); }
+            else { MC_PICK2(tiling10_1_2, cfg, 8); }
         }
         break;
-    case 11: r.lut_off = MC_ROW2(tiling11, cfg); r.nt = 4; break;
+    case 11: MC_PICK2(tiling11, cfg, 4); break;
     case 12:
         if (mc_test_face(v, MC_L2(test12, cfg, 0))) {
-            if (mc_test_face(v, MC_L2(test12, cfg, 1))) { r.lut_off = MC_ROW2(tiling12_1_1_, cfg); r.nt = 4; }
-            else { r.lut_off = MC_ROW2(tiling12_2, cfg); r.nt = 8; }
+            if (mc_test_face(v, MC_L2(test12, cfg, 1))) { MC_PICK2(tiling12_1_1_, cfg, 4); }
+            else { MC_PICK2(tiling12_2, cfg, 8); }
         } else {
-            if (mc_test_face(v, MC_L2(test12, cfg, 1))) { r.lut_off = MC_ROW2(tiling12_2_, cfg); r.nt = 8; }
-            else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test12, cfg, 2))) { r.lut_off = MC_ROW2(tiling12_1_1, cfg); r.nt = 4; }
-            else { r.lut_off = MC_ROW2(tiling12_1_2, cfg); r.nt = 8; }
+            if (mc_test_face(v, MC_L2(test12, cfg, 1))) { MC_PICK2(tiling12_2_, cfg, 8); }
+            else if (mc_test_internal(lut, v, cas, cfg, 0, MC_L2(test12, cfg, 2))) { MC_PICK2(tiling12_1_1, cfg, 4); }
+            else { MC_PICK2(tiling12_1_2, cfg, 8); }
         }
         break;
     case 13: {
@@ -225,57 +234,59 @@ __device__ __forceinline__ Tiling mc_resolve(const int8_t* lut, const V& v)
         for (int k = 0; k < 6; k++)
             if (mc_test_face(v, MC_L2(test13, cfg, k))) sub += 1 << k;
         sub = MC_L1(subconfig13, sub);
-        if (sub == 0) { r.lut_off = MC_ROW2(tiling13_1, cfg); r.nt = 4; }
-        else if (sub >= 1 && sub <= 6) { r.lut_off = MC_ROW3(tiling13_2, cfg, sub - 1); r.nt = 6; }
-        else if (sub >= 7 && sub <= 18) { r.lut_off = MC_ROW3(tiling13_3, cfg, sub - 7); r.nt = 10; }
-        else if (sub >= 19 && sub <= 22) { r.lut_off = MC_ROW3(tiling13_4, cfg, sub - 19); r.nt = 12; }
+        if (sub == 0) { MC_PICK2(tiling13_1, cfg, 4); }
+        else if (sub >= 1 && sub <= 6) { MC_PICK3(tiling13_2, cfg, sub - 1, 6); }
+        else if (sub >= 7 && sub <= 18) { MC_PICK3(tiling13_3, cfg, sub - 7, 10); }
+        else if (sub >= 19 && sub <= 22) { MC_PICK3(tiling13_4, cfg, sub - 19, 12); }
         else if (sub >= 23 && sub <= 26) {
             const int s5 = sub - 23;
-            if (mc_test_internal(lut, v, cas, cfg, s5, MC_L2(test13, cfg, 6))) { r.lut_off = MC_ROW3(tiling13_5_1, cfg, s5); r.nt = 6; }
-            else { r.lut_off = MC_ROW3(tiling13_5_2, cfg, s5); r.nt = 10; }
+            if (mc_test_internal(lut, v, cas, cfg, s5, MC_L2(test13, cfg, 6))) { MC_PICK3(tiling13_5_1, cfg, s5, 6); }
+            else { MC_PICK3(tiling13_5_2, cfg, s5, 10); }
         }
-        else if (sub >= 27 && sub <= 38) { r.lut_off = MC_ROW3(tiling13_3_, cfg, sub - 27); r.nt = 10; }
-        else if (sub >= 39 && sub <= 44) { r.lut_off = MC_ROW3(tiling13_2_, cfg, sub - 39); r.nt = 6; }
-        else if (sub == 45) { r.lut_off = MC_ROW2(tiling13_1_, cfg); r.nt = 4; }
+        else if (sub >= 27 && sub <= 38) { MC_PICK3(tiling13_3_, cfg, sub - 27, 10); }
+        else if (sub >= 39 && sub <= 44) { MC_PICK3(tiling13_2_, cfg, sub - 39, 6); }
+        else if (sub == 45) { MC_PICK2(tiling13_1_, cfg, 4); }
         // else: "Impossible case 13?" (MarchingCubes.cs:365) -- the cell emits nothing
         break;
     }
-    case 14: r.lut_off = MC_ROW2(tiling14, cfg); r.nt = 4; break;
+    case 14: MC_PICK2(tiling14, cfg, 4); break;
     default: break;
     }
     return r;
 }
 
-// ---- edge geometry ----------------------------------------------------------
+// ---- edge geometry (pure ALU: tiny tables indexed per lane would each be a dependent
+// vector-memory round trip) -------------------------------------------------------------
 // Edge e of a cell lies on a grid edge with direction dir (0=X,1=Y,2=Z; 3 = the cell's
-// centre vertex) based at voxel (x+ox, y+oy, z+oz) -- the face-layer slot j of
-// Cell.cs:371-441.
-__constant__ int8_t c_edge_dir[13] = {0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2, 3};
-__constant__ int8_t c_edge_ox[13] = {0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0};
-__constant__ int8_t c_edge_oy[13] = {0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0};
-__constant__ int8_t c_edge_oz[13] = {0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0};
-// The (up to) four cells around a grid edge in sweep order (z outer, y, x inner) as
-// offsets from the base voxel, and the id the edge has inside each of them.
-__constant__ int8_t c_share_dx[3][4] = {{0, 0, 0, 0}, {-1, 0, -1, 0}, {-1, 0, -1, 0}};
-__constant__ int8_t c_share_dy[3][4] = {{-1, 0, -1, 0}, {0, 0, 0, 0}, {-1, -1, 0, 0}};
-__constant__ int8_t c_share_dz[3][4] = {{-1, -1, 0, 0}, {-1, -1, 0, 0}, {0, 0, 0, 0}};
-__constant__ int8_t c_share_edge[3][4] = {{6, 4, 2, 0}, {5, 7, 1, 3}, {10, 11, 9, 8}};
-
-// Corner k (v0..v7 order) -> voxel offsets.
-__constant__ int8_t c_corner_dx[8] = {0, 1, 1, 0, 0, 1, 1, 0};
-__constant__ int8_t c_corner_dy[8] = {0, 0, 1, 1, 0, 0, 1, 1};
-__constant__ int8_t c_corner_dz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+// centre vertex) based at voxel (x+ox, y+oy, z+oz) -- the face-layer slot j of Cell.cs:371-441.
+__device__ __forceinline__ int mc_edge_dir(int e) { return e < 8 ? (e & 1) : (e < 12 ? 2 : 3); }
+__device__ __forceinline__ int mc_edge_ox(int e) { return (0x622 >> e) & 1; }   // e = 1,5,9,10
+__device__ __forceinline__ int mc_edge_oy(int e) { return (0xC44 >> e) & 1; }   // e = 2,6,10,11
+__device__ __forceinline__ int mc_edge_oz(int e) { return (0x0F0 >> e) & 1; }   // e = 4..7
+// The (up to) four cells around a grid edge in sweep order (z outer, y, x inner), s = 0..3,
+// as offsets from the base voxel, and the id the edge has inside each of them:
+//   X: (0,-1,-1) (0,0,-1) (0,-1,0) (0,0,0)  ids 6,4,2,0
+//   Y: (-1,0,-1) (0,0,-1) (-1,0,0) (0,0,0)  ids 5,7,1,3
+//   Z: (-1,-1,0) (0,-1,0) (-1,0,0) (0,0,0)  ids 10,11,9,8
+__device__ __forceinline__ int mc_share_dx(int dir, int s) { return (dir != 0 && !(s & 1)) ? -1 : 0; }
+__device__ __forceinline__ int mc_share_dy(int dir, int s) { return (dir == 0 ? !(s & 1) : (dir == 2 && s < 2)) ? -1 : 0; }
+__device__ __forceinline__ int mc_share_dz(int dir, int s) { return (dir < 2 && s < 2) ? -1 : 0; }
+__device__ __forceinline__ int mc_share_edge(int dir, int s) { return (int)((0x89ba31750246ull >> (4 * (dir * 4 + s))) & 15ull); }
 // bit-order index -> corner number (Cell.cs:453-460: vv[2]=v3, vv[3]=v2, vv[6]=v7, vv[7]=v6)
-__constant__ int8_t c_bit_to_corner[8] = {0, 1, 3, 2, 4, 5, 7, 6};
+__device__ __forceinline__ int mc_bit_to_corner(int i) { return i ^ ((i >> 1) & 1); }
+// corner k (v0..v7 order) -> voxel offsets
+__device__ __forceinline__ int mc_corner_dx(int k) { return ((k + 1) >> 1) & 1; }
+__device__ __forceinline__ int mc_corner_dy(int k) { return (k >> 1) & 1; }
+__device__ __forceinline__ int mc_corner_dz(int k) { return k >> 2; }
 
 // Corner gradients of Cell.cs:491-498, component j of corner k (corner order):
-// vg[k][j] = v[c_grad_a[k][j]] - v[c_grad_b[k][j]].
-__constant__ int8_t c_grad_a[8][3] = {{0, 0, 0}, {0, 1, 1}, {3, 1, 2}, {3, 0, 3}, {4, 4, 0}, {4, 5, 1}, {7, 5, 2}, {7, 4, 3}};
-__constant__ int8_t c_grad_b[8][3] = {{1, 3, 4}, {1, 2, 5}, {2, 2, 6}, {2, 3, 7}, {5, 7, 4}, {5, 6, 5}, {6, 6, 6}, {6, 7, 7}};
+// vg[k][j] = v[a] - v[b], (a,b) packed 3 bits per corner.
 template <class V>
 __device__ __forceinline__ double mc_corner_gradient(const V& v, int k, int j)
 {
-    return v[c_grad_a[k][j]] - v[c_grad_b[k][j]];
+    const unsigned pa = j == 0 ? 0xfe46c0u : (j == 1 ? 0x96c048u : 0x688688u);
+    const unsigned pb = j == 0 ? 0xdad489u : (j == 1 ? 0xfb7693u : 0xfacfacu);
+    return v[(pa >> (3 * k)) & 7u] - v[(pb >> (3 * k)) & 7u];
 }
 
 }  // namespace sdfk

@@ -384,6 +384,21 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, con
 // ---------------------------------------------------------------------------
 // K3: resolve tilings + vertex creation; per-chunk totals of (vertices, triangles)
 // ---------------------------------------------------------------------------
+// Which of its 12 edges does cell (x,y,z) CREATE when no cell of the volume is "dead"?
+// Exactly those no earlier in-range cell of the sweep shares (table c_pred reduced to the
+// three facts x>0, y>0, z>0): bit e set = created here.
+__device__ __forceinline__ unsigned positional_own_mask(bool X, bool Y, bool Z)
+{
+    unsigned m = (1u << 5) | (1u << 6) | (1u << 10);
+    if (!Y) m |= (1u << 4) | (1u << 9);
+    if (!X) m |= (1u << 7) | (1u << 11);
+    if (!Z) m |= (1u << 1) | (1u << 2);
+    if (!Y && !Z) m |= 1u << 0;
+    if (!X && !Z) m |= 1u << 3;
+    if (!X && !Y) m |= 1u << 8;
+    return m;
+}
+
 __global__ __launch_bounds__(256) void k_resolve(McParams P)
 {
     __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
@@ -411,12 +426,15 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
             uint64_t own = 0;
             if (t.nt > 0) {
                 if (counted) {
+                    const unsigned pmask = positional_own_mask(x > 0, y > 0, P.z0 + z > 0) | (1u << 12);
                     uint32_t seen = 0;
-                    for (int k = 0; k < 3 * t.nt; k++) {
+                    for (int k = 0; k < 3 * t.nt; k++) {   // creation order = first reference in the row
                         const int e = s_lut[t.lut_off + k];
                         if (seen & (1u << e)) continue;
                         seen |= 1u << e;
-                        const bool mine = (e == 12) || !edge_has_live_predecessor(P, s_lut, e, x, y, z, check_dead, col);
+                        bool mine = (pmask >> e) & 1u;
+                        if (check_dead && !mine)   // an earlier sharer exists: is any of them alive?
+                            mine = !edge_has_live_predecessor(P, s_lut, e, x, y, z, true, col);
                         if (mine) {
                             own |= (uint64_t)e << (4 * nown);
                             nown++;
@@ -424,9 +442,9 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
                     }
                 }
                 nt_emit = emit ? (uint32_t)t.nt : 0u;
-                info = (uint32_t)t.lut_off | (nt_emit << 14) | (nown << 18);
-                // every classified cell publishes its tiling: K4 reads it for the normals
-                P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = (uint32_t)t.lut_off | ((uint32_t)t.nt << 14);
+                info = (uint32_t)t.lut_off | (nt_emit << 14) | (nown << 18) | ((uint32_t)t.row << 22);
+                // every classified cell publishes its tiling row: K4 reads it for the normals
+                P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = (uint32_t)t.row | ((uint32_t)t.nt << 10);
             } else {
                 P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = 0u;
                 if (emit && (t.index == 0xA5 || t.index == 0x5A)) atomicAdd(&P.counters->n_dead, 1u);
@@ -481,37 +499,14 @@ __device__ __forceinline__ float v3len(float x, float y, float z) { return sqrtf
 
 __device__ __forceinline__ void load_corner_color(const McParams& P, int x, int y, int z, int corner, float* c)
 {
-    if (!P.colors) { c[0] = c[1] = c[2] = 0.0f; return; }
-    const size_t o = ((size_t)(x + c_corner_dx[corner]) * P.ny + (y + c_corner_dy[corner])) * P.nz + (z + c_corner_dz[corner]);
+    const size_t o = ((size_t)(x + mc_corner_dx(corner)) * P.ny + (y + mc_corner_dy(corner))) * P.nz + (z + mc_corner_dz(corner));
     const f3u q = *reinterpret_cast<const f3u*>(P.colors + o * 3);
     c[0] = q.x; c[1] = q.y; c[2] = q.z;
 }
 
-// Accumulate into n[] what a cell with corners v adds for its edge `es`, in the order of
-// Cell.cs:332-333/355-356: once per occurrence in the LUT row, corner 1 then corner 2.
-template <class V>
-__device__ __forceinline__ void add_cell_edge_gradients(const int8_t* lut, const V& v, int lut_off, int nt, int es, float* n)
-{
-    int occ = 0;
-    for (int k = 0; k < 3 * nt; k++) occ += (lut[lut_off + k] == es) ? 1 : 0;
-    if (!occ) return;
-    const int i1 = MC_L2(edgesrelz, es, 0) * 4 + MC_L2(edgesrely, es, 0) * 2 + MC_L2(edgesrelx, es, 0);
-    const int i2 = MC_L2(edgesrelz, es, 1) * 4 + MC_L2(edgesrely, es, 1) * 2 + MC_L2(edgesrelx, es, 1);
-    const double w1 = 1.0 / (MC_EPS + fabs(v[c_bit_to_corner[i1]]));
-    const double w2 = 1.0 / (MC_EPS + fabs(v[c_bit_to_corner[i2]]));
-    float g1[3], g2[3];
-    // NB: Cell.cs:157-158 indexes the corner-ordered gradient table with the BIT-order
-    // index (inherited quirk); reproduced: gradient of "corner i1", not of corner bit_to_corner[i1].
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        g1[j] = (float)(mc_corner_gradient(v, i1, j) * w1);
-        g2[j] = (float)(mc_corner_gradient(v, i2, j) * w2);
-    }
-    for (int o = 0; o < occ; o++) {
-        n[0] = n[0] + g1[0]; n[1] = n[1] + g1[1]; n[2] = n[2] + g1[2];
-        n[0] = n[0] + g2[0]; n[1] = n[1] + g2[1]; n[2] = n[2] + g2[2];
-    }
-}
+// the two end corners of cube edge e (Luts.cs:30-52), in the order of Luts.edgesrel{x,y,z}
+__device__ __forceinline__ int mc_edge_corner_a(int e) { return e < 8 ? e : e - 8; }
+__device__ __forceinline__ int mc_edge_corner_b(int e) { return e < 8 ? ((e & 4) | ((e + 1) & 3)) : e - 4; }
 
 // ---------------------------------------------------------------------------
 // K4: vertices
@@ -553,14 +548,21 @@ __device__ __forceinline__ void stage_block3(const McParams& P, int gx, int gy, 
 __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
     __shared__ float s_c[27 * 256];   // per-thread 3x3x3 voxel block: [(lx*3+ly)*3+lz][thread]
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
+    __shared__ uint64_t s_occ[MCLUT_NROWS];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_xy[256], s_z[256], s_info[256];
     __shared__ uint64_t s_own[256];
     __shared__ float s_red[6][4];
-    mc_load_lut_to_lds(s_lut);
-    const int8_t* lut = s_lut;
+    {   // per-row reference counts -> LDS (3 independent loads per lane)
+        const int t = (int)threadIdx.x;
+        const uint64_t a0 = c_rowocc[min(t, MCLUT_NROWS - 1)], a1 = c_rowocc[min(t + 256, MCLUT_NROWS - 1)];
+        const uint64_t a2 = c_rowocc[min(t + 512, MCLUT_NROWS - 1)];
+        static_assert(MCLUT_NROWS <= 768, "row table copy assumes <= 3 rounds");
+        if (t < MCLUT_NROWS) s_occ[t] = a0;
+        if (t + 256 < MCLUT_NROWS) s_occ[t + 256] = a1;
+        if (t + 512 < MCLUT_NROWS) s_occ[t + 512] = a2;
+    }
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
     const size_t nvox = (size_t)P.nx * P.ny * P.nz;
@@ -589,20 +591,31 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
             const uint32_t vi = chunk_vbase + j;   // chunk prefix + in-chunk prefix: serial vertex id
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
-            const int dir = c_edge_dir[e];
-            const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
+            const int dir = mc_edge_dir(e);
+            const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
             P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx] = vi;
             if (z < P.lay_emit_begin) continue;   // context layer: only its vertex ids are needed
             const uint32_t out = vi - nghost;
             if (out >= M.cap_vertices) { P.counters->overflow = 1u; continue; }
-            const int lut_off = (int)(info & 0x3fffu);
-            const int nt_row = (int)((info >> 14) & 15u);
-            float pos[3], colr[3], nrm[3] = {0.0f, 0.0f, 0.0f};
+            const int own_row = (int)(info >> 22);
+            float pos[3], colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
+            // tilings of the in-range cells around this grid edge (sweep order), published by K3;
+            // issued before the voxel block so that all global loads of this vertex overlap
+            unsigned okmask = 0;
+            uint32_t tinfo[4] = {0u, 0u, 0u, 0u};
+            if (e != 12) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int cx = gx + mc_share_dx(dir, s), cy = gy + mc_share_dy(dir, s), cz = gz + mc_share_dz(dir, s);
+                    const bool ok = cell_in_range(P, cx, cy, cz);
+                    okmask |= ok ? (1u << s) : 0u;
+                    if (ok) tinfo[s] = P.emap[4 * nvox + ((size_t)cz * P.ny + cy) * P.nx + cx];
+                }
+            }
             // voxel block around the edge's base point (for the centre vertex: around the cell)
             stage_block3(P, gx, gy, gz, col);
-            // the creator cell inside the block
-            const CornersNbr v{col, x - gx + 1, y - gy + 1, z - gz + 1, iso};
+            const CornersNbr v{col, x - gx + 1, y - gy + 1, z - gz + 1, iso};   // the creator cell
             if (e == 12) {
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
@@ -610,15 +623,17 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const double wk = 1.0 / (MC_EPS + fabs(v[k]));
-                    fx += (double)((k == 1 || k == 2 || k == 5 || k == 6) ? 1 : 0) * wk;
-                    fy += (double)((k == 2 || k == 3 || k == 6 || k == 7) ? 1 : 0) * wk;
-                    fz += (double)(k >= 4 ? 1 : 0) * wk;
+                    fx += (double)mc_corner_dx(k) * wk;
+                    fy += (double)mc_corner_dy(k) * wk;
+                    fz += (double)mc_corner_dz(k) * wk;
                     ff += wk;
-                    float ck[3];
-                    load_corner_color(P, x, y, z, k, ck);
-                    const float wf = (float)wk;
-                    if (k == 0) { fc[0] = ck[0] * wf; fc[1] = ck[1] * wf; fc[2] = ck[2] * wf; }
-                    else { fc[0] = fc[0] + ck[0] * wf; fc[1] = fc[1] + ck[1] * wf; fc[2] = fc[2] + ck[2] * wf; }
+                    if (P.colors) {
+                        float ck[3];
+                        load_corner_color(P, x, y, z, k, ck);
+                        const float wf = (float)wk;
+                        if (k == 0) { fc[0] = ck[0] * wf; fc[1] = ck[1] * wf; fc[2] = ck[2] * wf; }
+                        else { fc[0] = fc[0] + ck[0] * wf; fc[1] = fc[1] + ck[1] * wf; fc[2] = fc[2] + ck[2] * wf; }
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 3; jj++) {
                         const double term = wk * mc_corner_gradient(v, k, jj);
@@ -628,53 +643,75 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 pos[0] = (float)((double)xs + stp * fx / ff);
                 pos[1] = (float)((double)ys + stp * fy / ff);
                 pos[2] = (float)((double)zs + stp * fz / ff);
+                if (P.colors) {
 #pragma unroll
-                for (int jj = 0; jj < 3; jj++) colr[jj] = (float)((double)fc[jj] / ff);
+                    for (int jj = 0; jj < 3; jj++) colr[jj] = (float)((double)fc[jj] / ff);
+                }
                 const float g0 = (float)gsum[0], g1 = (float)gsum[1], g2 = (float)gsum[2];
-                int occ = 0;
-                for (int k = 0; k < 3 * nt_row; k++) occ += (lut[lut_off + k] == 12) ? 1 : 0;
+                const int occ = (int)((s_occ[own_row] >> 48) & 15ull);
                 for (int o = 0; o < occ; o++) { nrm[0] = nrm[0] + g0; nrm[1] = nrm[1] + g1; nrm[2] = nrm[2] + g2; }
             } else {
-                // tilings of the in-range cells around this grid edge (sweep order), published by K3
-                unsigned okmask = 0;
-                uint32_t tinfo[4];
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int cx = gx + c_share_dx[dir][s], cy = gy + c_share_dy[dir][s], cz = gz + c_share_dz[dir][s];
-                    const bool ok = cell_in_range(P, cx, cy, cz);
-                    okmask |= ok ? (1u << s) : 0u;
-                    tinfo[s] = 0;
-                    if (ok) tinfo[s] = P.emap[4 * nvox + ((size_t)cz * P.ny + cy) * P.nx + cx];
-                }
-                // Cell.AddFaceFromEdgeIndex, Cell.cs:314-350 (creator-cell frame)
-                const int dx1 = MC_L2(edgesrelx, e, 0), dx2 = MC_L2(edgesrelx, e, 1);
-                const int dy1 = MC_L2(edgesrely, e, 0), dy2 = MC_L2(edgesrely, e, 1);
-                const int dz1 = MC_L2(edgesrelz, e, 0), dz2 = MC_L2(edgesrelz, e, 1);
-                const int c1 = c_bit_to_corner[dz1 * 4 + dy1 * 2 + dx1], c2 = c_bit_to_corner[dz2 * 4 + dy2 * 2 + dx2];
+                // Cell.AddFaceFromEdgeIndex, Cell.cs:314-350, in the creator cell's frame.
+                // (index1,index2) of Cell.cs:318-319 are the bit-order ids of the edge's end corners.
+                const int c1 = mc_edge_corner_a(e), c2 = mc_edge_corner_b(e);
                 const double w1 = 1.0 / (MC_EPS + fabs(v[c1]));
                 const double w2 = 1.0 / (MC_EPS + fabs(v[c2]));
-                double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0;
-                fx += (double)dx1 * w1; fy += (double)dy1 * w1; fz += (double)dz1 * w1; ff += w1;
-                fx += (double)dx2 * w2; fy += (double)dy2 * w2; fz += (double)dz2 * w2; ff += w2;
-                float ca[3], cb[3];
-                load_corner_color(P, x, y, z, c1, ca);
-                load_corner_color(P, x, y, z, c2, cb);
-                const float w1f = (float)w1, w2f = (float)w2;
-                pos[0] = (float)((double)xs + stp * fx / ff);
-                pos[1] = (float)((double)ys + stp * fy / ff);
-                pos[2] = (float)((double)zs + stp * fz / ff);
-#pragma unroll
-                for (int jj = 0; jj < 3; jj++) {
-                    const float cj = ca[jj] * w1f + cb[jj] * w2f;
-                    colr[jj] = (float)((double)cj / ff);
+                const double ff = w1 + w2;                       // (0 + w1) + w2
+                const int d1 = dir == 0 ? mc_corner_dx(c1) : (dir == 1 ? mc_corner_dy(c1) : mc_corner_dz(c1));
+                // the two weights by position along the edge: low = base voxel, high = base + 1
+                const double w_lo = d1 ? w2 : w1, w_hi = d1 ? w1 : w2;
+                if (P.step == 1 && ff > 0.0 && isfinite(ff)) {
+                    // stp = 1: off the edge axis both corners share the offset o, so
+                    // (o*w1 + o*w2)/ff is exactly o; on the axis it is w_hi/ff (one division).
+                    const double t = w_hi / ff;
+                    pos[0] = dir == 0 ? (float)((double)gx + t) : (float)(xs + mc_corner_dx(c1));
+                    pos[1] = dir == 1 ? (float)((double)gy + t) : (float)(ys + mc_corner_dy(c1));
+                    pos[2] = dir == 2 ? (float)((double)(gz + P.z0) + t) : (float)(zs + mc_corner_dz(c1));
+                } else {
+                    double fx = 0.0, fy = 0.0, fz = 0.0;
+                    fx += (double)mc_corner_dx(c1) * w1; fy += (double)mc_corner_dy(c1) * w1; fz += (double)mc_corner_dz(c1) * w1;
+                    fx += (double)mc_corner_dx(c2) * w2; fy += (double)mc_corner_dy(c2) * w2; fz += (double)mc_corner_dz(c2) * w2;
+                    pos[0] = (float)((double)xs + stp * fx / ff);
+                    pos[1] = (float)((double)ys + stp * fy / ff);
+                    pos[2] = (float)((double)zs + stp * fz / ff);
                 }
-                // normal: gather over the cells around the edge, in sweep order
+                if (P.colors) {
+                    float ca[3], cb[3];
+                    load_corner_color(P, x, y, z, c1, ca);
+                    load_corner_color(P, x, y, z, c2, cb);
+                    const float w1f = (float)w1, w2f = (float)w2;
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++) {
+                        const float cj = ca[jj] * w1f + cb[jj] * w2f;
+                        colr[jj] = (float)((double)cj / ff);
+                    }
+                }
+                // normal: gather over the cells around the edge, in sweep order.  Every sharer
+                // sees the same two end voxels, so the two weights are computed once.
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const int nts = (int)((tinfo[s] >> 14) & 15u);
+                    const int nts = (int)((tinfo[s] >> 10) & 15u);
                     if (!((okmask >> s) & 1u) || nts == 0) continue;
-                    const CornersNbr vs{col, c_share_dx[dir][s] + 1, c_share_dy[dir][s] + 1, c_share_dz[dir][s] + 1, iso};
-                    add_cell_edge_gradients(lut, vs, (int)(tinfo[s] & 0x3fffu), nts, c_share_edge[dir][s], nrm);
+                    const int es = mc_share_edge(dir, s);
+                    const int occ = (int)((s_occ[tinfo[s] & 1023u] >> (4 * es)) & 15ull);
+                    if (!occ) continue;
+                    const CornersNbr vs{col, mc_share_dx(dir, s) + 1, mc_share_dy(dir, s) + 1, mc_share_dz(dir, s) + 1, iso};
+                    const int a = mc_edge_corner_a(es), b = mc_edge_corner_b(es);
+                    const int da = dir == 0 ? mc_corner_dx(a) : (dir == 1 ? mc_corner_dy(a) : mc_corner_dz(a));
+                    const double wa = da ? w_hi : w_lo, wb = da ? w_lo : w_hi;
+                    // NB: Cell.cs:157-158 indexes the corner-ordered gradient table with the
+                    // BIT-order index (inherited quirk); reproduced.
+                    const int i1 = mc_bit_to_corner(a), i2 = mc_bit_to_corner(b);   // involution: corner -> bit order
+                    float g1[3], g2[3];
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++) {
+                        g1[jj] = (float)(mc_corner_gradient(vs, i1, jj) * wa);
+                        g2[jj] = (float)(mc_corner_gradient(vs, i2, jj) * wb);
+                    }
+                    for (int o = 0; o < occ; o++) {
+                        nrm[0] = nrm[0] + g1[0]; nrm[1] = nrm[1] + g1[1]; nrm[2] = nrm[2] + g1[2];
+                        nrm[0] = nrm[0] + g2[0]; nrm[1] = nrm[1] + g2[1]; nrm[2] = nrm[2] + g2[2];
+                    }
                 }
             }
             // Cell.NegativeNormals (Cell.cs:97-109), then Mesh.Transform (Mesh.cs:47-64)
@@ -796,8 +833,8 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
                     const uint32_t k = j - s_pre[rr];
                     const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
                     const int e = s_lut[s_lo[rr] + k];
-                    const int dir = c_edge_dir[e];
-                    const int gx = x + c_edge_ox[e], gy = y + c_edge_oy[e], gz = z + c_edge_oz[e];
+                    const int dir = mc_edge_dir(e);
+                    const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
                     vi[u] = P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx];
                 }
             }

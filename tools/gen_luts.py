@@ -109,6 +109,41 @@ def fnv1a(vals):
     return h
 
 
+TILING_NT = {  # triangles per row of every tiling table (MarchingCubes.cs:94-371)
+    "tiling1": 1, "tiling2": 2, "tiling3_1": 2, "tiling3_2": 4, "tiling4_1": 2, "tiling4_2": 6, "tiling5": 3,
+    "tiling6_1_1": 3, "tiling6_1_2": 9, "tiling6_2": 5, "tiling7_1": 3, "tiling7_2": 5, "tiling7_3": 9,
+    "tiling7_4_1": 5, "tiling7_4_2": 9, "tiling8": 2, "tiling9": 4, "tiling10_1_1": 4, "tiling10_1_1_": 4,
+    "tiling10_1_2": 8, "tiling10_2": 8, "tiling10_2_": 8, "tiling11": 4, "tiling12_1_1": 4, "tiling12_1_1_": 4,
+    "tiling12_1_2": 8, "tiling12_2": 8, "tiling12_2_": 8, "tiling13_1": 4, "tiling13_1_": 4, "tiling13_2": 6,
+    "tiling13_2_": 6, "tiling13_3": 10, "tiling13_3_": 10, "tiling13_4": 12, "tiling13_5_1": 6, "tiling13_5_2": 10,
+    "tiling14": 4,
+}
+
+
+def row_table(tables):
+    """Derived index over all triangle rows: row id -> (blob offset, nt, occurrence word).
+    occurrence word: 4 bits per vertex id 0..12 = how often the row references it."""
+    rows, bases = [], {}
+    off = 0
+    for name, shape, vals in tables:
+        if name in TILING_NT:
+            nt = TILING_NT[name]
+            rowlen = shape[-1]
+            assert rowlen == 3 * nt, (name, shape, nt)
+            nrows = len(vals) // rowlen
+            bases[name] = len(rows)
+            for r in range(nrows):
+                row = vals[r * rowlen:(r + 1) * rowlen]
+                occ = 0
+                for e in range(13):
+                    c = row.count(e)
+                    assert c < 16
+                    occ |= c << (4 * e)
+                rows.append((off + r * rowlen, nt, occ))
+        off += len(vals)
+    return rows, bases
+
+
 def emit_header(path, guard, prefix, tables, note):
     off = 0
     lines = []
@@ -127,6 +162,13 @@ def emit_header(path, guard, prefix, tables, note):
         off += len(vals)
         blob.extend(vals)
     lines.append(f"#define {prefix}BLOB_SIZE {off}")
+    rows, bases = row_table(tables)
+    for name, b in bases.items():
+        lines.append(f"#define {prefix}ROWBASE_{name} {b}")
+    lines.append(f"#define {prefix}NROWS {len(rows)}")
+    lines.append(f"#define {prefix}ROWOFF_VALUES " + ",".join(str(r[0]) for r in rows))
+    lines.append(f"#define {prefix}ROWNT_VALUES " + ",".join(str(r[1]) for r in rows))
+    lines.append(f"#define {prefix}ROWOCC_VALUES " + ",".join("0x%xull" % r[2] for r in rows))
     lines.append(f"#define {prefix}BLOB_VALUES \\")
     row = []
     chunks = []
