@@ -57,6 +57,7 @@ struct Tiling {
 // from the tiling tables by tools/gen_luts.py; replaces scanning the row (Cell.cs:238-265
 // visits every entry) when only the NUMBER of references to one edge is needed.
 __constant__ uint64_t c_rowocc[MCLUT_NROWS] = {MCLUT_ROWOCC_VALUES};
+__constant__ uint8_t c_rownt[MCLUT_NROWS] = {MCLUT_ROWNT_VALUES};   // triangles of each row
 
 // Corner accessors.  The Lewiner tables index the eight corners with run-time indices; a
 // per-thread register array indexed that way is demoted to scratch memory by the compiler,

@@ -21,9 +21,13 @@
 //   K4  vertices  one lane per created vertex: position/colour in the creator's frame, normal
 //                 as a gather over the <=4 cells around the edge in sweep order (bit-exact
 //                 float32 accumulation order, no atomics).
-//   K5  triangles one lane per triangle index, vertex ids from a sparse per-grid-edge map.
+//   K5  triangles one lane per triangle index: the vertex id of an edge is its creator cell's
+//                 first vertex id + the edge's rank in the creator's list.
 //
-// Lookup tables are copied from __constant__ to LDS per workgroup.  No MFMA: nothing here
+// After K3 the volume is not touched again: records carry the cells' corner values, and
+// neighbouring / creator cells are found through a per-row start table + a short search in
+// the sorted record list, so K4/K5 work on compact, cache-resident arrays only (no per-voxel
+// maps).  Lookup tables are copied from __constant__ to LDS per workgroup.  No MFMA: nothing here
 // is a contraction.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -212,12 +216,15 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
         if (threadIdx.x == 0) P.blockcnt[b] = total;
         return;
     }
-    if (cnt) {
+    {
         uint32_t pos = (uint32_t)(P.blockcnt[b] + pre);   // blockcnt now holds the exclusive prefix
+        uint32_t* rowstart = P.rowstart + (size_t)(z - P.lay_count_begin) * P.ncy + y0;
+        if (b == (int)gridDim.x - 1 && threadIdx.x == 255) rowstart[rows] = (uint32_t)(P.blockcnt[b] + total);   // sentinel
         int y_l = sb / P.nxw, xw = sb % P.nxw;
         for (int s = sb; s < se; s++) {
             uint64_t m13;
             uint64_t m = segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13);
+            if (xw == 0) rowstart[y_l] = pos;   // first record of cell row (z, y0 + y_l)
             const uint32_t yz = (uint32_t)(y0 + y_l) << 16;
             while (m) {
                 const int bit = __builtin_ctzll(m);
@@ -408,22 +415,23 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
     __syncthreads();
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const bool check_dead = P.counters->n_case13 != 0;
-    const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     const int nchunks = (int)((n + 255u) >> 8);
     float* col = s_v + threadIdx.x;
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint32_t i = (uint32_t)c * 256u + threadIdx.x;
-        uint32_t nown = 0, nt_emit = 0;
+        uint32_t nown = 0, nt_emit = 0, info = 0;
+        uint64_t own = 0;
         if (i < n) {
             const uint32_t xy = P.rec_xy[i];
             const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), z = (int)P.rec_z[i];
             stage_corners(P.values, P.ny, P.nz, x, y, z, col, 256);
+            // the record keeps the corner values: K4 never goes back to the volume
+            *reinterpret_cast<float4*>(P.rec_corners + (size_t)i * 8) = make_float4(col[0], col[256], col[2 * 256], col[3 * 256]);
+            *reinterpret_cast<float4*>(P.rec_corners + (size_t)i * 8 + 4) = make_float4(col[4 * 256], col[5 * 256], col[6 * 256], col[7 * 256]);
             const CornersLds v{col, 256, (double)P.iso};
             const Tiling t = mc_resolve(s_lut, v);
             const bool counted = z < P.lay_emit_end;     // the layer above is context only
             const bool emit = counted && z >= P.lay_emit_begin;
-            uint32_t info = 0;
-            uint64_t own = 0;
             if (t.nt > 0) {
                 if (counted) {
                     const unsigned pmask = positional_own_mask(x > 0, y > 0, P.z0 + z > 0) | (1u << 12);
@@ -443,27 +451,28 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
                 }
                 nt_emit = emit ? (uint32_t)t.nt : 0u;
                 info = (uint32_t)t.lut_off | (nt_emit << 14) | (nown << 18) | ((uint32_t)t.row << 22);
-                // every classified cell publishes its tiling row: K4 reads it for the normals
-                P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = (uint32_t)t.row | ((uint32_t)t.nt << 10);
-            } else {
-                P.emap[4 * nvox + ((size_t)z * P.ny + y) * P.nx + x] = 0u;
-                if (emit && (t.index == 0xA5 || t.index == 0x5A)) atomicAdd(&P.counters->n_dead, 1u);
+            } else if (emit && (t.index == 0xA5 || t.index == 0x5A)) {
+                atomicAdd(&P.counters->n_dead, 1u);
             }
+        }
+        // in-chunk prefix and chunk total of (created vertices, triangles), packed v << 31 | t
+        uint64_t total;
+        const uint64_t pre = block_excl_scan_u64(((uint64_t)nown << 31) | nt_emit, s_wave, &total);
+        if (i < n) {
             P.rec_info[i] = info;
             P.rec_own[i] = own;
+            P.rec_pre[i] = (uint32_t)(pre >> 31) | ((uint32_t)(pre & 0x7fffffffull) << 16);
         }
-        // (created vertices, triangles) of the chunk, packed as v << 31 | t
-        uint64_t total;
-        (void)block_excl_scan_u64(((uint64_t)nown << 31) | nt_emit, s_wave, &total);
         if (threadIdx.x == 0) P.chunktot[c] = total;
     }
 }
 
 // ---------------------------------------------------------------------------
-// K4 / K5 helpers: workgroup-level re-balancing.  A chunk of 256 cells owns a variable
-// number of output items each (created vertices / triangle indices).  An exclusive prefix
-// in LDS plus a binary search turns "one lane per cell" into "one lane per output item".
+// K4 / K5 helpers
 // ---------------------------------------------------------------------------
+// Workgroup-level re-balancing: a chunk of 256 cells owns a variable number of output items
+// each (created vertices / triangle indices).  An exclusive prefix in LDS plus a binary
+// search turns "one lane per cell" into "one lane per output item".
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* s_pre /*[257]*/, uint32_t* s_wave /*[4]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -495,6 +504,24 @@ __device__ __forceinline__ int find_owner_256(const uint32_t* s_pre, uint32_t j)
     return lo;
 }
 
+// Record index of active cell (cx,cy,cz), or -1.  Records are sorted by (z, y, x) and
+// rowstart[] gives the span of each cell row, so this is a search over the handful of
+// active cells of one row.  Cells sharing a sign-changing edge are always active, hence
+// always found when their layer is listed.
+__device__ __forceinline__ int find_record(const McParams& P, int cx, int cy, int cz)
+{
+    if (cz < P.lay_count_begin || cz >= P.lay_list_end) return -1;
+    const uint32_t* rs = P.rowstart + (size_t)(cz - P.lay_count_begin) * P.ncy + cy;
+    uint32_t a = rs[0], b = rs[1];
+    while (b - a > 4u) {   // long rows: bisect
+        const uint32_t mid = (a + b) >> 1;
+        if ((int)(P.rec_xy[mid] & 0xffffu) <= cx) a = mid; else b = mid;
+    }
+    for (uint32_t k = a; k < b; k++)
+        if ((int)(P.rec_xy[k] & 0xffffu) == cx) return (int)k;
+    return -1;
+}
+
 __device__ __forceinline__ float v3len(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
 
 __device__ __forceinline__ void load_corner_color(const McParams& P, int x, int y, int z, int corner, float* c)
@@ -508,64 +535,35 @@ __device__ __forceinline__ void load_corner_color(const McParams& P, int x, int 
 __device__ __forceinline__ int mc_edge_corner_a(int e) { return e < 8 ? e : e - 8; }
 __device__ __forceinline__ int mc_edge_corner_b(int e) { return e < 8 ? ((e & 4) | ((e + 1) & 3)) : e - 4; }
 
+__device__ __forceinline__ void corners_to_column(const float4& lo, const float4& hi, float* col)
+{
+    col[0] = lo.x; col[256] = lo.y; col[2 * 256] = lo.z; col[3 * 256] = lo.w;
+    col[4 * 256] = hi.x; col[5 * 256] = hi.y; col[6 * 256] = hi.z; col[7 * 256] = hi.w;
+}
+
 // ---------------------------------------------------------------------------
 // K4: vertices
 // ---------------------------------------------------------------------------
-// The 3x3x3 voxel block around grid point (gx,gy,gz) -- origin (gx-1,gy-1,gz-1) -- into this
-// thread's LDS column: nine 16-byte loads (one per (x,y) row, z contiguous) instead of up
-// to 32 scattered dword loads.  Out-of-volume rows are clamped; their values are never used.
-__device__ __forceinline__ void stage_block3(const McParams& P, int gx, int gy, int gz, float* col)
-{
-    const int bz = gz - 1;
-    if (P.nz >= 4) {
-        const int zs = min(max(bz, 0), P.nz - 4);
-        const int sh = bz - zs;   // element of the float4 holding local z = 0
-        f4u q[9];
-#pragma unroll
-        for (int r = 0; r < 9; r++) {
-            const int x = min(max(gx - 1 + r / 3, 0), P.nx - 1), y = min(max(gy - 1 + r % 3, 0), P.ny - 1);
-            q[r] = *reinterpret_cast<const f4u*>(P.values + ((size_t)x * P.ny + y) * P.nz + zs);
-        }
-#pragma unroll
-        for (int r = 0; r < 9; r++) {
-#pragma unroll
-            for (int lz = 0; lz < 3; lz++) {
-                const int e = min(max(sh + lz, 0), 3);
-                const float v = e == 0 ? q[r].x : (e == 1 ? q[r].y : (e == 2 ? q[r].z : q[r].w));
-                col[(r * 3 + lz) * 256] = v;
-            }
-        }
-    } else {
-#pragma unroll 1
-        for (int r = 0; r < 27; r++) {
-            const int x = min(max(gx - 1 + r / 9, 0), P.nx - 1), y = min(max(gy - 1 + (r / 3) % 3, 0), P.ny - 1);
-            const int z = min(max(bz + r % 3, 0), P.nz - 1);
-            col[r * 256] = P.values[((size_t)x * P.ny + y) * P.nz + z];
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
-    __shared__ float s_c[27 * 256];   // per-thread 3x3x3 voxel block: [(lx*3+ly)*3+lz][thread]
+    __shared__ float s_c[8 * 256];   // this lane's current cell: [corner][thread]
     __shared__ uint64_t s_occ[MCLUT_NROWS];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_xy[256], s_z[256], s_info[256];
     __shared__ uint64_t s_own[256];
     __shared__ float s_red[6][4];
-    {   // per-row reference counts -> LDS (3 independent loads per lane)
+    {   // per-row reference counts / triangle counts -> LDS (independent loads per lane)
         const int t = (int)threadIdx.x;
+        static_assert(MCLUT_NROWS <= 768, "row table copy assumes <= 3 rounds");
         const uint64_t a0 = c_rowocc[min(t, MCLUT_NROWS - 1)], a1 = c_rowocc[min(t + 256, MCLUT_NROWS - 1)];
         const uint64_t a2 = c_rowocc[min(t + 512, MCLUT_NROWS - 1)];
-        static_assert(MCLUT_NROWS <= 768, "row table copy assumes <= 3 rounds");
         if (t < MCLUT_NROWS) s_occ[t] = a0;
         if (t + 256 < MCLUT_NROWS) s_occ[t + 256] = a1;
         if (t + 512 < MCLUT_NROWS) s_occ[t + 512] = a2;
     }
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
-    const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     const double iso = (double)P.iso;
     const double stp = (double)P.step;
     float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -589,33 +587,45 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int r = (int)(j - s_pre[rr]);
             const uint32_t info = s_info[rr];
             const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
+            if (z < P.lay_emit_begin) continue;   // context layer below a slab: numbered, not emitted
             const uint32_t vi = chunk_vbase + j;   // chunk prefix + in-chunk prefix: serial vertex id
+            const uint32_t out = vi - nghost;
+            if (out >= M.cap_vertices) { P.counters->overflow = 1u; continue; }
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = mc_edge_dir(e);
             const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
-            P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx] = vi;
-            if (z < P.lay_emit_begin) continue;   // context layer: only its vertex ids are needed
-            const uint32_t out = vi - nghost;
-            if (out >= M.cap_vertices) { P.counters->overflow = 1u; continue; }
+            const uint32_t own_rec = base + (uint32_t)rr;
             const int own_row = (int)(info >> 22);
             float pos[3], colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
-            // tilings of the in-range cells around this grid edge (sweep order), published by K3;
-            // issued before the voxel block so that all global loads of this vertex overlap
-            unsigned okmask = 0;
-            uint32_t tinfo[4] = {0u, 0u, 0u, 0u};
+            // records of the cells around this grid edge (sweep order) and their corner values:
+            // all loads of this vertex are issued before the first use
+            int rec[4] = {-1, -1, -1, -1};
+            int own_s = 3;
             if (e != 12) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int cx = gx + mc_share_dx(dir, s), cy = gy + mc_share_dy(dir, s), cz = gz + mc_share_dz(dir, s);
-                    const bool ok = cell_in_range(P, cx, cy, cz);
-                    okmask |= ok ? (1u << s) : 0u;
-                    if (ok) tinfo[s] = P.emap[4 * nvox + ((size_t)cz * P.ny + cy) * P.nx + cx];
+                    if (cx == x && cy == y && cz == z) { rec[s] = (int)own_rec; own_s = s; }
+                    else if (cx >= 0 && cy >= 0 && cx < P.ncx && cy < P.ncy) rec[s] = find_record(P, cx, cy, cz);
                 }
+            } else {
+                rec[3] = (int)own_rec;
             }
-            // voxel block around the edge's base point (for the centre vertex: around the cell)
-            stage_block3(P, gx, gy, gz, col);
-            const CornersNbr v{col, x - gx + 1, y - gy + 1, z - gz + 1, iso};   // the creator cell
+            float4 qlo[4], qhi[4];
+            uint32_t tinfo[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const uint32_t k = (uint32_t)max(rec[s], 0);
+                qlo[s] = *reinterpret_cast<const float4*>(P.rec_corners + (size_t)k * 8);
+                qhi[s] = *reinterpret_cast<const float4*>(P.rec_corners + (size_t)k * 8 + 4);
+                tinfo[s] = rec[s] >= 0 ? P.rec_info[k] : 0u;
+            }
+            // the creator cell
+            const float4 olo = own_s == 0 ? qlo[0] : (own_s == 1 ? qlo[1] : (own_s == 2 ? qlo[2] : qlo[3]));
+            const float4 ohi = own_s == 0 ? qhi[0] : (own_s == 1 ? qhi[1] : (own_s == 2 ? qhi[2] : qhi[3]));
+            corners_to_column(olo, ohi, col);
+            const CornersLds v{col, 256, iso};
             if (e == 12) {
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
@@ -690,12 +700,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 // sees the same two end voxels, so the two weights are computed once.
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const int nts = (int)((tinfo[s] >> 10) & 15u);
-                    if (!((okmask >> s) & 1u) || nts == 0) continue;
+                    if (tinfo[s] == 0u) continue;   // out of range, or a cell that emits nothing
+                    const int row = (int)(tinfo[s] >> 22);
                     const int es = mc_share_edge(dir, s);
-                    const int occ = (int)((s_occ[tinfo[s] & 1023u] >> (4 * es)) & 15ull);
+                    const int occ = (int)((s_occ[row] >> (4 * es)) & 15ull);
                     if (!occ) continue;
-                    const CornersNbr vs{col, mc_share_dx(dir, s) + 1, mc_share_dy(dir, s) + 1, mc_share_dz(dir, s) + 1, iso};
+                    corners_to_column(qlo[s], qhi[s], col);
+                    const CornersLds vs{col, 256, iso};
                     const int a = mc_edge_corner_a(es), b = mc_edge_corner_b(es);
                     const int da = dir == 0 ? mc_corner_dx(a) : (dir == 1 ? mc_corner_dy(a) : mc_corner_dz(a));
                     const double wa = da ? w_hi : w_lo, wb = da ? w_lo : w_hi;
@@ -794,6 +805,36 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partia
 // ---------------------------------------------------------------------------
 // K5: triangles
 // ---------------------------------------------------------------------------
+// Vertex id of edge e of cell (x,y,z) [record i]: the creator is the first LIVE cell of the
+// sweep around the grid edge; its first vertex id (chunk prefix + in-chunk prefix) plus the
+// rank of the edge in its creation list.
+__device__ __forceinline__ uint32_t vertex_id_of_edge(const McParams& P, uint32_t i, int x, int y, int z, int e)
+{
+    int io = (int)i, eo = e;
+    if (e != 12) {
+        const int dir = mc_edge_dir(e);
+        const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int cx = gx + mc_share_dx(dir, s), cy = gy + mc_share_dy(dir, s), cz = gz + mc_share_dz(dir, s);
+            if (cx == x && cy == y && cz == z) break;   // this cell itself is the first live sharer
+            if (cx < 0 || cy < 0 || cx >= P.ncx || cy >= P.ncy) continue;
+            const int k = find_record(P, cx, cy, cz);
+            if (k < 0) continue;
+            if (P.rec_info[k] == 0u) continue;          // "impossible 13": emits and creates nothing
+            io = k;
+            eo = mc_share_edge(dir, s);
+            break;
+        }
+    }
+    const uint64_t own = P.rec_own[io];
+    const uint32_t nown = (P.rec_info[io] >> 18) & 15u;
+    uint32_t rank = 0;
+    for (uint32_t q = 0; q < nown; q++)
+        if ((int)((own >> (4 * q)) & 15ull) == eo) rank = q;
+    return (uint32_t)(P.chunktot[(uint32_t)io >> 8] >> 31) + (P.rec_pre[io] & 0xffffu) + rank;
+}
+
 __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
@@ -803,7 +844,6 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
     mc_load_lut_to_lds(s_lut);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
-    const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_ni = 0;
@@ -817,33 +857,15 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
         }
         const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
         const size_t chunk_ibase = (size_t)(P.chunktot[base >> 8] & 0x7fffffffull) * 3;
-        // one lane per triangle index; four independent gathers in flight per lane
-        for (uint32_t j0 = threadIdx.x; j0 < total; j0 += 1024u) {
-            uint32_t vi[4];
-            size_t o[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t j = j0 + 256u * u;
-                ok[u] = j < total;
-                vi[u] = 0;
-                o[u] = chunk_ibase + j;   // serial position of this triangle index
-                if (ok[u]) {
-                    const int rr = find_owner_256(s_pre, j);
-                    const uint32_t k = j - s_pre[rr];
-                    const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
-                    const int e = s_lut[s_lo[rr] + k];
-                    const int dir = mc_edge_dir(e);
-                    const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
-                    vi[u] = P.emap[(size_t)dir * nvox + ((size_t)gz * P.ny + gy) * P.nx + gx];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (!ok[u]) continue;
-                if (o[u] >= M.cap_indices) { P.counters->overflow = 1u; continue; }
-                M.triangles[o[u]] = (int32_t)((int64_t)vi[u] - (int64_t)nghost + M.vertex_base);
-            }
+        for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
+            const size_t o = chunk_ibase + j;   // serial position of this triangle index
+            if (o >= M.cap_indices) { P.counters->overflow = 1u; continue; }
+            const int rr = find_owner_256(s_pre, j);
+            const uint32_t k = j - s_pre[rr];
+            const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
+            const int e = s_lut[s_lo[rr] + k];
+            const uint32_t vi = vertex_id_of_edge(P, base + (uint32_t)rr, x, y, z, e);
+            M.triangles[o] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
         }
     }
 }

@@ -37,12 +37,16 @@ struct McParams {
     int nyc;               // ceil(ncy / yb)
     uint64_t* blockcnt;    // active cells per logical block of k_compact; exclusive prefix after k_scan1<0>
     uint64_t* chunktot;    // (vertices << 31 | triangles) per 256-cell chunk; exclusive prefix after k_scan1<1>
-    uint32_t* rec_xy;      // active cells in serial-sweep order: x | y << 16
-    uint32_t* rec_z;       //                                     z (local layer)
-    uint32_t* rec_info;    // lut_off | nt << 14 | n_created << 18
+    // Active cells ("records") in serial-sweep order.  Everything the emit kernels read is
+    // compact (tens of MB, L2/MALL resident): no per-voxel maps.
+    uint32_t* rec_xy;      // x | y << 16
+    uint32_t* rec_z;       // z (local layer)
+    uint32_t* rowstart;    // [(z - lay_count_begin) * ncy + y] = first record of cell row (z,y); +1 sentinel
+    uint32_t* rec_info;    // lut_off | nt_emitted << 14 | n_created << 18 | row_id << 22   (0 = emits nothing)
     uint64_t* rec_own;     // created edge ids, 4 bits each, creation order
+    uint32_t* rec_pre;     // in-chunk exclusive prefix: created vertices | triangles << 16
+    float* rec_corners;    // 8 corner voxel values (v0..v7), 32 bytes per record
     uint32_t cap_active;
-    uint32_t* emap;        // [5][nz][ny][nx]: vertex id per grid edge X,Y,Z / cell centre; tiling per cell
     McCounters* counters;
 };
 

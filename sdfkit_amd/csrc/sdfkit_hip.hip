@@ -682,7 +682,6 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     // logical blocks of k_compact: `yb` cell rows of one layer, sign words staged in <= 40 KB of LDS
     P.yb = std::max(1, std::min(128, 2560 / P.nxw - 1));
     P.nyc = (P.ncy + P.yb - 1) / P.yb;
-    const size_t nvox = (size_t)P.nx * P.ny * P.nz;
     const size_t ncell = (size_t)P.ncx * P.ncy * P.ncz;
     size_t cap = std::max<size_t>(ncell / 12, 1u << 16);
     cap = std::min(cap, ncell);
@@ -695,7 +694,7 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
         P.bits = bits;
     }
     r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.nyc + 1);
-    r = r ? r : job_alloc(j, &P.emap, nvox * 5);
+    r = r ? r : job_alloc(j, &P.rowstart, (size_t)(P.lay_list_end - P.lay_count_begin) * P.ncy + 2);
     r = r ? r : job_alloc(j, &P.counters, 1);
     size_t act_idx = 0;
     auto alloc_records = [&](size_t c) -> int {
@@ -704,6 +703,8 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
         rr = rr ? rr : job_alloc(j, &P.rec_z, c);
         rr = rr ? rr : job_alloc(j, &P.rec_info, c);
         rr = rr ? rr : job_alloc(j, &P.rec_own, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
+        rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
         rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
         P.cap_active = (uint32_t)c;
         return rr;
