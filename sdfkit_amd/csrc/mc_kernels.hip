@@ -216,10 +216,37 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
         if (threadIdx.x == 0) P.blockcnt[b] = total;
         return;
     }
+    // exclusive prefix of this block = sum of the counts of all earlier blocks (a few thousand
+    // words, read cooperatively: cheaper than a separate scan launch); also the layer marks
+    uint64_t before = 0, ghost = 0, upto_emit_end = 0;
     {
-        uint32_t pos = (uint32_t)(P.blockcnt[b] + pre);   // blockcnt now holds the exclusive prefix
+        const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.nyc, ge = (P.lay_emit_end - P.lay_count_begin) * P.nyc;
+        const bool last = b == (int)gridDim.x - 1;
+        const int lim = last ? (int)gridDim.x : b;
+        for (int i = threadIdx.x; i < lim; i += 256) {
+            const uint64_t c = P.blockcnt[i];
+            if (i < b) before += c;
+            if (i < gb) ghost += c;
+            if (i < ge) upto_emit_end += c;
+        }
+        __shared__ uint64_t s_sum[3][4];
+        before = wave_sum_u64(before); ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { s_sum[0][wave] = before; s_sum[1][wave] = ghost; s_sum[2][wave] = upto_emit_end; }
+        __syncthreads();
+        before = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
+        if (last && threadIdx.x == 0) {
+            const uint64_t ng = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
+            const uint64_t ue = s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3];
+            P.counters->n_active = (uint32_t)(before + total);
+            P.counters->n_ghost_cells = (uint32_t)ng;
+            P.counters->n_emit_cells = (uint32_t)(ue - ng);
+        }
+    }
+    {
+        uint32_t pos = (uint32_t)(before + pre);
         uint32_t* rowstart = P.rowstart + (size_t)(z - P.lay_count_begin) * P.ncy + y0;
-        if (b == (int)gridDim.x - 1 && threadIdx.x == 255) rowstart[rows] = (uint32_t)(P.blockcnt[b] + total);   // sentinel
+        if (b == (int)gridDim.x - 1 && threadIdx.x == 255) rowstart[rows] = (uint32_t)(before + total);   // sentinel
         int y_l = sb / P.nxw, xw = sb % P.nxw;
         for (int s = sb; s < se; s++) {
             uint64_t m13;
@@ -240,18 +267,16 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     }
 }
 
-// One workgroup: in-place exclusive scan of data[0..n) (64-bit adds; a value may pack two
-// counters).  MODE 0: per-block active-cell counts -> n_active, n_ghost_records.
-// MODE 1: per-chunk (vertices << 31 | triangles) -> totals and nghost.
-template <int MODE>
-__global__ __launch_bounds__(1024) void k_scan1(McParams P)
+// One workgroup: in-place exclusive scan of the per-chunk (vertices << 31 | triangles)
+// totals -> chunk prefixes, grand totals, and the vertex count of the ghost layer.
+__global__ __launch_bounds__(1024) void k_scan_chunks(McParams P)
 {
     __shared__ uint64_t sm[16];
     __shared__ uint64_t s_carry;
-    uint64_t* data = MODE == 0 ? P.blockcnt : P.chunktot;
-    uint32_t n;
-    if (MODE == 0) n = (uint32_t)((P.lay_list_end - P.lay_count_begin) * P.nyc);
-    else n = (min(P.counters->n_active, P.cap_active) + 255u) >> 8;
+    __shared__ uint32_t s_part[16];
+    uint64_t* data = P.chunktot;
+    const uint32_t nrec = min(P.counters->n_active, P.cap_active);
+    const uint32_t n = (nrec + 255u) >> 8;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -272,38 +297,22 @@ __global__ __launch_bounds__(1024) void k_scan1(McParams P)
         if (threadIdx.x == 0) s_carry = carry + all;
         __syncthreads();
     }
-    if (MODE == 0) {
-        if (threadIdx.x == 0) {
-            const uint32_t tot = (uint32_t)s_carry;
-            P.counters->n_active = tot;
-            // cells listed below the first emitted layer (the "ghost" layer of a slab), and
-            // inside the emitted layers
-            const uint32_t gb = (uint32_t)((P.lay_emit_begin - P.lay_count_begin) * P.nyc);
-            const uint32_t ge = (uint32_t)((P.lay_emit_end - P.lay_count_begin) * P.nyc);
-            const uint32_t ng = gb == 0 ? 0u : (gb < n ? (uint32_t)data[gb] : tot);
-            P.counters->n_ghost_cells = ng;
-            P.counters->n_emit_cells = (ge < n ? (uint32_t)data[ge] : tot) - ng;
-        }
-    } else {
-        // vertices numbered before the first emitted cell: chunk prefix + in-chunk prefix
-        __shared__ uint32_t s_part[16];
-        const uint32_t nrec = min(P.counters->n_active, P.cap_active);
-        const uint32_t i0 = min(P.counters->n_ghost_cells, nrec);
-        const uint32_t c0 = i0 >> 8, r0 = i0 & 255u;
-        uint32_t part = 0;
-        if (threadIdx.x < r0) part = (P.rec_info[c0 * 256u + threadIdx.x] >> 18) & 15u;
+    // vertices numbered before the first emitted cell: chunk prefix + in-chunk prefix
+    const uint32_t i0 = min(P.counters->n_ghost_cells, nrec);
+    const uint32_t c0 = i0 >> 8, r0 = i0 & 255u;
+    uint32_t part = 0;
+    if (threadIdx.x < r0) part = (P.rec_info[c0 * 256u + threadIdx.x] >> 18) & 15u;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if (lane == 0) s_part[wave] = part;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t in_chunk = 0;
-            for (int w = 0; w < 16; w++) in_chunk += s_part[w];
-            const uint64_t basep = (c0 < n) ? data[c0] : s_carry;
-            P.counters->nghost = (uint32_t)(basep >> 31) + in_chunk;
-            P.counters->total_v = (uint32_t)(s_carry >> 31);
-            P.counters->total_t = (uint32_t)(s_carry & 0x7fffffffull);
-        }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) s_part[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t in_chunk = 0;
+        for (int w = 0; w < 16; w++) in_chunk += s_part[w];
+        const uint64_t basep = (c0 < n) ? data[c0] : s_carry;
+        P.counters->nghost = (uint32_t)(basep >> 31) + in_chunk;
+        P.counters->total_v = (uint32_t)(s_carry >> 31);
+        P.counters->total_t = (uint32_t)(s_carry & 0x7fffffffull);
     }
 }
 
@@ -325,6 +334,12 @@ __device__ __forceinline__ void stage_corners(const float* values, int ny, int n
     const f2u q3 = *reinterpret_cast<const f2u*>(p + sy), q2 = *reinterpret_cast<const f2u*>(p + sx + sy);
     col[0] = q0.x; col[stride] = q1.x; col[2 * stride] = q2.x; col[3 * stride] = q3.x;
     col[4 * stride] = q0.y; col[5 * stride] = q1.y; col[6 * stride] = q2.y; col[7 * stride] = q3.y;
+}
+
+__device__ __forceinline__ void corners_to_column(const float4& lo, const float4& hi, float* col)
+{
+    col[0] = lo.x; col[256] = lo.y; col[2 * 256] = lo.z; col[3 * 256] = lo.w;
+    col[4 * 256] = hi.x; col[5 * 256] = hi.y; col[6 * 256] = hi.z; col[7 * 256] = hi.w;
 }
 
 __device__ __forceinline__ bool cell_in_range(const McParams& P, int x, int y, int z)
@@ -406,6 +421,23 @@ __device__ __forceinline__ unsigned positional_own_mask(bool X, bool Y, bool Z)
     return m;
 }
 
+// K3a: corner values of every active cell -> its record.  The only sparse access to the
+// volume in the whole pipeline; one lane per record, four 8-byte loads in flight per lane,
+// full occupancy; the stores are 32 contiguous bytes per lane.
+__global__ __launch_bounds__(256) void k_gather_corners(McParams P)
+{
+    const uint32_t n = min(P.counters->n_active, P.cap_active);
+    const size_t sx = (size_t)P.ny * P.nz, sy = (size_t)P.nz;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t xy = P.rec_xy[i];
+        const float* p = P.values + (size_t)(xy & 0xffffu) * sx + (size_t)(xy >> 16) * sy + P.rec_z[i];
+        const f2u q0 = *reinterpret_cast<const f2u*>(p), q1 = *reinterpret_cast<const f2u*>(p + sx);
+        const f2u q3 = *reinterpret_cast<const f2u*>(p + sy), q2 = *reinterpret_cast<const f2u*>(p + sx + sy);
+        *reinterpret_cast<float4*>(P.rec_corners + (size_t)i * 8) = make_float4(q0.x, q1.x, q2.x, q3.x);
+        *reinterpret_cast<float4*>(P.rec_corners + (size_t)i * 8 + 4) = make_float4(q0.y, q1.y, q2.y, q3.y);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_resolve(McParams P)
 {
     __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
@@ -424,10 +456,8 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
         if (i < n) {
             const uint32_t xy = P.rec_xy[i];
             const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), z = (int)P.rec_z[i];
-            stage_corners(P.values, P.ny, P.nz, x, y, z, col, 256);
-            // the record keeps the corner values: K4 never goes back to the volume
-            *reinterpret_cast<float4*>(P.rec_corners + (size_t)i * 8) = make_float4(col[0], col[256], col[2 * 256], col[3 * 256]);
-            *reinterpret_cast<float4*>(P.rec_corners + (size_t)i * 8 + 4) = make_float4(col[4 * 256], col[5 * 256], col[6 * 256], col[7 * 256]);
+            corners_to_column(*reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8),
+                              *reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8 + 4), col);
             const CornersLds v{col, 256, (double)P.iso};
             const Tiling t = mc_resolve(s_lut, v);
             const bool counted = z < P.lay_emit_end;     // the layer above is context only
@@ -535,12 +565,6 @@ __device__ __forceinline__ void load_corner_color(const McParams& P, int x, int 
 __device__ __forceinline__ int mc_edge_corner_a(int e) { return e < 8 ? e : e - 8; }
 __device__ __forceinline__ int mc_edge_corner_b(int e) { return e < 8 ? ((e & 4) | ((e + 1) & 3)) : e - 4; }
 
-__device__ __forceinline__ void corners_to_column(const float4& lo, const float4& hi, float* col)
-{
-    col[0] = lo.x; col[256] = lo.y; col[2 * 256] = lo.z; col[3 * 256] = lo.w;
-    col[4 * 256] = hi.x; col[5 * 256] = hi.y; col[6 * 256] = hi.z; col[7 * 256] = hi.w;
-}
-
 // ---------------------------------------------------------------------------
 // K4: vertices
 // ---------------------------------------------------------------------------
@@ -587,10 +611,10 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int r = (int)(j - s_pre[rr]);
             const uint32_t info = s_info[rr];
             const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
-            if (z < P.lay_emit_begin) continue;   // context layer below a slab: numbered, not emitted
+            const bool emit = z >= P.lay_emit_begin;   // the layer below a slab is numbered, not emitted
             const uint32_t vi = chunk_vbase + j;   // chunk prefix + in-chunk prefix: serial vertex id
             const uint32_t out = vi - nghost;
-            if (out >= M.cap_vertices) { P.counters->overflow = 1u; continue; }
+            if (emit && out >= M.cap_vertices) { P.counters->overflow = 1u; continue; }
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = mc_edge_dir(e);
             const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
@@ -612,6 +636,15 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             } else {
                 rec[3] = (int)own_rec;
             }
+            // push this vertex's id into every live cell around the edge (K5 reads only its own record)
+            if (e == 12) {
+                P.rec_vid[(size_t)own_rec * 16 + 12] = vi;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    if (rec[s] >= 0) P.rec_vid[(size_t)rec[s] * 16 + mc_share_edge(dir, s)] = vi;
+            }
+            if (!emit) continue;
             float4 qlo[4], qhi[4];
             uint32_t tinfo[4];
 #pragma unroll
@@ -805,42 +838,12 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partia
 // ---------------------------------------------------------------------------
 // K5: triangles
 // ---------------------------------------------------------------------------
-// Vertex id of edge e of cell (x,y,z) [record i]: the creator is the first LIVE cell of the
-// sweep around the grid edge; its first vertex id (chunk prefix + in-chunk prefix) plus the
-// rank of the edge in its creation list.
-__device__ __forceinline__ uint32_t vertex_id_of_edge(const McParams& P, uint32_t i, int x, int y, int z, int e)
-{
-    int io = (int)i, eo = e;
-    if (e != 12) {
-        const int dir = mc_edge_dir(e);
-        const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int cx = gx + mc_share_dx(dir, s), cy = gy + mc_share_dy(dir, s), cz = gz + mc_share_dz(dir, s);
-            if (cx == x && cy == y && cz == z) break;   // this cell itself is the first live sharer
-            if (cx < 0 || cy < 0 || cx >= P.ncx || cy >= P.ncy) continue;
-            const int k = find_record(P, cx, cy, cz);
-            if (k < 0) continue;
-            if (P.rec_info[k] == 0u) continue;          // "impossible 13": emits and creates nothing
-            io = k;
-            eo = mc_share_edge(dir, s);
-            break;
-        }
-    }
-    const uint64_t own = P.rec_own[io];
-    const uint32_t nown = (P.rec_info[io] >> 18) & 15u;
-    uint32_t rank = 0;
-    for (uint32_t q = 0; q < nown; q++)
-        if ((int)((own >> (4 * q)) & 15ull) == eo) rank = q;
-    return (uint32_t)(P.chunktot[(uint32_t)io >> 8] >> 31) + (P.rec_pre[io] & 0xffffu) + rank;
-}
-
 __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_xy[256], s_z[256], s_lo[256];
+    __shared__ uint32_t s_lo[256];
     mc_load_lut_to_lds(s_lut);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
@@ -851,8 +854,6 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
         if (irec < n) {
             const uint32_t info = P.rec_info[irec];
             my_ni = 3u * ((info >> 14) & 15u);
-            s_xy[threadIdx.x] = P.rec_xy[irec];
-            s_z[threadIdx.x] = P.rec_z[irec];
             s_lo[threadIdx.x] = info & 0x3fffu;
         }
         const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
@@ -862,9 +863,8 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             if (o >= M.cap_indices) { P.counters->overflow = 1u; continue; }
             const int rr = find_owner_256(s_pre, j);
             const uint32_t k = j - s_pre[rr];
-            const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
             const int e = s_lut[s_lo[rr] + k];
-            const uint32_t vi = vertex_id_of_edge(P, base + (uint32_t)rr, x, y, z, e);
+            const uint32_t vi = P.rec_vid[(size_t)(base + (uint32_t)rr) * 16 + e];   // pushed by the creator (K4)
             M.triangles[o] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
         }
     }

@@ -46,6 +46,7 @@ struct McParams {
     uint64_t* rec_own;     // created edge ids, 4 bits each, creation order
     uint32_t* rec_pre;     // in-chunk exclusive prefix: created vertices | triangles << 16
     float* rec_corners;    // 8 corner voxel values (v0..v7), 32 bytes per record
+    uint32_t* rec_vid;     // [record][16]: vertex id of the cell's edge e (0..12), pushed by the creator
     uint32_t cap_active;
     McCounters* counters;
 };

@@ -597,15 +597,15 @@ int launch_classify(sdfk_march_job* j, bool redo_bits)
         const int nlog = (P.lay_list_end - P.lay_count_begin) * P.nyc;
         const size_t lds = (size_t)2 * (P.yb + 1) * P.nxw * sizeof(uint64_t);
         hipLaunchKernelGGL(k_compact<false>, dim3(nlog), dim3(256), lds, g.stream, P);
-        hipLaunchKernelGGL(k_scan1<0>, dim3(1), dim3(1024), 0, g.stream, P);
         hipLaunchKernelGGL(k_compact<true>, dim3(nlog), dim3(256), lds, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps("k_resolve");
         const int nchunks = (int)((P.cap_active + 255u) / 256u);
+        hipLaunchKernelGGL(k_gather_corners, dim3(std::min(nchunks, 256 * 8)), dim3(256), 0, g.stream, P);
         hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, 256 * 12)), dim3(256), 0, g.stream, P);
-        hipLaunchKernelGGL(k_scan1<1>, dim3(1), dim3(1024), 0, g.stream, P);
+        hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipMemcpyAsync(g.h_counters, P.counters, sizeof(McCounters), hipMemcpyDeviceToHost, g.stream));
@@ -705,6 +705,7 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
         rr = rr ? rr : job_alloc(j, &P.rec_own, c);
         rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
         rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
+        rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 16);
         rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
         P.cap_active = (uint32_t)c;
         return rr;
