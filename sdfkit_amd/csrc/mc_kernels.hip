@@ -212,35 +212,41 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     uint64_t total;
     const uint64_t pre = block_excl_scan_u64(cnt, s_wave, &total);
     if (!WRITE) {
-        if (n13) atomicAdd(&P.counters->n_case13, n13);
-        if (threadIdx.x == 0) P.blockcnt[b] = total;
+        // low 32 bits: active cells of the block; high 32 bits: its case-13 sign words
+        uint64_t t13;
+        (void)block_excl_scan_u64(n13, s_wave, &t13);
+        if (threadIdx.x == 0) P.blockcnt[b] = total | (t13 << 32);
         return;
     }
     // exclusive prefix of this block = sum of the counts of all earlier blocks (a few thousand
     // words, read cooperatively: cheaper than a separate scan launch); also the layer marks
-    uint64_t before = 0, ghost = 0, upto_emit_end = 0;
+    uint64_t before = 0, ghost = 0, upto_emit_end = 0, all13 = 0;
     {
         const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.nyc, ge = (P.lay_emit_end - P.lay_count_begin) * P.nyc;
         const bool last = b == (int)gridDim.x - 1;
         const int lim = last ? (int)gridDim.x : b;
         for (int i = threadIdx.x; i < lim; i += 256) {
-            const uint64_t c = P.blockcnt[i];
+            const uint64_t w = P.blockcnt[i];
+            const uint64_t c = w & 0xffffffffull;
             if (i < b) before += c;
             if (i < gb) ghost += c;
             if (i < ge) upto_emit_end += c;
+            all13 += w >> 32;
         }
-        __shared__ uint64_t s_sum[3][4];
+        __shared__ uint64_t s_sum[4][4];
         before = wave_sum_u64(before); ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end);
+        all13 = wave_sum_u64(all13);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { s_sum[0][wave] = before; s_sum[1][wave] = ghost; s_sum[2][wave] = upto_emit_end; }
+        if (lane == 0) { s_sum[0][wave] = before; s_sum[1][wave] = ghost; s_sum[2][wave] = upto_emit_end; s_sum[3][wave] = all13; }
         __syncthreads();
         before = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
-        if (last && threadIdx.x == 0) {
+        if (last && threadIdx.x == 0) {   // the last block sees every count: publish the totals
             const uint64_t ng = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
             const uint64_t ue = s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3];
             P.counters->n_active = (uint32_t)(before + total);
             P.counters->n_ghost_cells = (uint32_t)ng;
             P.counters->n_emit_cells = (uint32_t)(ue - ng);
+            P.counters->n_case13 = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
         }
     }
     {
@@ -280,9 +286,11 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(McParams P)
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t dead = 0;
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const uint64_t v = (i < n) ? data[i] : 0ull;
+        if (i < n) dead += P.chunkdead[i];
         const uint64_t incl = wave_incl_scan_u64(v);
         if (lane == 63) sm[wave] = incl;
         __syncthreads();
@@ -302,17 +310,27 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(McParams P)
     const uint32_t c0 = i0 >> 8, r0 = i0 & 255u;
     uint32_t part = 0;
     if (threadIdx.x < r0) part = (P.rec_info[c0 * 256u + threadIdx.x] >> 18) & 15u;
+    __shared__ uint32_t s_dead[16];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if (lane == 0) s_part[wave] = part;
+    for (int o = 32; o > 0; o >>= 1) { part += __shfl_xor(part, o); dead += __shfl_xor(dead, o); }
+    if (lane == 0) { s_part[wave] = part; s_dead[wave] = dead; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t in_chunk = 0;
-        for (int w = 0; w < 16; w++) in_chunk += s_part[w];
+        uint32_t in_chunk = 0, ndead = 0;
+        for (int w = 0; w < 16; w++) { in_chunk += s_part[w]; ndead += s_dead[w]; }
         const uint64_t basep = (c0 < n) ? data[c0] : s_carry;
-        P.counters->nghost = (uint32_t)(basep >> 31) + in_chunk;
-        P.counters->total_v = (uint32_t)(s_carry >> 31);
-        P.counters->total_t = (uint32_t)(s_carry & 0x7fffffffull);
+        McCounters c = *P.counters;
+        c.nghost = (uint32_t)(basep >> 31) + in_chunk;
+        c.total_v = (uint32_t)(s_carry >> 31);
+        c.total_t = (uint32_t)(s_carry & 0x7fffffffull);
+        c.n_dead = ndead;
+        c.overflow = 0;
+        *P.counters = c;
+        // mirror for the host (read after the stream has drained); `overflow` is only ever
+        // raised afterwards, directly in the mirror, by the emit kernels
+        McCounters* h = P.host_counters;
+        h->n_active = c.n_active; h->n_case13 = c.n_case13; h->n_dead = c.n_dead; h->total_v = c.total_v;
+        h->total_t = c.total_t; h->nghost = c.nghost; h->n_ghost_cells = c.n_ghost_cells; h->n_emit_cells = c.n_emit_cells;
     }
 }
 
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
     float* col = s_v + threadIdx.x;
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint32_t i = (uint32_t)c * 256u + threadIdx.x;
-        uint32_t nown = 0, nt_emit = 0, info = 0;
+        uint32_t nown = 0, nt_emit = 0, info = 0, dead = 0;
         uint64_t own = 0;
         if (i < n) {
             const uint32_t xy = P.rec_xy[i];
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
                 nt_emit = emit ? (uint32_t)t.nt : 0u;
                 info = (uint32_t)t.lut_off | (nt_emit << 14) | (nown << 18) | ((uint32_t)t.row << 22);
             } else if (emit && (t.index == 0xA5 || t.index == 0x5A)) {
-                atomicAdd(&P.counters->n_dead, 1u);
+                dead = 1;
             }
         }
         // in-chunk prefix and chunk total of (created vertices, triangles), packed v << 31 | t
@@ -493,7 +511,9 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
             P.rec_own[i] = own;
             P.rec_pre[i] = (uint32_t)(pre >> 31) | ((uint32_t)(pre & 0x7fffffffull) << 16);
         }
-        if (threadIdx.x == 0) P.chunktot[c] = total;
+        uint64_t ndead;
+        (void)block_excl_scan_u64(dead, s_wave, &ndead);
+        if (threadIdx.x == 0) { P.chunktot[c] = total; P.chunkdead[c] = (uint32_t)ndead; }
     }
 }
 
@@ -614,7 +634,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const bool emit = z >= P.lay_emit_begin;   // the layer below a slab is numbered, not emitted
             const uint32_t vi = chunk_vbase + j;   // chunk prefix + in-chunk prefix: serial vertex id
             const uint32_t out = vi - nghost;
-            if (emit && out >= M.cap_vertices) { P.counters->overflow = 1u; continue; }
+            if (emit && out >= M.cap_vertices) { P.host_counters->overflow = 1u; continue; }
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = mc_edge_dir(e);
             const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
@@ -804,15 +824,17 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     }
 }
 
-__global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partial, int nblk, float* __restrict__ bounds)
+// Mesh.Measure (Mesh.cs:30-45): reduce the per-workgroup AABB partials of K4.  Run by one
+// workgroup of K5 (K4 is complete by then), so it costs no launch of its own.
+__device__ __forceinline__ void reduce_bounds(const McMeshOut& M)
 {
     __shared__ float s_red[6][4];
     float r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int b = threadIdx.x; b < nblk; b += 256) {
+    for (int b = threadIdx.x; b < M.bounds_blocks; b += 256) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) r[j] = fminf(r[j], partial[(size_t)b * 6 + j]);
+        for (int j = 0; j < 3; j++) r[j] = fminf(r[j], M.bounds_partial[(size_t)b * 6 + j]);
 #pragma unroll
-        for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], partial[(size_t)b * 6 + j]);
+        for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], M.bounds_partial[(size_t)b * 6 + j]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -831,8 +853,10 @@ __global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partia
         const int j = threadIdx.x;
         float a = s_red[j][0];
         for (int w = 1; w < 4; w++) a = (j < 3) ? fminf(a, s_red[j][w]) : fmaxf(a, s_red[j][w]);
-        bounds[j] = a;
+        M.bounds[j] = a;
+        M.host_bounds[j] = a;
     }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -847,6 +871,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
     mc_load_lut_to_lds(s_lut);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
+    if (blockIdx.x == 0) reduce_bounds(M);   // K4 has completed (stream order): finish Mesh.Measure
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_ni = 0;
@@ -860,7 +885,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
         const size_t chunk_ibase = (size_t)(P.chunktot[base >> 8] & 0x7fffffffull) * 3;
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
             const size_t o = chunk_ibase + j;   // serial position of this triangle index
-            if (o >= M.cap_indices) { P.counters->overflow = 1u; continue; }
+            if (o >= M.cap_indices) { P.host_counters->overflow = 1u; continue; }
             const int rr = find_owner_256(s_pre, j);
             const uint32_t k = j - s_pre[rr];
             const int e = s_lut[s_lo[rr] + k];

@@ -47,8 +47,10 @@ struct McParams {
     uint32_t* rec_pre;     // in-chunk exclusive prefix: created vertices | triangles << 16
     float* rec_corners;    // 8 corner voxel values (v0..v7), 32 bytes per record
     uint32_t* rec_vid;     // [record][16]: vertex id of the cell's edge e (0..12), pushed by the creator
+    uint32_t* chunkdead;   // "impossible case 13" cells per 256-cell chunk
     uint32_t cap_active;
-    McCounters* counters;
+    McCounters* counters;       // device copy; every field is written by a kernel (no memset)
+    McCounters* host_counters;  // pinned, device-mapped mirror the host reads after ONE sync
 };
 
 struct McMeshOut {
@@ -63,6 +65,9 @@ struct McMeshOut {
     float sc[3], tr[3];    // Mesh.Transform: v*sc + tr (MarchingCubes.cs:85-90)
     float inv[3];          // diagonal of transpose(inverse(scale)) (Mesh.cs:49-55)
     float* bounds_partial; // [grid][6]
+    int bounds_blocks;     // number of k_vertices workgroups
+    float* bounds;         // device float[6] (Mesh.Min, Mesh.Max)
+    float* host_bounds;    // pinned, device-mapped mirror
 };
 
 }  // namespace sdfk

@@ -62,9 +62,17 @@ struct Context {
     std::vector<int64_t> prof_n;
     std::vector<ProfSpan> prof_pending;
     std::vector<hipEvent_t> prof_event_pool;
-    // pinned host scratch for counter read-back
-    McCounters* h_counters = nullptr;
-    float* h_bounds = nullptr;
+    // pinned, device-mapped result slots: kernels mirror their counters / mesh bounds here,
+    // the host reads them after its single stream sync (no copy kernel, no memset)
+    struct HostSlot { McCounters c; float bounds[8]; };
+    static constexpr int NSLOTS = 64;
+    HostSlot* slots = nullptr;      // host view
+    HostSlot* slots_dev = nullptr;  // device view
+    int slot_next = 0;
+    // sizes seen last time for a (shape, iso-independent) key: lets a repeat call launch the
+    // whole pipeline speculatively and synchronise once
+    struct Hint { uint32_t n_active, nv, ni; };
+    std::map<uint64_t, Hint> hints;
 };
 
 Context g;
@@ -222,6 +230,7 @@ struct sdfk_mesh {
     float h_min[3] = {0, 0, 0}, h_max[3] = {0, 0, 0};
     bool bounds_valid = false;
     int64_t n_active = 0, n_case13 = 0;
+    size_t cap_v = 0, cap_i = 0;   // allocated capacity (>= nv, ni)
 };
 
 struct sdfk_march_job {
@@ -234,6 +243,9 @@ struct sdfk_march_job {
     float gmin[3], gmax[3];
     bool finished = false;
     bool empty = false;
+    bool have_bits = false;
+    int slot = 0;                  // index of the pinned result slot
+    size_t rec_first = 0;          // first entry of `owned` that belongs to the record arrays
 };
 
 // ---------------------------------------------------------------------------
@@ -261,8 +273,9 @@ extern "C" int sdfk_init(int device)
         return fail(SDFK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
     g.stream = g.own_stream;
-    HIPCHK(hipHostMalloc((void**)&g.h_counters, sizeof(McCounters)));
-    HIPCHK(hipHostMalloc((void**)&g.h_bounds, 6 * sizeof(float)));
+    HIPCHK(hipHostMalloc((void**)&g.slots, sizeof(Context::HostSlot) * Context::NSLOTS, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&g.slots_dev, g.slots, 0));
+    memset(g.slots, 0, sizeof(Context::HostSlot) * Context::NSLOTS);
     g.device = device;
     g.inited = true;
     return SDFK_OK;
@@ -280,10 +293,10 @@ extern "C" void sdfk_shutdown(void)
     g.free_blocks.clear();
     for (auto& kv : g.live_blocks) (void)hipFree(kv.first);
     g.live_blocks.clear();
-    if (g.h_counters) (void)hipHostFree(g.h_counters);
-    if (g.h_bounds) (void)hipHostFree(g.h_bounds);
-    g.h_counters = nullptr;
-    g.h_bounds = nullptr;
+    if (g.slots) (void)hipHostFree(g.slots);
+    g.slots = nullptr;
+    g.slots_dev = nullptr;
+    g.hints.clear();
     if (g.own_stream) (void)hipStreamDestroy(g.own_stream);
     g.own_stream = nullptr;
     g.stream = nullptr;
@@ -420,7 +433,8 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!v) return;
-    if (g.inited) (void)hipStreamSynchronize(g.stream);
+    // no sync: the pool is stream-ordered (every kernel and copy runs on g.stream, so a block
+    // handed out again is only touched by work queued after its previous user)
     dev_free(v->values);
     dev_free(v->colors);
     dev_free(v->bits);
@@ -570,11 +584,31 @@ void job_release(sdfk_march_job* j)
     }
 }
 
-int launch_classify(sdfk_march_job* j, bool redo_bits)
+int alloc_records(sdfk_march_job* j, size_t c)
 {
     McParams& P = j->P;
-    HIPCHK(hipMemsetAsync(P.counters, 0, sizeof(McCounters), g.stream));
-    if (redo_bits) {
+    for (size_t k = j->rec_first; k < j->owned.size(); k++) dev_free(j->owned[k]);
+    j->owned.resize(j->rec_first);
+    int rr = 0;
+    rr = rr ? rr : job_alloc(j, &P.rec_xy, c);
+    rr = rr ? rr : job_alloc(j, &P.rec_z, c);
+    rr = rr ? rr : job_alloc(j, &P.rec_info, c);
+    rr = rr ? rr : job_alloc(j, &P.rec_own, c);
+    rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
+    rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
+    rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 16);
+    rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunkdead, c / 256 + 2);
+    P.cap_active = (uint32_t)c;
+    return rr;
+}
+
+// classification: sign bits (unless cached) -> ordered compaction -> corner gather ->
+// resolve -> chunk scan.  Launches only; nothing here waits for the GPU.
+int launch_classify(sdfk_march_job* j)
+{
+    McParams& P = j->P;
+    if (!j->have_bits) {
         uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
         if (P.nz % 4 == 0) {
@@ -591,6 +625,7 @@ int launch_classify(sdfk_march_job* j, bool redo_bits)
             hipLaunchKernelGGL(k_signbits_generic, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso);
         }
         HIPCHK(hipGetLastError());
+        j->have_bits = true;
     }
     {
         ProfScope ps("k_compact");
@@ -600,23 +635,33 @@ int launch_classify(sdfk_march_job* j, bool redo_bits)
         hipLaunchKernelGGL(k_compact<true>, dim3(nlog), dim3(256), lds, g.stream, P);
         HIPCHK(hipGetLastError());
     }
+    const int nchunks = (int)((P.cap_active + 255u) / 256u);
+    {
+        ProfScope ps("k_gather_corners");
+        hipLaunchKernelGGL(k_gather_corners, dim3(std::min(nchunks, 256 * 8)), dim3(256), 0, g.stream, P);
+        HIPCHK(hipGetLastError());
+    }
     {
         ProfScope ps("k_resolve");
-        const int nchunks = (int)((P.cap_active + 255u) / 256u);
-        hipLaunchKernelGGL(k_gather_corners, dim3(std::min(nchunks, 256 * 8)), dim3(256), 0, g.stream, P);
         hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, 256 * 12)), dim3(256), 0, g.stream, P);
         hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(g.h_counters, P.counters, sizeof(McCounters), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    j->c = *g.h_counters;
     return SDFK_OK;
 }
 
-// The job works on `v` (or on a subsampled copy when step > 1).
-int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end,
-                     sdfk_march_job** out, int64_t* n_vertices, int64_t* n_indices)
+// the one host<->device rendezvous of a march: drain the stream, read the mirrored counters
+int wait_counters(sdfk_march_job* j)
+{
+    HIPCHK(hipStreamSynchronize(g.stream));
+    j->c = g.slots[j->slot].c;
+    return SDFK_OK;
+}
+
+// Builds the job for `v` (or for a subsampled copy when step > 1); no kernel except the
+// optional subsample is launched here.
+int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end, size_t cap_records,
+              sdfk_march_job** out)
 {
     *out = nullptr;
     if (step < 1) return fail(SDFK_ERR_INVALID, "step must be >= 1");
@@ -626,13 +671,16 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     j->gnx = v->nx; j->gny = v->ny; j->gnz = v->nz_global;
     memcpy(j->gmin, v->gmin, sizeof j->gmin);
     memcpy(j->gmax, v->gmax, sizeof j->gmax);
+    j->slot = g.slot_next;
+    g.slot_next = (g.slot_next + 1) % Context::NSLOTS;
+    memset(&g.slots[j->slot], 0, sizeof(Context::HostSlot));
     const sdfk_volume* w = v;
     if (step > 1) {
         // MarchingCubes.cs:49-80 touches only voxels at multiples of step
         sdfk_volume* s = new sdfk_volume(*v);
         s->nx = (v->nx - 1) / step + 1; s->ny = (v->ny - 1) / step + 1; s->nz = (v->nz - 1) / step + 1;
         s->nz_global = s->nz;
-        s->values = nullptr; s->colors = nullptr;
+        s->values = nullptr; s->colors = nullptr; s->bits = nullptr; s->bits_valid = false;
         j->sub = s;
         int r = dev_alloc((void**)&s->values, s->nvox() * sizeof(float));
         if (!r && v->colors) r = dev_alloc((void**)&s->colors, s->nvox() * 3 * sizeof(float));
@@ -661,9 +709,10 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     P.lay_emit_end = layer_end - w->z0;
     P.lay_count_begin = layer_begin > 0 ? P.lay_emit_begin - 1 : P.lay_emit_begin;
     P.lay_list_end = std::min(P.lay_emit_end + 1, P.ncz);   // the layer above feeds seam normals
-    const bool empty = (P.ncx <= 0 || P.ncy <= 0 || P.ncz <= 0 || layer_begin == layer_end);
-    if (!empty) {
-        // context planes the slab must hold (see sdfkit_hip.h)
+    j->empty = (P.ncx <= 0 || P.ncy <= 0 || P.ncz <= 0 || layer_begin == layer_end);
+    memset(&j->c, 0, sizeof j->c);
+    if (j->empty) { *out = j; return SDFK_OK; }
+    {   // context planes the slab must hold (see sdfkit_hip.h)
         const int need_lo = std::max(layer_begin - 2, 0), need_hi = std::min(layer_end + 2, w->nz_global);
         if (w->z0 > need_lo || w->z0 + w->nz < need_hi) {
             job_release(j); delete j;
@@ -671,23 +720,15 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
                         w->z0, w->z0 + w->nz, need_lo, need_hi, layer_begin, layer_end);
         }
     }
-    memset(&j->c, 0, sizeof j->c);
-    j->empty = empty;
-    if (empty) {
-        *out = j;
-        if (n_vertices) *n_vertices = 0;
-        if (n_indices) *n_indices = 0;
-        return SDFK_OK;
-    }
     // logical blocks of k_compact: `yb` cell rows of one layer, sign words staged in <= 40 KB of LDS
     P.yb = std::max(1, std::min(128, 2560 / P.nxw - 1));
     P.nyc = (P.ncy + P.yb - 1) / P.yb;
     const size_t ncell = (size_t)P.ncx * P.ncy * P.ncz;
-    size_t cap = std::max<size_t>(ncell / 12, 1u << 16);
-    cap = std::min(cap, ncell);
+    if (cap_records == 0) cap_records = std::max<size_t>(ncell / 12, 1u << 16);
+    cap_records = std::min(cap_records, ncell);
     int r = 0;
-    const bool have_bits = (step == 1 && v->bits && v->bits_valid && v->bits_iso == iso);
-    if (have_bits) P.bits = v->bits;   // written by the fused sampling kernel; owned by the volume
+    j->have_bits = (step == 1 && v->bits && v->bits_valid && v->bits_iso == iso);
+    if (j->have_bits) P.bits = v->bits;   // written by the fused sampling kernel; owned by the volume
     else {
         uint64_t* bits = nullptr;
         r = r ? r : job_alloc(j, &bits, (size_t)P.nz * P.ny * P.nxw + 1);
@@ -696,66 +737,37 @@ int march_begin_impl(const sdfk_volume* v, float iso, int step, int layer_begin,
     r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.nyc + 1);
     r = r ? r : job_alloc(j, &P.rowstart, (size_t)(P.lay_list_end - P.lay_count_begin) * P.ncy + 2);
     r = r ? r : job_alloc(j, &P.counters, 1);
-    size_t act_idx = 0;
-    auto alloc_records = [&](size_t c) -> int {
-        int rr = 0;
-        rr = rr ? rr : job_alloc(j, &P.rec_xy, c);
-        rr = rr ? rr : job_alloc(j, &P.rec_z, c);
-        rr = rr ? rr : job_alloc(j, &P.rec_info, c);
-        rr = rr ? rr : job_alloc(j, &P.rec_own, c);
-        rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
-        rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
-        rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 16);
-        rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
-        P.cap_active = (uint32_t)c;
-        return rr;
-    };
-    act_idx = j->owned.size();
-    r = r ? r : alloc_records(cap);
+    P.host_counters = &g.slots_dev[j->slot].c;
+    j->rec_first = j->owned.size();
+    r = r ? r : alloc_records(j, cap_records);
     if (r) { job_release(j); delete j; return r; }
-    r = launch_classify(j, !have_bits);
-    if (!r && j->c.n_active > P.cap_active) {
-        // active-cell list too small: grow to the exact need and redo from the compaction
-        for (size_t k = act_idx; k < j->owned.size(); k++) dev_free(j->owned[k]);
-        j->owned.resize(act_idx);
-        r = alloc_records(j->c.n_active);
-        r = r ? r : launch_classify(j, false);
-    }
-    if (r) { job_release(j); delete j; return r; }
-    if (n_vertices) *n_vertices = (int64_t)j->c.total_v - (int64_t)j->c.nghost;
-    if (n_indices) *n_indices = (int64_t)j->c.total_t * 3;
     *out = j;
     return SDFK_OK;
 }
 
-int march_finish_impl(sdfk_march_job* j, int64_t vertex_base, sdfk_mesh** out)
+int alloc_mesh(sdfk_mesh** out, size_t cap_v, size_t cap_i)
 {
-    *out = nullptr;
-    if (j->finished) return fail(SDFK_ERR_INVALID, "march job already finished");
     sdfk_mesh* m = new sdfk_mesh();
-    m->nv = (int64_t)j->c.total_v - (int64_t)j->c.nghost;
-    m->ni = (int64_t)j->c.total_t * 3;
-    m->n_active = j->c.n_emit_cells;
-    m->n_case13 = j->c.n_dead;
-    if (vertex_base + m->nv >= (int64_t(1) << 31)) { delete m; return fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])"); }
     int r = 0;
-    r = r ? r : dev_alloc((void**)&m->vertices, (size_t)std::max<int64_t>(m->nv, 1) * 3 * sizeof(float));
-    r = r ? r : dev_alloc((void**)&m->colors, (size_t)std::max<int64_t>(m->nv, 1) * 3 * sizeof(float));
-    r = r ? r : dev_alloc((void**)&m->normals, (size_t)std::max<int64_t>(m->nv, 1) * 3 * sizeof(float));
-    r = r ? r : dev_alloc((void**)&m->triangles, (size_t)std::max<int64_t>(m->ni, 1) * sizeof(int32_t));
-    r = r ? r : dev_alloc((void**)&m->bounds, 6 * sizeof(float));
+    r = r ? r : dev_alloc((void**)&m->vertices, std::max<size_t>(cap_v, 1) * 3 * sizeof(float));
+    r = r ? r : dev_alloc((void**)&m->colors, std::max<size_t>(cap_v, 1) * 3 * sizeof(float));
+    r = r ? r : dev_alloc((void**)&m->normals, std::max<size_t>(cap_v, 1) * 3 * sizeof(float));
+    r = r ? r : dev_alloc((void**)&m->triangles, std::max<size_t>(cap_i, 1) * sizeof(int32_t));
+    r = r ? r : dev_alloc((void**)&m->bounds, 8 * sizeof(float));
     if (r) { sdfk_mesh_free(m); return r; }
-    j->finished = true;
-    if (j->empty || j->c.n_active == 0) {
-        m->bounds_valid = true;  // Mesh.Measure leaves Min/Max at zero for an empty mesh (Mesh.cs:32)
-        *out = m;
-        return SDFK_OK;
-    }
+    m->cap_v = cap_v; m->cap_i = cap_i;
+    *out = m;
+    return SDFK_OK;
+}
+
+// emit: vertices (+ AABB partials) then triangles (+ AABB reduction).  Launches only.
+int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
+{
     McMeshOut M;
     memset(&M, 0, sizeof M);
     M.vertices = m->vertices; M.colors = m->colors; M.normals = m->normals; M.triangles = m->triangles;
-    M.cap_vertices = (uint32_t)m->nv;
-    M.cap_indices = (size_t)m->ni;
+    M.cap_vertices = (uint32_t)m->cap_v;
+    M.cap_indices = m->cap_i;
     M.vertex_base = vertex_base;
     // MarchingCubes.cs:85-90 (row-vector T*S*T) and Mesh.cs:49-55, all float32
     const int nn[3] = {j->gnx, j->gny, j->gnz};
@@ -774,12 +786,14 @@ int march_finish_impl(sdfk_march_job* j, int64_t vertex_base, sdfk_mesh** out)
         const float inv_det = 1.0f / det;
         M.inv[0] = yz * inv_det; M.inv[1] = xz * inv_det; M.inv[2] = xy * inv_det;
     }
-    const int vgrid = grid_for(j->c.n_active, 256, 256 * 8);
-    if (int rr = job_alloc(j, &M.bounds_partial, (size_t)vgrid * 6)) { sdfk_mesh_free(m); return rr; }
+    const int vgrid = grid_for(j->P.cap_active, 256, 256 * 8);
+    if (int rr = job_alloc(j, &M.bounds_partial, (size_t)vgrid * 6)) return rr;
+    M.bounds_blocks = vgrid;
+    M.bounds = m->bounds;
+    M.host_bounds = g.slots_dev[j->slot].bounds;
     {
         ProfScope ps("k_vertices");
         hipLaunchKernelGGL(k_vertices, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
-        hipLaunchKernelGGL(k_bounds, dim3(1), dim3(256), 0, g.stream, (const float*)M.bounds_partial, vgrid, m->bounds);
         HIPCHK(hipGetLastError());
     }
     {
@@ -787,6 +801,99 @@ int march_finish_impl(sdfk_march_job* j, int64_t vertex_base, sdfk_mesh** out)
         hipLaunchKernelGGL(k_triangles, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
         HIPCHK(hipGetLastError());
     }
+    return SDFK_OK;
+}
+
+void finalize_mesh(sdfk_march_job* j, sdfk_mesh* m, bool have_bounds)
+{
+    const uint32_t nghost = j->c.nghost;
+    m->nv = (int64_t)j->c.total_v - (int64_t)nghost;
+    m->ni = (int64_t)j->c.total_t * 3;
+    m->n_active = j->c.n_emit_cells;
+    m->n_case13 = j->c.n_dead;
+    if (m->nv == 0) { m->bounds_valid = true; return; }   // Mesh.Measure leaves Min/Max at zero (Mesh.cs:32)
+    if (have_bounds) {
+        memcpy(m->h_min, g.slots[j->slot].bounds, 12);
+        memcpy(m->h_max, g.slots[j->slot].bounds + 3, 12);
+        m->bounds_valid = true;
+    }
+}
+
+uint64_t hint_key(const sdfk_volume* v, int step)
+{
+    return ((uint64_t)v->nx << 44) ^ ((uint64_t)v->ny << 24) ^ ((uint64_t)v->nz << 4) ^ (uint64_t)(step & 15);
+}
+
+// MarchingCubes.CreateMesh on a whole volume.
+int march_whole(const sdfk_volume* v, float iso, int step, sdfk_mesh** out)
+{
+    *out = nullptr;
+    const int layer_end = std::max(v->nz_global - 1, 0);
+    const uint64_t key = hint_key(v, step);
+    auto it = g.hints.find(key);
+    if (it != g.hints.end()) {
+        // Fast path: sizes of the previous mesh of this shape (+25 % and a floor) size every
+        // buffer; classification AND emit are queued back to back; ONE sync at the end.
+        const Context::Hint h = it->second;
+        sdfk_march_job* j = nullptr;
+        int r = setup_job(v, iso, step, 0, layer_end, (size_t)h.n_active + h.n_active / 4 + 4096, &j);
+        if (r) return r;
+        sdfk_mesh* m = nullptr;
+        if (!j->empty) {
+            r = alloc_mesh(&m, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
+            r = r ? r : launch_classify(j);
+            r = r ? r : launch_emit(j, m, 0);
+            r = r ? r : wait_counters(j);
+            const bool fits = !r && j->c.n_active <= j->P.cap_active && j->c.overflow == 0 &&
+                              (size_t)(j->c.total_v - j->c.nghost) <= m->cap_v && (size_t)j->c.total_t * 3 <= m->cap_i;
+            if (!r && fits) {
+                finalize_mesh(j, m, true);
+                g.hints[key] = Context::Hint{j->c.n_active, (uint32_t)m->nv, (uint32_t)m->ni};
+                job_release(j);
+                delete j;
+                *out = m;
+                return SDFK_OK;
+            }
+            if (m) sdfk_mesh_free(m);
+            job_release(j);
+            delete j;
+            if (r) return r;
+            // the guess was too small: fall through to the exact two-phase path
+        } else {
+            job_release(j);
+            delete j;
+        }
+    }
+    // Exact path: classify, wait for the counts, size the outputs exactly, emit.
+    sdfk_march_job* j = nullptr;
+    int r = setup_job(v, iso, step, 0, layer_end, 0, &j);
+    if (r) return r;
+    sdfk_mesh* m = nullptr;
+    if (j->empty) {
+        r = alloc_mesh(&m, 0, 0);
+        if (!r) m->bounds_valid = true;
+    } else {
+        r = launch_classify(j);
+        r = r ? r : wait_counters(j);
+        if (!r && j->c.n_active > j->P.cap_active) {   // record list too small: exact size, redo
+            r = alloc_records(j, j->c.n_active);
+            r = r ? r : launch_classify(j);
+            r = r ? r : wait_counters(j);
+        }
+        r = r ? r : alloc_mesh(&m, (size_t)(j->c.total_v - j->c.nghost), (size_t)j->c.total_t * 3);
+        if (!r && j->c.n_active > 0) {
+            r = launch_emit(j, m, 0);
+            r = r ? r : wait_counters(j);
+            if (!r && j->c.overflow) r = fail(SDFK_ERR_HIP, "marching cubes: output capacity exceeded unexpectedly");
+        }
+        if (!r) {
+            finalize_mesh(j, m, j->c.n_active > 0);
+            g.hints[key] = Context::Hint{j->c.n_active, (uint32_t)m->nv, (uint32_t)m->ni};
+        }
+    }
+    job_release(j);
+    delete j;
+    if (r) { if (m) sdfk_mesh_free(m); return r; }
     *out = m;
     return SDFK_OK;
 }
@@ -798,24 +905,57 @@ extern "C" int sdfk_march_begin(const sdfk_volume* v, float iso_value, int32_t l
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!v || !job) return fail(SDFK_ERR_INVALID, "sdfk_march_begin: null argument");
+    *job = nullptr;
     if (int r = require_init()) return r;
-    return march_begin_impl(v, iso_value, 1, layer_begin, layer_end, job, n_vertices, n_indices);
+    sdfk_march_job* j = nullptr;
+    int r = setup_job(v, iso_value, 1, layer_begin, layer_end, 0, &j);
+    if (r) return r;
+    if (!j->empty) {
+        r = launch_classify(j);
+        r = r ? r : wait_counters(j);
+        if (!r && j->c.n_active > j->P.cap_active) {
+            r = alloc_records(j, j->c.n_active);
+            r = r ? r : launch_classify(j);
+            r = r ? r : wait_counters(j);
+        }
+        if (r) { job_release(j); delete j; return r; }
+    }
+    if (n_vertices) *n_vertices = (int64_t)j->c.total_v - (int64_t)j->c.nghost;
+    if (n_indices) *n_indices = (int64_t)j->c.total_t * 3;
+    *job = j;
+    return SDFK_OK;
 }
 
-extern "C" int sdfk_march_finish(sdfk_march_job* job, int64_t vertex_base, sdfk_mesh** out)
+extern "C" int sdfk_march_finish(sdfk_march_job* j, int64_t vertex_base, sdfk_mesh** out)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!job || !out) return fail(SDFK_ERR_INVALID, "sdfk_march_finish: null argument");
+    if (!j || !out) return fail(SDFK_ERR_INVALID, "sdfk_march_finish: null argument");
+    *out = nullptr;
     if (int r = require_init()) return r;
-    return march_finish_impl(job, vertex_base, out);
+    if (j->finished) return fail(SDFK_ERR_INVALID, "march job already finished");
+    const int64_t nv = (int64_t)j->c.total_v - (int64_t)j->c.nghost;
+    if (vertex_base + nv >= (int64_t(1) << 31)) return fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])");
+    sdfk_mesh* m = nullptr;
+    int r = alloc_mesh(&m, (size_t)nv, (size_t)j->c.total_t * 3);
+    if (r) return r;
+    j->finished = true;
+    const bool work = !j->empty && j->c.n_active > 0;
+    if (work) {
+        r = launch_emit(j, m, vertex_base);
+        r = r ? r : wait_counters(j);
+        if (!r && j->c.overflow) r = fail(SDFK_ERR_HIP, "marching cubes: output capacity exceeded unexpectedly");
+        if (r) { sdfk_mesh_free(m); return r; }
+    }
+    finalize_mesh(j, m, work);
+    *out = m;
+    return SDFK_OK;
 }
 
 extern "C" void sdfk_march_job_free(sdfk_march_job* job)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!job) return;
-    if (g.inited) (void)hipStreamSynchronize(g.stream);
-    job_release(job);
+    job_release(job);   // stream-ordered pool: no sync needed
     delete job;
 }
 
@@ -826,15 +966,7 @@ extern "C" int sdfk_march(const sdfk_volume* v, float iso_value, int32_t step, s
     *out = nullptr;
     if (int r = require_init()) return r;
     if (v->z0 != 0 || v->nz != v->nz_global) return fail(SDFK_ERR_INVALID, "sdfk_march needs a whole volume; use sdfk_march_begin/finish for slabs");
-    sdfk_march_job* j = nullptr;
-    int r = march_begin_impl(v, iso_value, step, 0, std::max(v->nz_global - 1, 0), &j, nullptr, nullptr);
-    if (r) return r;
-    r = march_finish_impl(j, 0, out);
-    // the emit kernels read job buffers: release them only after the stream has drained
-    if (!r && !j->empty) r = (hipStreamSynchronize(g.stream) == hipSuccess) ? SDFK_OK : fail(SDFK_ERR_HIP, "stream sync failed");
-    job_release(j);
-    delete j;
-    return r;
+    return march_whole(v, iso_value, step, out);
 }
 
 extern "C" int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32_t ny, int32_t nz,
@@ -894,9 +1026,10 @@ extern "C" int sdfk_mesh_bounds(const sdfk_mesh* mc, float min[3], float max[3])
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = require_init()) return r;
     if (!m->bounds_valid) {
-        HIPCHK(hipMemcpyAsync(g.h_bounds, m->bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+        float hb[6];
+        HIPCHK(hipMemcpyAsync(hb, m->bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
-        if (m->nv > 0) { memcpy(m->h_min, g.h_bounds, 12); memcpy(m->h_max, g.h_bounds + 3, 12); }
+        if (m->nv > 0) { memcpy(m->h_min, hb, 12); memcpy(m->h_max, hb + 3, 12); }
         m->bounds_valid = true;
     }
     if (min) memcpy(min, m->h_min, 12);
@@ -945,8 +1078,7 @@ extern "C" void sdfk_mesh_free(sdfk_mesh* m)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return;
-    if (g.inited) (void)hipStreamSynchronize(g.stream);
-    dev_free(m->vertices);
+    dev_free(m->vertices);   // stream-ordered pool: no sync needed
     dev_free(m->colors);
     dev_free(m->normals);
     dev_free(m->triangles);
