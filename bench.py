@@ -75,7 +75,7 @@ def load_pmc_traffic(kernel, n):
         return None
     try:
         d = json.load(open(p))
-        return d.get(f"{kernel}@{n}")
+        return d.get(f"{kernel}@{n}")  # bytes per launch, or None when that kernel/size was not profiled
     except Exception:
         return None
 
