@@ -1,0 +1,411 @@
+// SdfKit.hpp -- header-only C++ host layer over the C ABI (sdfkit_hip.h) that mirrors the
+// reference's public API for the hot path: same type and member names, argument meaning,
+// defaults and error behaviour as praeclarum/SdfKit (C#), so that code written against
+//   Sdfs / SdfFuncs / SdfExprs / Voxels / MarchingCubes / Mesh
+// ports line by line (tests/cpp/reference_suite.cpp restates the reference's NUnit tests).
+// The C# shim of INTEGRATION.md is the same layer in the reference's own language; .NET is
+// not available in the build image, C++ is.
+//
+// All compute runs in libsdfkit_hip.so on the GPU.  SDFs are symbolic: arithmetic on
+// SdfKit::Val records float32 SSA instructions (the role LINQ expression trees play in the
+// reference, GlobalUsings.cs:16), lowered by sdfk_program_create (JIT, like SdfExpr.cs:225-273).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sdfkit_hip.h"
+
+namespace SdfKit {
+
+struct Vector3 {
+    float X = 0, Y = 0, Z = 0;
+    Vector3() = default;
+    Vector3(float x, float y, float z) : X(x), Y(y), Z(z) {}
+    explicit Vector3(float v) : X(v), Y(v), Z(v) {}
+    static Vector3 One() { return Vector3(1, 1, 1); }
+    static Vector3 Zero() { return Vector3(0, 0, 0); }
+    float Length() const { return std::sqrt((X * X + Y * Y) + Z * Z); }
+};
+inline Vector3 operator+(Vector3 a, Vector3 b) { return {a.X + b.X, a.Y + b.Y, a.Z + b.Z}; }
+inline Vector3 operator-(Vector3 a, Vector3 b) { return {a.X - b.X, a.Y - b.Y, a.Z - b.Z}; }
+inline Vector3 operator*(Vector3 a, float s) { return {a.X * s, a.Y * s, a.Z * s}; }
+inline Vector3 operator*(float s, Vector3 a) { return a * s; }
+
+inline void Check(int status)
+{
+    if (status != SDFK_OK) throw std::runtime_error(std::string("sdfkit_hip: ") + sdfk_last_error());
+}
+inline void EnsureInit()
+{
+    static bool done = false;
+    if (!done) { Check(sdfk_init(0)); done = true; }
+}
+
+// ---------------------------------------------------------------------------------------
+// symbolic float32 values (one SSA instruction each)
+// ---------------------------------------------------------------------------------------
+struct Builder {
+    std::vector<sdfk_op> ops;
+    int emit(int opcode, int a = -1, int b = -1, int c = -1, int d = -1, float imm = 0.f)
+    {
+        ops.push_back(sdfk_op{opcode, a, b, c, d, imm});
+        return (int)ops.size() - 1;
+    }
+};
+
+struct Val {
+    Builder* b = nullptr;
+    int id = -1;
+    float k = 0;            // constant payload while not yet bound to a builder
+    Val() = default;
+    Val(float c) : k(c) {}  // NOLINT: literals convert implicitly, like C# float literals
+    Val(Builder* bb, int i) : b(bb), id(i) {}
+    int bind(Builder* bb) const { return b ? id : bb->emit(SDFK_OP_CONST, -1, -1, -1, -1, k); }
+};
+inline Builder* builder_of(const Val& a, const Val& c) { return a.b ? a.b : c.b; }
+inline Val bin(int op, const Val& a, const Val& c)
+{
+    Builder* b = builder_of(a, c);
+    if (!b) {   // two literals: the same IEEE binary32 operation, done here
+        switch (op) {
+        case SDFK_OP_ADD: return Val(a.k + c.k);
+        case SDFK_OP_SUB: return Val(a.k - c.k);
+        case SDFK_OP_MUL: return Val(a.k * c.k);
+        case SDFK_OP_DIV: return Val(a.k / c.k);
+        default: throw std::logic_error("SdfKit::Val: this operation needs a symbolic operand");
+        }
+    }
+    const int ia = a.bind(b), ic = c.bind(b);
+    return Val(b, b->emit(op, ia, ic));
+}
+inline Val un(int op, const Val& a)
+{
+    if (!a.b) {
+        switch (op) {
+        case SDFK_OP_NEG: return Val(-a.k);
+        case SDFK_OP_ABS: return Val(std::fabs(a.k));
+        case SDFK_OP_SQRT: return Val(std::sqrt(a.k));
+        case SDFK_OP_FLOOR: return Val(std::floor(a.k));
+        default: throw std::logic_error("SdfKit::Val: this operation needs a symbolic operand");
+        }
+    }
+    return Val(a.b, a.b->emit(op, a.id));
+}
+inline Val operator+(const Val& a, const Val& c) { return bin(SDFK_OP_ADD, a, c); }
+inline Val operator-(const Val& a, const Val& c) { return bin(SDFK_OP_SUB, a, c); }
+inline Val operator*(const Val& a, const Val& c) { return bin(SDFK_OP_MUL, a, c); }
+inline Val operator/(const Val& a, const Val& c) { return bin(SDFK_OP_DIV, a, c); }
+inline Val operator-(const Val& a) { return un(SDFK_OP_NEG, a); }
+
+struct MathF {   // System.MathF members used by the catalogue
+    static Val Sqrt(const Val& a) { return un(SDFK_OP_SQRT, a); }
+    static Val Abs(const Val& a) { return un(SDFK_OP_ABS, a); }
+    static Val Floor(const Val& a) { return un(SDFK_OP_FLOOR, a); }
+    static Val Max(const Val& a, const Val& c) { return bin(SDFK_OP_MAX_IEEE, a, c); }
+    static Val Min(const Val& a, const Val& c) { return bin(SDFK_OP_MIN_IEEE, a, c); }
+};
+
+struct Vec3 {   // System.Numerics.Vector3 over symbolic components
+    Val X, Y, Z;
+    Vec3() = default;
+    Vec3(Val x, Val y, Val z) : X(x), Y(y), Z(z) {}
+    Vec3(Vector3 v) : X(v.X), Y(v.Y), Z(v.Z) {}  // NOLINT
+    Val Length() const { return MathF::Sqrt((X * X + Y * Y) + Z * Z); }
+    static Vec3 Abs(const Vec3& a) { return {MathF::Abs(a.X), MathF::Abs(a.Y), MathF::Abs(a.Z)}; }
+    static Vec3 Max(const Vec3& a, const Vec3& c) { return {bin(SDFK_OP_MAX_SEL, a.X, c.X), bin(SDFK_OP_MAX_SEL, a.Y, c.Y), bin(SDFK_OP_MAX_SEL, a.Z, c.Z)}; }
+    static Vec3 Min(const Vec3& a, const Vec3& c) { return {bin(SDFK_OP_MIN_SEL, a.X, c.X), bin(SDFK_OP_MIN_SEL, a.Y, c.Y), bin(SDFK_OP_MIN_SEL, a.Z, c.Z)}; }
+    static Val Dot(const Vec3& a, const Vec3& c) { return (a.X * c.X + a.Y * c.Y) + a.Z * c.Z; }
+};
+inline Vec3 operator+(const Vec3& a, const Vec3& c) { return {a.X + c.X, a.Y + c.Y, a.Z + c.Z}; }
+inline Vec3 operator-(const Vec3& a, const Vec3& c) { return {a.X - c.X, a.Y - c.Y, a.Z - c.Z}; }
+inline Vec3 operator*(const Val& s, const Vec3& a) { return {s * a.X, s * a.Y, s * a.Z}; }
+inline Vec3 operator/(const Vec3& a, const Val& s) { return {a.X / s, a.Y / s, a.Z / s}; }
+
+struct Vec4 {   // SdfOutput = Vector4(colour, distance)
+    Val X, Y, Z, W;
+    Vec4() = default;
+    Vec4(const Vec3& c, Val w) : X(c.X), Y(c.Y), Z(c.Z), W(w) {}
+    Vec4(Val x, Val y, Val z, Val w) : X(x), Y(y), Z(z), W(w) {}
+};
+
+inline Val Mod(const Val& a, const Val& c) { return a - c * MathF::Floor(a / c); }                       // VectorData.cs:697-698
+inline Val VMax(const Vec3& v) { return MathF::Max(MathF::Max(v.X, v.Y), v.Z); }                         // VectorData.cs:860-861
+inline Val SelectLt(const Val& a, const Val& c, const Val& t, const Val& f)
+{
+    Builder* b = a.b ? a.b : (c.b ? c.b : (t.b ? t.b : f.b));
+    return Val(b, b->emit(SDFK_OP_SEL_LT, a.bind(b), c.bind(b), t.bind(b), f.bind(b)));
+}
+
+// ---------------------------------------------------------------------------------------
+// Sdf / SdfFunc
+// ---------------------------------------------------------------------------------------
+using PointFn = std::function<Vec4(Vec3)>;
+using SdfIndexedOutputModifierFunc = std::function<Vec3(Vec3 /*index*/, Vec3 /*position*/, Vec4 /*output*/)>;
+
+class Mesh;
+class Voxels;
+
+// The reference's `Sdf` delegate (Sdf.cs:8), restricted to SDFs that have a GPU program.
+class Sdf {
+public:
+    Sdf(PointFn fn, bool writesColor) : st_(std::make_shared<State>()) { st_->fn = std::move(fn); st_->writesColor = writesColor; }
+    bool WritesColor() const { return st_->writesColor; }
+    sdfk_program* Program() const
+    {
+        if (!st_->prog) {
+            EnsureInit();
+            Builder b;
+            Vec3 p(Val(&b, b.emit(SDFK_OP_X)), Val(&b, b.emit(SDFK_OP_Y)), Val(&b, b.emit(SDFK_OP_Z)));
+            Vec4 o = st_->fn(p);
+            int32_t out[4] = {-1, -1, -1, o.W.bind(&b)};
+            if (st_->writesColor) { out[0] = o.X.bind(&b); out[1] = o.Y.bind(&b); out[2] = o.Z.bind(&b); }
+            Check(sdfk_program_create(b.ops.data(), (int32_t)b.ops.size(), out, st_->writesColor ? 1 : 0, &st_->prog));
+        }
+        return st_->prog;
+    }
+    // SdfEx.WithColor (Sdf.cs:101-115)
+    Sdf WithColor(Vector3 color) const { PointFn f = st_->fn; return Sdf([f, color](Vec3 p) { return Vec4(Vec3(color), f(p).W); }, true); }
+    Sdf WithColor(float r, float g, float b) const { return WithColor(Vector3(r, g, b)); }
+    // SdfEx.ToVoxels / ToMesh (Sdf.cs:49-63)
+    inline Voxels ToVoxels(Vector3 min, Vector3 max, int nx, int ny, int nz, int batchSize = 2048, int maxDegreeOfParallelism = -1, bool clipToBounds = true) const;
+    inline Mesh ToMesh(Vector3 min, Vector3 max, int nx, int ny, int nz, int batchSize = 2048, int maxDegreeOfParallelism = -1,
+                       bool clipToBounds = true, float isoValue = 0.0f, int step = 1, const std::function<void(float)>& progress = nullptr) const;
+
+private:
+    struct State {
+        PointFn fn;
+        bool writesColor = true;
+        sdfk_program* prog = nullptr;
+        ~State() { if (prog) sdfk_program_destroy(prog); }
+    };
+    std::shared_ptr<State> st_;
+};
+
+// per-point SDF (SdfFunc delegate / SdfExpr tree): SdfFuncEx + SdfExprEx members
+class SdfFunc {
+public:
+    SdfFunc(PointFn f) : fn(std::move(f)) {}  // NOLINT
+    PointFn fn;
+    Sdf ToSdf() const { return Sdf(fn, true); }                                                    // Sdf.cs:301-313, SdfExpr.cs:208-211
+    SdfFunc Translate(Vector3 off) const { PointFn f = fn; return SdfFunc([f, off](Vec3 p) { return f(p - Vec3(off)); }); }     // Sdf.cs:315-326
+    SdfFunc Translate(float x, float y, float z) const { return Translate(Vector3(x, y, z)); }
+    SdfFunc WithColor(Vector3 c) const { PointFn f = fn; return SdfFunc([f, c](Vec3 p) { return Vec4(Vec3(c), f(p).W); }); }    // Sdf.cs:328-340
+    SdfFunc WithColor(float r, float g, float b) const { return WithColor(Vector3(r, g, b)); }
+    SdfFunc Color(float r, float g, float b) const { return WithColor(r, g, b); }                  // SdfExpr.cs:143-147
+    SdfFunc ModifyInput(std::function<Vec3(Vec3)> m) const { PointFn f = fn; return SdfFunc([f, m](Vec3 p) { return f(m(p)); }); }  // SdfExpr.cs:79-89
+    static Val Rep(const Val& c, float s) { Val sv(s); return Mod(c + sv * Val(0.5f), sv) - sv * Val(0.5f); }
+    static Val Idx(const Val& c, float s) { Val sv(s); return MathF::Floor((c + sv * Val(0.5f)) / sv); }
+    SdfFunc RepeatX(float sx) const { return ModifyInput([sx](Vec3 p) { return Vec3(Rep(p.X, sx), p.Y, p.Z); }); }              // SdfExpr.cs:149-153
+    SdfFunc RepeatY(float sy) const { return ModifyInput([sy](Vec3 p) { return Vec3(p.X, Rep(p.Y, sy), p.Z); }); }              // SdfExpr.cs:197-201
+    SdfFunc RepeatXY(float sx, float sy) const { return ModifyInput([sx, sy](Vec3 p) { return Vec3(Rep(p.X, sx), Rep(p.Y, sy), p.Z); }); }  // SdfExpr.cs:155-161
+    SdfFunc RepeatXY(float sx, float sy, SdfIndexedOutputModifierFunc mod) const                  // SdfExpr.cs:163-178
+    {
+        PointFn f = fn;
+        return SdfFunc([f, sx, sy, mod](Vec3 p) {
+            Vec3 mp(Rep(p.X, sx), Rep(p.Y, sy), p.Z);
+            Vec3 index(Idx(p.X, sx), Idx(p.Y, sy), Val(0.0f));
+            Vec4 d = f(mp);
+            return Vec4(mod(index, mp, d), d.W);
+        });
+    }
+    SdfFunc RepeatXZ(float sx, float sz, SdfIndexedOutputModifierFunc mod) const                  // SdfExpr.cs:180-195
+    {
+        PointFn f = fn;
+        return SdfFunc([f, sx, sz, mod](Vec3 p) {
+            Vec3 mp(Rep(p.X, sx), p.Y, Rep(p.Z, sz));
+            Vec3 index(Idx(p.X, sx), Val(0.0f), Idx(p.Z, sz));
+            Vec4 d = f(mp);
+            return Vec4(mod(index, mp, d), d.W);
+        });
+    }
+};
+
+inline Val BoxDistance(Vec3 p, Vector3 bounds)
+{   // Vector3.Max(wd, Zero).Length() + VMax(Vector3.Min(wd, Zero))     Sdf.cs:134-136
+    Vec3 wd = Vec3::Abs(p) - Vec3(bounds);
+    return Vec3::Max(wd, Vec3(Vector3::Zero())).Length() + VMax(Vec3::Min(wd, Vec3(Vector3::Zero())));
+}
+
+struct SdfFuncs {   // Sdf.cs:217-249
+    static SdfFunc Box(Vector3 bounds) { return SdfFunc([bounds](Vec3 p) { return Vec4(Vec3(Vector3::One()), BoxDistance(p, bounds)); }); }
+    static SdfFunc Box(float b) { return Box(Vector3(b)); }
+    static SdfFunc Sphere(float r) { return SdfFunc([r](Vec3 p) { return Vec4(Vec3(Vector3::One()), p.Length() - Val(r)); }); }
+    static SdfFunc Union(SdfFunc a, SdfFunc b)
+    {
+        return SdfFunc([a, b](Vec3 p) {
+            Vec4 da = a.fn(p), db = b.fn(p);   // da.W < db.W ? da : db
+            return Vec4(SelectLt(da.W, db.W, da.X, db.X), SelectLt(da.W, db.W, da.Y, db.Y), SelectLt(da.W, db.W, da.Z, db.Z), SelectLt(da.W, db.W, da.W, db.W));
+        });
+    }
+};
+
+struct SdfExprs {   // SdfExpr.cs:16-69
+    static SdfFunc Box(Vector3 bounds) { return SdfFuncs::Box(bounds); }
+    static SdfFunc Box(float b) { return SdfFuncs::Box(b); }
+    static SdfFunc Cylinder(float r, float h, Vector3 color = Vector3::One())
+    {
+        return SdfFunc([r, h, color](Vec3 p) { return Vec4(Vec3(color), MathF::Max(MathF::Sqrt(p.X * p.X + p.Z * p.Z) - Val(r), MathF::Abs(p.Y) - Val(h))); });
+    }
+    static SdfFunc Solid(std::function<Val(Vec3)> dist, Vector3 color = Vector3::One()) { return SdfFunc([dist, color](Vec3 p) { return Vec4(Vec3(color), dist(p)); }); }
+    static SdfFunc Sphere(float r, Vector3 color = Vector3::One()) { return SdfFunc([r, color](Vec3 p) { return Vec4(Vec3(color), p.Length() - Val(r)); }); }
+    static SdfFunc Union(SdfFunc a, SdfFunc b) { return SdfFuncs::Union(a, b); }
+};
+
+struct Sdfs {   // Sdf.cs:118-215 (batched delegates that only assign .W leave colour zero)
+    static Sdf Box(Vector3 bounds) { return Sdf([bounds](Vec3 p) { return Vec4(Val(0.f), Val(0.f), Val(0.f), BoxDistance(p, bounds)); }, false); }
+    static Sdf Box(float b) { return Box(Vector3(b)); }
+    static Sdf Cylinder(float radius, float height) { return SdfExprs::Cylinder(radius, height).ToSdf(); }
+    static Sdf Plane(Vector3 n, float d) { return Sdf([n, d](Vec3 p) { return Vec4(Val(0.f), Val(0.f), Val(0.f), Vec3::Dot(p, Vec3(n)) + Val(d)); }, false); }
+    static Sdf PlaneXY(float z = 0) { return Plane(Vector3(0, 0, 1), z); }
+    static Sdf PlaneXZ(float y = 0) { return Plane(Vector3(0, 1, 0), y); }
+    static Sdf Solid(SdfFunc f) { return Sdf(f.fn, true); }
+    static Sdf Solid(std::function<Val(Vec3)> dist, Vector3 color = Vector3::One()) { return Sdf([dist, color](Vec3 p) { return Vec4(Vec3(color), dist(p)); }, true); }
+    static Sdf Sphere(float radius) { return Sdf([radius](Vec3 p) { return Vec4(Val(0.f), Val(0.f), Val(0.f), p.Length() - Val(radius)); }, false); }
+};
+
+// ---------------------------------------------------------------------------------------
+// Mesh (Mesh.cs:8-64)
+// ---------------------------------------------------------------------------------------
+class Mesh {
+public:
+    std::vector<Vector3> Vertices, Colors, Normals;
+    std::vector<int32_t> Triangles;
+    Vector3 Min, Max;
+    Vector3 Center() const { return (Min + Max) * 0.5f; }
+    Vector3 Size() const { return Max - Min; }
+    float Radius() const { return (Max - Min).Length() * 0.5f; }
+    static Mesh FromHandle(sdfk_mesh* h)
+    {
+        Mesh m;
+        int64_t nv = 0, ni = 0;
+        Check(sdfk_mesh_counts(h, &nv, &ni));
+        m.Vertices.resize(nv); m.Colors.resize(nv); m.Normals.resize(nv); m.Triangles.resize(ni);
+        Check(sdfk_mesh_copy(h, &m.Vertices.data()->X, &m.Colors.data()->X, &m.Normals.data()->X, m.Triangles.data()));
+        Check(sdfk_mesh_bounds(h, &m.Min.X, &m.Max.X));
+        sdfk_mesh_free(h);
+        return m;
+    }
+};
+
+inline void ReportProgress(const std::function<void(float)>& progress, int nz, int step)
+{   // MarchingCubes.cs:53-81: one report per z layer, (float)z / (nz - 2*step)
+    if (!progress) return;
+    const int zb = nz - 2 * step;
+    for (int z = -step; z < zb;) { z += step; progress((float)z / (float)zb); }
+}
+
+// ---------------------------------------------------------------------------------------
+// Voxels (Voxels.cs)
+// ---------------------------------------------------------------------------------------
+class Voxels {
+public:
+    int NX, NY, NZ;
+    float DX, DY, DZ;
+    Vector3 Min, Max;
+    Voxels(Vector3 min, Vector3 max, int nx, int ny, int nz) : NX(nx), NY(ny), NZ(nz), Min(min), Max(max)
+    {
+        DX = nx >= 1 ? (max.X - min.X) / (float)nx : 0.0f;
+        DY = ny >= 1 ? (max.Y - min.Y) / (float)ny : 0.0f;
+        DZ = nz >= 1 ? (max.Z - min.Z) / (float)nz : 0.0f;
+    }
+    Voxels(Voxels&& o) noexcept { *this = std::move(o); }
+    Voxels& operator=(Voxels&& o) noexcept
+    {
+        NX = o.NX; NY = o.NY; NZ = o.NZ; DX = o.DX; DY = o.DY; DZ = o.DZ; Min = o.Min; Max = o.Max;
+        h_ = o.h_; o.h_ = nullptr; hasColors_ = o.hasColors_; values_ = std::move(o.values_); hostNewer_ = o.hostNewer_;
+        return *this;
+    }
+    ~Voxels() { if (h_) sdfk_volume_free(h_); }
+    Vector3 Center() const { return (Min + Max) * 0.5f; }
+    Vector3 Size() const { return Max - Min; }
+
+    // Voxels.SampleSdf (instance, Voxels.cs:72-125; static, :169-174).  batchSize and
+    // maxDegreeOfParallelism are accepted and ignored on the GPU.
+    void SampleSdf(const Sdf& sdf, int batchSize = 2048, int maxDegreeOfParallelism = -1) { Sample(sdf, false); }
+    static Voxels SampleSdf(const Sdf& sdf, Vector3 min, Vector3 max, int nx, int ny, int nz, int batchSize = 2048, int maxDegreeOfParallelism = -1)
+    {
+        Voxels v(min, max, nx, ny, nz);
+        v.Sample(sdf, false);
+        return v;
+    }
+    void Sample(const Sdf& sdf, bool clip)
+    {
+        Ensure(sdf.WritesColor());
+        Check(sdfk_sample(sdf.Program(), h_, clip ? 1 : 0));
+        values_.clear();
+        hostNewer_ = false;
+    }
+    void ClipToBounds()   // Voxels.cs:133-167
+    {
+        Sync();
+        Check(sdfk_volume_clip_to_bounds(h_));
+        values_.clear();
+    }
+    // indexer v[ix,iy,iz] (Voxels.cs:42-46): host copy of Values, z fastest
+    float& operator()(int ix, int iy, int iz)
+    {
+        if (values_.empty()) {
+            values_.assign((size_t)NX * NY * NZ, 0.0f);
+            if (h_) Check(sdfk_volume_download(h_, values_.data(), nullptr));
+        }
+        hostNewer_ = true;
+        return values_[((size_t)ix * NY + iy) * NZ + iz];
+    }
+    inline Mesh ToMesh(float isoValue = 0.0f, int step = 1, const std::function<void(float)>& progress = nullptr);
+    sdfk_volume* Sync()
+    {
+        Ensure(hasColors_);
+        if (hostNewer_ && !values_.empty()) { Check(sdfk_volume_upload(h_, values_.data(), nullptr)); hostNewer_ = false; }
+        return h_;
+    }
+
+private:
+    void Ensure(bool colors)
+    {
+        EnsureInit();
+        if (h_ && colors && !hasColors_) { sdfk_volume_free(h_); h_ = nullptr; }
+        if (!h_) { Check(sdfk_volume_create(NX, NY, NZ, &Min.X, &Max.X, colors ? 1 : 0, &h_)); hasColors_ = colors; }
+    }
+    sdfk_volume* h_ = nullptr;
+    bool hasColors_ = false;
+    std::vector<float> values_;
+    bool hostNewer_ = false;
+};
+
+struct MarchingCubes {
+    // MarchingCubes.CreateMesh(Voxels, isoValue = 0, step = 1, progress = null)  (MarchingCubes.cs:39)
+    static Mesh CreateMesh(Voxels& volume, float isoValue = 0.0f, int step = 1, const std::function<void(float)>& progress = nullptr)
+    {
+        sdfk_mesh* m = nullptr;
+        Check(sdfk_march(volume.Sync(), isoValue, step, &m));
+        ReportProgress(progress, volume.NZ, step);
+        return Mesh::FromHandle(m);
+    }
+};
+
+inline Mesh Voxels::ToMesh(float isoValue, int step, const std::function<void(float)>& progress) { return MarchingCubes::CreateMesh(*this, isoValue, step, progress); }
+
+inline Voxels Sdf::ToVoxels(Vector3 min, Vector3 max, int nx, int ny, int nz, int, int, bool clipToBounds) const
+{
+    Voxels v(min, max, nx, ny, nz);
+    v.Sample(*this, clipToBounds);
+    return v;
+}
+
+inline Mesh Sdf::ToMesh(Vector3 min, Vector3 max, int nx, int ny, int nz, int, int, bool clipToBounds, float isoValue, int step,
+                        const std::function<void(float)>& progress) const
+{
+    EnsureInit();
+    sdfk_mesh* m = nullptr;
+    Check(sdfk_sample_march(Program(), &min.X, &max.X, nx, ny, nz, clipToBounds ? 1 : 0, isoValue, step, &m));
+    ReportProgress(progress, nz, step);
+    return Mesh::FromHandle(m);
+}
+
+}  // namespace SdfKit

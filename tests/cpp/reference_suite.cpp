@@ -1,0 +1,171 @@
+// reference_suite.cpp -- the reference's NUnit tests for the hot path, restated against the
+// C++ host layer (include/SdfKit.hpp) so that they read like the originals:
+//   Tests/MarchingCubesTests.cs (8 tests), Tests/SdfTests.cs (3), Tests/VolumeTests.cs (those
+//   that do not need an opaque CPU delegate).  Expected values are the literals asserted by the
+// reference.  Runs on the GPU through libsdfkit_hip.so (tests/test_gpu_cpp_host.py builds it).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "SdfKit.hpp"
+
+using namespace SdfKit;
+
+static int g_fail = 0, g_run = 0;
+#define ARE_EQUAL(expected, actual)                                                                     \
+    do { if (!((expected) == (actual))) { printf("  FAIL %s:%d: expected %s == %s (%g vs %g)\n", __FILE__, __LINE__, #expected, #actual, (double)(expected), (double)(actual)); g_fail++; } } while (0)
+#define ARE_EQUAL_TOL(expected, actual, tol)                                                            \
+    do { if (!(std::fabs((double)(expected) - (double)(actual)) <= (tol))) { printf("  FAIL %s:%d: |%s - %s| = %g > %g\n", __FILE__, __LINE__, #expected, #actual, std::fabs((double)(expected) - (double)(actual)), (double)(tol)); g_fail++; } } while (0)
+#define IS_TRUE(c) do { if (!(c)) { printf("  FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); g_fail++; } } while (0)
+#define TEST(name) static void name(); static void run_##name() { g_run++; printf("%s\n", #name); name(); } static void name()
+
+TEST(ColoredSpheres)   // MarchingCubesTests.cs:11-28
+{
+    float r = 1.0f;
+    auto sdf = SdfFuncs::Union(SdfFuncs::Sphere(r * 0.4f).WithColor(1.0f, 0.2f, 0.3f).Translate(-1, 0, 0),
+                               SdfFuncs::Sphere(r * 0.2f).WithColor(0.1f, 1.0f, 0.3f).Translate(1, 0, 0));
+    auto volume = Voxels::SampleSdf(sdf.ToSdf(), -3.0f * Vector3::One(), 3.0f * Vector3::One(), 32, 32, 32);
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1);
+    ARE_EQUAL(104, (int)mesh.Vertices.size());
+    ARE_EQUAL(104, (int)mesh.Colors.size());
+    IS_TRUE(mesh.Colors[0].X > 0.5f);
+}
+
+TEST(Sphere5)   // MarchingCubesTests.cs:31-45
+{
+    float r = 1.0f;
+    auto volume = Voxels::SampleSdf(Sdfs::Sphere(r), -1.5f * Vector3::One(), 1.5f * Vector3::One(), 5, 5, 5);
+    ARE_EQUAL(5, volume.NX);
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1);
+    ARE_EQUAL(54, (int)mesh.Vertices.size());
+    ARE_EQUAL_TOL(mesh.Center().Length(), 0.0f, 1e-6f);
+    ARE_EQUAL_TOL(r, mesh.Size().X / 2.0f, 0.3f);
+}
+
+TEST(Sphere10)   // MarchingCubesTests.cs:48-62
+{
+    float r = 2.0f;
+    auto volume = Voxels::SampleSdf(Sdfs::Sphere(r), -2.5f * Vector3::One(), 2.5f * Vector3::One(), 10, 10, 10);
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1);
+    ARE_EQUAL(312, (int)mesh.Vertices.size());
+    ARE_EQUAL_TOL(mesh.Center().Length(), 0.0f, 1e-6f);
+    ARE_EQUAL_TOL(r, mesh.Size().X / 2.0f, 0.2f);
+}
+
+TEST(UnclippedSphere10)   // MarchingCubesTests.cs:65-79
+{
+    int n = 10;
+    auto volume = Voxels::SampleSdf(Sdfs::Sphere(2.0f), -1.0f * Vector3::One(), Vector3::One(), n, n, n);
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1);
+    ARE_EQUAL(0, (int)mesh.Vertices.size());
+    ARE_EQUAL(0, (int)mesh.Triangles.size());
+}
+
+TEST(ClippedSphere10)   // MarchingCubesTests.cs:82-98
+{
+    int n = 10;
+    auto volume = Voxels::SampleSdf(Sdfs::Sphere(2.0f), -1.0f * Vector3::One(), Vector3::One(), n, n, n);
+    volume.ClipToBounds();
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1);
+    ARE_EQUAL(384, (int)mesh.Vertices.size());
+    ARE_EQUAL_TOL(mesh.Center().Length(), 0.0f, 1e-6f);
+    ARE_EQUAL_TOL(2.0f, mesh.Size().X, 1e-1f);
+}
+
+TEST(Box10)   // MarchingCubesTests.cs:101-115
+{
+    float r = 2.0f;
+    auto volume = Voxels::SampleSdf(Sdfs::Box(r), -2.5f * Vector3::One(), 2.5f * Vector3::One(), 10, 10, 10);
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1);
+    ARE_EQUAL(384, (int)mesh.Vertices.size());
+    ARE_EQUAL_TOL(mesh.Center().Length(), 0.0f, 1e-6f);
+    ARE_EQUAL_TOL(r, mesh.Size().X / 2.0f, 3e-1f);
+}
+
+TEST(Cylinder50)   // MarchingCubesTests.cs:118-138
+{
+    int n = 50;
+    auto volume = Voxels::SampleSdf(Sdfs::Cylinder(1, 3), Vector3(-1.5f, -3.5f, -1.5f), Vector3(1.5f, 3.5f, 1.5f), n, n, n);
+    ARE_EQUAL(n, volume.NX);
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1);
+    ARE_EQUAL(7456, (int)mesh.Vertices.size());
+    ARE_EQUAL_TOL(0.0f, mesh.Center().X, 1e-6f);
+    ARE_EQUAL_TOL(0.0f, mesh.Center().Y, 1e-6f);
+    ARE_EQUAL_TOL(0.0f, mesh.Center().Z, 1e-6f);
+    ARE_EQUAL_TOL(1, mesh.Size().X / 2.0f, 1e-1f);
+}
+
+TEST(Sphere128Progress)   // MarchingCubesTests.cs:141-171
+{
+    float r = 3.0f;
+    auto volume = Voxels::SampleSdf(Sdfs::Sphere(r), -3.1f * Vector3::One(), 3.1f * Vector3::One(), 128, 128, 128);
+    bool gotZero = false, gotOne = false, inRange = true;
+    auto progress = [&](float f) {
+        if (!(f >= 0.0f && f <= 1.0f)) inRange = false;
+        if (f < 1e-6f) gotZero = true;
+        else if (1.0f - f < 1e-6f) gotOne = true;
+    };
+    auto mesh = MarchingCubes::CreateMesh(volume, 0.0f, 1, progress);
+    ARE_EQUAL(72240, (int)mesh.Vertices.size());
+    IS_TRUE(inRange); IS_TRUE(gotZero); IS_TRUE(gotOne);
+    ARE_EQUAL_TOL(mesh.Center().Length(), 0.0f, 1e-6f);
+    ARE_EQUAL_TOL(r, mesh.Size().X / 2.0f, 0.1f);
+}
+
+TEST(CreateVolumeSphere)   // SdfTests.cs:12-26 (the delegate there is (1,1,1, p.Length() - r))
+{
+    float r = 0.5f;
+    auto sdf = Sdfs::Solid([r](Vec3 p) { return p.Length() - Val(r); });
+    auto v = sdf.ToVoxels(Vector3(-1, -1, -1), Vector3(1, 1, 1), 128, 128, 128);
+    ARE_EQUAL_TOL(-0.5f, v(63, 63, 63), 2.0e-2f);
+}
+
+TEST(CreateMeshSphere)   // SdfTests.cs:29-39
+{
+    int n = 32;
+    auto mesh = Sdfs::Sphere(0.5f).ToMesh(Vector3(-1, -1, -1), Vector3(1, 1, 1), n, n, n);
+    ARE_EQUAL(1248, (int)mesh.Vertices.size());
+}
+
+TEST(SolidSphere)   // SdfTests.cs:42-52
+{
+    float r = 0.5f;
+    int n = 32;
+    auto sdf = SdfExprs::Solid([r](Vec3 p) { return p.Length() - Val(r); }).ToSdf();
+    auto mesh = sdf.ToMesh(Vector3(-1, -1, -1), Vector3(1, 1, 1), n, n, n);
+    ARE_EQUAL(1248, (int)mesh.Vertices.size());
+}
+
+TEST(EmptyVolumeDims)   // VolumeTests.cs:11-38
+{
+    Voxels v(-1.0f * Vector3::One(), Vector3::One(), 5, 7, 11);
+    ARE_EQUAL(5, v.NX); ARE_EQUAL(7, v.NY); ARE_EQUAL(11, v.NZ);
+    ARE_EQUAL_TOL(2.0f, v.Size().X, 1e-6f);
+}
+
+TEST(SphereCenterValue)   // VolumeTests.cs:83-106
+{
+    auto v = Voxels::SampleSdf(Sdfs::Sphere(0.5f), -1.0f * Vector3::One(), Vector3::One(), 5, 5, 5);
+    ARE_EQUAL_TOL(-0.5f, v(2, 2, 2), 1e-3f);
+}
+
+TEST(ReadmeSceneRepeatXY)   // README.md:24-30 scene through the expression API, 64^3
+{
+    auto sdf = SdfExprs::Sphere(0.5f)
+                   .RepeatXY(1.125f, 1.125f, [](Vec3 i, Vec3 p, Vec4 d) { return Val(0.9f) * Vec3(Vector3::One()) - Vec3::Abs(i) / Val(6.0f); })
+                   .ToSdf();
+    auto mesh = sdf.ToMesh(-2.8125f * Vector3::One(), 2.8125f * Vector3::One(), 64, 64, 64);
+    IS_TRUE(mesh.Vertices.size() > 1000);
+    IS_TRUE(mesh.Triangles.size() % 3 == 0);
+    for (auto& c : mesh.Colors) { if (!(c.X >= 0.9f - 0.5f - 1e-5f && c.X <= 0.9f + 1e-5f)) { IS_TRUE(false); break; } }
+}
+
+int main()
+{
+    run_ColoredSpheres(); run_Sphere5(); run_Sphere10(); run_UnclippedSphere10(); run_ClippedSphere10(); run_Box10();
+    run_Cylinder50(); run_Sphere128Progress(); run_CreateVolumeSphere(); run_CreateMeshSphere(); run_SolidSphere();
+    run_EmptyVolumeDims(); run_SphereCenterValue(); run_ReadmeSceneRepeatXY();
+    printf("%d tests, %d failures\n", g_run, g_fail);
+    sdfk_shutdown();
+    return g_fail ? 1 : 0;
+}
