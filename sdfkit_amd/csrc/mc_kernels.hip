@@ -588,16 +588,59 @@ __device__ __forceinline__ int mc_edge_corner_b(int e) { return e < 8 ? ((e & 4)
 // ---------------------------------------------------------------------------
 // K4: vertices
 // ---------------------------------------------------------------------------
+// Records are sorted by (z, y, x), so everything a chunk of 256 consecutive records needs
+// from its neighbours lives in two CONTIGUOUS windows of the record list:
+//   W1 = the chunk itself up to the end of the row after its last row   (+x, +y sharers)
+//   W2 = the same rows (+1) of the next layer                           (+z, +y+z sharers)
+// (a vertex is created by the FIRST cell of the sweep around its edge, so the other sharers
+// are always at +x/+y/+z).  The windows -- coordinates, tiling info, the 8 corner values --
+// and the matching slices of rowstart[] are staged in LDS with coalesced loads; the
+// per-vertex work then runs on LDS only.  Sharers that fall outside a truncated window take
+// a slow path through global memory.
+constexpr int K4_WMAX = 640;   // window slots (both windows together)
+constexpr int K4_RMAX = 288;   // rowstart entries staged per window
+
+struct CornersGlobal {          // 8 corner values of a record, read from global memory (slow path)
+    const float* p;
+    double iso;
+    __device__ __forceinline__ double operator[](int k) const { return (double)p[k] - iso; }
+};
+
+// contribution of one sharer cell to the normal of the vertex on its edge `es`, in the order
+// of Cell.cs:332-333/355-356: once per occurrence in the LUT row, corner 1 then corner 2
+template <class V>
+__device__ __forceinline__ void add_sharer_gradients(const V& vs, int es, int occ, int dir, double w_lo, double w_hi, float* nrm)
+{
+    const int a = mc_edge_corner_a(es), b = mc_edge_corner_b(es);
+    const int da = dir == 0 ? mc_corner_dx(a) : (dir == 1 ? mc_corner_dy(a) : mc_corner_dz(a));
+    const double wa = da ? w_hi : w_lo, wb = da ? w_lo : w_hi;
+    // NB: Cell.cs:157-158 indexes the corner-ordered gradient table with the BIT-order index
+    // (inherited quirk); reproduced.
+    const int i1 = mc_bit_to_corner(a), i2 = mc_bit_to_corner(b);   // involution: corner -> bit order
+    float g1[3], g2[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+        g1[jj] = (float)(mc_corner_gradient(vs, i1, jj) * wa);
+        g2[jj] = (float)(mc_corner_gradient(vs, i2, jj) * wb);
+    }
+    for (int o = 0; o < occ; o++) {
+        nrm[0] = nrm[0] + g1[0]; nrm[1] = nrm[1] + g1[1]; nrm[2] = nrm[2] + g1[2];
+        nrm[0] = nrm[0] + g2[0]; nrm[1] = nrm[1] + g2[1]; nrm[2] = nrm[2] + g2[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
-    __shared__ float s_c[8 * 256];   // this lane's current cell: [corner][thread]
+    __shared__ float s_wc[8 * K4_WMAX];          // window corner values: [corner][slot]
+    __shared__ uint32_t s_wxy[K4_WMAX], s_winfo[K4_WMAX];
+    __shared__ uint32_t s_rs[2][K4_RMAX];
     __shared__ uint64_t s_occ[MCLUT_NROWS];
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_xy[256], s_z[256], s_info[256];
     __shared__ uint64_t s_own[256];
+    __shared__ int s_meta[8];
     __shared__ float s_red[6][4];
-    {   // per-row reference counts / triangle counts -> LDS (independent loads per lane)
+    {   // per-row reference counts -> LDS (independent loads per lane)
         const int t = (int)threadIdx.x;
         static_assert(MCLUT_NROWS <= 768, "row table copy assumes <= 3 rounds");
         const uint64_t a0 = c_rowocc[min(t, MCLUT_NROWS - 1)], a1 = c_rowocc[min(t + 256, MCLUT_NROWS - 1)];
@@ -608,77 +651,133 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     }
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
+    const int nrows_total = (P.lay_list_end - P.lay_count_begin) * P.ncy;
     const double iso = (double)P.iso;
     const double stp = (double)P.step;
     float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    float* col = s_c + threadIdx.x;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t cnt = min(256u, n - base);
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_nown = 0;
-        __syncthreads();   // previous chunk is done with the s_* record fields
-        if (irec < n) {
-            const uint32_t info = P.rec_info[irec];
-            my_nown = (info >> 18) & 15u;
-            s_xy[threadIdx.x] = P.rec_xy[irec];
-            s_z[threadIdx.x] = P.rec_z[irec];
-            s_info[threadIdx.x] = info;
+        __syncthreads();   // previous chunk is done with all s_* arrays
+        // ---- phase A: own chunk fields; rows spanned by the chunk
+        if (threadIdx.x < cnt) {
+            my_nown = (P.rec_info[irec] >> 18) & 15u;
             s_own[threadIdx.x] = P.rec_own[irec];
         }
-        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);
-        const uint32_t chunk_vbase = (uint32_t)(P.chunktot[base >> 8] >> 31);   // scanned by k_scan1<1>
-        for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per created vertex
-            const int rr = find_owner_256(s_pre, j);
+        if (threadIdx.x == 0) {
+            const uint32_t xyf = P.rec_xy[base], xyl = P.rec_xy[base + cnt - 1];
+            const int zf = (int)P.rec_z[base], zl = (int)P.rec_z[base + cnt - 1];
+            s_meta[0] = (zf - P.lay_count_begin) * P.ncy + (int)(xyf >> 16);   // r_f
+            s_meta[1] = (zl - P.lay_count_begin) * P.ncy + (int)(xyl >> 16);   // r_l
+        }
+        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs)
+        const int r_f = s_meta[0], r_l = s_meta[1];
+        // ---- phase B: rowstart slices of the two windows: rows [r_f, r_l+2] and the same + ncy
+        const int nrs = min(r_l - r_f + 3, K4_RMAX);
+        for (int i = threadIdx.x; i < 2 * nrs; i += 256) {
+            const int w = i >= nrs, k = w ? i - nrs : i;
+            s_rs[w][k] = P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)];
+        }
+        __syncthreads();
+        // ---- phase C: the windows themselves
+        const uint32_t w1_start = base;                              // +x / +y sharers come after the chunk start
+        const uint32_t w1_cnt = min(s_rs[0][nrs - 1] - w1_start, (uint32_t)K4_WMAX);
+        const uint32_t w2_start = s_rs[1][0];
+        const uint32_t w2_cnt = min(s_rs[1][nrs - 1] - w2_start, (uint32_t)K4_WMAX - w1_cnt);
+        {
+            const uint32_t wtot = w1_cnt + w2_cnt;
+            uint32_t rxy[3], rin[3];
+            float4 rlo[3], rhi[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t slot = threadIdx.x + 256u * k;
+                if (slot < wtot) {
+                    const uint32_t g = slot < w1_cnt ? w1_start + slot : w2_start + (slot - w1_cnt);
+                    rxy[k] = P.rec_xy[g];
+                    rin[k] = P.rec_info[g];
+                    rlo[k] = *reinterpret_cast<const float4*>(P.rec_corners + (size_t)g * 8);
+                    rhi[k] = *reinterpret_cast<const float4*>(P.rec_corners + (size_t)g * 8 + 4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t slot = threadIdx.x + 256u * k;
+                if (slot < wtot) {
+                    s_wxy[slot] = rxy[k];
+                    s_winfo[slot] = rin[k];
+                    float* c = s_wc + slot;
+                    c[0] = rlo[k].x; c[K4_WMAX] = rlo[k].y; c[2 * K4_WMAX] = rlo[k].z; c[3 * K4_WMAX] = rlo[k].w;
+                    c[4 * K4_WMAX] = rhi[k].x; c[5 * K4_WMAX] = rhi[k].y; c[6 * K4_WMAX] = rhi[k].z; c[7 * K4_WMAX] = rhi[k].w;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t chunk_vbase = (uint32_t)(P.chunktot[base >> 8] >> 31);   // scanned by k_scan_chunks
+        // ---- per created vertex
+        for (uint32_t j = threadIdx.x; j < total; j += 256u) {
+            const int rr = find_owner_256(s_pre, j);   // = window slot of the creator (W1 starts at the chunk)
             const int r = (int)(j - s_pre[rr]);
-            const uint32_t info = s_info[rr];
-            const int x = (int)(s_xy[rr] & 0xffffu), y = (int)(s_xy[rr] >> 16), z = (int)s_z[rr];
-            const bool emit = z >= P.lay_emit_begin;   // the layer below a slab is numbered, not emitted
-            const uint32_t vi = chunk_vbase + j;   // chunk prefix + in-chunk prefix: serial vertex id
-            const uint32_t out = vi - nghost;
-            if (emit && out >= M.cap_vertices) { P.host_counters->overflow = 1u; continue; }
+            const uint32_t info = s_winfo[rr];
+            const int x = (int)(s_wxy[rr] & 0xffffu), y = (int)(s_wxy[rr] >> 16);
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = mc_edge_dir(e);
-            const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
+            // layer of the creator: rows of W1 are r_f.. ; recover z from the row of this slot
             const uint32_t own_rec = base + (uint32_t)rr;
-            const int own_row = (int)(info >> 22);
-            float pos[3], colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
-            const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
-            // records of the cells around this grid edge (sweep order) and their corner values:
-            // all loads of this vertex are issued before the first use
-            int rec[4] = {-1, -1, -1, -1};
-            int own_s = 3;
+            const int z = (int)P.rec_z[own_rec];
+            const bool emit = z >= P.lay_emit_begin;   // the layer below a slab is numbered, not emitted
+            const uint32_t vi = chunk_vbase + j;       // chunk prefix + in-chunk prefix: serial vertex id
+            const uint32_t out = vi - nghost;
+            if (emit && out >= M.cap_vertices) { P.host_counters->overflow = 1u; continue; }
+            const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
+            // sharer cells (sweep order): window slot, or -1 = none, or -2-k = record k via the slow path
+            int sl[4] = {-1, -1, -1, -1};
             if (e != 12) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int cx = gx + mc_share_dx(dir, s), cy = gy + mc_share_dy(dir, s), cz = gz + mc_share_dz(dir, s);
-                    if (cx == x && cy == y && cz == z) { rec[s] = (int)own_rec; own_s = s; }
-                    else if (cx >= 0 && cy >= 0 && cx < P.ncx && cy < P.ncy) rec[s] = find_record(P, cx, cy, cz);
+                    if (cx == x && cy == y && cz == z) { sl[s] = rr; continue; }
+                    if (cx < 0 || cy < 0 || cz < P.lay_count_begin || cx >= P.ncx || cy >= P.ncy || cz >= P.lay_list_end) continue;
+                    const int row = (cz - P.lay_count_begin) * P.ncy + cy;
+                    int w = -1, k = 0;
+                    if (row >= r_f && row - r_f + 1 < nrs) { w = 0; k = row - r_f; }
+                    else if (row >= r_f + P.ncy && row - r_f - P.ncy + 1 < nrs) { w = 1; k = row - r_f - P.ncy; }
+                    bool in_window = false;
+                    if (w >= 0) {
+                        const uint32_t ra = s_rs[w][k], rb = s_rs[w][k + 1];
+                        const uint32_t ws = w ? w2_start : w1_start, wc = w ? w2_cnt : w1_cnt, off = w ? w1_cnt : 0u;
+                        if (ra >= ws && rb <= ws + wc) {
+                            in_window = true;
+                            uint32_t lo = ra - ws + off, hi = rb - ws + off;
+                            while (hi - lo > 4u) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if ((int)(s_wxy[mid] & 0xffffu) <= cx) lo = mid; else hi = mid;
+                            }
+                            for (uint32_t q = lo; q < hi; q++)
+                                if ((int)(s_wxy[q] & 0xffffu) == cx) sl[s] = (int)q;
+                        }
+                    }
+                    if (!in_window) {
+                        const int g = find_record(P, cx, cy, cz);
+                        if (g >= 0) sl[s] = -2 - g;
+                    }
                 }
             } else {
-                rec[3] = (int)own_rec;
+                sl[3] = rr;
             }
             // push this vertex's id into every live cell around the edge (K5 reads only its own record)
-            if (e == 12) {
-                P.rec_vid[(size_t)own_rec * 16 + 12] = vi;
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-                    if (rec[s] >= 0) P.rec_vid[(size_t)rec[s] * 16 + mc_share_edge(dir, s)] = vi;
-            }
-            if (!emit) continue;
-            float4 qlo[4], qhi[4];
-            uint32_t tinfo[4];
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const uint32_t k = (uint32_t)max(rec[s], 0);
-                qlo[s] = *reinterpret_cast<const float4*>(P.rec_corners + (size_t)k * 8);
-                qhi[s] = *reinterpret_cast<const float4*>(P.rec_corners + (size_t)k * 8 + 4);
-                tinfo[s] = rec[s] >= 0 ? P.rec_info[k] : 0u;
+                if (sl[s] == -1) continue;
+                const uint32_t g = sl[s] >= 0 ? ((uint32_t)sl[s] < w1_cnt ? w1_start + (uint32_t)sl[s] : w2_start + ((uint32_t)sl[s] - w1_cnt))
+                                              : (uint32_t)(-2 - sl[s]);
+                P.rec_vid[(size_t)g * 16 + (e == 12 ? 12 : mc_share_edge(dir, s))] = vi;
             }
-            // the creator cell
-            const float4 olo = own_s == 0 ? qlo[0] : (own_s == 1 ? qlo[1] : (own_s == 2 ? qlo[2] : qlo[3]));
-            const float4 ohi = own_s == 0 ? qhi[0] : (own_s == 1 ? qhi[1] : (own_s == 2 ? qhi[2] : qhi[3]));
-            corners_to_column(olo, ohi, col);
-            const CornersLds v{col, 256, iso};
+            if (!emit) continue;
+            const int own_row = (int)(info >> 22);
+            float pos[3], colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
+            const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
+            const CornersLds v{s_wc + rr, K4_WMAX, iso};   // the creator cell
             if (e == 12) {
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
@@ -753,28 +852,17 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 // sees the same two end voxels, so the two weights are computed once.
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    if (tinfo[s] == 0u) continue;   // out of range, or a cell that emits nothing
-                    const int row = (int)(tinfo[s] >> 22);
+                    if (sl[s] == -1) continue;
                     const int es = mc_share_edge(dir, s);
-                    const int occ = (int)((s_occ[row] >> (4 * es)) & 15ull);
-                    if (!occ) continue;
-                    corners_to_column(qlo[s], qhi[s], col);
-                    const CornersLds vs{col, 256, iso};
-                    const int a = mc_edge_corner_a(es), b = mc_edge_corner_b(es);
-                    const int da = dir == 0 ? mc_corner_dx(a) : (dir == 1 ? mc_corner_dy(a) : mc_corner_dz(a));
-                    const double wa = da ? w_hi : w_lo, wb = da ? w_lo : w_hi;
-                    // NB: Cell.cs:157-158 indexes the corner-ordered gradient table with the
-                    // BIT-order index (inherited quirk); reproduced.
-                    const int i1 = mc_bit_to_corner(a), i2 = mc_bit_to_corner(b);   // involution: corner -> bit order
-                    float g1[3], g2[3];
-#pragma unroll
-                    for (int jj = 0; jj < 3; jj++) {
-                        g1[jj] = (float)(mc_corner_gradient(vs, i1, jj) * wa);
-                        g2[jj] = (float)(mc_corner_gradient(vs, i2, jj) * wb);
-                    }
-                    for (int o = 0; o < occ; o++) {
-                        nrm[0] = nrm[0] + g1[0]; nrm[1] = nrm[1] + g1[1]; nrm[2] = nrm[2] + g1[2];
-                        nrm[0] = nrm[0] + g2[0]; nrm[1] = nrm[1] + g2[1]; nrm[2] = nrm[2] + g2[2];
+                    if (sl[s] >= 0) {
+                        const uint32_t ti = s_winfo[sl[s]];
+                        const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;
+                        if (occ) add_sharer_gradients(CornersLds{s_wc + sl[s], K4_WMAX, iso}, es, occ, dir, w_lo, w_hi, nrm);
+                    } else {   // outside the staged windows: through global memory
+                        const uint32_t g = (uint32_t)(-2 - sl[s]);
+                        const uint32_t ti = P.rec_info[g];
+                        const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;
+                        if (occ) add_sharer_gradients(CornersGlobal{P.rec_corners + (size_t)g * 8, iso}, es, occ, dir, w_lo, w_hi, nrm);
                     }
                 }
             }
@@ -800,7 +888,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             bmax[0] = fmaxf(bmax[0], px); bmax[1] = fmaxf(bmax[1], py); bmax[2] = fmaxf(bmax[2], pz);
         }
     }
-    // per-workgroup AABB partials (Mesh.Measure, Mesh.cs:30-45), reduced by k_bounds
+    // per-workgroup AABB partials (Mesh.Measure, Mesh.cs:30-45), reduced by K5's first workgroup
     float r[6] = {bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2]};
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
