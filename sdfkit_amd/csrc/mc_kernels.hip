@@ -558,11 +558,13 @@ __device__ __forceinline__ int find_owner_256(const uint32_t* s_pre, uint32_t j)
 // rowstart[] gives the span of each cell row, so this is a search over the handful of
 // active cells of one row.  Cells sharing a sign-changing edge are always active, hence
 // always found when their layer is listed.
-__device__ __forceinline__ int find_record(const McParams& P, int cx, int cy, int cz)
+// `n` = number of records actually stored (the list may have been cut at its capacity when a
+// speculative launch under-estimated it; row starts beyond that must never be dereferenced).
+__device__ __forceinline__ int find_record(const McParams& P, uint32_t n, int cx, int cy, int cz)
 {
     if (cz < P.lay_count_begin || cz >= P.lay_list_end) return -1;
     const uint32_t* rs = P.rowstart + (size_t)(cz - P.lay_count_begin) * P.ncy + cy;
-    uint32_t a = rs[0], b = rs[1];
+    uint32_t a = min(rs[0], n), b = min(rs[1], n);
     while (b - a > 4u) {   // long rows: bisect
         const uint32_t mid = (a + b) >> 1;
         if ((int)(P.rec_xy[mid] & 0xffffu) <= cx) a = mid; else b = mid;
@@ -677,12 +679,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         const int nrs = min(r_l - r_f + 3, K4_RMAX);
         for (int i = threadIdx.x; i < 2 * nrs; i += 256) {
             const int w = i >= nrs, k = w ? i - nrs : i;
-            s_rs[w][k] = P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)];
+            s_rs[w][k] = min(P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)], n);   // never past the stored records
         }
         __syncthreads();
         // ---- phase C: the windows themselves
         const uint32_t w1_start = base;                              // +x / +y sharers come after the chunk start
-        const uint32_t w1_cnt = min(s_rs[0][nrs - 1] - w1_start, (uint32_t)K4_WMAX);
+        // (at least the chunk itself: the row slice may have been cut at K4_RMAX rows)
+        const uint32_t w1_cnt = min(max(s_rs[0][nrs - 1], base + cnt) - w1_start, (uint32_t)K4_WMAX);
         const uint32_t w2_start = s_rs[1][0];
         const uint32_t w2_cnt = min(s_rs[1][nrs - 1] - w2_start, (uint32_t)K4_WMAX - w1_cnt);
         {
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                         }
                     }
                     if (!in_window) {
-                        const int g = find_record(P, cx, cy, cz);
+                        const int g = find_record(P, n, cx, cy, cz);
                         if (g >= 0) sl[s] = -2 - g;
                     }
                 }
