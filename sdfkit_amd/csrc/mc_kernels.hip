@@ -513,7 +513,15 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
         }
         uint64_t ndead;
         (void)block_excl_scan_u64(dead, s_wave, &ndead);
-        if (threadIdx.x == 0) { P.chunktot[c] = total; P.chunkdead[c] = (uint32_t)ndead; }
+        if (threadIdx.x == 0) {
+            P.chunktot[c] = total;
+            P.chunkdead[c] = (uint32_t)ndead;
+            // rows spanned by the chunk: lets K4 fetch its windows without first reading records
+            const uint32_t first = (uint32_t)c * 256u, last = min(first + 255u, n - 1u);
+            const uint32_t rf = (P.rec_z[first] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[first] >> 16);
+            const uint32_t rl = (P.rec_z[last] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[last] >> 16);
+            P.chunkwin[c] = make_uint4(rf, rl, 0u, 0u);
+        }
     }
 }
 
@@ -631,7 +639,7 @@ __device__ __forceinline__ void add_sharer_gradients(const V& vs, int es, int oc
     }
 }
 
-__global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
+__global__ __launch_bounds__(256, 4) void k_vertices(McParams P, McMeshOut M)
 {
     __shared__ float s_wc[8 * K4_WMAX];          // window corner values: [corner][slot]
     __shared__ uint32_t s_wxy[K4_WMAX], s_winfo[K4_WMAX];
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_own[256];
-    __shared__ int s_meta[8];
+    __shared__ uint32_t s_z[256];
     __shared__ float s_red[6][4];
     {   // per-row reference counts -> LDS (independent loads per lane)
         const int t = (int)threadIdx.x;
@@ -662,26 +670,21 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_nown = 0;
         __syncthreads();   // previous chunk is done with all s_* arrays
-        // ---- phase A: own chunk fields; rows spanned by the chunk
+        // ---- phase A: own chunk fields, and the rowstart slices of the two windows: rows
+        // [r_f, r_l+2] and the same + ncy (r_f, r_l were left per chunk by k_resolve)
+        const uint4 cw = P.chunkwin[base >> 8];
+        const int r_f = (int)cw.x, r_l = (int)cw.y;
+        const int nrs = min(r_l - r_f + 3, K4_RMAX);
         if (threadIdx.x < cnt) {
             my_nown = (P.rec_info[irec] >> 18) & 15u;
             s_own[threadIdx.x] = P.rec_own[irec];
+            s_z[threadIdx.x] = P.rec_z[irec];
         }
-        if (threadIdx.x == 0) {
-            const uint32_t xyf = P.rec_xy[base], xyl = P.rec_xy[base + cnt - 1];
-            const int zf = (int)P.rec_z[base], zl = (int)P.rec_z[base + cnt - 1];
-            s_meta[0] = (zf - P.lay_count_begin) * P.ncy + (int)(xyf >> 16);   // r_f
-            s_meta[1] = (zl - P.lay_count_begin) * P.ncy + (int)(xyl >> 16);   // r_l
-        }
-        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs)
-        const int r_f = s_meta[0], r_l = s_meta[1];
-        // ---- phase B: rowstart slices of the two windows: rows [r_f, r_l+2] and the same + ncy
-        const int nrs = min(r_l - r_f + 3, K4_RMAX);
         for (int i = threadIdx.x; i < 2 * nrs; i += 256) {
             const int w = i >= nrs, k = w ? i - nrs : i;
             s_rs[w][k] = min(P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)], n);   // never past the stored records
         }
-        __syncthreads();
+        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs)
         // ---- phase C: the windows themselves
         const uint32_t w1_start = base;                              // +x / +y sharers come after the chunk start
         // (at least the chunk itself: the row slice may have been cut at K4_RMAX rows)
@@ -725,9 +728,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int x = (int)(s_wxy[rr] & 0xffffu), y = (int)(s_wxy[rr] >> 16);
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = mc_edge_dir(e);
-            // layer of the creator: rows of W1 are r_f.. ; recover z from the row of this slot
-            const uint32_t own_rec = base + (uint32_t)rr;
-            const int z = (int)P.rec_z[own_rec];
+            const int z = (int)s_z[rr];
             const bool emit = z >= P.lay_emit_begin;   // the layer below a slab is numbered, not emitted
             const uint32_t vi = chunk_vbase + j;       // chunk prefix + in-chunk prefix: serial vertex id
             const uint32_t out = vi - nghost;

@@ -213,6 +213,48 @@ def test_impossible_case13_cells(gpu):
     assert_mesh_equal(m, om)
 
 
+def test_speculative_sizes_too_small_are_recovered(gpu):
+    """A repeat call with the same grid shape is launched speculatively with buffers sized from
+    the previous mesh; when the new mesh is much larger the library must notice and redo it."""
+    mn, mx, n = [-1.5] * 3, [1.5] * 3, 56
+    small = Sdfs.Sphere(0.2).ToMesh(mn, mx, n, n, n, clipToBounds=False)           # sets the size hint
+    assert 0 < len(small.Vertices) < 2000
+    for name in ("union8", "readme_repeat_xy"):
+        scene, sdf = S.CATALOGUE[name]()
+        ov, oc = O.sample(scene, [-2.8125] * 3, [2.8125] * 3, n, n, n)
+        O.clip_to_bounds(ov, [-2.8125] * 3, [2.8125] * 3)
+        om = O.march(ov, oc, [-2.8125] * 3, [2.8125] * 3)
+        assert len(om.vertices) > 20 * len(small.Vertices)
+        assert_mesh_equal(sdf.ToMesh([-2.8125] * 3, [2.8125] * 3, n, n, n), om)
+        small = Sdfs.Sphere(0.2).ToMesh(mn, mx, n, n, n, clipToBounds=False)       # shrink the hint again
+    v = Voxels.SampleSdf(Sdfs.Sphere(0.2), mn, mx, n, n, n)                           # and the volume is intact
+    ov, _ = O.sample(S.sphere_w(0.2)[0], mn, mx, n, n, n)
+    assert np.array_equal(v.Values, ov)
+
+
+def test_sparse_rows_volume(gpu):
+    """Isolated blobs far apart: a 256-cell chunk of the sweep spans hundreds of (mostly empty)
+    cell rows and several layers, so neighbour windows are cut and the slow path is used."""
+    rng = np.random.default_rng(5)
+    shape = (70, 66, 41)
+    v = np.full(shape, -1.0, np.float32) - rng.uniform(0, 1, shape).astype(np.float32)
+    c = rng.uniform(0, 1, shape + (3,)).astype(np.float32)
+    for x in range(3, shape[0] - 3, 9):
+        for y in range(2, shape[1] - 3, 11):
+            for z in range(2, shape[2] - 3, 6):
+                v[x:x + 2, y, z] = rng.uniform(0.2, 2.0, 2)
+    om = O.march(v, c, [-1] * 3, [1] * 3)
+    assert len(om.vertices) > 3000
+    m = MarchingCubes.CreateMesh(Voxels(v, c, [-1] * 3, [1] * 3))
+    assert_mesh_equal(m, om)
+    # and a surface with exactly one active cell per cell row (a plane x = const)
+    scene, sdf = S.plane_w((1.0, 0.0, 0.0), 0.013)
+    mn, mx, n = [-1] * 3, [1] * 3, (33, 90, 47)
+    ov, oc = O.sample(scene, mn, mx, *n)
+    om = O.march(ov, oc, mn, mx)
+    assert_mesh_equal(sdf.ToMesh(mn, mx, *n, clipToBounds=False), om)
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (2, 2, 2), (1, 5, 5), (5, 1, 5), (5, 5, 1), (2, 3, 65), (65, 2, 3), (3, 70, 2), (130, 3, 4)])
 def test_degenerate_and_ragged_shapes(gpu, shape):
     rng = np.random.default_rng(sum(shape))
