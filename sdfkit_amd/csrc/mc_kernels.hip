@@ -639,7 +639,7 @@ __device__ __forceinline__ void add_sharer_gradients(const V& vs, int es, int oc
     }
 }
 
-__global__ __launch_bounds__(256, 4) void k_vertices(McParams P, McMeshOut M)
+__global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
     __shared__ float s_wc[8 * K4_WMAX];          // window corner values: [corner][slot]
     __shared__ uint32_t s_wxy[K4_WMAX], s_winfo[K4_WMAX];
