@@ -126,7 +126,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    force_dist = os.environ.get("SDFK_BENCH_FORCE_DIST") == "1"   # exercise the sharded path on one rank
+    if world == 1 and force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    if world == 1 and not force_dist:
         def step():
             m = C.c_void_p()
             N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
@@ -217,7 +222,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_n)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         worker.close()
         dist.barrier()
         dist.destroy_process_group()
