@@ -140,17 +140,12 @@ def main():
             L.sdfk_mesh_free(m)
             return a.value, b.value
     else:
-        worker = D.GpuSlabWorker(sdf, mn, mx, n, n, n, rank, world, clip, 0.0)
-        bufs = {}
-
-        def make_buffer(nbytes):
-            if nbytes not in bufs:
-                bufs[nbytes] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            return bufs[nbytes]
+        # one sync + one RCCL all-gather per step (sdfkit_amd/dist.py: SlabSession)
+        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev)
+        totals = torch.zeros(2, dtype=torch.int64, device=dev)
 
         def step():
-            g, nvs, nis = D.sharded_step(worker, None, dev, make_buffer)
-            return sum(nvs), sum(nis)
+            return worker.step()
 
     for _ in range(args.warmup):
         nv, ni = step()
@@ -160,6 +155,10 @@ def main():
         nv, ni = step()
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1 or force_dist:   # per-rank counts -> totals of the whole mesh (outside the timed region)
+        totals[0], totals[1] = nv, ni
+        dist.all_reduce(totals)
+        nv, ni = int(totals[0].item()), int(totals[1].item())
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -132,6 +132,27 @@ int sdfk_march_begin(const sdfk_volume* v, float iso_value, int32_t layer_begin,
 int sdfk_march_finish(sdfk_march_job* job, int64_t vertex_base, sdfk_mesh** out);
 void sdfk_march_job_free(sdfk_march_job* job);
 
+/* One-call slab forms (one host sync each): buffers are sized from the previous call with the
+ * same slab shape, classification and emit are queued back to back, and the exact two-phase
+ * path is taken only when that guess was too small.  `vertex_base` is added to every index;
+ * pass 0 to get slab-local indices and rebase after the gather (sdfk_slabs_rebase). */
+int sdfk_march_slab(const sdfk_volume* v, float iso_value, int32_t layer_begin, int32_t layer_end,
+                    int64_t vertex_base, sdfk_mesh** out);
+int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
+                           int32_t layer_begin, int32_t layer_end, int64_t vertex_base, sdfk_mesh** out);
+
+/* Self-describing slab payload for a single padded all-gather: 64-byte header
+ * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; pad } followed by
+ * Vertices | Colors | Normals (3 floats per vertex each) | Triangles (int32).  Written device
+ * to device into `dst` (capacity_bytes); *needed_bytes = header + arrays.  If it does not fit,
+ * only the header is written and SDFK_OK is still returned (the caller sees needed > capacity). */
+#define SDFK_SLAB_HEADER_BYTES 64
+int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_t* needed_bytes);
+/* `gathered` = world payloads of stride_bytes each (device memory, as produced by an
+ * all-gather of sdfk_mesh_pack buffers with slab-local indices): adds to the indices of slab r
+ * the vertex counts of slabs 0..r-1, in one launch, reading the counts from the headers. */
+int sdfk_slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes);
+
 /* ---- Mesh (Mesh.cs:8-64) ----------------------------------------------------
  * Vertices/Colors/Normals: 3 floats each per vertex; Triangles: int32 indices
  * (Mesh.cs:10-13).  Vertices/Normals are already transformed to world space

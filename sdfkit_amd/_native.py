@@ -54,6 +54,10 @@ SIGNATURES = {
     "sdfk_march_begin": (C.c_int, [_vp, _f, _i32, _i32, _vpp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_march_finish": (C.c_int, [_vp, _i64, _vpp]),
     "sdfk_march_job_free": (None, [_vp]),
+    "sdfk_march_slab": (C.c_int, [_vp, _f, _i32, _i32, _i64, _vpp]),
+    "sdfk_sample_march_slab": (C.c_int, [_vp, _vp, _i32, _f, _i32, _i32, _i64, _vpp]),
+    "sdfk_mesh_pack": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
+    "sdfk_slabs_rebase": (C.c_int, [_vp, _i32, _i64]),
     "sdfk_mesh_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_mesh_bounds": (C.c_int, [_vp, _fp, _fp]),
     "sdfk_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

@@ -1004,6 +1004,34 @@ __global__ __launch_bounds__(256) void k_clip(float* __restrict__ values, int nx
     }
 }
 
+// ---- Z-slab exchange helpers (sdfkit_amd/dist.py) ------------------------------------------
+struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; float pad[6]; };
+static_assert(sizeof(SlabHeader) == 64, "SDFK_SLAB_HEADER_BYTES");
+
+__global__ void k_slab_header(SlabHeader* dst, int64_t nv, int64_t ni, const float* __restrict__ bounds)
+{
+    if (threadIdx.x == 0) {
+        SlabHeader h;
+        h.nv = nv; h.ni = ni;
+        for (int k = 0; k < 3; k++) { h.bmin[k] = nv ? bounds[k] : 0.0f; h.bmax[k] = nv ? bounds[3 + k] : 0.0f; }
+        for (int k = 0; k < 6; k++) h.pad[k] = 0.0f;
+        *dst = h;
+    }
+}
+
+// slab r of the gathered buffer: indices += sum of the vertex counts of slabs 0..r-1
+__global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathered, int world, int64_t stride)
+{
+    const int r = blockIdx.y;
+    int64_t base = 0;
+    for (int q = 0; q < r; q++) base += reinterpret_cast<const SlabHeader*>(gathered + (size_t)q * stride)->nv;
+    if (r == 0 || base == 0) return;
+    const SlabHeader* h = reinterpret_cast<const SlabHeader*>(gathered + (size_t)r * stride);
+    int32_t* t = reinterpret_cast<int32_t*>(gathered + (size_t)r * stride + sizeof(SlabHeader) + (size_t)h->nv * 36);
+    const int64_t n = h->ni;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) t[i] += (int32_t)base;
+}
+
 // step > 1 (MarchingCubes.cs:49-80): the sweep only ever touches voxels whose indices are
 // multiples of `step`; gather them into a dense volume and mesh that with unit cells.
 __global__ __launch_bounds__(256) void k_subsample(const float* __restrict__ src, const float* __restrict__ srcc,

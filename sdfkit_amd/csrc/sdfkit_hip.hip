@@ -820,30 +820,30 @@ void finalize_mesh(sdfk_march_job* j, sdfk_mesh* m, bool have_bounds)
     }
 }
 
-uint64_t hint_key(const sdfk_volume* v, int step)
+uint64_t hint_key(const sdfk_volume* v, int step, int layer_begin, int layer_end)
 {
-    return ((uint64_t)v->nx << 44) ^ ((uint64_t)v->ny << 24) ^ ((uint64_t)v->nz << 4) ^ (uint64_t)(step & 15);
+    uint64_t k = ((uint64_t)v->nx << 44) ^ ((uint64_t)v->ny << 24) ^ ((uint64_t)v->nz << 4) ^ (uint64_t)(step & 15);
+    return k * 0x9E3779B97F4A7C15ull ^ ((uint64_t)(uint32_t)layer_begin << 32 | (uint32_t)layer_end) ^ ((uint64_t)v->z0 << 17);
 }
 
-// MarchingCubes.CreateMesh on a whole volume.
-int march_whole(const sdfk_volume* v, float iso, int step, sdfk_mesh** out)
+// MarchingCubes.CreateMesh on the cell layers [layer_begin, layer_end) of a volume / slab.
+int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end, int64_t vertex_base, sdfk_mesh** out)
 {
     *out = nullptr;
-    const int layer_end = std::max(v->nz_global - 1, 0);
-    const uint64_t key = hint_key(v, step);
+    const uint64_t key = hint_key(v, step, layer_begin, layer_end);
     auto it = g.hints.find(key);
     if (it != g.hints.end()) {
         // Fast path: sizes of the previous mesh of this shape (+25 % and a floor) size every
         // buffer; classification AND emit are queued back to back; ONE sync at the end.
         const Context::Hint h = it->second;
         sdfk_march_job* j = nullptr;
-        int r = setup_job(v, iso, step, 0, layer_end, (size_t)h.n_active + h.n_active / 4 + 4096, &j);
+        int r = setup_job(v, iso, step, layer_begin, layer_end, (size_t)h.n_active + h.n_active / 4 + 4096, &j);
         if (r) return r;
         sdfk_mesh* m = nullptr;
         if (!j->empty) {
             r = alloc_mesh(&m, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
             r = r ? r : launch_classify(j);
-            r = r ? r : launch_emit(j, m, 0);
+            r = r ? r : launch_emit(j, m, vertex_base);
             r = r ? r : wait_counters(j);
             const bool fits = !r && j->c.n_active <= j->P.cap_active && j->c.overflow == 0 &&
                               (size_t)(j->c.total_v - j->c.nghost) <= m->cap_v && (size_t)j->c.total_t * 3 <= m->cap_i;
@@ -867,7 +867,7 @@ int march_whole(const sdfk_volume* v, float iso, int step, sdfk_mesh** out)
     }
     // Exact path: classify, wait for the counts, size the outputs exactly, emit.
     sdfk_march_job* j = nullptr;
-    int r = setup_job(v, iso, step, 0, layer_end, 0, &j);
+    int r = setup_job(v, iso, step, layer_begin, layer_end, 0, &j);
     if (r) return r;
     sdfk_mesh* m = nullptr;
     if (j->empty) {
@@ -882,8 +882,10 @@ int march_whole(const sdfk_volume* v, float iso, int step, sdfk_mesh** out)
             r = r ? r : wait_counters(j);
         }
         r = r ? r : alloc_mesh(&m, (size_t)(j->c.total_v - j->c.nghost), (size_t)j->c.total_t * 3);
+        if (!r && vertex_base + (int64_t)(j->c.total_v - j->c.nghost) >= (int64_t(1) << 31))
+            r = fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])");
         if (!r && j->c.n_active > 0) {
-            r = launch_emit(j, m, 0);
+            r = launch_emit(j, m, vertex_base);
             r = r ? r : wait_counters(j);
             if (!r && j->c.overflow) r = fail(SDFK_ERR_HIP, "marching cubes: output capacity exceeded unexpectedly");
         }
@@ -966,8 +968,61 @@ extern "C" int sdfk_march(const sdfk_volume* v, float iso_value, int32_t step, s
     if (!v || !out) return fail(SDFK_ERR_INVALID, "sdfk_march: null argument");
     *out = nullptr;
     if (int r = require_init()) return r;
-    if (v->z0 != 0 || v->nz != v->nz_global) return fail(SDFK_ERR_INVALID, "sdfk_march needs a whole volume; use sdfk_march_begin/finish for slabs");
-    return march_whole(v, iso_value, step, out);
+    if (v->z0 != 0 || v->nz != v->nz_global) return fail(SDFK_ERR_INVALID, "sdfk_march needs a whole volume; use sdfk_march_slab for slabs");
+    return march_range(v, iso_value, step, 0, std::max(v->nz_global - 1, 0), 0, out);
+}
+
+extern "C" int sdfk_march_slab(const sdfk_volume* v, float iso_value, int32_t layer_begin, int32_t layer_end,
+                               int64_t vertex_base, sdfk_mesh** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!v || !out) return fail(SDFK_ERR_INVALID, "sdfk_march_slab: null argument");
+    *out = nullptr;
+    if (int r = require_init()) return r;
+    return march_range(v, iso_value, 1, layer_begin, layer_end, vertex_base, out);
+}
+
+extern "C" int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
+                                      int32_t layer_begin, int32_t layer_end, int64_t vertex_base, sdfk_mesh** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !slab || !out) return fail(SDFK_ERR_INVALID, "sdfk_sample_march_slab: null argument");
+    *out = nullptr;
+    if (int r = require_init()) return r;
+    if (int r = sample_impl(p, slab, clip_to_bounds, iso_value)) return r;
+    return march_range(slab, iso_value, 1, layer_begin, layer_end, vertex_base, out);
+}
+
+extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_t* needed_bytes)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!m || !dst) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: null argument");
+    if (int r = require_init()) return r;
+    const int64_t vb = m->nv * 12, need = SDFK_SLAB_HEADER_BYTES + 3 * vb + m->ni * 4;
+    if (needed_bytes) *needed_bytes = need;
+    if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: capacity below the header size");
+    hipLaunchKernelGGL(k_slab_header, dim3(1), dim3(64), 0, g.stream, (SlabHeader*)dst, (int64_t)m->nv, (int64_t)m->ni, (const float*)m->bounds);
+    HIPCHK(hipGetLastError());
+    if (need > capacity_bytes) return SDFK_OK;
+    char* q = (char*)dst + SDFK_SLAB_HEADER_BYTES;
+    if (vb) {
+        HIPCHK(hipMemcpyAsync(q, m->vertices, vb, hipMemcpyDeviceToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(q + vb, m->colors, vb, hipMemcpyDeviceToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(q + 2 * vb, m->normals, vb, hipMemcpyDeviceToDevice, g.stream));
+    }
+    if (m->ni) HIPCHK(hipMemcpyAsync(q + 3 * vb, m->triangles, m->ni * 4, hipMemcpyDeviceToDevice, g.stream));
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!gathered || world < 1 || stride_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_slabs_rebase: bad argument");
+    if (int r = require_init()) return r;
+    if (world == 1) return SDFK_OK;
+    hipLaunchKernelGGL(k_slabs_rebase, dim3(64, world), dim3(256), 0, g.stream, (char*)gathered, (int)world, (int64_t)stride_bytes);
+    HIPCHK(hipGetLastError());
+    return SDFK_OK;
 }
 
 extern "C" int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32_t ny, int32_t nz,

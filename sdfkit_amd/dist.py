@@ -97,6 +97,25 @@ class GpuSlabWorker:
         vb = nv * 12
         N.check(N.lib().sdfk_mesh_copy_device(self.mesh, p, p + vb, p + 2 * vb, p + 3 * vb))
 
+    def run_local(self):
+        """One-call form: sample the slab and mesh its layers with slab-LOCAL vertex ids
+        (sdfk_sample_march_slab, one host sync).  Returns (n_vertices, n_indices)."""
+        N = self.N
+        self.release()
+        m = C.c_void_p()
+        N.check(N.lib().sdfk_sample_march_slab(self.prog, self.vol, 1 if self.clip else 0, C.c_float(self.iso),
+                                               self.lb, self.le, 0, C.byref(m)))
+        self.mesh = m
+        nv, ni = C.c_int64(), C.c_int64()
+        N.check(N.lib().sdfk_mesh_counts(m, C.byref(nv), C.byref(ni)))
+        return nv.value, ni.value
+
+    def pack_self_describing(self, buf):
+        """sdfk_mesh_pack into the uint8 torch tensor `buf`; returns the bytes needed."""
+        need = C.c_int64()
+        self.N.check(self.N.lib().sdfk_mesh_pack(self.mesh, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(need)))
+        return need.value
+
     def release(self):
         N = self.N
         if self.mesh is not None:
@@ -202,3 +221,83 @@ def sharded_to_mesh(sdf, mn, mx, nx, ny, nz, clip_to_bounds=True, iso=0.0, group
     finally:
         w.close()
     return Mesh(V, Cc, Nn, T, bmin, bmax)
+
+
+# ---------------------------------------------------------------------------
+# steady-state form: ONE host sync and ONE collective per step
+# ---------------------------------------------------------------------------
+SLAB_HEADER_BYTES = 64  # SDFK_SLAB_HEADER_BYTES
+
+
+class SlabSession:
+    """Repeated sharded sample -> mesh of the same grid (what bench.py --gpus N times).
+
+    Per step and rank: sample + mesh the slab with slab-local ids (one sync, buffers sized from
+    the previous step), pack a self-describing payload (header = counts + bounds), ONE padded
+    all-gather over RCCL, one kernel that rebases the gathered indices from the headers.  The
+    payload stride is agreed once, on the first step, with a count all-gather (+50 % head-room);
+    a later slab that outgrows it raises (use sharded_to_mesh for one-off meshes)."""
+
+    def __init__(self, sdf, mn, mx, nx, ny, nz, clip_to_bounds=True, iso=0.0, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        from . import _native as N
+        self.N, self.group = N, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.worker = GpuSlabWorker(sdf, mn, mx, nx, ny, nz, self.rank, self.world, clip_to_bounds, iso)
+        self.stride = None
+        self.buf = self.gathered = None
+
+    def step(self):
+        import torch
+        import torch.distributed as dist
+        nv, ni = self.worker.run_local()
+        need = SLAB_HEADER_BYTES + 36 * nv + 4 * ni
+        if self.stride is None:   # first step only (every rank takes this branch together)
+            t = torch.tensor([need], dtype=torch.int64, device=self.device)
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(out, t, group=self.group)
+            mx = max(int(x.item()) for x in out)
+            self.stride = ((mx + mx // 2 + 4096) + 255) // 256 * 256
+            self.buf = torch.empty(self.stride, dtype=torch.uint8, device=self.device)
+            self.gathered = torch.empty((self.world, self.stride), dtype=torch.uint8, device=self.device)
+        if need > self.stride:
+            raise RuntimeError(f"slab payload grew to {need} B (> agreed stride {self.stride} B)")
+        self.worker.pack_self_describing(self.buf)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.buf, group=self.group)
+        else:
+            dist.all_gather([self.gathered[r] for r in range(self.world)], self.buf, group=self.group)
+        self.N.check(self.N.lib().sdfk_slabs_rebase(C.c_void_p(self.gathered.data_ptr()), self.world, self.stride))
+        return nv, ni
+
+    def mesh(self):
+        """Host copy of the last gathered mesh (synchronises)."""
+        import torch
+        from .api import Mesh
+        torch.cuda.current_stream().synchronize()
+        V, Cc, Nn, T, mn, mx = unpack_self_describing(self.gathered.cpu().numpy())
+        return Mesh(V, Cc, Nn, T, mn, mx)
+
+    def close(self):
+        self.worker.close()
+
+
+def unpack_self_describing(g):
+    """g: [world, stride] uint8 array of rebased sdfk_mesh_pack payloads -> concatenated arrays."""
+    V, Cc, Nn, T, mins, maxs = [], [], [], [], [], []
+    for row in g:
+        nv, ni = (int(x) for x in row[:16].view(np.int64))
+        b = row[16:40].view(np.float32)
+        o, vb = SLAB_HEADER_BYTES, nv * 12
+        V.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
+        Cc.append(row[o + vb:o + 2 * vb].view(np.float32).reshape(-1, 3))
+        Nn.append(row[o + 2 * vb:o + 3 * vb].view(np.float32).reshape(-1, 3))
+        T.append(row[o + 3 * vb:o + 3 * vb + 4 * ni].view(np.int32))
+        if nv:
+            mins.append(b[0:3]); maxs.append(b[3:6])
+    mn = np.min(np.stack(mins), axis=0) if mins else np.zeros(3, np.float32)
+    mx = np.max(np.stack(maxs), axis=0) if maxs else np.zeros(3, np.float32)
+    return (np.concatenate(V), np.concatenate(Cc), np.concatenate(Nn), np.concatenate(T),
+            mn.astype(np.float32), mx.astype(np.float32))

@@ -402,3 +402,35 @@ def test_slab_with_dead_cells_at_the_seam(gpu):
         L.sdfk_mesh_free(m); L.sdfk_march_job_free(job); L.sdfk_volume_free(vol)
     assert np.array_equal(np.concatenate(got_t), om.triangles)
     assert np.array_equal(np.concatenate(got_v), om.vertices)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_one_call_pack_and_rebase(gpu, world):
+    """The steady-state sharded form (dist.SlabSession minus the collective): one-call slab
+    marches with slab-local ids, self-describing payloads placed side by side as an all-gather
+    would, one rebase launch -> identical to the single-volume mesh."""
+    import torch
+    from sdfkit_amd import dist as D
+    scene, sdf = S.readme_repeat_xy()
+    mn, mx, dims = [-2.8125] * 3, [2.8125] * 3, (44, 40, 48)
+    whole = sdf.ToMesh(mn, mx, *dims)
+    N.check(N.lib().sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    try:
+        for _ in range(2):   # second round runs on the speculative (hinted) path
+            workers = [D.GpuSlabWorker(sdf, mn, mx, *dims, r, world, True, 0.0) for r in range(world)]
+            counts = [w.run_local() for w in workers]
+            stride = max(D.SLAB_HEADER_BYTES + 36 * a + 4 * b for a, b in counts) + 512
+            g = torch.zeros((world, stride), dtype=torch.uint8, device="cuda")
+            for r, w in enumerate(workers):
+                assert w.pack_self_describing(g[r]) <= stride
+            N.check(N.lib().sdfk_slabs_rebase(C.c_void_p(g.data_ptr()), world, stride))
+            torch.cuda.synchronize()
+            V, Cc, Nn, T, bmin, bmax = D.unpack_self_describing(g.cpu().numpy())
+            for w in workers:
+                w.close()
+            assert np.array_equal(T, whole.Triangles)
+            assert np.array_equal(V, whole.Vertices) and np.array_equal(Cc, whole.Colors)
+            assert np.array_equal(Nn, whole.Normals, equal_nan=True)
+            assert np.array_equal(bmin, whole.Min) and np.array_equal(bmax, whole.Max)
+    finally:
+        N.check(N.lib().sdfk_set_stream(None))
