@@ -36,6 +36,9 @@
 
 namespace sdfk {
 
+constexpr int K4_WMAX = 640;   // k_vertices: record-window slots staged in LDS (both windows together)
+constexpr int K4_RMAX = 288;   // k_vertices: rowstart entries staged per window
+
 // ---------------------------------------------------------------------------
 // K1: sign bits
 // ---------------------------------------------------------------------------
@@ -520,7 +523,14 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
             const uint32_t first = (uint32_t)c * 256u, last = min(first + 255u, n - 1u);
             const uint32_t rf = (P.rec_z[first] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[first] >> 16);
             const uint32_t rl = (P.rec_z[last] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[last] >> 16);
-            P.chunkwin[c] = make_uint4(rf, rl, 0u, 0u);
+            // ... and the record ranges of its two neighbour windows (see k_vertices)
+            const uint32_t nrows = (uint32_t)((P.lay_list_end - P.lay_count_begin) * P.ncy);
+            const uint32_t nrs = min(rl - rf + 3u, (uint32_t)K4_RMAX);
+            const uint32_t w1e = min(P.rowstart[min(rf + nrs - 1u, nrows)], n);
+            const uint32_t w2s = min(P.rowstart[min(rf + (uint32_t)P.ncy, nrows)], n);
+            const uint32_t w2e = min(P.rowstart[min(rf + (uint32_t)P.ncy + nrs - 1u, nrows)], n);
+            P.chunkwin[c] = make_uint4(rf, rl, w1e, w2s);
+            P.chunkwin2[c] = w2e;
         }
     }
 }
@@ -607,8 +617,6 @@ __device__ __forceinline__ int mc_edge_corner_b(int e) { return e < 8 ? ((e & 4)
 // and the matching slices of rowstart[] are staged in LDS with coalesced loads; the
 // per-vertex work then runs on LDS only.  Sharers that fall outside a truncated window take
 // a slow path through global memory.
-constexpr int K4_WMAX = 640;   // window slots (both windows together)
-constexpr int K4_RMAX = 288;   // rowstart entries staged per window
 
 struct CornersGlobal {          // 8 corner values of a record, read from global memory (slow path)
     const float* p;
@@ -670,11 +678,17 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_nown = 0;
         __syncthreads();   // previous chunk is done with all s_* arrays
-        // ---- phase A: own chunk fields, and the rowstart slices of the two windows: rows
-        // [r_f, r_l+2] and the same + ncy (r_f, r_l were left per chunk by k_resolve)
+        // ---- one batch of loads: own chunk fields, rowstart slices of the two windows (rows
+        // [r_f, r_l+2] and the same + ncy) and the windows themselves.  Rows and window
+        // ranges were left per chunk by k_resolve, so nothing here waits on another load.
         const uint4 cw = P.chunkwin[base >> 8];
         const int r_f = (int)cw.x, r_l = (int)cw.y;
         const int nrs = min(r_l - r_f + 3, K4_RMAX);
+        const uint32_t w1_start = base;                              // +x / +y sharers come after the chunk start
+        // (at least the chunk itself: the row slice may have been cut at K4_RMAX rows)
+        const uint32_t w1_cnt = min(max(cw.z, base + cnt) - w1_start, (uint32_t)K4_WMAX);
+        const uint32_t w2_start = cw.w;
+        const uint32_t w2_cnt = min(P.chunkwin2[base >> 8] - w2_start, (uint32_t)K4_WMAX - w1_cnt);
         if (threadIdx.x < cnt) {
             my_nown = (P.rec_info[irec] >> 18) & 15u;
             s_own[threadIdx.x] = P.rec_own[irec];
@@ -684,13 +698,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int w = i >= nrs, k = w ? i - nrs : i;
             s_rs[w][k] = min(P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)], n);   // never past the stored records
         }
-        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs)
-        // ---- phase C: the windows themselves
-        const uint32_t w1_start = base;                              // +x / +y sharers come after the chunk start
-        // (at least the chunk itself: the row slice may have been cut at K4_RMAX rows)
-        const uint32_t w1_cnt = min(max(s_rs[0][nrs - 1], base + cnt) - w1_start, (uint32_t)K4_WMAX);
-        const uint32_t w2_start = s_rs[1][0];
-        const uint32_t w2_cnt = min(s_rs[1][nrs - 1] - w2_start, (uint32_t)K4_WMAX - w1_cnt);
         {
             const uint32_t wtot = w1_cnt + w2_cnt;
             uint32_t rxy[3], rin[3];
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 }
             }
         }
-        __syncthreads();
+        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs: LDS is complete)
         const uint32_t chunk_vbase = (uint32_t)(P.chunktot[base >> 8] >> 31);   // scanned by k_scan_chunks
         // ---- per created vertex
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {

@@ -48,7 +48,8 @@ struct McParams {
     float* rec_corners;    // 8 corner voxel values (v0..v7), 32 bytes per record
     uint32_t* rec_vid;     // [record][16]: vertex id of the cell's edge e (0..12), pushed by the creator
     uint32_t* chunkdead;   // "impossible case 13" cells per 256-cell chunk
-    uint4* chunkwin;       // per chunk: (first row, last row, -, -) of its records (K4 window set-up)
+    uint4* chunkwin;       // per chunk: (first row, last row, end of window 1, start of window 2) (K4 set-up)
+    uint32_t* chunkwin2;   // per chunk: end of window 2
     uint32_t cap_active;
     McCounters* counters;       // device copy; every field is written by a kernel (no memset)
     McCounters* host_counters;  // pinned, device-mapped mirror the host reads after ONE sync

@@ -600,6 +600,7 @@ int alloc_records(sdfk_march_job* j, size_t c)
     rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkdead, c / 256 + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkwin, c / 256 + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunkwin2, c / 256 + 2);
     P.cap_active = (uint32_t)c;
     return rr;
 }
