@@ -126,6 +126,36 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exclusive prefix of v over the 256 lanes of the workgroup, *total = workgroup sum; `red` is
+// summed over the workgroup on the side (same barriers) and returned through the reference
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t& red, uint32_t* total)
+{
+    __shared__ uint32_t s_incl[4], s_red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(incl, o);
+        if (lane >= o) incl += n;
+    }
+    const uint32_t r = wave_sum_u32(red);
+    __syncthreads();
+    if (lane == 63) { s_incl[wave] = incl; s_red[wave] = r; }
+    __syncthreads();
+    uint32_t pre = incl - v;
+    for (int w = 0; w < wave; w++) pre += s_incl[w];
+    *total = s_incl[0] + s_incl[1] + s_incl[2] + s_incl[3];
+    red = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    return pre;
+}
+
 // exclusive prefix of v over the 256 lanes of the workgroup; *total = workgroup sum
 __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_wave /*[4]*/, uint64_t* total)
 {
@@ -145,133 +175,143 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t shr1_in(uint64_t w, uint64_t next) { return (w >> 1) | (next << 63); }
 
-// activity of the 64 cells x = 64*xw .. 64*xw+63 of row (y_l, z) from the staged sign words
-__device__ __forceinline__ uint64_t segment_mask(const uint64_t* lo, const uint64_t* hi, int nxw, int ncx,
-                                                 int y_l, int xw, uint64_t& m13)
+typedef unsigned long long u64x2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// five consecutive sign words (two 16-byte loads + one 8-byte load; the buffer is padded)
+__device__ __forceinline__ void load_words5(const uint64_t* p, uint64_t* w)
 {
-    const uint64_t* r00 = lo + y_l * nxw + xw;   // (y  , z  )
-    const uint64_t* r01 = r00 + nxw;             // (y+1, z  )
-    const uint64_t* r10 = hi + y_l * nxw + xw;   // (y  , z+1)
-    const uint64_t* r11 = r10 + nxw;             // (y+1, z+1)
-    const bool more = xw + 1 < nxw;
-    const uint64_t a = r00[0], b = r01[0], c = r10[0], d = r11[0];
-    const uint64_t as = shr1_in(a, more ? r00[1] : 0), bs = shr1_in(b, more ? r01[1] : 0);
-    const uint64_t cs = shr1_in(c, more ? r10[1] : 0), ds = shr1_in(d, more ? r11[1] : 0);
-    const int rem = ncx - xw * 64;   // cells of this word: x = 64*xw + bit, valid while x < ncx
-    const uint64_t valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-    const uint64_t all1 = a & as & b & bs & c & cs & d & ds;
-    const uint64_t any1 = a | as | b | bs | c | cs | d | ds;
-    // corner sign words 0xA5 / 0x5A (case 13): v0=a v1=as v2=bs v3=b v4=c v5=cs v6=ds v7=d
-    const uint64_t pa5 = a & bs & cs & d & ~as & ~b & ~c & ~ds;
-    const uint64_t p5a = ~a & ~bs & ~cs & ~d & as & b & c & ds;
-    m13 = (pa5 | p5a) & valid;
-    return (any1 & ~all1) & valid;
+    const u64x2u lo = *reinterpret_cast<const u64x2u*>(p);
+    const u64x2u hi = *reinterpret_cast<const u64x2u*>(p + 2);
+    w[0] = lo.x; w[1] = lo.y; w[2] = hi.x; w[3] = hi.y; w[4] = p[4];
 }
 
-// Logical block b = (layer z, chunk of `yb` cell rows); logical order == sweep order.
-// Dynamic LDS: two planes of (yb+1) rows x nxw sign words.  WRITE = false: count the active
-// cells of the block; WRITE = true: write them at blockpre[b] + in-block prefix.
+// activity of the 64 cells x = 64*xw .. 64*xw+63 of one cell row: a/b/c/d = sign words of the
+// voxel rows (y,z) (y+1,z) (y,z+1) (y+1,z+1), *n = the following word of the same row.
+// `rem` = number of cells of this word that exist (x < ncx); the word after the last one of a
+// row may hold anything: it only reaches bit 63, a cell that never exists.
+// Corners: v0=a v1=as v2=bs v3=b v4=c v5=cs v6=ds v7=d.  A cell is active when some corner
+// differs from v0; its sign word is 0xA5 or 0x5A (case 13) when v1,v3,v4,v6 differ from v0 and
+// v2,v5,v7 equal it.
+__device__ __forceinline__ uint64_t segment_mask(uint64_t a, uint64_t an, uint64_t b, uint64_t bn, uint64_t c, uint64_t cn,
+                                                 uint64_t d, uint64_t dn, int rem, uint64_t& m13)
+{
+    const uint64_t as = shr1_in(a, an), bs = shr1_in(b, bn), cs = shr1_in(c, cn), ds = shr1_in(d, dn);
+    const uint64_t valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+    const uint64_t x1 = a ^ as, x3 = a ^ b, x4 = a ^ c, x6 = a ^ ds;
+    const uint64_t eq = (a ^ bs) | (a ^ cs) | (a ^ d);
+    m13 = (x1 & x3 & x4 & x6) & ~eq & valid;
+    return (x1 | x3 | x4 | x6 | eq) & valid;
+}
+
+// A sign plane is a flat array of ny*nxw words and cell row y uses voxel rows y and y+1, so
+// segment i = y*nxw + xw (64 cells) reads words i, i+1, i+nxw, i+nxw+1 of planes z and z+1:
+// sweep order == i order.  Logical block b = (layer, 1024 consecutive segments); each lane owns
+// 4 consecutive segments and keeps their words in registers (20 words, five 16/8-byte loads per
+// voxel row).  WRITE = false: count the active cells of the block; WRITE = true: write them at
+// (sum of the earlier blocks) + in-block prefix.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_compact(McParams P)
 {
-    extern __shared__ uint64_t s_bits[];
     __shared__ uint64_t s_wave[4];
-    const int plane = (P.yb + 1) * P.nxw;
     const int b = blockIdx.x;
-    const int z = P.lay_count_begin + b / P.nyc;
-    const int y0 = (b % P.nyc) * P.yb;
-    const int rows = min(P.yb, P.ncy - y0);
-    const int nwords = (rows + 1) * P.nxw;
-    const uint64_t* g0 = P.bits + ((size_t)z * P.ny + y0) * P.nxw;
-    const uint64_t* g1 = g0 + (size_t)P.ny * P.nxw;
-    {   // (yb+1)*nxw <= 2560 words per plane: at most 10 per lane; all loads issued up front
-        uint64_t r0[10], r1[10];
-#pragma unroll
-        for (int k = 0; k < 10; k++) {
-            const int i = (int)threadIdx.x + 256 * k;
-            if (i < nwords) { r0[k] = g0[i]; r1[k] = g1[i]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 10; k++) {
-            const int i = (int)threadIdx.x + 256 * k;
-            if (i < nwords) { s_bits[i] = r0[k]; s_bits[plane + i] = r1[k]; }
-        }
-    }
-    __syncthreads();
-    // each lane owns `per` CONSECUTIVE segments, so lane order == sweep order
-    const int nsegs = rows * P.nxw;
-    const int per = (nsegs + 255) >> 8;
-    const int sb = min((int)threadIdx.x * per, nsegs), se = min(sb + per, nsegs);
+    const int lay = b / P.bpl;
+    const int z = P.lay_count_begin + lay;
+    const int nseg = P.ncy * P.nxw;
+    const int i0 = (b - lay * P.bpl) * 1024 + 4 * (int)threadIdx.x;
+    uint64_t m[4] = {0, 0, 0, 0};
     uint32_t cnt = 0, n13 = 0;
-    {
-        int y_l = sb / P.nxw, xw = sb % P.nxw;
-        for (int s = sb; s < se; s++) {
+    int y = 0, xw = 0;
+    // the count pass recorded which wavefronts found nothing: those skip the sign words here
+    const bool look = !WRITE || P.wavecnt[b * 4 + (int)(threadIdx.x >> 6)] != 0;
+    if (i0 < nseg) {
+        y = i0 / P.nxw;
+        xw = i0 - y * P.nxw;
+    }
+    if (look && i0 < nseg) {
+        const size_t plane = (size_t)P.ny * P.nxw;
+        const uint64_t* f0 = P.bits + (size_t)z * plane + i0;
+        uint64_t wa[5], wb[5], wc[5], wd[5];
+        load_words5(f0, wa);
+        load_words5(f0 + P.nxw, wb);
+        load_words5(f0 + plane, wc);
+        load_words5(f0 + plane + P.nxw, wd);
+        int xk = xw;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rem = (i0 + k < nseg) ? P.ncx - xk * 64 : 0;
             uint64_t m13;
-            cnt += (uint32_t)__popcll(segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13));
+            m[k] = segment_mask(wa[k], wa[k + 1], wb[k], wb[k + 1], wc[k], wc[k + 1], wd[k], wd[k + 1], rem, m13);
+            cnt += (uint32_t)__popcll(m[k]);
             n13 += (uint32_t)__popcll(m13);
-            if (++xw == P.nxw) { xw = 0; y_l++; }
+            if (++xk == P.nxw) xk = 0;
         }
     }
-    uint64_t total;
-    const uint64_t pre = block_excl_scan_u64(cnt, s_wave, &total);
     if (!WRITE) {
-        // low 32 bits: active cells of the block; high 32 bits: its case-13 sign words
-        uint64_t t13;
-        (void)block_excl_scan_u64(n13, s_wave, &t13);
-        if (threadIdx.x == 0) P.blockcnt[b] = total | (t13 << 32);
+        // low 32 bits: active cells of the block; high 32 bits: its case-13 sign words (rare)
+        __shared__ uint32_t s_cnt[4], s_n13;
+        if (threadIdx.x == 0) s_n13 = 0;
+        const uint32_t wsum = wave_sum_u32(cnt);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            s_cnt[threadIdx.x >> 6] = wsum;
+            P.wavecnt[b * 4 + (threadIdx.x >> 6)] = wsum;   // lets the write pass skip empty wavefronts
+        }
+        if (n13) atomicAdd(&s_n13, n13);
+        __syncthreads();
+        if (threadIdx.x == 0) P.blockcnt[b] = (uint64_t)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]) | ((uint64_t)s_n13 << 32);
         return;
     }
     // exclusive prefix of this block = sum of the counts of all earlier blocks (a few thousand
-    // words, read cooperatively: cheaper than a separate scan launch); also the layer marks
-    uint64_t before = 0, ghost = 0, upto_emit_end = 0, all13 = 0;
-    {
-        const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.nyc, ge = (P.lay_emit_end - P.lay_count_begin) * P.nyc;
-        const bool last = b == (int)gridDim.x - 1;
-        const int lim = last ? (int)gridDim.x : b;
-        for (int i = threadIdx.x; i < lim; i += 256) {
+    // words, read cooperatively: cheaper than a separate scan launch)
+    uint32_t before = 0;
+    for (int i = threadIdx.x; i < b; i += 256) before += (uint32_t)P.blockcnt[i];
+    uint32_t total;
+    const uint32_t pre = block_excl_scan_u32(cnt, before, &total);   // also reduces `before` over the workgroup
+    if (b == (int)gridDim.x - 1) {   // the last block publishes the totals and the layer marks
+        uint64_t ghost = 0, upto_emit_end = 0, all13 = 0;
+        const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.bpl, ge = (P.lay_emit_end - P.lay_count_begin) * P.bpl;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
             const uint64_t w = P.blockcnt[i];
             const uint64_t c = w & 0xffffffffull;
-            if (i < b) before += c;
             if (i < gb) ghost += c;
             if (i < ge) upto_emit_end += c;
             all13 += w >> 32;
         }
-        __shared__ uint64_t s_sum[4][4];
-        before = wave_sum_u64(before); ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end);
-        all13 = wave_sum_u64(all13);
+        __shared__ uint64_t s_sum[3][4];
+        ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { s_sum[0][wave] = before; s_sum[1][wave] = ghost; s_sum[2][wave] = upto_emit_end; s_sum[3][wave] = all13; }
+        if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; }
         __syncthreads();
-        before = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
-        if (last && threadIdx.x == 0) {   // the last block sees every count: publish the totals
-            const uint64_t ng = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
-            const uint64_t ue = s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3];
-            P.counters->n_active = (uint32_t)(before + total);
+        if (threadIdx.x == 0) {
+            const uint64_t ng = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
+            const uint64_t ue = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
+            P.counters->n_active = before + total;
             P.counters->n_ghost_cells = (uint32_t)ng;
             P.counters->n_emit_cells = (uint32_t)(ue - ng);
-            P.counters->n_case13 = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
+            P.counters->n_case13 = (uint32_t)(s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]);
+            P.rowstart[(size_t)(lay + 1) * P.ncy] = before + total;   // sentinel
         }
     }
-    {
-        uint32_t pos = (uint32_t)(before + pre);
-        uint32_t* rowstart = P.rowstart + (size_t)(z - P.lay_count_begin) * P.ncy + y0;
-        if (b == (int)gridDim.x - 1 && threadIdx.x == 255) rowstart[rows] = (uint32_t)(before + total);   // sentinel
-        int y_l = sb / P.nxw, xw = sb % P.nxw;
-        for (int s = sb; s < se; s++) {
-            uint64_t m13;
-            uint64_t m = segment_mask(s_bits, s_bits + plane, P.nxw, P.ncx, y_l, xw, m13);
-            if (xw == 0) rowstart[y_l] = pos;   // first record of cell row (z, y0 + y_l)
-            const uint32_t yz = (uint32_t)(y0 + y_l) << 16;
-            while (m) {
-                const int bit = __builtin_ctzll(m);
-                m &= m - 1;
-                if (pos < P.cap_active) {
-                    P.rec_xy[pos] = (uint32_t)(xw * 64 + bit) | yz;
-                    P.rec_z[pos] = (uint32_t)z;
+    if (i0 < nseg) {
+        uint32_t pos = before + pre;
+        uint32_t* rowstart = P.rowstart + (size_t)lay * P.ncy;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < nseg) {
+                if (xw == 0) rowstart[y] = pos;   // first record of cell row (z, y)
+                const uint32_t yz = (uint32_t)y << 16;
+                uint64_t mk = m[k];
+                while (mk) {
+                    const int bit = __builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    if (pos < P.cap_active) {
+                        P.rec_xy[pos] = (uint32_t)(xw * 64 + bit) | yz;
+                        P.rec_z[pos] = (uint32_t)z;
+                    }
+                    pos++;
                 }
-                pos++;
+                if (++xw == P.nxw) { xw = 0; y++; }
             }
-            if (++xw == P.nxw) { xw = 0; y_l++; }
         }
     }
 }

@@ -33,9 +33,9 @@ struct McParams {
     int step;              // scale of cell coordinates in vertex positions (Cell.cs:345-347)
     // workspace
     const uint64_t* bits;  // [nz][ny][nxw]: bit b of word xw = (value(64*xw+b, y, z) > iso)
-    int yb;                // y rows per logical block of k_compact
-    int nyc;               // ceil(ncy / yb)
-    uint64_t* blockcnt;    // active cells per logical block of k_compact; exclusive prefix after k_scan1<0>
+    int bpl;               // logical blocks of k_compact per layer: ceil(ncy * nxw / 1024)
+    uint64_t* blockcnt;    // per logical block of k_compact: active cells | case-13 sign words << 32
+    uint32_t* wavecnt;     // active cells per wavefront of the count pass ([block][4])
     uint64_t* chunktot;    // (vertices << 31 | triangles) per 256-cell chunk; exclusive prefix after k_scan1<1>
     // Active cells ("records") in serial-sweep order.  Everything the emit kernels read is
     // compact (tens of MB, L2/MALL resident): no per-voxel maps.

@@ -217,7 +217,7 @@ struct sdfk_volume {
     bool bits_valid = false;
     size_t nvox() const { return (size_t)nx * ny * nz; }
     int nxw() const { return (nx + 63) / 64; }
-    size_t nbitwords() const { return (size_t)nz * ny * nxw() + 1; }
+    size_t nbitwords() const { return (size_t)nz * ny * nxw() + 8; }   // k_compact reads 4 words past a row pair
 };
 
 struct sdfk_mesh {
@@ -631,10 +631,9 @@ int launch_classify(sdfk_march_job* j)
     }
     {
         ProfScope ps("k_compact");
-        const int nlog = (P.lay_list_end - P.lay_count_begin) * P.nyc;
-        const size_t lds = (size_t)2 * (P.yb + 1) * P.nxw * sizeof(uint64_t);
-        hipLaunchKernelGGL(k_compact<false>, dim3(nlog), dim3(256), lds, g.stream, P);
-        hipLaunchKernelGGL(k_compact<true>, dim3(nlog), dim3(256), lds, g.stream, P);
+        const int nlog = (P.lay_list_end - P.lay_count_begin) * P.bpl;
+        hipLaunchKernelGGL(k_compact<false>, dim3(nlog), dim3(256), 0, g.stream, P);
+        hipLaunchKernelGGL(k_compact<true>, dim3(nlog), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     const int nchunks = (int)((P.cap_active + 255u) / 256u);
@@ -722,9 +721,8 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
                         w->z0, w->z0 + w->nz, need_lo, need_hi, layer_begin, layer_end);
         }
     }
-    // logical blocks of k_compact: `yb` cell rows of one layer, sign words staged in <= 40 KB of LDS
-    P.yb = std::max(1, std::min(128, 2560 / P.nxw - 1));
-    P.nyc = (P.ncy + P.yb - 1) / P.yb;
+    // logical blocks of k_compact: 1024 consecutive 64-cell segments of one layer
+    P.bpl = (int)(((size_t)P.ncy * P.nxw + 1023) / 1024);
     const size_t ncell = (size_t)P.ncx * P.ncy * P.ncz;
     if (cap_records == 0) cap_records = std::max<size_t>(ncell / 12, 1u << 16);
     cap_records = std::min(cap_records, ncell);
@@ -733,10 +731,11 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     if (j->have_bits) P.bits = v->bits;   // written by the fused sampling kernel; owned by the volume
     else {
         uint64_t* bits = nullptr;
-        r = r ? r : job_alloc(j, &bits, (size_t)P.nz * P.ny * P.nxw + 1);
+        r = r ? r : job_alloc(j, &bits, (size_t)P.nz * P.ny * P.nxw + 8);   // k_compact reads 4 words past a row pair
         P.bits = bits;
     }
-    r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.nyc + 1);
+    r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl + 1);
+    r = r ? r : job_alloc(j, &P.wavecnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl * 4 + 4);
     r = r ? r : job_alloc(j, &P.rowstart, (size_t)(P.lay_list_end - P.lay_count_begin) * P.ncy + 2);
     r = r ? r : job_alloc(j, &P.counters, 1);
     P.host_counters = &g.slots_dev[j->slot].c;
