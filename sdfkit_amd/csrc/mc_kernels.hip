@@ -316,57 +316,50 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     }
 }
 
-// One workgroup: in-place exclusive scan of the per-chunk (vertices << 31 | triangles)
-// totals -> chunk prefixes, grand totals, and the vertex count of the ghost layer.
-__global__ __launch_bounds__(1024) void k_scan_chunks(McParams P)
+// Sum of the per-chunk (vertices << 31 | triangles) totals of chunks [from, to) over the
+// workgroup (a few thousand words at most, L2 resident): every workgroup derives the prefix of
+// its own chunk this way instead of waiting for a separate scan launch.
+__device__ __forceinline__ uint64_t chunk_totals_sum(const uint64_t* chunktot, uint32_t from, uint32_t to, uint64_t* s_part /*[4]*/)
 {
-    __shared__ uint64_t sm[16];
-    __shared__ uint64_t s_carry;
-    __shared__ uint32_t s_part[16];
-    uint64_t* data = P.chunktot;
-    const uint32_t nrec = min(P.counters->n_active, P.cap_active);
-    const uint32_t n = (nrec + 255u) >> 8;
-    if (threadIdx.x == 0) s_carry = 0;
+    uint64_t v = 0;
+    for (uint32_t i = from + threadIdx.x; i < to; i += 256u) v += chunktot[i];
+    v = wave_sum_u64(v);
+    __syncthreads();   // s_part may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t dead = 0;
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint64_t v = (i < n) ? data[i] : 0ull;
-        if (i < n) dead += P.chunkdead[i];
-        const uint64_t incl = wave_incl_scan_u64(v);
-        if (lane == 63) sm[wave] = incl;
-        __syncthreads();
-        uint64_t wpre = 0, all = 0;
-        for (int w = 0; w < 16; w++) {
-            if (w < wave) wpre += sm[w];
-            all += sm[w];
-        }
-        const uint64_t carry = s_carry;
-        if (i < n) data[i] = carry + wpre + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + all;
-        __syncthreads();
-    }
+    return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// Grand totals, the vertex count of the ghost layer, dead cells: published to the device
+// counters and to the host mirror by ONE workgroup after k_resolve has completed (workgroup 0
+// of k_vertices, or k_publish when the host wants the counts before emitting).
+__device__ __forceinline__ void publish_totals(const McParams& P)
+{
+    const uint32_t nrec = min(P.counters->n_active, P.cap_active);
+    const uint32_t nch = (nrec + 255u) >> 8;
     // vertices numbered before the first emitted cell: chunk prefix + in-chunk prefix
     const uint32_t i0 = min(P.counters->n_ghost_cells, nrec);
-    const uint32_t c0 = i0 >> 8, r0 = i0 & 255u;
-    uint32_t part = 0;
-    if (threadIdx.x < r0) part = (P.rec_info[c0 * 256u + threadIdx.x] >> 18) & 15u;
-    __shared__ uint32_t s_dead[16];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { part += __shfl_xor(part, o); dead += __shfl_xor(dead, o); }
-    if (lane == 0) { s_part[wave] = part; s_dead[wave] = dead; }
+    const uint32_t c0 = i0 >> 8;
+    uint64_t all = 0, upto = 0, dead = 0;
+    for (uint32_t i = threadIdx.x; i < nch; i += 256u) {
+        const uint64_t v = P.chunktot[i];
+        all += v;
+        if (i < c0) upto += v;
+        dead += P.chunkdead[i];
+    }
+    all = wave_sum_u64(all); upto = wave_sum_u64(upto); dead = wave_sum_u64(dead);
+    __shared__ uint64_t s_tot[3][4];
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_tot[0][w] = all; s_tot[1][w] = upto; s_tot[2][w] = dead; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t in_chunk = 0, ndead = 0;
-        for (int w = 0; w < 16; w++) { in_chunk += s_part[w]; ndead += s_dead[w]; }
-        const uint64_t basep = (c0 < n) ? data[c0] : s_carry;
+        all = s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
+        upto = s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3];
+        dead = s_tot[2][0] + s_tot[2][1] + s_tot[2][2] + s_tot[2][3];
         McCounters c = *P.counters;
-        c.nghost = (uint32_t)(basep >> 31) + in_chunk;
-        c.total_v = (uint32_t)(s_carry >> 31);
-        c.total_t = (uint32_t)(s_carry & 0x7fffffffull);
-        c.n_dead = ndead;
+        c.total_v = (uint32_t)(all >> 31);
+        c.total_t = (uint32_t)(all & 0x7fffffffull);
+        c.nghost = i0 < nrec ? (uint32_t)(upto >> 31) + (P.rec_pre[i0] & 0xffffu) : c.total_v;
+        c.n_dead = (uint32_t)dead;
         c.overflow = 0;
         *P.counters = c;
         // mirror for the host (read after the stream has drained); `overflow` is only ever
@@ -376,6 +369,8 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(McParams P)
         h->total_t = c.total_t; h->nghost = c.nghost; h->n_ghost_cells = c.n_ghost_cells; h->n_emit_cells = c.n_emit_cells;
     }
 }
+
+__global__ __launch_bounds__(256) void k_publish(McParams P) { publish_totals(P); }
 
 // ---------------------------------------------------------------------------
 // shared helpers
@@ -708,11 +703,22 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         if (t + 512 < MCLUT_NROWS) s_occ[t + 512] = a2;
     }
     const uint32_t n = min(P.counters->n_active, P.cap_active);
-    const uint32_t nghost = P.counters->nghost;
     const int nrows_total = (P.lay_list_end - P.lay_count_begin) * P.ncy;
     const double iso = (double)P.iso;
     const double stp = (double)P.step;
     float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    __shared__ uint64_t s_part[4];
+    // vertices numbered below the first emitted layer (slab runs): prefix of record n_ghost_cells
+    uint32_t nghost = 0;
+    {
+        const uint32_t i0 = min(P.counters->n_ghost_cells, n);
+        if (i0 > 0)   // (all records ghost: every chunk counts)
+            nghost = (uint32_t)(chunk_totals_sum(P.chunktot, 0, i0 < n ? i0 >> 8 : (n + 255u) >> 8, s_part) >> 31) +
+                     (i0 < n ? (P.rec_pre[i0] & 0xffffu) : 0u);
+    }
+    if (blockIdx.x == 0) publish_totals(P);   // k_resolve has completed (stream order)
+    uint64_t chunk_prefix = 0;
+    uint32_t prefix_upto = 0;
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t cnt = min(256u, n - base);
         const uint32_t irec = base + threadIdx.x;
@@ -765,8 +771,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 }
             }
         }
+        // chunk prefix = totals of all earlier chunks (advanced incrementally when a workgroup
+        // takes more than one chunk); left in chunkpre[] for k_triangles
+        chunk_prefix += chunk_totals_sum(P.chunktot, prefix_upto, base >> 8, s_part);
+        prefix_upto = base >> 8;
+        if (threadIdx.x == 0) P.chunkpre[base >> 8] = chunk_prefix;
         const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs: LDS is complete)
-        const uint32_t chunk_vbase = (uint32_t)(P.chunktot[base >> 8] >> 31);   // scanned by k_scan_chunks
+        const uint32_t chunk_vbase = (uint32_t)(chunk_prefix >> 31);
         // ---- per created vertex
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {
             const int rr = find_owner_256(s_pre, j);   // = window slot of the creator (W1 starts at the chunk)
@@ -1021,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             s_lo[threadIdx.x] = info & 0x3fffu;
         }
         const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
-        const size_t chunk_ibase = (size_t)(P.chunktot[base >> 8] & 0x7fffffffull) * 3;
+        const size_t chunk_ibase = (size_t)(P.chunkpre[base >> 8] & 0x7fffffffull) * 3;   // left by k_vertices
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
             const size_t o = chunk_ibase + j;   // serial position of this triangle index
             if (o >= M.cap_indices) { P.host_counters->overflow = 1u; continue; }

@@ -36,7 +36,8 @@ struct McParams {
     int bpl;               // logical blocks of k_compact per layer: ceil(ncy * nxw / 1024)
     uint64_t* blockcnt;    // per logical block of k_compact: active cells | case-13 sign words << 32
     uint32_t* wavecnt;     // active cells per wavefront of the count pass ([block][4])
-    uint64_t* chunktot;    // (vertices << 31 | triangles) per 256-cell chunk; exclusive prefix after k_scan1<1>
+    uint64_t* chunktot;    // (vertices << 31 | triangles) per 256-cell chunk (k_resolve)
+    uint64_t* chunkpre;    // exclusive prefix of chunktot, per chunk (k_vertices, read by k_triangles)
     // Active cells ("records") in serial-sweep order.  Everything the emit kernels read is
     // compact (tens of MB, L2/MALL resident): no per-voxel maps.
     uint32_t* rec_xy;      // x | y << 16

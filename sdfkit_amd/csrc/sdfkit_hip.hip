@@ -598,6 +598,7 @@ int alloc_records(sdfk_march_job* j, size_t c)
     rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
     rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 16);
     rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunkpre, c / 256 + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkdead, c / 256 + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkwin, c / 256 + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkwin2, c / 256 + 2);
@@ -607,7 +608,7 @@ int alloc_records(sdfk_march_job* j, size_t c)
 
 // classification: sign bits (unless cached) -> ordered compaction -> corner gather ->
 // resolve -> chunk scan.  Launches only; nothing here waits for the GPU.
-int launch_classify(sdfk_march_job* j)
+int launch_classify(sdfk_march_job* j, bool publish)
 {
     McParams& P = j->P;
     if (!j->have_bits) {
@@ -645,7 +646,9 @@ int launch_classify(sdfk_march_job* j)
     {
         ProfScope ps("k_resolve");
         hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, 256 * 12)), dim3(256), 0, g.stream, P);
-        hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, g.stream, P);
+        // totals for the host: workgroup 0 of k_vertices publishes them, unless the caller
+        // needs the counts before (or without) emitting
+        if (publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     return SDFK_OK;
@@ -842,7 +845,7 @@ int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int 
         sdfk_mesh* m = nullptr;
         if (!j->empty) {
             r = alloc_mesh(&m, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
-            r = r ? r : launch_classify(j);
+            r = r ? r : launch_classify(j, false);
             r = r ? r : launch_emit(j, m, vertex_base);
             r = r ? r : wait_counters(j);
             const bool fits = !r && j->c.n_active <= j->P.cap_active && j->c.overflow == 0 &&
@@ -874,11 +877,11 @@ int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int 
         r = alloc_mesh(&m, 0, 0);
         if (!r) m->bounds_valid = true;
     } else {
-        r = launch_classify(j);
+        r = launch_classify(j, true);
         r = r ? r : wait_counters(j);
         if (!r && j->c.n_active > j->P.cap_active) {   // record list too small: exact size, redo
             r = alloc_records(j, j->c.n_active);
-            r = r ? r : launch_classify(j);
+            r = r ? r : launch_classify(j, true);
             r = r ? r : wait_counters(j);
         }
         r = r ? r : alloc_mesh(&m, (size_t)(j->c.total_v - j->c.nghost), (size_t)j->c.total_t * 3);
@@ -914,11 +917,11 @@ extern "C" int sdfk_march_begin(const sdfk_volume* v, float iso_value, int32_t l
     int r = setup_job(v, iso_value, 1, layer_begin, layer_end, 0, &j);
     if (r) return r;
     if (!j->empty) {
-        r = launch_classify(j);
+        r = launch_classify(j, true);
         r = r ? r : wait_counters(j);
         if (!r && j->c.n_active > j->P.cap_active) {
             r = alloc_records(j, j->c.n_active);
-            r = r ? r : launch_classify(j);
+            r = r ? r : launch_classify(j, true);
             r = r ? r : wait_counters(j);
         }
         if (r) { job_release(j); delete j; return r; }
