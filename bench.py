@@ -132,13 +132,33 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world == 1 and not force_dist:
-        def step():
-            m = C.c_void_p()
-            N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+        # sdfk_sample_march returns its mesh handle while the kernels are still queued (the
+        # sizes are a guess from the previous mesh of this shape; the first accessor waits and
+        # verifies).  Steps are therefore enqueued DEPTH ahead of the one whose counts are read
+        # back: every step is still checked, but the host never idles the GPU in between.
+        DEPTH = int(os.environ.get("SDFK_BENCH_DEPTH", "3"))
+        inflight, last = [], [0, 0]
+
+        def retire(m):
             a, b = C.c_int64(), C.c_int64()
             N.check(L.sdfk_mesh_counts(m, C.byref(a), C.byref(b)))
             L.sdfk_mesh_free(m)
-            return a.value, b.value
+            if last[0] and (a.value, b.value) != tuple(last):
+                raise SystemExit(f"mesh changed between steps: {last} -> {(a.value, b.value)}")
+            last[0], last[1] = a.value, b.value
+
+        def step():
+            m = C.c_void_p()
+            N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+            inflight.append(m)
+            if len(inflight) > DEPTH:
+                retire(inflight.pop(0))
+            return tuple(last)
+
+        def drain():
+            while inflight:
+                retire(inflight.pop(0))
+            return tuple(last)
     else:
         # one sync + one RCCL all-gather per step (sdfkit_amd/dist.py: SlabSession)
         worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev)
@@ -147,12 +167,17 @@ def main():
         def step():
             return worker.step()
 
-    for _ in range(args.warmup):
+        def drain():
+            return nv, ni
+
+    for _ in range(max(args.warmup, 1) + 4):   # (the extra steps fill the allocator's pool: untimed set-up)
         nv, ni = step()
+    nv, ni = drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nv, ni = step()
+    nv, ni = drain()   # every queued step has completed and been checked before the clock stops
     barrier()
     dt = time.perf_counter() - t0
     if world > 1 or force_dist:   # per-rank counts -> totals of the whole mesh (outside the timed region)
@@ -171,6 +196,7 @@ def main():
     N.check(L.sdfk_profile_enable(1))
     for _ in range(args.steps):
         step()
+    drain()
     barrier()
     N.check(L.sdfk_profile_enable(0))
     prof = N.profile_snapshot()

@@ -86,9 +86,23 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_sample_vec4(SampleArgs A)
 // (value > iso) of every lane go to LDS; then, with lane = x, four __ballot()s per LDS column
 // produce the 64-bit X-words bits[z][y][xw] the marching-cubes classifier reads -- the
 // volume itself is never re-read densely.
-extern "C" __global__ __launch_bounds__(256) void sdfk_sample_bits(SampleArgs A)
+#ifndef SDFK_SAMPLE_WAVES
+#define SDFK_SAMPLE_WAVES 4
+#endif
+typedef float sdfk_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sdfk_store4(float* p, float a, float b, float c, float d)
+{
+    const sdfk_f4 t = {a, b, c, d};
+#if SDFK_SAMPLE_NT
+    __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(p));
+#else
+    *reinterpret_cast<sdfk_f4*>(p) = t;
+#endif
+}
+extern "C" __global__ __launch_bounds__(64 * SDFK_SAMPLE_WAVES) void sdfk_sample_bits(SampleArgs A)
 {
     constexpr int PITCH = 68;   // 17 dwords: lane = x reads hit 32 distinct banks
+    constexpr int NW = SDFK_SAMPLE_WAVES;
     __shared__ unsigned char nib[64 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int zc = blockIdx.x * 256;
@@ -106,7 +120,7 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_sample_bits(SampleArgs A)
         pz[k] = A.mz + (float)zg * A.dz;
         edge_z[k] = (zg == 0) | (zg == A.nz_global - 1);
     }
-    for (int r = wave; r < 64; r += 4) {
+    for (int r = wave; r < 64; r += NW) {
         const int ix = xw * 64 + r;
         unsigned n = 0;
         if (ix < A.nx && zok) {
@@ -119,19 +133,19 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_sample_bits(SampleArgs A)
                 if (A.clip && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
             const long o = ((long)ix * A.ny + iy) * A.nz + z;
-            *reinterpret_cast<float4*>(A.values + o) = make_float4(w[0], w[1], w[2], w[3]);
+            sdfk_store4(A.values + o, w[0], w[1], w[2], w[3]);
             if (A.colors) {
-                float4* c = reinterpret_cast<float4*>(A.colors + o * 3);
-                c[0] = make_float4(cr[0], cg[0], cb[0], cr[1]);
-                c[1] = make_float4(cg[1], cb[1], cr[2], cg[2]);
-                c[2] = make_float4(cb[2], cr[3], cg[3], cb[3]);
+                float* c = A.colors + o * 3;
+                sdfk_store4(c, cr[0], cg[0], cb[0], cr[1]);
+                sdfk_store4(c + 4, cg[1], cb[1], cr[2], cg[2]);
+                sdfk_store4(c + 8, cb[2], cr[3], cg[3], cb[3]);
             }
             n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
         }
         nib[r * PITCH + lane] = (unsigned char)n;
     }
     __syncthreads();
-    for (int q = wave; q < 64; q += 4) {
+    for (int q = wave; q < 64; q += NW) {
         const unsigned n = nib[lane * PITCH + q];
         const unsigned long long b0 = __ballot(n & 1u), b1 = __ballot(n & 2u), b2 = __ballot(n & 4u), b3 = __ballot(n & 8u);
         const int zq = zc + 4 * q;

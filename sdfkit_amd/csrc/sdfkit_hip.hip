@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -25,6 +26,7 @@ using namespace sdfk;
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string t_err;
+static int g_sample_waves = 4;   // wavefronts per workgroup of sdfk_sample_bits (compiled into the program)
 static int fail(int code, const char* fmt, ...)
 {
     char buf[1024];
@@ -44,6 +46,9 @@ static int fail(int code, const char* fmt, ...)
 // ---------------------------------------------------------------------------
 // context: device, stream, caching device allocator, profiling events
 // ---------------------------------------------------------------------------
+struct sdfk_mesh;
+struct sdfk_volume;
+
 namespace {
 
 struct ProfSpan { int name_id; hipEvent_t a, b; };
@@ -51,10 +56,23 @@ struct ProfSpan { int name_id; hipEvent_t a, b; };
 struct Context {
     bool inited = false;
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // the stream work is queued on right now (= the current lane's)
+    hipStream_t user_stream = nullptr;   // lane 0: the caller's stream (sdfk_set_stream) or own_stream
     hipStream_t own_stream = nullptr;
-    std::multimap<size_t, void*> free_blocks;   // caching allocator: size class -> block
-    std::map<void*, size_t> live_blocks;
+    // Lanes.  Lane 0 is the caller-visible stream.  Lanes 1..NSIDE are internal streams that
+    // self-contained jobs (sdfk_sample_march: no input but the program, output read only after
+    // a host-side wait) alternate between, so that the store-bound sampling kernel of one job
+    // overlaps the latency-bound marching-cubes kernels of the previous one.
+    // The caching allocator is stream-ordered PER LANE: a block goes back to the pool of the
+    // lane it was allocated on and is only handed out again to work queued on that lane.
+    static constexpr int NSIDE = 4;
+    struct Lane { hipStream_t stream = nullptr; std::multimap<size_t, void*> free_blocks; };
+    Lane lanes[1 + NSIDE];
+    int cur_lane = 0;
+    int side_lanes = 2;         // SDFK_LANES=0 disables the side lanes (everything on lane 0)
+    int next_side = 0;
+    struct Block { size_t size; int lane; };
+    std::map<void*, Block> live_blocks;
     // profiling
     bool prof_on = false;
     std::vector<std::string> prof_names;
@@ -73,6 +91,10 @@ struct Context {
     // whole pipeline speculatively and synchronise once
     struct Hint { uint32_t n_active, nv, ni; };
     std::map<uint64_t, Hint> hints;
+    // meshes returned by the speculative path whose kernels may still be queued (oldest first)
+    std::deque<sdfk_mesh*> pending;
+    static constexpr size_t MAX_PENDING = 6;
+    int jobs_since_sync = 0;   // bounds the queue depth when nobody ever reads a result
 };
 
 Context g;
@@ -89,22 +111,25 @@ int dev_alloc(void** p, size_t n)
 {
     if (n == 0) n = 1;
     const size_t c = size_class(n);
-    auto it = g.free_blocks.find(c);
-    if (it != g.free_blocks.end()) {
+    auto& pool = g.lanes[g.cur_lane].free_blocks;
+    auto it = pool.find(c);
+    if (it != pool.end()) {
         *p = it->second;
-        g.free_blocks.erase(it);
-        g.live_blocks[*p] = c;
+        pool.erase(it);
+        g.live_blocks[*p] = Context::Block{c, g.cur_lane};
         return SDFK_OK;
     }
     hipError_t e = hipMalloc(p, c);
     if (e != hipSuccess) {
-        // drop the cache and retry once
-        for (auto& kv : g.free_blocks) (void)hipFree(kv.second);
-        g.free_blocks.clear();
+        // drop the caches and retry once (hipFree waits for the device: no block is in use after it)
+        for (auto& lane : g.lanes) {
+            for (auto& kv : lane.free_blocks) (void)hipFree(kv.second);
+            lane.free_blocks.clear();
+        }
         e = hipMalloc(p, c);
         if (e != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", c, hipGetErrorString(e));
     }
-    g.live_blocks[*p] = c;
+    g.live_blocks[*p] = Context::Block{c, g.cur_lane};
     return SDFK_OK;
 }
 
@@ -113,8 +138,21 @@ void dev_free(void* p)
     if (!p) return;
     auto it = g.live_blocks.find(p);
     if (it == g.live_blocks.end()) return;
-    g.free_blocks.emplace(it->second, p);
+    g.lanes[it->second.lane].free_blocks.emplace(it->second.size, p);
     g.live_blocks.erase(it);
+}
+
+// queue on lane `k` for the lifetime of the scope (allocations included)
+struct LaneScope {
+    int saved;
+    explicit LaneScope(int k) : saved(g.cur_lane) { g.cur_lane = k; g.stream = g.lanes[k].stream; }
+    ~LaneScope() { g.cur_lane = saved; g.stream = g.lanes[saved].stream; }
+};
+
+void sync_all_lanes()
+{
+    for (auto& lane : g.lanes)
+        if (lane.stream) (void)hipStreamSynchronize(lane.stream);
 }
 
 int prof_name_id(const char* name)
@@ -231,6 +269,21 @@ struct sdfk_mesh {
     bool bounds_valid = false;
     int64_t n_active = 0, n_case13 = 0;
     size_t cap_v = 0, cap_i = 0;   // allocated capacity (>= nv, ni)
+    // Deferred completion.  The speculative path returns the mesh while its kernels are still
+    // queued; the first accessor waits for `done`, checks the size guess against the counters
+    // the kernels mirrored to the host and, if the guess was too small, redoes the job exactly.
+    sdfk_march_job* pending = nullptr;
+    hipEvent_t done = nullptr;
+    const sdfk_volume* src = nullptr;   // the volume the job read (kept unchanged until resolved)
+    bool owns_src = false;              // temporary volume of sdfk_sample_march / sdfk_march_host
+    float iso = 0.0f;
+    int step = 1, layer_begin = 0, layer_end = 0;
+    int64_t vertex_base = 0;
+    uint64_t key = 0;
+    int status = 0;                     // sticky error of a failed resolution
+    std::string error;
+    int lane = 0;                       // lane the buffers belong to
+    bool used_on_main = false;          // lane-0 work (copies, packing, the caller) may still be reading them
 };
 
 struct sdfk_march_job {
@@ -247,6 +300,14 @@ struct sdfk_march_job {
     int slot = 0;                  // index of the pinned result slot
     size_t rec_first = 0;          // first entry of `owned` that belongs to the record arrays
 };
+
+namespace {
+int mesh_resolve(sdfk_mesh* m);
+void resolve_dependents(const sdfk_volume* v);
+void free_mesh_buffers(sdfk_mesh* m);
+void drop_source(sdfk_mesh* m);
+void job_release(sdfk_march_job* j);
+}
 
 // ---------------------------------------------------------------------------
 // lifetime
@@ -272,7 +333,12 @@ extern "C" int sdfk_init(int device)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SDFK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
-    g.stream = g.own_stream;
+    g.user_stream = g.stream = g.own_stream;
+    g.lanes[0].stream = g.own_stream;
+    for (int k = 1; k <= Context::NSIDE; k++) HIPCHK(hipStreamCreateWithFlags(&g.lanes[k].stream, hipStreamNonBlocking));
+    g.cur_lane = 0;
+    if (const char* e = getenv("SDFK_LANES")) g.side_lanes = std::max(0, std::min(Context::NSIDE, atoi(e)));
+    if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
     HIPCHK(hipHostMalloc((void**)&g.slots, sizeof(Context::HostSlot) * Context::NSLOTS, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&g.slots_dev, g.slots, 0));
     memset(g.slots, 0, sizeof(Context::HostSlot) * Context::NSLOTS);
@@ -285,21 +351,30 @@ extern "C" void sdfk_shutdown(void)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g.inited) return;
+    while (!g.pending.empty()) (void)mesh_resolve(g.pending.front());
     (void)hipStreamSynchronize(g.stream);
     prof_drain();
     for (auto e : g.prof_event_pool) (void)hipEventDestroy(e);
     g.prof_event_pool.clear();
-    for (auto& kv : g.free_blocks) (void)hipFree(kv.second);
-    g.free_blocks.clear();
+    sync_all_lanes();
+    for (auto& lane : g.lanes) {
+        for (auto& kv : lane.free_blocks) (void)hipFree(kv.second);
+        lane.free_blocks.clear();
+    }
     for (auto& kv : g.live_blocks) (void)hipFree(kv.first);
     g.live_blocks.clear();
+    for (int k = 1; k <= Context::NSIDE; k++) {
+        if (g.lanes[k].stream) (void)hipStreamDestroy(g.lanes[k].stream);
+        g.lanes[k].stream = nullptr;
+    }
+    g.lanes[0].stream = nullptr;
     if (g.slots) (void)hipHostFree(g.slots);
     g.slots = nullptr;
     g.slots_dev = nullptr;
     g.hints.clear();
     if (g.own_stream) (void)hipStreamDestroy(g.own_stream);
     g.own_stream = nullptr;
-    g.stream = nullptr;
+    g.stream = g.user_stream = nullptr;
     g.inited = false;
 }
 
@@ -308,7 +383,9 @@ extern "C" int sdfk_set_stream(void* hip_stream)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (int r = require_init()) return r;
     HIPCHK(hipStreamSynchronize(g.stream));
-    g.stream = hip_stream ? (hipStream_t)hip_stream : g.own_stream;
+    g.user_stream = hip_stream ? (hipStream_t)hip_stream : g.own_stream;
+    g.lanes[0].stream = g.user_stream;
+    g.stream = g.lanes[g.cur_lane].stream;
     return SDFK_OK;
 }
 
@@ -317,6 +394,8 @@ extern "C" int sdfk_synchronize(void)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (int r = require_init()) return r;
     HIPCHK(hipStreamSynchronize(g.stream));
+    sync_all_lanes();
+    g.jobs_since_sync = 0;
     return SDFK_OK;
 }
 
@@ -332,8 +411,14 @@ static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_sample.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(SDFK_ERR_COMPILE, "hiprtcCreateProgram failed");
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off"};
-    hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    // experiment knobs (defaults are the tuned values)
+    const char* ew = getenv("SDFK_SAMPLE_WAVES");
+    const char* en = getenv("SDFK_SAMPLE_NT");
+    g_sample_waves = ew ? std::max(1, std::min(16, atoi(ew))) : 4;
+    const std::string dw = "-DSDFK_SAMPLE_WAVES=" + std::to_string(g_sample_waves);
+    const std::string dn = std::string("-DSDFK_SAMPLE_NT=") + (en && atoi(en) ? "1" : "0");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dw.c_str(), dn.c_str()};
+    hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
@@ -433,6 +518,7 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!v) return;
+    resolve_dependents(v);
     // no sync: the pool is stream-ordered (every kernel and copy runs on g.stream, so a block
     // handed out again is only touched by work queued after its previous user)
     dev_free(v->values);
@@ -447,6 +533,7 @@ extern "C" int sdfk_volume_upload(sdfk_volume* v, const float* values, const flo
     if (!v || !values) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: null argument");
     if (int r = require_init()) return r;
     if (colors3 && !v->colors) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: volume was created without colours");
+    resolve_dependents(v);
     v->bits_valid = false;
     HIPCHK(hipMemcpyAsync(v->values, values, v->nvox() * sizeof(float), hipMemcpyHostToDevice, g.stream));
     if (colors3) HIPCHK(hipMemcpyAsync(v->colors, colors3, v->nvox() * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream));
@@ -470,7 +557,9 @@ extern "C" int sdfk_volume_download(const sdfk_volume* v, float* values, float* 
 
 extern "C" int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void** colors3)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!v) return fail(SDFK_ERR_INVALID, "null volume");
+    resolve_dependents(v);   // the caller may write through these pointers
     if (values) *values = v->values;
     if (colors3) *colors3 = v->colors;
     return SDFK_OK;
@@ -502,6 +591,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
     A.z0 = v->z0; A.nz_global = v->nz_global;
     A.clip = clip_to_bounds ? 1 : 0;
     A.outside = outside;
+    resolve_dependents(v);
     v->bits_valid = false;
     void* params[] = {&A};
     if ((v->nz % 4) == 0) {
@@ -515,7 +605,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.iso = iso_hint;
         ProfScope ps("sdfk_sample_bits");
         HIPCHK(hipModuleLaunchKernel(p->fn_bits, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny, (unsigned)v->nxw(),
-                                     256, 1, 1, 0, g.stream, params, nullptr));
+                                     64u * (unsigned)g_sample_waves, 1, 1, 0, g.stream, params, nullptr));
         v->bits_iso = iso_hint;
         v->bits_valid = true;
         return SDFK_OK;
@@ -550,6 +640,7 @@ extern "C" int sdfk_volume_clip_to_bounds(sdfk_volume* v)
     if (int r = require_init()) return r;
     float d[3], m[3], outside;
     grid_constants(v, d, m, &outside);
+    resolve_dependents(v);
     v->bits_valid = false;
     ProfScope ps("k_clip");
     hipLaunchKernelGGL(k_clip, dim3(grid_for(v->nvox())), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->z0, v->nz_global, outside);
@@ -658,6 +749,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
 int wait_counters(sdfk_march_job* j)
 {
     HIPCHK(hipStreamSynchronize(g.stream));
+    if (g.side_lanes == 0) g.jobs_since_sync = 0;
     j->c = g.slots[j->slot].c;
     return SDFK_OK;
 }
@@ -675,6 +767,10 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     j->gnx = v->nx; j->gny = v->ny; j->gnz = v->nz_global;
     memcpy(j->gmin, v->gmin, sizeof j->gmin);
     memcpy(j->gmax, v->gmax, sizeof j->gmax);
+    if (++g.jobs_since_sync >= Context::NSLOTS / 2) {   // a result slot is never reused while its job may still run
+        sync_all_lanes();
+        g.jobs_since_sync = 0;
+    }
     j->slot = g.slot_next;
     g.slot_next = (g.slot_next + 1) % Context::NSLOTS;
     memset(&g.slots[j->slot], 0, sizeof(Context::HostSlot));
@@ -759,6 +855,7 @@ int alloc_mesh(sdfk_mesh** out, size_t cap_v, size_t cap_i)
     r = r ? r : dev_alloc((void**)&m->triangles, std::max<size_t>(cap_i, 1) * sizeof(int32_t));
     r = r ? r : dev_alloc((void**)&m->bounds, 8 * sizeof(float));
     if (r) { sdfk_mesh_free(m); return r; }
+    m->lane = g.cur_lane;
     m->cap_v = cap_v; m->cap_i = cap_i;
     *out = m;
     return SDFK_OK;
@@ -829,46 +926,11 @@ uint64_t hint_key(const sdfk_volume* v, int step, int layer_begin, int layer_end
     return k * 0x9E3779B97F4A7C15ull ^ ((uint64_t)(uint32_t)layer_begin << 32 | (uint32_t)layer_end) ^ ((uint64_t)v->z0 << 17);
 }
 
-// MarchingCubes.CreateMesh on the cell layers [layer_begin, layer_end) of a volume / slab.
-int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end, int64_t vertex_base, sdfk_mesh** out)
+// Exact path: classify, wait for the counts, size the outputs exactly, emit.
+int march_exact(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end, int64_t vertex_base,
+                uint64_t key, sdfk_mesh** out)
 {
     *out = nullptr;
-    const uint64_t key = hint_key(v, step, layer_begin, layer_end);
-    auto it = g.hints.find(key);
-    if (it != g.hints.end()) {
-        // Fast path: sizes of the previous mesh of this shape (+25 % and a floor) size every
-        // buffer; classification AND emit are queued back to back; ONE sync at the end.
-        const Context::Hint h = it->second;
-        sdfk_march_job* j = nullptr;
-        int r = setup_job(v, iso, step, layer_begin, layer_end, (size_t)h.n_active + h.n_active / 4 + 4096, &j);
-        if (r) return r;
-        sdfk_mesh* m = nullptr;
-        if (!j->empty) {
-            r = alloc_mesh(&m, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
-            r = r ? r : launch_classify(j, false);
-            r = r ? r : launch_emit(j, m, vertex_base);
-            r = r ? r : wait_counters(j);
-            const bool fits = !r && j->c.n_active <= j->P.cap_active && j->c.overflow == 0 &&
-                              (size_t)(j->c.total_v - j->c.nghost) <= m->cap_v && (size_t)j->c.total_t * 3 <= m->cap_i;
-            if (!r && fits) {
-                finalize_mesh(j, m, true);
-                g.hints[key] = Context::Hint{j->c.n_active, (uint32_t)m->nv, (uint32_t)m->ni};
-                job_release(j);
-                delete j;
-                *out = m;
-                return SDFK_OK;
-            }
-            if (m) sdfk_mesh_free(m);
-            job_release(j);
-            delete j;
-            if (r) return r;
-            // the guess was too small: fall through to the exact two-phase path
-        } else {
-            job_release(j);
-            delete j;
-        }
-    }
-    // Exact path: classify, wait for the counts, size the outputs exactly, emit.
     sdfk_march_job* j = nullptr;
     int r = setup_job(v, iso, step, layer_begin, layer_end, 0, &j);
     if (r) return r;
@@ -902,6 +964,131 @@ int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int 
     if (r) { if (m) sdfk_mesh_free(m); return r; }
     *out = m;
     return SDFK_OK;
+}
+
+void free_mesh_buffers(sdfk_mesh* m)
+{
+    dev_free(m->vertices);   // stream-ordered pool: no sync needed
+    dev_free(m->colors);
+    dev_free(m->normals);
+    dev_free(m->triangles);
+    dev_free(m->bounds);
+    m->vertices = m->colors = m->normals = m->bounds = nullptr;
+    m->triangles = nullptr;
+}
+
+void drop_source(sdfk_mesh* m)
+{
+    if (m->owns_src && m->src) sdfk_volume_free(const_cast<sdfk_volume*>(m->src));
+    m->src = nullptr;
+    m->owns_src = false;
+}
+
+// Completes a mesh of the speculative path (see sdfk_mesh): no-op for a finished mesh.
+int mesh_resolve(sdfk_mesh* m)
+{
+    if (m->status) { t_err = m->error; return m->status; }
+    if (!m->pending) return SDFK_OK;
+    LaneScope on_lane(m->lane);   // an exact re-run queues (and allocates) where the first attempt did
+    sdfk_march_job* j = m->pending;
+    m->pending = nullptr;
+    for (auto it = g.pending.begin(); it != g.pending.end(); ++it)
+        if (*it == m) { g.pending.erase(it); break; }
+    int r = SDFK_OK;
+    const hipError_t e = hipEventSynchronize(m->done);
+    (void)hipEventDestroy(m->done);
+    m->done = nullptr;
+    if (e != hipSuccess) r = fail(SDFK_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+    j->c = g.slots[j->slot].c;
+    const bool fits = j->c.n_active <= j->P.cap_active && j->c.overflow == 0 &&
+                      (size_t)(j->c.total_v - j->c.nghost) <= m->cap_v && (size_t)j->c.total_t * 3 <= m->cap_i;
+    if (!r && fits) {
+        if (m->vertex_base + (int64_t)(j->c.total_v - j->c.nghost) >= (int64_t(1) << 31))
+            r = fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])");
+        else {
+            finalize_mesh(j, m, true);
+            g.hints[m->key] = Context::Hint{j->c.n_active, (uint32_t)m->nv, (uint32_t)m->ni};
+        }
+    }
+    job_release(j);
+    delete j;
+    if (!r && !fits) {   // the guess was too small: the exact two-phase path, into the same handle
+        sdfk_mesh* x = nullptr;
+        r = march_exact(m->src, m->iso, m->step, m->layer_begin, m->layer_end, m->vertex_base, m->key, &x);
+        if (!r) {
+            free_mesh_buffers(m);
+            m->nv = x->nv; m->ni = x->ni;
+            m->vertices = x->vertices; m->colors = x->colors; m->normals = x->normals; m->triangles = x->triangles;
+            m->bounds = x->bounds;
+            memcpy(m->h_min, x->h_min, sizeof m->h_min);
+            memcpy(m->h_max, x->h_max, sizeof m->h_max);
+            m->bounds_valid = x->bounds_valid;
+            m->n_active = x->n_active; m->n_case13 = x->n_case13;
+            m->cap_v = x->cap_v; m->cap_i = x->cap_i;
+            delete x;
+        }
+    }
+    drop_source(m);
+    if (r) { m->nv = m->ni = 0; m->status = r; m->error = t_err; }
+    return r;
+}
+
+// every pending mesh that still depends on the contents of `v` (called before `v` changes or dies)
+void resolve_dependents(const sdfk_volume* v)
+{
+    for (;;) {
+        sdfk_mesh* hit = nullptr;
+        for (sdfk_mesh* m : g.pending)
+            if (m->src == v) { hit = m; break; }
+        if (!hit) return;
+        (void)mesh_resolve(hit);   // an error stays in the mesh (sticky)
+    }
+}
+
+// MarchingCubes.CreateMesh on the cell layers [layer_begin, layer_end) of a volume / slab.
+int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end, int64_t vertex_base, sdfk_mesh** out)
+{
+    *out = nullptr;
+    const uint64_t key = hint_key(v, step, layer_begin, layer_end);
+    auto it = g.hints.find(key);
+    if (it != g.hints.end()) {
+        // Speculative path: the sizes of the previous mesh of this shape (+25 % and a floor)
+        // size every buffer; classification AND emit are queued back to back and the handle
+        // is returned without waiting: the host meets the GPU only when a result is read.
+        const Context::Hint h = it->second;
+        sdfk_march_job* j = nullptr;
+        int r = setup_job(v, iso, step, layer_begin, layer_end, (size_t)h.n_active + h.n_active / 4 + 4096, &j);
+        if (r) return r;
+        if (!j->empty) {
+            sdfk_mesh* m = nullptr;
+            r = alloc_mesh(&m, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
+            r = r ? r : launch_classify(j, false);
+            r = r ? r : launch_emit(j, m, vertex_base);
+            if (!r) {
+                hipError_t e = hipEventCreateWithFlags(&m->done, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(m->done, g.stream);
+                if (e != hipSuccess) r = fail(SDFK_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+            }
+            if (r) {
+                (void)hipStreamSynchronize(g.stream);
+                if (m) { if (m->done) (void)hipEventDestroy(m->done); m->done = nullptr; sdfk_mesh_free(m); }
+                job_release(j);
+                delete j;
+                return r;
+            }
+            m->pending = j;
+            m->src = v;
+            m->iso = iso; m->step = step; m->layer_begin = layer_begin; m->layer_end = layer_end;
+            m->vertex_base = vertex_base; m->key = key;
+            g.pending.push_back(m);
+            while (g.pending.size() > Context::MAX_PENDING) (void)mesh_resolve(g.pending.front());
+            *out = m;
+            return SDFK_OK;
+        }
+        job_release(j);
+        delete j;
+    }
+    return march_exact(v, iso, step, layer_begin, layer_end, vertex_base, key, out);
 }
 
 }  // namespace
@@ -1001,6 +1188,8 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m || !dst) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: null argument");
     if (int r = require_init()) return r;
+    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
+    const_cast<sdfk_mesh*>(m)->used_on_main = true;
     const int64_t vb = m->nv * 12, need = SDFK_SLAB_HEADER_BYTES + 3 * vb + m->ni * 4;
     if (needed_bytes) *needed_bytes = need;
     if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: capacity below the header size");
@@ -1039,7 +1228,8 @@ extern "C" int sdfk_march_host(const float* values, const float* colors3, int32_
     if (r) return r;
     r = sdfk_volume_upload(v, values, colors3);
     if (!r) r = sdfk_march(v, iso_value, step, out);
-    sdfk_volume_free(v);
+    if (!r && (*out)->pending && (*out)->src == v) (*out)->owns_src = true;   // freed when the mesh is resolved
+    else sdfk_volume_free(v);
     return r;
 }
 
@@ -1049,13 +1239,23 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!p || !out) return fail(SDFK_ERR_INVALID, "sdfk_sample_march: null argument");
+    if (int r = require_init()) return r;
+    // self-contained job (no input but the program; the output is only read after a host-side
+    // wait): consecutive calls alternate between the side lanes and overlap on the GPU
+    int lane = 0;
+    if (g.side_lanes > 0 && g.cur_lane == 0) {
+        lane = 1 + g.next_side;
+        g.next_side = (g.next_side + 1) % g.side_lanes;
+    }
+    LaneScope on_lane(lane);
     sdfk_volume* v = nullptr;
     int r = sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
     if (r) return r;
     r = require_init();
     if (!r) r = sample_impl(p, v, clip_to_bounds, step == 1 ? iso_value : 0.0f);
     if (!r) r = sdfk_march(v, iso_value, step, out);
-    sdfk_volume_free(v);
+    if (!r && (*out)->pending && (*out)->src == v) (*out)->owns_src = true;   // freed when the mesh is resolved
+    else sdfk_volume_free(v);
     return r;
 }
 
@@ -1064,7 +1264,9 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
 // ---------------------------------------------------------------------------
 extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     if (n_vertices) *n_vertices = m->nv;
     if (n_indices) *n_indices = m->ni;
     return SDFK_OK;
@@ -1072,7 +1274,9 @@ extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t
 
 extern "C" int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case13_cells)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     if (n_active_cells) *n_active_cells = m->n_active;
     if (n_case13_cells) *n_case13_cells = m->n_case13;
     return SDFK_OK;
@@ -1084,6 +1288,7 @@ extern "C" int sdfk_mesh_bounds(const sdfk_mesh* mc, float min[3], float max[3])
     sdfk_mesh* m = const_cast<sdfk_mesh*>(mc);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = require_init()) return r;
+    if (int r = mesh_resolve(m)) return r;
     if (!m->bounds_valid) {
         float hb[6];
         HIPCHK(hipMemcpyAsync(hb, m->bounds, 6 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
@@ -1101,6 +1306,7 @@ extern "C" int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* color
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = require_init()) return r;
+    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     const size_t vb = (size_t)m->nv * 3 * sizeof(float);
     if (vertices3 && vb) HIPCHK(hipMemcpyAsync(vertices3, m->vertices, vb, hipMemcpyDeviceToHost, g.stream));
     if (colors3 && vb) HIPCHK(hipMemcpyAsync(colors3, m->colors, vb, hipMemcpyDeviceToHost, g.stream));
@@ -1115,6 +1321,8 @@ extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* 
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = require_init()) return r;
+    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
+    const_cast<sdfk_mesh*>(m)->used_on_main = true;
     const size_t vb = (size_t)m->nv * 3 * sizeof(float);
     if (vertices3 && vb) HIPCHK(hipMemcpyAsync(vertices3, m->vertices, vb, hipMemcpyDeviceToDevice, g.stream));
     if (colors3 && vb) HIPCHK(hipMemcpyAsync(colors3, m->colors, vb, hipMemcpyDeviceToDevice, g.stream));
@@ -1125,7 +1333,10 @@ extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* 
 
 extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, void** normals3, void** triangles)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;   // (the buffers may be replaced by an exact re-run)
+    const_cast<sdfk_mesh*>(m)->used_on_main = true;
     if (vertices3) *vertices3 = m->vertices;
     if (colors3) *colors3 = m->colors;
     if (normals3) *normals3 = m->normals;
@@ -1137,11 +1348,25 @@ extern "C" void sdfk_mesh_free(sdfk_mesh* m)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return;
-    dev_free(m->vertices);   // stream-ordered pool: no sync needed
-    dev_free(m->colors);
-    dev_free(m->normals);
-    dev_free(m->triangles);
-    dev_free(m->bounds);
+    if (m->pending) {   // never read: drop the queued job's workspace (stream-ordered, no wait)
+        for (auto it = g.pending.begin(); it != g.pending.end(); ++it)
+            if (*it == m) { g.pending.erase(it); break; }
+        job_release(m->pending);
+        delete m->pending;
+        m->pending = nullptr;
+        if (m->done) (void)hipEventDestroy(m->done);
+    }
+    drop_source(m);
+    if (m->lane != 0 && m->used_on_main && g.inited) {
+        // lane-0 work may still read the buffers: their lane must not reuse them before that
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+            (void)hipEventRecord(ev, g.lanes[0].stream);
+            (void)hipStreamWaitEvent(g.lanes[m->lane].stream, ev, 0);
+            (void)hipEventDestroy(ev);
+        }
+    }
+    free_mesh_buffers(m);
     delete m;
 }
 
