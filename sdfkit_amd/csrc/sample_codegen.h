@@ -156,6 +156,44 @@ extern "C" __global__ __launch_bounds__(64 * SDFK_SAMPLE_WAVES) void sdfk_sample
     }
 }
 
+// Corner values of the active cells, RE-EVALUATED instead of gathered: for a volume this very
+// program has just sampled, the 8 corners of cell (x,y,z) are 8 more evaluations of the same
+// float32 expression (same point arithmetic, same clip rule), bit-identical to what the
+// sampling kernel stored -- and 8 evaluations per ACTIVE cell (a surface, not a volume) are
+// far cheaper than 4 scattered 8-byte loads per cell from a [x][y][z] grid.
+// Corner order v0..v7 = (0,0,0) (1,0,0) (1,1,0) (0,1,0) (0,0,1) (1,0,1) (1,1,1) (0,1,1) (Cell.cs:24-31).
+__device__ __forceinline__ float sdfk_voxel(const SampleArgs& A, int ix, int iy, int iz)
+{
+    const float px = A.mx + (float)ix * A.dx;
+    const float py = A.my + (float)iy * A.dy;
+    const int zg = A.z0 + iz;
+    const float pz = A.mz + (float)zg * A.dz;
+    float r, g, b, w;
+    sdf_eval(px, py, pz, r, g, b, w);
+    if (A.clip && ((ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1) | (zg == 0) | (zg == A.nz_global - 1)))
+        w = A.outside;
+    return w;
+}
+
+extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A, const unsigned* __restrict__ rec_xy,
+                                                                     const unsigned* __restrict__ rec_z,
+                                                                     float* __restrict__ rec_corners,
+                                                                     const unsigned* __restrict__ n_active, unsigned cap)
+{
+    const unsigned n = *n_active < cap ? *n_active : cap;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const unsigned xy = rec_xy[i];
+        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), z = (int)rec_z[i];
+        const float c0 = sdfk_voxel(A, x, y, z), c1 = sdfk_voxel(A, x + 1, y, z);
+        const float c2 = sdfk_voxel(A, x + 1, y + 1, z), c3 = sdfk_voxel(A, x, y + 1, z);
+        const float c4 = sdfk_voxel(A, x, y, z + 1), c5 = sdfk_voxel(A, x + 1, y, z + 1);
+        const float c6 = sdfk_voxel(A, x + 1, y + 1, z + 1), c7 = sdfk_voxel(A, x, y + 1, z + 1);
+        float4* o = reinterpret_cast<float4*>(rec_corners + (size_t)i * 8);
+        o[0] = make_float4(c0, c1, c2, c3);
+        o[1] = make_float4(c4, c5, c6, c7);
+    }
+}
+
 // same, one voxel per lane-iteration (nz not a multiple of 4)
 extern "C" __global__ __launch_bounds__(256) void sdfk_sample_scalar(SampleArgs A)
 {

@@ -239,7 +239,9 @@ struct sdfk_program {
     hipFunction_t fn_vec4 = nullptr;
     hipFunction_t fn_bits = nullptr;
     hipFunction_t fn_scalar = nullptr;
+    hipFunction_t fn_corners = nullptr;
     int writes_color = 0;
+    int refs = 1;   // the caller's handle + volumes it has sampled + queued jobs that launch from its module
 };
 
 struct sdfk_volume {
@@ -253,6 +255,11 @@ struct sdfk_volume {
     uint64_t* bits = nullptr;
     float bits_iso = 0.0f;
     bool bits_valid = false;
+    // the program whose output `values` still is, with the arguments it ran with (nullptr once
+    // the values may have changed): marching cubes then re-evaluates cell corners instead of
+    // gathering them
+    sdfk_program* sampled_by = nullptr;
+    SampleArgs sampled_args;
     size_t nvox() const { return (size_t)nx * ny * nz; }
     int nxw() const { return (nx + 63) / 64; }
     size_t nbitwords() const { return (size_t)nz * ny * nxw() + 8; }   // k_compact reads 4 words past a row pair
@@ -297,6 +304,8 @@ struct sdfk_march_job {
     bool finished = false;
     bool empty = false;
     bool have_bits = false;
+    sdfk_program* eval_prog = nullptr;   // corners by re-evaluation (holds a reference)
+    SampleArgs eval_args;
     int slot = 0;                  // index of the pinned result slot
     size_t rec_first = 0;          // first entry of `owned` that belongs to the record arrays
 };
@@ -307,6 +316,8 @@ void resolve_dependents(const sdfk_volume* v);
 void free_mesh_buffers(sdfk_mesh* m);
 void drop_source(sdfk_mesh* m);
 void job_release(sdfk_march_job* j);
+void program_release(sdfk_program* p);
+void volume_values_changed(sdfk_volume* v);
 }
 
 // ---------------------------------------------------------------------------
@@ -459,6 +470,7 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     hipError_t e = hipModuleLoadData(&p->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_vec4, p->module, "sdfk_sample_vec4");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_scalar, p->module, "sdfk_sample_scalar");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_corners, p->module, "sdfk_corners_eval");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
     if (e != hipSuccess) {
         if (p->module) (void)hipModuleUnload(p->module);
@@ -475,9 +487,25 @@ extern "C" void sdfk_program_destroy(sdfk_program* p)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!p) return;
-    if (g.inited) (void)hipStreamSynchronize(g.stream);
+    program_release(p);
+}
+
+namespace {
+void program_release(sdfk_program* p)
+{
+    if (!p || --p->refs > 0) return;
+    if (g.inited) sync_all_lanes();   // kernels of this module may still be queued
     if (p->module) (void)hipModuleUnload(p->module);
     delete p;
+}
+
+// `values` no longer are what a program computed / what the cached sign bits describe
+void volume_values_changed(sdfk_volume* v)
+{
+    v->bits_valid = false;
+    if (v->sampled_by) program_release(v->sampled_by);
+    v->sampled_by = nullptr;
+}
 }
 
 // ---------------------------------------------------------------------------
@@ -519,6 +547,7 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!v) return;
     resolve_dependents(v);
+    volume_values_changed(v);   // (drops the reference to the program that sampled it)
     // no sync: the pool is stream-ordered (every kernel and copy runs on g.stream, so a block
     // handed out again is only touched by work queued after its previous user)
     dev_free(v->values);
@@ -534,7 +563,7 @@ extern "C" int sdfk_volume_upload(sdfk_volume* v, const float* values, const flo
     if (int r = require_init()) return r;
     if (colors3 && !v->colors) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: volume was created without colours");
     resolve_dependents(v);
-    v->bits_valid = false;
+    volume_values_changed(v);
     HIPCHK(hipMemcpyAsync(v->values, values, v->nvox() * sizeof(float), hipMemcpyHostToDevice, g.stream));
     if (colors3) HIPCHK(hipMemcpyAsync(v->colors, colors3, v->nvox() * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));  // the caller's arrays are not retained
@@ -559,7 +588,8 @@ extern "C" int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!v) return fail(SDFK_ERR_INVALID, "null volume");
-    resolve_dependents(v);   // the caller may write through these pointers
+    resolve_dependents(v);   // the caller may write through these pointers: no cached view of
+    volume_values_changed(const_cast<sdfk_volume*>(v));   // the values stays valid
     if (values) *values = v->values;
     if (colors3) *colors3 = v->colors;
     return SDFK_OK;
@@ -592,7 +622,13 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
     A.clip = clip_to_bounds ? 1 : 0;
     A.outside = outside;
     resolve_dependents(v);
-    v->bits_valid = false;
+    volume_values_changed(v);
+    auto sampled = [&]() {   // from here on `values` are this program's output
+        sdfk_program* q = const_cast<sdfk_program*>(p);
+        q->refs++;
+        v->sampled_by = q;
+        v->sampled_args = A;
+    };
     void* params[] = {&A};
     if ((v->nz % 4) == 0) {
         // fused sampling + sign bits (iso known or guessed 0): marching cubes then skips its
@@ -608,6 +644,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
                                      64u * (unsigned)g_sample_waves, 1, 1, 0, g.stream, params, nullptr));
         v->bits_iso = iso_hint;
         v->bits_valid = true;
+        sampled();
         return SDFK_OK;
     }
     const int nzu = v->nz;      // one voxel per lane-iteration
@@ -622,6 +659,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
     A.row_stride = (int)(nblk * tr);
     ProfScope ps("sdfk_sample_scalar");
     HIPCHK(hipModuleLaunchKernel(p->fn_scalar, (unsigned)nblk, 1, 1, (unsigned)tz, (unsigned)tr, 1, 0, g.stream, params, nullptr));
+    sampled();
     return SDFK_OK;
 }
 
@@ -641,7 +679,7 @@ extern "C" int sdfk_volume_clip_to_bounds(sdfk_volume* v)
     float d[3], m[3], outside;
     grid_constants(v, d, m, &outside);
     resolve_dependents(v);
-    v->bits_valid = false;
+    volume_values_changed(v);
     ProfScope ps("k_clip");
     hipLaunchKernelGGL(k_clip, dim3(grid_for(v->nvox())), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->z0, v->nz_global, outside);
     HIPCHK(hipGetLastError());
@@ -667,6 +705,8 @@ void job_release(sdfk_march_job* j)
 {
     for (void* p : j->owned) dev_free(p);
     j->owned.clear();
+    if (j->eval_prog) program_release(j->eval_prog);
+    j->eval_prog = nullptr;
     if (j->sub) {
         dev_free(j->sub->values);
         dev_free(j->sub->colors);
@@ -729,7 +769,13 @@ int launch_classify(sdfk_march_job* j, bool publish)
         HIPCHK(hipGetLastError());
     }
     const int nchunks = (int)((P.cap_active + 255u) / 256u);
-    {
+    if (j->eval_prog) {   // the volume still is this program's output: evaluate the corners
+        ProfScope ps("sdfk_corners_eval");
+        const unsigned* n_active = &P.counters->n_active;
+        void* params[] = {&j->eval_args, &P.rec_xy, &P.rec_z, &P.rec_corners, &n_active, &P.cap_active};
+        HIPCHK(hipModuleLaunchKernel(j->eval_prog->fn_corners, (unsigned)std::min(nchunks, 256 * 8), 1, 1, 256, 1, 1, 0,
+                                     g.stream, params, nullptr));
+    } else {
         ProfScope ps("k_gather_corners");
         hipLaunchKernelGGL(k_gather_corners, dim3(std::min(nchunks, 256 * 8)), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
@@ -780,7 +826,7 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
         sdfk_volume* s = new sdfk_volume(*v);
         s->nx = (v->nx - 1) / step + 1; s->ny = (v->ny - 1) / step + 1; s->nz = (v->nz - 1) / step + 1;
         s->nz_global = s->nz;
-        s->values = nullptr; s->colors = nullptr; s->bits = nullptr; s->bits_valid = false;
+        s->values = nullptr; s->colors = nullptr; s->bits = nullptr; s->bits_valid = false; s->sampled_by = nullptr;
         j->sub = s;
         int r = dev_alloc((void**)&s->values, s->nvox() * sizeof(float));
         if (!r && v->colors) r = dev_alloc((void**)&s->colors, s->nvox() * 3 * sizeof(float));
@@ -826,6 +872,11 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     if (cap_records == 0) cap_records = std::max<size_t>(ncell / 12, 1u << 16);
     cap_records = std::min(cap_records, ncell);
     int r = 0;
+    if (step == 1 && v->sampled_by && !getenv("SDFK_NO_CORNER_EVAL")) {
+        j->eval_prog = v->sampled_by;
+        j->eval_prog->refs++;
+        j->eval_args = v->sampled_args;
+    }
     j->have_bits = (step == 1 && v->bits && v->bits_valid && v->bits_iso == iso);
     if (j->have_bits) P.bits = v->bits;   // written by the fused sampling kernel; owned by the volume
     else {

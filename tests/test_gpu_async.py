@@ -1,0 +1,113 @@
+"""Deferred completion of meshes (speculative path), the internal lanes and the re-evaluated
+cell corners: results must not depend on WHEN a mesh is read, on what happens to its source
+volume in between, or on which corner path (gather from the volume / re-evaluation of the
+program) produced the records.  All through the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdfkit_amd import MarchingCubes, Mesh, Sdfs, Voxels
+from sdfkit_amd import _native as N
+from tests import scenes as S
+from tests.test_gpu_parity import assert_mesh_equal
+
+pytestmark = pytest.mark.gpu
+
+MN, MX = [-2.8125] * 3, [2.8125] * 3
+
+
+def oracle_mesh(scene, mn, mx, dims, clip):
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    if clip:
+        O.clip_to_bounds(ov, mn, mx)
+    return O.march(ov, oc, mn, mx)
+
+
+def raw_sample_march(sdf, mn, mx, dims, clip):
+    """sdfk_sample_march without touching the result: returns the (possibly pending) handle."""
+    L = N.lib()
+    m = C.c_void_p()
+    N.check(L.sdfk_sample_march(sdf.program(), N.f3(mn), N.f3(mx), *dims, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+    return m
+
+
+@pytest.mark.parametrize("name", ["readme_repeat_xy", "union8", "sphere_w"])
+def test_corner_reevaluation_equals_gather(gpu, name):
+    scene, sdf = S.CATALOGUE[name]()
+    dims = (44, 40, 48)
+    om = oracle_mesh(scene, MN, MX, dims, True)
+    a = sdf.ToMesh(MN, MX, *dims)                       # corners re-evaluated by the program
+    os.environ["SDFK_NO_CORNER_EVAL"] = "1"
+    try:
+        b = sdf.ToMesh(MN, MX, *dims)                   # corners gathered from the stored volume
+    finally:
+        del os.environ["SDFK_NO_CORNER_EVAL"]
+    assert_mesh_equal(a, om)
+    assert_mesh_equal(b, om)
+    for f in ("Vertices", "Colors", "Normals", "Triangles"):
+        assert np.array_equal(getattr(a, f), getattr(b, f), equal_nan=True)
+
+
+def test_many_queued_meshes_read_late_and_out_of_order(gpu):
+    """More jobs than pending slots, alternating shapes and scenes, read back in reverse."""
+    jobs = []
+    for rep in range(3):      # the first round sets the size hints, later rounds are speculative
+        for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("union8", (36, 40, 32)), ("sdf_with_color", (40, 36, 44))):
+            scene, sdf = S.CATALOGUE[name]()
+            jobs.append((name, dims, scene, raw_sample_march(sdf, MN, MX, dims, True), sdf))
+    for name, dims, scene, h, _ in reversed(jobs):
+        m = Mesh._from_handle(h)
+        assert_mesh_equal(m, oracle_mesh(scene, MN, MX, dims, True))
+
+
+def test_unread_meshes_can_be_freed(gpu):
+    """Nobody ever reads these: freeing a pending mesh must neither wait nor corrupt later work
+    (more jobs than the ring of result slots)."""
+    L = N.lib()
+    scene, sdf = S.CATALOGUE["union8"]()
+    dims = (36, 40, 32)
+    om = oracle_mesh(scene, MN, MX, dims, True)
+    assert_mesh_equal(sdf.ToMesh(MN, MX, *dims), om)    # hint
+    for _ in range(150):
+        L.sdfk_mesh_free(raw_sample_march(sdf, MN, MX, dims, True))
+    assert_mesh_equal(sdf.ToMesh(MN, MX, *dims), om)
+
+
+def test_source_volume_changes_after_march(gpu):
+    """CreateMesh(volume) may return before the GPU is done; the volume is then overwritten /
+    freed: the mesh must still be the mesh of the OLD contents."""
+    scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
+    dims = (40, 36, 44)
+    om = oracle_mesh(scene, MN, MX, dims, True)
+    L = N.lib()
+    for mutate in ("resample", "clip", "upload", "free"):
+        vol = sdf.ToVoxels(MN, MX, *dims, clipToBounds=True)
+        MarchingCubes.CreateMesh(vol)                   # hint for this shape
+        h = C.c_void_p()
+        N.check(L.sdfk_march(vol._h, C.c_float(0.0), 1, C.byref(h)))   # pending handle
+        if mutate == "resample":
+            vol._sample(Sdfs.Sphere(0.3))
+        elif mutate == "clip":
+            vol._sample(Sdfs.Sphere(3.0))
+            vol.ClipToBounds()
+        elif mutate == "upload":
+            vol[3, 4, 5] = 7.0
+            vol._sync_to_device()
+        else:
+            vol._free()
+        assert_mesh_equal(Mesh._from_handle(h), om)
+
+
+def test_speculative_guess_too_small_is_redone_on_first_read(gpu):
+    n = 96
+    small = Sdfs.Sphere(0.2)
+    scene, big = S.CATALOGUE["union8"]()
+    assert len(small.ToMesh([-1.5] * 3, [1.5] * 3, n, n, n, clipToBounds=False).Vertices) < 2000   # hint: tiny mesh
+    handles = [raw_sample_march(big, MN, MX, (n, n, n), True) for _ in range(3)]      # all under-sized
+    om = oracle_mesh(scene, MN, MX, (n, n, n), True)
+    assert len(om.vertices) > 12000   # far beyond hint * 1.25 + 4096
+    for h in handles:
+        assert_mesh_equal(Mesh._from_handle(h), om)
