@@ -36,9 +36,10 @@ def test_library_exports_every_declared_symbol():
     assert lib.sdfk_abi_version() == 1
 
 
-def test_library_contains_gfx950_code_object():
+def test_library_contains_gfx950_code_object(tmp_path):
+    # (--offloading extracts the bundles into the working directory: keep them out of the tree)
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", N.library_path()],
-                         capture_output=True, text=True).stdout
+                         capture_output=True, text=True, cwd=str(tmp_path)).stdout
     assert "gfx950" in out
 
 
