@@ -37,8 +37,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_library_contains_gfx950_code_object(tmp_path):
-    # (--offloading extracts the bundles into the working directory: keep them out of the tree)
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", N.library_path()],
+    # (--offloading extracts the bundles next to its input: work on a copy outside the tree)
+    import shutil
+    copy = shutil.copy(N.library_path(), str(tmp_path / "lib.so"))
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", copy],
                          capture_output=True, text=True, cwd=str(tmp_path)).stdout
     assert "gfx950" in out
 
