@@ -105,6 +105,34 @@ __global__ __launch_bounds__(256) void k_signbits_generic(const float* __restric
     }
 }
 
+// bits8[y][x/8][z] (one byte = the sign bits of 8 consecutive x, written by the fused sampling
+// kernel) -> bits[z][y][xw]: word xw is the 8 bytes x/8 = 8*xw .. 8*xw+7 of the same (y, z).
+// Workgroup = (128 z, one y, 8 words): 64 byte-rows x 128 B go through LDS, every z then
+// leaves as 64 contiguous bytes.
+__global__ __launch_bounds__(256) void k_bits_transpose(const uint8_t* __restrict__ bits8, uint64_t* __restrict__ bits,
+                                                        int nx8, int ny, int nz, int nxw)
+{
+    __shared__ __attribute__((aligned(4))) uint8_t t[64][132];
+    const int iy = blockIdx.y, z0 = blockIdx.x * 128, xw0 = blockIdx.z * 8, row0 = xw0 * 8;
+    for (int k = threadIdx.x; k < 64 * 32; k += 256) {
+        const int row = k >> 5, c = (k & 31) * 4;
+        unsigned v = 0;   // (nz % 4 == 0: a 4-byte group is all inside or all outside)
+        if (row0 + row < nx8 && z0 + c < nz)
+            v = *reinterpret_cast<const unsigned*>(bits8 + ((size_t)iy * nx8 + row0 + row) * nz + z0 + c);
+        *reinterpret_cast<unsigned*>(&t[row][c]) = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 128 * 8; k += 256) {
+        const int zz = k >> 3, xw = k & 7;
+        if (z0 + zz < nz && xw0 + xw < nxw) {
+            uint64_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) w |= (uint64_t)t[xw * 8 + b][zz] << (8 * b);
+            bits[((size_t)(z0 + zz) * ny + iy) * nxw + xw0 + xw] = w;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // workgroup / grid scan helpers
 // ---------------------------------------------------------------------------

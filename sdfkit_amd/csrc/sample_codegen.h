@@ -16,7 +16,7 @@
 // One definition, used both by the host (below) and pasted into the generated source.
 #define SDFK_SAMPLE_ARGS_BODY                                                                   \
     float* values; float* colors; float mx, my, mz, dx, dy, dz; int nx, ny, nz; int z0, nz_global; \
-    int clip; float outside; int nzu; int row_stride; unsigned long long* bits; int nxw; float iso;
+    int clip; float outside; int nzu; int row_stride; unsigned char* bits8; int nx8; float iso;
 
 struct SampleArgs { SDFK_SAMPLE_ARGS_BODY };
 
@@ -80,17 +80,17 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_sample_vec4(SampleArgs A)
     }
 }
 
-// Fused form (nz % 4 == 0): sampling AND the marching-cubes sign bits in one pass over the
-// grid.  A workgroup owns 64 x-rows x 256 z of one y: lane = 4 consecutive z (one 16-byte
-// store, 1 KiB contiguous per wave instruction), each wave walks 16 rows.  The 4 sign bits
-// (value > iso) of every lane go to LDS; then, with lane = x, four __ballot()s per LDS column
-// produce the 64-bit X-words bits[z][y][xw] the marching-cubes classifier reads -- the
-// volume itself is never re-read densely.
-#ifndef SDFK_SAMPLE_WAVES
-#define SDFK_SAMPLE_WAVES 4
-#endif
+// Fused form (nz % 4 == 0): sampling AND the marching-cubes sign bits in one pass over the grid.
+// A workgroup = 8 wavefronts = 8 consecutive x rows x 256 z of one y.  Every lane evaluates 4
+// consecutive z and issues exactly ONE 16-byte nontemporal store (1 KiB contiguous per
+// wavefront): the shape that reaches the plain-fill store rate of the MI355X -- more stores per
+// lane, or other workgroup sizes, measurably lose bandwidth (tools/ubench/ub_store.hip).
+// Sign bits (value > iso): each lane leaves a nibble in LDS; wavefront 0 turns the 8 rows'
+// nibbles into 4 bytes per lane (bit r of byte k = row r at z + k) and stores 256 contiguous
+// bytes of bits8[y][x/8][z].  k_bits_transpose (mc_kernels.hip) regroups those bytes into the
+// X-packed words the marching-cubes classifier reads; the volume is never re-read densely.
 typedef float sdfk_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void sdfk_store4(float* p, float a, float b, float c, float d)
+__device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float c, float d)
 {
     const sdfk_f4 t = {a, b, c, d};
 #if SDFK_SAMPLE_NT
@@ -99,16 +99,17 @@ __device__ __forceinline__ void sdfk_store4(float* p, float a, float b, float c,
     *reinterpret_cast<sdfk_f4*>(p) = t;
 #endif
 }
-extern "C" __global__ __launch_bounds__(64 * SDFK_SAMPLE_WAVES) void sdfk_sample_bits(SampleArgs A)
+#ifndef SDFK_SAMPLE_RPW
+#define SDFK_SAMPLE_RPW 2   // x rows per wavefront (stores per lane); workgroup = 8 / RPW wavefronts
+#endif
+template <bool CLIP>
+__device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
 {
-    constexpr int PITCH = 68;   // 17 dwords: lane = x reads hit 32 distinct banks
-    constexpr int NW = SDFK_SAMPLE_WAVES;
-    __shared__ unsigned char nib[64 * PITCH];
+    constexpr int RPW = SDFK_SAMPLE_RPW;
+    __shared__ unsigned char nib[8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int zc = blockIdx.x * 256;
-    const int iy = blockIdx.y;
-    const int xw = blockIdx.z;
-    const int z = zc + 4 * lane;
+    const int iy = blockIdx.y, x8 = blockIdx.z;
+    const int z = blockIdx.x * 256 + 4 * lane;
     const bool zok = z < A.nz;
     const float py = A.my + (float)iy * A.dy;
     const bool edge_y = (iy == 0) | (iy == A.ny - 1);
@@ -120,8 +121,10 @@ extern "C" __global__ __launch_bounds__(64 * SDFK_SAMPLE_WAVES) void sdfk_sample
         pz[k] = A.mz + (float)zg * A.dz;
         edge_z[k] = (zg == 0) | (zg == A.nz_global - 1);
     }
-    for (int r = wave; r < 64; r += NW) {
-        const int ix = xw * 64 + r;
+#pragma unroll
+    for (int rr = 0; rr < RPW; rr++) {
+        const int r = wave * RPW + rr;
+        const int ix = x8 * 8 + r;
         unsigned n = 0;
         if (ix < A.nx && zok) {
             const float px = A.mx + (float)ix * A.dx;
@@ -130,31 +133,33 @@ extern "C" __global__ __launch_bounds__(64 * SDFK_SAMPLE_WAVES) void sdfk_sample
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 sdf_eval(px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
-                if (A.clip && (edge_xy || edge_z[k])) w[k] = A.outside;
+                if (CLIP && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
             const long o = ((long)ix * A.ny + iy) * A.nz + z;
-            sdfk_store4(A.values + o, w[0], w[1], w[2], w[3]);
-            if (A.colors) {
-                float* c = A.colors + o * 3;
-                sdfk_store4(c, cr[0], cg[0], cb[0], cr[1]);
-                sdfk_store4(c + 4, cg[1], cb[1], cr[2], cg[2]);
-                sdfk_store4(c + 8, cb[2], cr[3], cg[3], cb[3]);
+            sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
+            if (A.colors) {   // 48 contiguous bytes per lane: plain stores (nontemporal ones are far slower here)
+                float4* c = reinterpret_cast<float4*>(A.colors + o * 3);
+                c[0] = make_float4(cr[0], cg[0], cb[0], cr[1]);
+                c[1] = make_float4(cg[1], cb[1], cr[2], cg[2]);
+                c[2] = make_float4(cb[2], cr[3], cg[3], cb[3]);
             }
             n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
         }
-        nib[r * PITCH + lane] = (unsigned char)n;
+        nib[r][lane] = (unsigned char)n;
     }
     __syncthreads();
-    for (int q = wave; q < 64; q += NW) {
-        const unsigned n = nib[lane * PITCH + q];
-        const unsigned long long b0 = __ballot(n & 1u), b1 = __ballot(n & 2u), b2 = __ballot(n & 4u), b3 = __ballot(n & 8u);
-        const int zq = zc + 4 * q;
-        if (lane < 4 && zq < A.nz) {
-            const unsigned long long wd = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-            A.bits[((long)(zq + lane) * A.ny + iy) * A.nxw + xw] = wd;
+    if (wave == 0 && zok) {
+        unsigned out = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned q = nib[r][lane];
+            out |= ((q & 1u) << r) | (((q >> 1) & 1u) << (8 + r)) | (((q >> 2) & 1u) << (16 + r)) | (((q >> 3) & 1u) << (24 + r));
         }
+        *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * A.nz + z) = out;
     }
 }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true>(A); }
 
 // Corner values of the active cells, RE-EVALUATED instead of gathered: for a volume this very
 // program has just sampled, the 8 corners of cell (x,y,z) are 8 more evaluations of the same

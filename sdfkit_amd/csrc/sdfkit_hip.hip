@@ -26,7 +26,7 @@ using namespace sdfk;
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string t_err;
-static int g_sample_waves = 4;   // wavefronts per workgroup of sdfk_sample_bits (compiled into the program)
+static int g_sample_rpw = 2;   // x rows per wavefront of sdfk_sample_bits (compiled into the programs)
 static int fail(int code, const char* fmt, ...)
 {
     char buf[1024];
@@ -238,6 +238,7 @@ struct sdfk_program {
     hipModule_t module = nullptr;
     hipFunction_t fn_vec4 = nullptr;
     hipFunction_t fn_bits = nullptr;
+    hipFunction_t fn_bits_clip = nullptr;
     hipFunction_t fn_scalar = nullptr;
     hipFunction_t fn_corners = nullptr;
     int writes_color = 0;
@@ -253,6 +254,7 @@ struct sdfk_volume {
     // sign bits (value > bits_iso) packed along X, written by the fused sampling kernel;
     // valid until Values change (upload / ClipToBounds)
     uint64_t* bits = nullptr;
+    uint8_t* bits8 = nullptr;         // the sampling kernel's byte form of the same bits ([y][x/8][z])
     float bits_iso = 0.0f;
     bool bits_valid = false;
     // the program whose output `values` still is, with the arguments it ran with (nullptr once
@@ -262,6 +264,7 @@ struct sdfk_volume {
     SampleArgs sampled_args;
     size_t nvox() const { return (size_t)nx * ny * nz; }
     int nxw() const { return (nx + 63) / 64; }
+    int nx8() const { return (nx + 7) / 8; }
     size_t nbitwords() const { return (size_t)nz * ny * nxw() + 8; }   // k_compact reads 4 words past a row pair
 };
 
@@ -422,13 +425,14 @@ static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_sample.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(SDFK_ERR_COMPILE, "hiprtcCreateProgram failed");
-    // experiment knobs (defaults are the tuned values)
-    const char* ew = getenv("SDFK_SAMPLE_WAVES");
-    const char* en = getenv("SDFK_SAMPLE_NT");
-    g_sample_waves = ew ? std::max(1, std::min(16, atoi(ew))) : 4;
-    const std::string dw = "-DSDFK_SAMPLE_WAVES=" + std::to_string(g_sample_waves);
-    const std::string dn = std::string("-DSDFK_SAMPLE_NT=") + (en && atoi(en) ? "1" : "0");
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dw.c_str(), dn.c_str()};
+    // experiment knobs (the defaults are the tuned values)
+    const char* en = getenv("SDFK_SAMPLE_NT");    // 0: plain instead of nontemporal stores of the values
+    const char* er = getenv("SDFK_SAMPLE_RPW");   // x rows per wavefront of the fused sampling kernel (1, 2 or 4)
+    g_sample_rpw = er ? atoi(er) : 2;
+    if (g_sample_rpw != 1 && g_sample_rpw != 2 && g_sample_rpw != 4) g_sample_rpw = 2;
+    const std::string dn = std::string("-DSDFK_SAMPLE_NT=") + (en && !atoi(en) ? "0" : "1");
+    const std::string dr = "-DSDFK_SAMPLE_RPW=" + std::to_string(g_sample_rpw);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dn.c_str(), dr.c_str()};
     hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t ls = 0;
@@ -472,6 +476,7 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_scalar, p->module, "sdfk_sample_scalar");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_corners, p->module, "sdfk_corners_eval");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip, p->module, "sdfk_sample_bits_clip");
     if (e != hipSuccess) {
         if (p->module) (void)hipModuleUnload(p->module);
         delete p;
@@ -553,6 +558,7 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
     dev_free(v->values);
     dev_free(v->colors);
     dev_free(v->bits);
+    dev_free(v->bits8);
     delete v;
 }
 
@@ -636,12 +642,24 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         if (!v->bits) {
             if (int r = dev_alloc((void**)&v->bits, v->nbitwords() * sizeof(uint64_t))) return r;
         }
-        A.bits = (unsigned long long*)v->bits;
-        A.nxw = v->nxw();
+        if (!v->bits8) {
+            if (int r = dev_alloc((void**)&v->bits8, (size_t)v->ny * v->nx8() * v->nz + 64)) return r;
+        }
+        A.bits8 = v->bits8;
+        A.nx8 = v->nx8();
         A.iso = iso_hint;
-        ProfScope ps("sdfk_sample_bits");
-        HIPCHK(hipModuleLaunchKernel(p->fn_bits, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny, (unsigned)v->nxw(),
-                                     64u * (unsigned)g_sample_waves, 1, 1, 0, g.stream, params, nullptr));
+        {
+            ProfScope ps("sdfk_sample_bits");
+            HIPCHK(hipModuleLaunchKernel(clip_to_bounds ? p->fn_bits_clip : p->fn_bits, (unsigned)((v->nz + 255) / 256),
+                                         (unsigned)v->ny, (unsigned)v->nx8(), 512u / (unsigned)g_sample_rpw, 1, 1, 0, g.stream,
+                                         params, nullptr));
+        }
+        {
+            ProfScope ps("k_bits_transpose");
+            hipLaunchKernelGGL(k_bits_transpose, dim3((v->nz + 127) / 128, v->ny, (v->nxw() + 7) / 8), dim3(256), 0, g.stream,
+                               v->bits8, v->bits, v->nx8(), v->ny, v->nz, v->nxw());
+            HIPCHK(hipGetLastError());
+        }
         v->bits_iso = iso_hint;
         v->bits_valid = true;
         sampled();
@@ -826,7 +844,7 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
         sdfk_volume* s = new sdfk_volume(*v);
         s->nx = (v->nx - 1) / step + 1; s->ny = (v->ny - 1) / step + 1; s->nz = (v->nz - 1) / step + 1;
         s->nz_global = s->nz;
-        s->values = nullptr; s->colors = nullptr; s->bits = nullptr; s->bits_valid = false; s->sampled_by = nullptr;
+        s->values = nullptr; s->colors = nullptr; s->bits = nullptr; s->bits8 = nullptr; s->bits_valid = false; s->sampled_by = nullptr;
         j->sub = s;
         int r = dev_alloc((void**)&s->values, s->nvox() * sizeof(float));
         if (!r && v->colors) r = dev_alloc((void**)&s->colors, s->nvox() * 3 * sizeof(float));

@@ -65,6 +65,53 @@ __global__ __launch_bounds__(256) void k_xstride1(float* v)
     st4<false>(v + ((size_t)ix * N + iy) * N + zc + 4 * lane, make_float4(1.f, 2.f, 3.f, 4.f));
 }
 
+// x8 tile: 8 x-rows x 256 z of one y per workgroup; 512 lanes (1 store each) or 256 lanes (2 stores);
+// sign bits leave as BYTES (8 x-bits) in bitsT[y][x8][z], z contiguous: 256 B coalesced per workgroup
+template <int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS) void k_x8(float* v, uint8_t* bitsT)
+{
+    __shared__ unsigned char nib[8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int zc = blockIdx.x * 256, iy = blockIdx.y, x8 = blockIdx.z;
+    const int z = zc + 4 * lane;
+    for (int r = wave; r < 8; r += THREADS / 64) {
+        const int ix = x8 * 8 + r;
+        float w[4];
+        for (int k = 0; k < 4; k++) w[k] = val(ix, iy, z + k);
+        st4<NT>(v + ((size_t)ix * N + iy) * N + z, make_float4(w[0], w[1], w[2], w[3]));
+        nib[r][lane] = (unsigned char)((w[0] > 0 ? 1u : 0u) | (w[1] > 0 ? 2u : 0u) | (w[2] > 0 ? 4u : 0u) | (w[3] > 0 ? 8u : 0u));
+    }
+    __syncthreads();
+    if (wave == 0) {   // lane = 4 consecutive z: byte k = bit k of the 8 rows' nibbles
+        unsigned out = 0;
+        for (int r = 0; r < 8; r++) {
+            const unsigned n = nib[r][lane];
+            out |= ((n & 1u) << r) | (((n >> 1) & 1u) << (8 + r)) | (((n >> 2) & 1u) << (16 + r)) | (((n >> 3) & 1u) << (24 + r));
+        }
+        *reinterpret_cast<unsigned*>(bitsT + ((size_t)iy * (N / 8) + x8) * N + z) = out;
+    }
+}
+
+// bitsT[y][x8][z] (bytes) -> bits[z][y][xw] (u64 = the 8 bytes x8 = 8*xw..8*xw+7): workgroup = (y, 128 z)
+__global__ __launch_bounds__(256) void k_bits_transpose(const uint8_t* __restrict__ bitsT, uint64_t* __restrict__ bits)
+{
+    __shared__ uint8_t t[64][128 + 4];
+    const int iy = blockIdx.y, z0 = blockIdx.x * 128;
+    // 64 rows (x8) x 128 B: 2048 dwords, 8 per lane
+    for (int k = threadIdx.x; k < 64 * 32; k += 256) {
+        const int row = k >> 5, c = (k & 31) * 4;
+        *reinterpret_cast<unsigned*>(&t[row][c]) = *reinterpret_cast<const unsigned*>(bitsT + ((size_t)iy * 64 + row) * N + z0 + c);
+    }
+    __syncthreads();
+    // 128 z x 8 words: 1024 words, 4 per lane; consecutive lanes -> consecutive xw of one z (64 B lines)
+    for (int k = threadIdx.x; k < 128 * 8; k += 256) {
+        const int zz = k >> 3, xw = k & 7;
+        uint64_t w = 0;
+        for (int b = 0; b < 8; b++) w |= (uint64_t)t[xw * 8 + b][zz] << (8 * b);
+        bits[((size_t)(z0 + zz) * N + iy) * 8 + xw] = w;
+    }
+}
+
 // V1: current tile: block (zc in 256s, y, xw); wave w rows r=w,w+4..; lane = 4 z
 template <bool NT, bool BITS>
 __global__ __launch_bounds__(256) void k_cur(float* v, uint64_t* bits)
@@ -177,6 +224,15 @@ int main()
     RUN("fullz y4 nt", hipLaunchKernelGGL((k_fullz<true, 4>), dim3(N / 4, N / 64), dim3(256), 0, 0, v));
     RUN("rows16", hipLaunchKernelGGL(k_rows<false>, dim3(N * N / 16), dim3(256), 0, 0, v));
     RUN("rows16 nt", hipLaunchKernelGGL(k_rows<true>, dim3(N * N / 16), dim3(256), 0, 0, v));
+    uint8_t* bitsT = (uint8_t*)bits + (nv / 8 + 64) / 2;   // (harness only: reuse the allocation)
+    CK(hipMalloc(&bitsT, nv / 8 + 64));
+    RUN("x8 t512", hipLaunchKernelGGL((k_x8<512, false>), dim3(2, N, N / 8), dim3(512), 0, 0, v, bitsT));
+    RUN("x8 t512 nt", hipLaunchKernelGGL((k_x8<512, true>), dim3(2, N, N / 8), dim3(512), 0, 0, v, bitsT));
+    RUN("x8 t256", hipLaunchKernelGGL((k_x8<256, false>), dim3(2, N, N / 8), dim3(256), 0, 0, v, bitsT));
+    RUN("x8 t256 nt", hipLaunchKernelGGL((k_x8<256, true>), dim3(2, N, N / 8), dim3(256), 0, 0, v, bitsT));
+    RUN("bits transpose", hipLaunchKernelGGL(k_bits_transpose, dim3(N / 128, N), dim3(256), 0, 0, bitsT, bits));
+    RUN("x8 t512 + transpose", hipLaunchKernelGGL((k_x8<512, false>), dim3(2, N, N / 8), dim3(512), 0, 0, v, bitsT);
+        hipLaunchKernelGGL(k_bits_transpose, dim3(N / 128, N), dim3(256), 0, 0, bitsT, bits));
 #define TILE(TZ, TH) RUN("tile z" #TZ " t" #TH " nt", hipLaunchKernelGGL((k_tile<TZ, TH, true>), dim3(N / TZ, N, N / 64), dim3(TH), 0, 0, v)); \
                      RUN("tile z" #TZ " t" #TH "   ", hipLaunchKernelGGL((k_tile<TZ, TH, false>), dim3(N / TZ, N, N / 64), dim3(TH), 0, 0, v))
     TILE(256, 256); TILE(256, 512); TILE(256, 1024); TILE(512, 1024); TILE(128, 256); TILE(128, 512); TILE(128, 1024);
