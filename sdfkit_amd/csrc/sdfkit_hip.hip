@@ -351,8 +351,6 @@ extern "C" int sdfk_init(int device)
     g.lanes[0].stream = g.own_stream;
     for (int k = 1; k <= Context::NSIDE; k++) HIPCHK(hipStreamCreateWithFlags(&g.lanes[k].stream, hipStreamNonBlocking));
     g.cur_lane = 0;
-    if (const char* e = getenv("SDFK_LANES")) g.side_lanes = std::max(0, std::min(Context::NSIDE, atoi(e)));
-    if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
     HIPCHK(hipHostMalloc((void**)&g.slots, sizeof(Context::HostSlot) * Context::NSLOTS, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&g.slots_dev, g.slots, 0));
     memset(g.slots, 0, sizeof(Context::HostSlot) * Context::NSLOTS);
@@ -813,7 +811,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
 int wait_counters(sdfk_march_job* j)
 {
     HIPCHK(hipStreamSynchronize(g.stream));
-    if (g.side_lanes == 0) g.jobs_since_sync = 0;
+    if (g.cur_lane == 0 && g.side_lanes == 0) g.jobs_since_sync = 0;
     j->c = g.slots[j->slot].c;
     return SDFK_OK;
 }
@@ -1312,6 +1310,12 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     // self-contained job (no input but the program; the output is only read after a host-side
     // wait): consecutive calls alternate between the side lanes and overlap on the GPU
     int lane = 0;
+    if (const char* e = getenv("SDFK_LANES")) {   // read per call: measurement passes switch the overlap off and on
+        g.side_lanes = std::max(0, std::min(Context::NSIDE, atoi(e)));
+        if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
+    } else {
+        g.side_lanes = 2;
+    }
     if (g.side_lanes > 0 && g.cur_lane == 0) {
         lane = 1 + g.next_side;
         g.next_side = (g.next_side + 1) % g.side_lanes;

@@ -1,0 +1,18 @@
+#!/bin/bash
+# On the GPU box: everything profiles/ needs for a round.  usage: tools/gpu_round_profiles.sh r01
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"; export TMPDIR=/tmp
+O=gpurun_out/profiles_$tag; mkdir -p $O
+python3 bench.py > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_under_rocprof.json 2>/dev/null
+SDFK_LANES=0 rocprofv3 --kernel-trace --stats -d $R/$O/stats_serial -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_serial_under_rocprof.json 2>/dev/null
+SDFK_LANES=0 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
+SDFK_LANES=0 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/pmc_w/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv > $O/pmc_hbm_traffic.txt
+cp $O/stats/s_kernel_stats.csv $O/kernel_stats.csv
+cp $O/stats_serial/s_kernel_stats.csv $O/kernel_stats_serial.csv
+rm -rf $O/stats $O/stats_serial $O/pmc_w $O/pmc_f
+grep "^{" $O/bench.json | cut -c1-400
+cut -d, -f1,2,4 $O/kernel_stats_serial.csv | cut -c1-100
+cat $O/pmc_hbm_traffic.txt | head -12
