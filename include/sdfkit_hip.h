@@ -69,6 +69,7 @@ int sdfk_init(int device);
 void sdfk_shutdown(void);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int sdfk_set_stream(void* hip_stream);
+/* Waits for everything the library has queued (the caller's stream and the internal ones). */
 int sdfk_synchronize(void);
 const char* sdfk_last_error(void);
 
@@ -95,6 +96,8 @@ int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global, const flo
 /* host <-> device copies of Voxels.Values / Voxels.Colors (colors may be NULL) */
 int sdfk_volume_upload(sdfk_volume* v, const float* values, const float* colors3);
 int sdfk_volume_download(const sdfk_volume* v, float* values, float* colors3);
+/* Raw device pointers (the caller may write through them: cached sign bits are dropped and
+ * meshes that still depend on the volume are completed first). */
 int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void** colors3);
 void sdfk_volume_free(sdfk_volume* v);
 
@@ -107,14 +110,26 @@ int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds);
 int sdfk_volume_clip_to_bounds(sdfk_volume* v);
 
 /* ---- MarchingCubes.CreateMesh (MarchingCubes.cs:39-92) ----------------------
- * One-shot forms.  The mesh is left on the device; query with sdfk_mesh_*. */
+ * One-shot forms.  The mesh is left on the device; query with sdfk_mesh_*.
+ *
+ * Completion is DEFERRED: a repeat call for a grid shape sizes its buffers from the previous
+ * mesh of that shape, queues every kernel and returns the handle without waiting for the GPU.
+ * The first sdfk_mesh_* accessor waits, verifies the size guess and, if it was too small, redoes
+ * the job exactly -- the caller never sees a difference except in timing, and errors of the job
+ * are reported by that accessor.  The library keeps the source volume's contents alive for that:
+ * modifying or freeing a volume (upload, sample, clip, free, device_ptrs) first completes the
+ * meshes that still depend on it.  sdfk_mesh_free on an unread mesh does not wait. */
 int sdfk_march(const sdfk_volume* v, float iso_value, int32_t step, sdfk_mesh** out);
 /* Host-array form: `values`/`colors3` are the managed Voxels.Values / Voxels.Colors arrays
  * pinned by the shim for the duration of the call (colors3 may be NULL = zeros). */
 int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32_t ny, int32_t nz,
                     const float min[3], const float max[3], float iso_value, int32_t step,
                     sdfk_mesh** out);
-/* SdfEx.ToMesh (Sdf.cs:59-63): sample (+clip) and mesh without leaving the device. */
+/* SdfEx.ToMesh (Sdf.cs:59-63): sample (+clip) and mesh without leaving the device.
+ * Self-contained jobs: consecutive calls are queued on two internal streams in turn (not on the
+ * sdfk_set_stream stream) and overlap on the GPU; their results are safe to use from any stream
+ * once an accessor has returned.  SDFK_LANES=0 in the environment (read per call) keeps them on
+ * the caller's stream. */
 int sdfk_sample_march(const sdfk_program* p, const float min[3], const float max[3],
                       int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds,
                       float iso_value, int32_t step, sdfk_mesh** out);
@@ -132,7 +147,7 @@ int sdfk_march_begin(const sdfk_volume* v, float iso_value, int32_t layer_begin,
 int sdfk_march_finish(sdfk_march_job* job, int64_t vertex_base, sdfk_mesh** out);
 void sdfk_march_job_free(sdfk_march_job* job);
 
-/* One-call slab forms (one host sync each): buffers are sized from the previous call with the
+/* One-call slab forms (deferred completion as above): buffers are sized from the previous call with the
  * same slab shape, classification and emit are queued back to back, and the exact two-phase
  * path is taken only when that guess was too small.  `vertex_base` is added to every index;
  * pass 0 to get slab-local indices and rebase after the gather (sdfk_slabs_rebase). */
