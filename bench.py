@@ -162,14 +162,21 @@ def main():
             return tuple(last)
     else:
         # one sync + one RCCL all-gather per step (sdfkit_amd/dist.py: SlabSession)
-        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev)
+        # three steps in flight: no host wait inside a step (sdfkit_amd/dist.py: SlabSession)
+        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev, depth=int(os.environ.get("SDFK_BENCH_DEPTH", "3")) or 1)
         totals = torch.zeros(2, dtype=torch.int64, device=dev)
+        last = [0, 0]
 
         def step():
-            return worker.step()
+            if len(worker.queue) == worker.depth:
+                last[0], last[1] = worker.collect()
+            worker.submit()
+            return tuple(last)
 
         def drain():
-            return nv, ni
+            while worker.queue:
+                last[0], last[1] = worker.collect()
+            return tuple(last)
 
     for _ in range(max(args.warmup, 1) + 4):   # (the extra steps fill the allocator's pool: untimed set-up)
         nv, ni = step()

@@ -160,7 +160,11 @@ int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t cli
  * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; pad } followed by
  * Vertices | Colors | Normals (3 floats per vertex each) | Triangles (int32).  Written device
  * to device into `dst` (capacity_bytes); *needed_bytes = header + arrays.  If it does not fit,
- * only the header is written and SDFK_OK is still returned (the caller sees needed > capacity). */
+ * only the header is written and SDFK_OK is still returned (the caller sees needed > capacity).
+ * For a mesh whose job is still queued (deferred completion) nothing waits: the device packs
+ * from the job's own counters, *needed_bytes = -1, and the header says what happened -- counts
+ * >= 0 (arrays present if they fit the capacity), or nv = ni = -1 when the speculative buffers
+ * of that job were too small (complete the mesh with any accessor and pack again). */
 #define SDFK_SLAB_HEADER_BYTES 64
 int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_t* needed_bytes);
 /* `gathered` = world payloads of stride_bytes each (device memory, as produced by an

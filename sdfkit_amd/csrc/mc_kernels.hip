@@ -1105,14 +1105,64 @@ __global__ void k_slab_header(SlabHeader* dst, int64_t nv, int64_t ni, const flo
     }
 }
 
+// Packing of a mesh whose job is still queued (no host knowledge of the counts): header and
+// arrays are written by the device from the job's counters.  A speculative job whose buffers
+// turned out too small leaves nv = ni = -1 in the header (the host redoes that step); a
+// payload that does not fit `capacity` leaves the header only.
+struct PackArgs {
+    const McCounters* counters;   // of the queued job
+    uint32_t cap_active, cap_v;
+    uint64_t cap_i;
+    const float* vertices;
+    const float* colors;
+    const float* normals;
+    const int32_t* triangles;
+    const float* bounds;          // device float[6], written by k_triangles
+    char* dst;
+    int64_t capacity;
+};
+
+__global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
+{
+    const McCounters c = *A.counters;
+    const bool ok = c.n_active <= A.cap_active && c.overflow == 0 && (uint64_t)(c.total_v - c.nghost) <= (uint64_t)A.cap_v &&
+                    (uint64_t)c.total_t * 3u <= A.cap_i;
+    const int64_t nv = ok ? (int64_t)(c.total_v - c.nghost) : -1, ni = ok ? (int64_t)c.total_t * 3 : -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SlabHeader h;
+        h.nv = nv; h.ni = ni;
+        for (int k = 0; k < 3; k++) { h.bmin[k] = nv > 0 ? A.bounds[k] : 0.0f; h.bmax[k] = nv > 0 ? A.bounds[3 + k] : 0.0f; }
+        for (int k = 0; k < 6; k++) h.pad[k] = 0.0f;
+        *reinterpret_cast<SlabHeader*>(A.dst) = h;
+    }
+    if (!ok || (int64_t)sizeof(SlabHeader) + 36 * nv + 4 * ni > A.capacity) return;
+    // [V | C | N | T] as one run of 4-byte words
+    const int64_t nf = nv * 3, total = 3 * nf + ni;
+    uint32_t* out = reinterpret_cast<uint32_t*>(A.dst + sizeof(SlabHeader));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        uint32_t w;
+        if (i < nf) w = __float_as_uint(A.vertices[i]);
+        else if (i < 2 * nf) w = __float_as_uint(A.colors[i - nf]);
+        else if (i < 3 * nf) w = __float_as_uint(A.normals[i - 2 * nf]);
+        else w = (uint32_t)A.triangles[i - 3 * nf];
+        out[i] = w;
+    }
+}
+
 // slab r of the gathered buffer: indices += sum of the vertex counts of slabs 0..r-1
+// (nothing is touched when a header is marked invalid: that step is redone by the host)
 __global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathered, int world, int64_t stride)
 {
     const int r = blockIdx.y;
     int64_t base = 0;
-    for (int q = 0; q < r; q++) base += reinterpret_cast<const SlabHeader*>(gathered + (size_t)q * stride)->nv;
+    for (int q = 0; q < world; q++) {
+        const int64_t nvq = reinterpret_cast<const SlabHeader*>(gathered + (size_t)q * stride)->nv;
+        if (nvq < 0) return;
+        if (q < r) base += nvq;
+    }
     if (r == 0 || base == 0) return;
     const SlabHeader* h = reinterpret_cast<const SlabHeader*>(gathered + (size_t)r * stride);
+    if ((int64_t)sizeof(SlabHeader) + 36 * h->nv + 4 * h->ni > stride) return;   // header-only payload
     int32_t* t = reinterpret_cast<int32_t*>(gathered + (size_t)r * stride + sizeof(SlabHeader) + (size_t)h->nv * 36);
     const int64_t n = h->ni;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) t[i] += (int32_t)base;

@@ -1255,8 +1255,28 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m || !dst) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: null argument");
     if (int r = require_init()) return r;
-    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     const_cast<sdfk_mesh*>(m)->used_on_main = true;
+    if (m->pending && !m->status) {
+        // the job is still queued: the device packs from the job's own counters, the host is
+        // not involved (needed_bytes is unknown here: -1; the header carries the counts)
+        if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: capacity below the header size");
+        PackArgs A;
+        A.counters = m->pending->P.counters;
+        A.cap_active = m->pending->P.cap_active;
+        A.cap_v = (uint32_t)std::min<size_t>(m->cap_v, 0xffffffffu);
+        A.cap_i = m->cap_i;
+        A.vertices = m->vertices; A.colors = m->colors; A.normals = m->normals; A.triangles = m->triangles;
+        A.bounds = m->bounds;
+        A.dst = (char*)dst;
+        A.capacity = capacity_bytes;
+        if (m->lane != g.cur_lane) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: queued mesh belongs to another stream");
+        ProfScope ps("k_pack");
+        hipLaunchKernelGGL(k_pack_pending, dim3(grid_for(m->cap_v * 9 + m->cap_i, 256, 1024)), dim3(256), 0, g.stream, A);
+        HIPCHK(hipGetLastError());
+        if (needed_bytes) *needed_bytes = -1;
+        return SDFK_OK;
+    }
+    if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     const int64_t vb = m->nv * 12, need = SDFK_SLAB_HEADER_BYTES + 3 * vb + m->ni * 4;
     if (needed_bytes) *needed_bytes = need;
     if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: capacity below the header size");

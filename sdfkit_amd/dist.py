@@ -110,6 +110,19 @@ class GpuSlabWorker:
         N.check(N.lib().sdfk_mesh_counts(m, C.byref(nv), C.byref(ni)))
         return nv.value, ni.value
 
+    def enqueue(self, buf):
+        """Asynchronous form of run_local + pack_self_describing: queues sample, mesh and the
+        device-side pack into the uint8 torch tensor `buf` and returns without waiting; the
+        counts are in the payload header (-1 = this job's speculative buffers were too small)."""
+        N = self.N
+        self.release()
+        m = C.c_void_p()
+        N.check(N.lib().sdfk_sample_march_slab(self.prog, self.vol, 1 if self.clip else 0, C.c_float(self.iso),
+                                               self.lb, self.le, 0, C.byref(m)))
+        need = C.c_int64()
+        N.check(N.lib().sdfk_mesh_pack(m, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(need)))
+        N.lib().sdfk_mesh_free(m)   # stream-ordered: the pack above still reads it
+
     def pack_self_describing(self, buf):
         """sdfk_mesh_pack into the uint8 torch tensor `buf`; returns the bytes needed."""
         need = C.c_int64()
@@ -224,7 +237,7 @@ def sharded_to_mesh(sdf, mn, mx, nx, ny, nz, clip_to_bounds=True, iso=0.0, group
 
 
 # ---------------------------------------------------------------------------
-# steady-state form: ONE host sync and ONE collective per step
+# steady-state form: ONE collective per step, NO host wait inside a step
 # ---------------------------------------------------------------------------
 SLAB_HEADER_BYTES = 64  # SDFK_SLAB_HEADER_BYTES
 
@@ -232,56 +245,173 @@ SLAB_HEADER_BYTES = 64  # SDFK_SLAB_HEADER_BYTES
 class SlabSession:
     """Repeated sharded sample -> mesh of the same grid (what bench.py --gpus N times).
 
-    Per step and rank: sample + mesh the slab with slab-local ids (one sync, buffers sized from
-    the previous step), pack a self-describing payload (header = counts + bounds), ONE padded
-    all-gather over RCCL, one kernel that rebases the gathered indices from the headers.  The
-    payload stride is agreed once, on the first step, with a count all-gather (+50 % head-room);
-    a later slab that outgrows it raises (use sharded_to_mesh for one-off meshes)."""
+    A step, per rank, is queued without waiting for the GPU: sample + mesh the slab with
+    slab-local ids (buffers sized from the previous step), pack a self-describing payload ON THE
+    DEVICE (header = counts + bounds, written from the job's own counters), ONE padded all-gather
+    over RCCL, one kernel that rebases the gathered indices from the headers, and an asynchronous
+    copy of the `world` headers to pinned host memory.  `submit()` queues a step into the next of
+    `depth` slots (own slab volume, send and gather buffers each); `collect()` waits for the
+    OLDEST queued step only, reads its headers and returns this rank's counts -- so with
+    depth > 1 the host never idles the GPU or the links between steps.  `step()` = submit +
+    collect (one step in flight).
 
-    def __init__(self, sdf, mn, mx, nx, ny, nz, clip_to_bounds=True, iso=0.0, group=None, device=None):
+    The payload stride is agreed once, on the first step, with a count all-gather (+50 %
+    head-room); a later slab that outgrows it raises (use sharded_to_mesh for one-off meshes).
+    A step whose speculative buffers were too small on ANY rank is marked in that rank's
+    header; every rank sees it after the gather and all of them redo that step on the exact
+    (synchronising) path -- same decision everywhere, so the collectives stay matched.
+
+    `make_worker(slot)` returns the compute backend of a slot: `run_local() -> (nv, ni)`
+    (synchronous, exact), `pack_self_describing(buf)`, `enqueue(buf)` (asynchronous form of the
+    two) and `close()`.  `rebase(gathered, world, stride)` adds the vertex bases to the gathered
+    indices in place.  The defaults are the product ones (GpuSlabWorker, sdfk_slabs_rebase);
+    tests/test_dist_gloo.py drives the same protocol on CPU tensors over gloo with fixtures."""
+
+    def __init__(self, sdf=None, mn=None, mx=None, nx=0, ny=0, nz=0, clip_to_bounds=True, iso=0.0, group=None,
+                 device=None, depth=1, make_worker=None, rebase=None):
         import torch
         import torch.distributed as dist
-        from . import _native as N
-        self.N, self.group = N, group
+        self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.worker = GpuSlabWorker(sdf, mn, mx, nx, ny, nz, self.rank, self.world, clip_to_bounds, iso)
-        self.stride = None
-        self.buf = self.gathered = None
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        if make_worker is None:
+            def make_worker(slot):
+                return GpuSlabWorker(sdf, mn, mx, nx, ny, nz, self.rank, self.world, clip_to_bounds, iso)
+        if rebase is None:
+            from . import _native as N
 
-    def step(self):
+            def rebase(gathered, world, stride):
+                N.check(N.lib().sdfk_slabs_rebase(C.c_void_p(gathered.data_ptr()), world, stride))
+        self.rebase = rebase
+        self.depth = max(int(depth), 1)
+        self.workers = [make_worker(k) for k in range(self.depth)]
+        self.worker = self.workers[0]
+        self.stride = None
+        self.buf = [None] * self.depth
+        self.gathered_slots = [None] * self.depth
+        self.hdr_host = [None] * self.depth
+        self.ready = [None] * self.depth
+        self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.queue = []          # slots in submission order
+        self.next_slot = 0
+        self.gathered = None     # gather buffer of the step collected last
+        self.redone = 0          # steps that had to be redone on the exact path
+
+    # -- helpers ----------------------------------------------------------------
+    def _all_gather(self, slot):
+        import torch.distributed as dist
+        g, b = self.gathered_slots[slot], self.buf[slot]
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(g.view(-1), b, group=self.group)
+        else:
+            dist.all_gather([g[r] for r in range(self.world)], b, group=self.group)
+        self.rebase(g, self.world, self.stride)
+
+    def _agree_stride(self, need):
         import torch
         import torch.distributed as dist
-        nv, ni = self.worker.run_local()
+        t = torch.tensor([need], dtype=torch.int64, device=self.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        mx = max(int(x.item()) for x in out)
+        self.stride = ((mx + mx // 2 + 4096) + 255) // 256 * 256
+        for k in range(self.depth):
+            self.buf[k] = torch.zeros(self.stride, dtype=torch.uint8, device=self.device)
+            self.gathered_slots[k] = torch.zeros((self.world, self.stride), dtype=torch.uint8, device=self.device)
+            h = torch.zeros((self.world, SLAB_HEADER_BYTES), dtype=torch.uint8)
+            self.hdr_host[k] = h.pin_memory() if self.on_gpu else h
+
+    def _exact_step(self, slot):
+        """Synchronous, exact form of a step (first step, and the redo of a failed one)."""
+        w = self.workers[slot]
+        nv, ni = w.run_local()
         need = SLAB_HEADER_BYTES + 36 * nv + 4 * ni
         if self.stride is None:   # first step only (every rank takes this branch together)
-            t = torch.tensor([need], dtype=torch.int64, device=self.device)
-            out = [torch.empty_like(t) for _ in range(self.world)]
-            dist.all_gather(out, t, group=self.group)
-            mx = max(int(x.item()) for x in out)
-            self.stride = ((mx + mx // 2 + 4096) + 255) // 256 * 256
-            self.buf = torch.empty(self.stride, dtype=torch.uint8, device=self.device)
-            self.gathered = torch.empty((self.world, self.stride), dtype=torch.uint8, device=self.device)
+            self._agree_stride(need)
         if need > self.stride:
             raise RuntimeError(f"slab payload grew to {need} B (> agreed stride {self.stride} B)")
-        self.worker.pack_self_describing(self.buf)
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.buf, group=self.group)
-        else:
-            dist.all_gather([self.gathered[r] for r in range(self.world)], self.buf, group=self.group)
-        self.N.check(self.N.lib().sdfk_slabs_rebase(C.c_void_p(self.gathered.data_ptr()), self.world, self.stride))
+        w.pack_self_describing(self.buf[slot])
+        self._all_gather(slot)
         return nv, ni
 
-    def mesh(self):
-        """Host copy of the last gathered mesh (synchronises)."""
+    def _headers(self, slot):
         import torch
+        if self.on_gpu:
+            self.ready[slot].synchronize()
+            h = self.hdr_host[slot]
+        else:
+            h = self.gathered_slots[slot][:, :SLAB_HEADER_BYTES].contiguous()
+        counts = h.numpy()[:, :16].copy().view(np.int64)   # [world, 2] = (nv, ni)
+        return counts
+
+    # -- pipeline ---------------------------------------------------------------
+    def submit(self):
+        """Queue one step into the next slot (collect()s the oldest one first when all slots are taken)."""
+        import torch
+        if len(self.queue) == self.depth:
+            raise RuntimeError("all slots are in flight: collect() first")
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % self.depth
+        if self.stride is None:
+            counts = self._exact_step(slot)        # bootstrap: sizes, stride, hints
+            self.queue.append((slot, counts))
+            return
+        self.workers[slot].enqueue(self.buf[slot])
+        self._all_gather(slot)
+        if self.on_gpu:
+            cur = torch.cuda.current_stream(self.device)
+            done = torch.cuda.Event()
+            done.record(cur)
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(done)
+                self.hdr_host[slot].copy_(self.gathered_slots[slot][:, :SLAB_HEADER_BYTES], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self.ready[slot] = ev
+        self.queue.append((slot, None))
+
+    def collect(self):
+        """Wait for the oldest queued step; returns this rank's (n_vertices, n_indices)."""
+        slot, counts = self.queue.pop(0)
+        if counts is None:
+            hdr = self._headers(slot)
+            if (hdr < 0).any():                     # some rank's guess was too small: everybody redoes the step
+                self.redone += 1
+                counts = self._exact_step(slot)
+            else:
+                need = SLAB_HEADER_BYTES + 36 * hdr[:, 0] + 4 * hdr[:, 1]
+                if int(need.max()) > self.stride:
+                    raise RuntimeError(f"slab payload grew to {int(need.max())} B (> agreed stride {self.stride} B)")
+                counts = (int(hdr[self.rank, 0]), int(hdr[self.rank, 1]))
+        self.gathered = self.gathered_slots[slot]
+        return counts
+
+    def step(self):
+        self.submit()
+        return self.collect()
+
+    def drain(self):
+        out = None
+        while self.queue:
+            out = self.collect()
+        return out
+
+    def mesh(self):
+        """Host copy of the mesh of the step collected last (synchronises)."""
         from .api import Mesh
-        torch.cuda.current_stream().synchronize()
+        if self.on_gpu:
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
         V, Cc, Nn, T, mn, mx = unpack_self_describing(self.gathered.cpu().numpy())
         return Mesh(V, Cc, Nn, T, mn, mx)
 
     def close(self):
-        self.worker.close()
+        self.drain()
+        for w in self.workers:
+            w.close()
 
 
 def unpack_self_describing(g):

@@ -112,6 +112,129 @@ def test_slab_exchange_over_gloo(world):
     assert len({(nv, nt) for _, _, nv, nt in res}) == 1  # every rank holds the same full mesh
 
 
+class FixtureSessionWorker:
+    """SlabSession backend over fixtures: the self-describing payload (64-byte header, slab-LOCAL
+    indices) of this rank's part of a reference mesh; `fail_at` = enqueue calls that pretend the
+    speculative buffers were too small (header counts -1, no arrays)."""
+
+    def __init__(self, mesh, nx, ny, nz, rank, world, fail_at=()):
+        self.f = FixtureSlabWorker(mesh, nx, ny, nz, rank, world)
+        self.calls, self.fail_at = 0, set(fail_at)
+
+    def _payload(self):
+        f, m = self.f, self.f.m
+        nv, ni = f.v1 - f.v0, f.t1 - f.t0
+        v = m.vertices[f.v0:f.v1]
+        hdr = np.zeros(64, np.uint8)
+        hdr[:16] = np.array([nv, ni], np.int64).view(np.uint8)
+        if nv:
+            hdr[16:28] = v.min(axis=0).astype(np.float32).view(np.uint8)
+            hdr[28:40] = v.max(axis=0).astype(np.float32).view(np.uint8)
+        tri = (m.triangles[f.t0:f.t1].astype(np.int64) - f.v0).astype(np.int32)   # slab-local ids (may be negative: seam)
+        parts = [hdr, np.ascontiguousarray(v).view(np.uint8).ravel(),
+                 np.ascontiguousarray(m.colors[f.v0:f.v1]).view(np.uint8).ravel(),
+                 np.ascontiguousarray(m.normals[f.v0:f.v1]).view(np.uint8).ravel(), tri.view(np.uint8).ravel()]
+        return nv, ni, np.concatenate(parts)
+
+    def run_local(self):
+        nv, ni, _ = self._payload()
+        return nv, ni
+
+    def pack_self_describing(self, buf):
+        _, _, raw = self._payload()
+        buf[:len(raw)] = torch.from_numpy(raw.copy())
+
+    def enqueue(self, buf):
+        self.calls += 1
+        if self.calls in self.fail_at:
+            buf[:16] = torch.from_numpy(np.array([-1, -1], np.int64).view(np.uint8).copy())
+            return
+        self.pack_self_describing(buf)
+
+    def close(self):
+        pass
+
+
+def _rebase_host(gathered, world, stride):
+    """numpy twin of sdfk_slabs_rebase (test fixture only)."""
+    g = gathered.numpy()
+    nvs = [int(g[r, :8].view(np.int64)[0]) for r in range(world)]
+    if min(nvs) < 0:
+        return
+    base = 0
+    for r in range(world):
+        ni = int(g[r, 8:16].view(np.int64)[0])
+        o = 64 + 36 * nvs[r]
+        if o + 4 * ni <= stride and base:
+            g[r, o:o + 4 * ni].view(np.int32)[:] += base
+        base += nvs[r]
+
+
+def _session_worker(rank, world, port, dims, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from sdfkit_amd import dist as D
+        from tests import scenes as S
+        scene, _ = S.union8()
+        mn, mx = [-2.8125] * 3, [2.8125] * 3
+        v, c = O.sample(scene, mn, mx, *dims)
+        O.clip_to_bounds(v, mn, mx)
+        ref = O.march(v, c, mn, mx)
+        # rank 1 "fails" its 3rd queued step: every rank must redo exactly that step
+        fails = (3,) if rank == 1 else ()
+        workers = []
+
+        def make_worker(slot):
+            w = FixtureSessionWorker(ref, *dims, rank, world, fails if slot == 1 else ())
+            workers.append(w)
+            return w
+
+        ses = D.SlabSession(group=None, device="cpu", depth=3, make_worker=make_worker, rebase=_rebase_host)
+        ok, steps = True, 0
+        for it in range(9):            # keep the pipeline full: submit ahead, collect the oldest
+            if len(ses.queue) == ses.depth:
+                nv, ni = ses.collect()
+                steps += 1
+                m = ses.mesh()
+                ok &= (nv, ni) == workers[0].run_local()
+                ok &= (np.array_equal(m.Vertices, ref.vertices) and np.array_equal(m.Triangles, ref.triangles) and
+                       np.array_equal(m.Normals, ref.normals, equal_nan=True) and np.array_equal(m.Colors, ref.colors) and
+                       np.array_equal(m.Min, ref.min) and np.array_equal(m.Max, ref.max))
+            ses.submit()
+        while ses.queue:
+            ses.collect()
+            steps += 1
+            m = ses.mesh()
+            ok &= np.array_equal(m.Vertices, ref.vertices) and np.array_equal(m.Triangles, ref.triangles)
+        out_q.put((rank, bool(ok), steps, ses.redone))
+        ses.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_session_over_gloo(world):
+    """SlabSession with three steps in flight: payload headers carry the counts, a step one rank
+    marks as failed is redone by all ranks, collectives stay matched."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    dims = (22, 20, 19)
+    procs = [ctx.Process(target=_session_worker, args=(r, world, port, dims, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    assert all(steps == 9 for _, _, steps, _ in res), res
+    assert all(redone == 1 for _, _, _, redone in res), res
+
+
 def test_slab_partition_covers_all_layers():
     from sdfkit_amd import dist as D
     for n_layers in (0, 1, 7, 8, 511, 1023):

@@ -111,3 +111,59 @@ def test_speculative_guess_too_small_is_redone_on_first_read(gpu):
     assert len(om.vertices) > 12000   # far beyond hint * 1.25 + 4096
     for h in handles:
         assert_mesh_equal(Mesh._from_handle(h), om)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_queued_slabs_are_packed_by_the_device(gpu, world):
+    """GpuSlabWorker.enqueue: sample + mesh + pack of a slab without any host wait; payloads side
+    by side as an all-gather leaves them, one rebase launch -> the single-volume mesh.  Then the
+    same with size hints that are far too small: the headers must say so (-1), nothing else."""
+    import torch
+    from sdfkit_amd import dist as D
+    scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
+    dims = (44, 40, 48)
+    whole = sdf.ToMesh(MN, MX, *dims)
+    L = N.lib()
+    N.check(L.sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    try:
+        workers = [D.GpuSlabWorker(sdf, MN, MX, *dims, r, world, True, 0.0) for r in range(world)]
+        counts = [w.run_local() for w in workers]                       # exact path: sets the hints
+        stride = max(D.SLAB_HEADER_BYTES + 36 * a + 4 * b for a, b in counts) + 512
+        for _ in range(3):
+            g = torch.zeros((world, stride), dtype=torch.uint8, device="cuda")
+            for r, w in enumerate(workers):
+                w.enqueue(g[r])
+            N.check(L.sdfk_slabs_rebase(C.c_void_p(g.data_ptr()), world, stride))
+            torch.cuda.synchronize()
+            h = g[:, :16].cpu().numpy().view(np.int64)
+            assert [tuple(x) for x in h] == counts
+            V, Cc, Nn, T, bmin, bmax = D.unpack_self_describing(g.cpu().numpy())
+            assert np.array_equal(T, whole.Triangles) and np.array_equal(V, whole.Vertices)
+            assert np.array_equal(Cc, whole.Colors) and np.array_equal(Nn, whole.Normals, equal_nan=True)
+            assert np.array_equal(bmin, whole.Min) and np.array_equal(bmax, whole.Max)
+        for w in workers:
+            w.close()
+        # hints from a tiny mesh of the same slab shapes, then the big scene again: under-sized guesses
+        tiny = Sdfs.Sphere(0.05)
+        small = [D.GpuSlabWorker(tiny, MN, MX, *dims, r, world, True, 0.0) for r in range(world)]
+        for w in small:
+            w.run_local()
+            w.close()
+        big_dims_workers = [D.GpuSlabWorker(S.CATALOGUE["union8"]()[1], MN, MX, 4 * dims[0], 4 * dims[1], dims[2], r, world, True, 0.0)
+                            for r in range(world)]
+        tiny_same_shape = [D.GpuSlabWorker(tiny, MN, MX, 4 * dims[0], 4 * dims[1], dims[2], r, world, True, 0.0) for r in range(world)]
+        for w in tiny_same_shape:
+            w.run_local()
+            w.close()
+        g = torch.zeros((world, 1 << 20), dtype=torch.uint8, device="cuda")
+        for r, w in enumerate(big_dims_workers):
+            w.enqueue(g[r])
+        torch.cuda.synchronize()
+        h = g[:, :16].cpu().numpy().view(np.int64)
+        assert (h == -1).all(), h
+        exact = [w.run_local() for w in big_dims_workers]              # and the exact path still works afterwards
+        assert sum(nv for nv, _ in exact) > 20000
+        for w in big_dims_workers:
+            w.close()
+    finally:
+        N.check(L.sdfk_set_stream(None))
