@@ -26,6 +26,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 
 
+WORKLOADS = {
+    "sphere": "Sdfs.Sphere(1), bounds -1.5..1.5, no clip",
+    "repeatxy": "SdfExprs.Sphere(0.5).RepeatXY(1.125,1.125,colour), bounds -2.8125..2.8125, clipToBounds",
+    "union8": "nested SdfExprs.Union of 8 primitives (sphere/box/cylinder) at the octant centres, bounds -2.8125..2.8125, clipToBounds",
+}
+
+
 def scene_for(name):
     from sdfkit_amd import SdfExprs, Sdfs, Vec3
     if name == "sphere":
@@ -34,6 +41,18 @@ def scene_for(name):
         sdf = SdfExprs.Sphere(0.5).RepeatXY(1.125, 1.125,
                                             lambda i, p, d: 0.9 * Vec3.of(p.x.b, 1.0) - Vec3.Abs(i) / 6.0).ToSdf()
         return sdf, [-2.8125] * 3, [2.8125] * 3, True
+    if name == "union8":    # BASELINE C4: nested Union of 8 primitives at the octant centres of [-2,2]^3
+        prims, k = [], 0
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    q = (SdfExprs.Sphere(0.6), SdfExprs.Box(0.5), SdfExprs.Cylinder(0.4, 0.6))[k % 3]
+                    prims.append(q.Translate(sx, sy, sz))
+                    k += 1
+        prod = prims[0]
+        for q in prims[1:]:
+            prod = SdfExprs.Union(prod, q)
+        return prod.ToSdf(), [-2.8125] * 3, [2.8125] * 3, True
     raise SystemExit(f"unknown scene {name}")
 
 
@@ -46,6 +65,19 @@ def cpu_baseline(scene, n):
     if scene == "sphere":
         s.sphere_w(1.0)
         mn, mx, clip = [-1.5] * 3, [1.5] * 3, False
+    elif scene == "union8":
+        nodes, k = [], 0
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    n = (lambda: s.f_sphere(0.6), lambda: s.f_box(0.5), lambda: s.f_cylinder(0.4, 0.6))[k % 3]()
+                    nodes.append(s.f_translate(n, sx, sy, sz))
+                    k += 1
+        root = nodes[0]
+        for n in nodes[1:]:
+            root = s.f_union(root, n)
+        s.root = root
+        mn, mx, clip = [-2.8125] * 3, [2.8125] * 3, True
     else:
         s.f_repeat_xy_idx(s.f_sphere(0.5), 1.125, 1.125, O.CF_README)
         mn, mx, clip = [-2.8125] * 3, [2.8125] * 3, True
@@ -86,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=512, help="grid edge")
-    ap.add_argument("--scene", default="sphere", choices=["sphere", "repeatxy"])
+    ap.add_argument("--scene", default="sphere", choices=["sphere", "repeatxy", "union8"])
     ap.add_argument("--cpu-n", type=int, default=256, help="grid edge of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -252,7 +284,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 (sampling) / f64 (cell math)",
             "data": "synthetic",
-            "config": {"workload": f"{'Sdfs.Sphere(1), bounds -1.5..1.5, no clip' if args.scene == 'sphere' else 'SdfExprs.Sphere(0.5).RepeatXY(1.125,1.125,colour), bounds -2.8125..2.8125, clipToBounds'}"
+            "config": {"workload": f"{WORKLOADS[args.scene]}"
                                    f", {n}^3 voxels, iso 0, step 1; Voxels.SampleSdf -> MarchingCubes.CreateMesh, device-resident",
                        "grid": [n, n, n], "vertices": nv, "triangles": ni // 3,
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, RCCL all-gather of slab meshes"},

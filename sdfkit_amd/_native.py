@@ -6,6 +6,7 @@ used, an exception is raised.
 """
 import ctypes as C
 import os
+import sys
 
 from . import build as _build
 
@@ -87,6 +88,15 @@ def lib():
             except Exception as e:  # no silent fallback
                 if not os.path.exists(path):
                     raise RuntimeError(f"libsdfkit_hip.so is missing and could not be built with hipcc: {e}") from e
+        # PyTorch's ROCm wheels bundle their own HIP runtime, and the runtime a process loads
+        # FIRST is the one that owns the GPU: loading this library before torch leaves torch
+        # without a device ("No HIP GPUs are available").  Where torch is installed, load it
+        # first so that torch tensors / streams and this library share one runtime.
+        if "torch" not in sys.modules and os.environ.get("SDFKIT_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol

@@ -167,3 +167,46 @@ def test_queued_slabs_are_packed_by_the_device(gpu, world):
             w.close()
     finally:
         N.check(L.sdfk_set_stream(None))
+
+
+def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
+    """BASELINE config C4 at its full size on ONE GPU: 1024^3 CSG union of 8 primitives, meshed
+    whole and as the 8 Z slabs the 8-GPU run uses (queued back to back, packed by the device,
+    rebased in one launch).  Size-independent properties + slabs == whole, bit for bit."""
+    import torch
+    from sdfkit_amd import dist as D
+    scene, sdf = S.CATALOGUE["union8"]()
+    n, world = 1024, 8
+    L = N.lib()
+    N.check(L.sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    try:
+        whole = sdf.ToMesh(MN, MX, n, n, n)
+        nv, t = len(whole.Vertices), whole.Triangles
+        assert nv > 1_000_000 and t.min() == 0 and t.max() == nv - 1
+        first = np.full(nv, len(t), np.int64)
+        np.minimum.at(first, t, np.arange(len(t)))
+        assert np.all(np.diff(first) > 0)                       # numbered in order of first reference
+        assert np.abs(np.linalg.norm(whole.Normals.astype(np.float64), axis=1) - 1).max() < 1e-5
+        assert np.all(whole.Min >= np.float32(-2.8125)) and np.all(whole.Max <= np.float32(2.8125))
+        tri = t.reshape(-1, 3)
+        e = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
+        key = e[:, 0].astype(np.int64) * nv + e[:, 1]
+        _, cnt = np.unique(key, return_counts=True)
+        assert np.all(cnt == 2)                                  # closed surface
+        workers = [D.GpuSlabWorker(sdf, MN, MX, n, n, n, r, world, True, 0.0) for r in range(world)]
+        counts = [w.run_local() for w in workers]
+        assert sum(a for a, _ in counts) == nv and sum(b for _, b in counts) == len(t)
+        stride = (max(D.SLAB_HEADER_BYTES + 36 * a + 4 * b for a, b in counts) + 4096 + 255) // 256 * 256
+        g = torch.zeros((world, stride), dtype=torch.uint8, device="cuda")
+        for r, w in enumerate(workers):
+            w.enqueue(g[r])
+        N.check(L.sdfk_slabs_rebase(C.c_void_p(g.data_ptr()), world, stride))
+        torch.cuda.synchronize()
+        V, Cc, Nn, T, bmin, bmax = D.unpack_self_describing(g.cpu().numpy())
+        for w in workers:
+            w.close()
+        assert np.array_equal(T, whole.Triangles) and np.array_equal(V, whole.Vertices)
+        assert np.array_equal(Cc, whole.Colors) and np.array_equal(Nn, whole.Normals, equal_nan=True)
+        assert np.array_equal(bmin, whole.Min) and np.array_equal(bmax, whole.Max)
+    finally:
+        N.check(L.sdfk_set_stream(None))
