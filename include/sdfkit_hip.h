@@ -172,6 +172,23 @@ int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_
  * the vertex counts of slabs 0..r-1, in one launch, reading the counts from the headers. */
 int sdfk_slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes);
 
+/* ---- RayMarcher (RayMarcher.cs:45-211) ---------------------------------------
+ * RenderDepth (depth != NULL) and / or Render (rgb != NULL) of the program's SDF by sphere
+ * tracing: one ray per pixel, `depth_iterations` steps, 6 more evaluations for the normal,
+ * Lambert shading and the sky colour exactly as RayMarcher.Render (RayMarcher.cs:134-169).
+ * camera_position and view_projection_inverse (row-major M11..M44) are what GetCameraRays
+ * (RayMarcher.cs:97-112) derives from ViewTransform / field of view / planes with
+ * System.Numerics; the shim computes them with the BCL and passes them in.  Images are
+ * FloatData.Values / Vec3Data.Values layout: pixel (column i, row j) at j*width + i, 3 floats
+ * per pixel for rgb.  sdfk_raymarch fills host arrays (synchronous); sdfk_raymarch_device
+ * leaves the images in caller-owned device buffers, asynchronously on the library stream. */
+int sdfk_raymarch(const sdfk_program* p, int32_t width, int32_t height, const float camera_position[3],
+                  const float view_projection_inverse[16], float near_plane, float far_plane,
+                  int32_t depth_iterations, float* depth, float* rgb);
+int sdfk_raymarch_device(const sdfk_program* p, int32_t width, int32_t height, const float camera_position[3],
+                         const float view_projection_inverse[16], float near_plane, float far_plane,
+                         int32_t depth_iterations, void* depth_dev, void* rgb_dev);
+
 /* ---- Mesh (Mesh.cs:8-64) ----------------------------------------------------
  * Vertices/Colors/Normals: 3 floats each per vertex; Triangles: int32 indices
  * (Mesh.cs:10-13).  Vertices/Normals are already transformed to world space

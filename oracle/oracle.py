@@ -27,7 +27,7 @@ class _Node(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libsdfk_oracle.so")
-    srcs = [os.path.join(_HERE, n) for n in ("sdfk_oracle.c", "sdfk_oracle.h", "lewiner_luts.h")]
+    srcs = [os.path.join(_HERE, n) for n in ("sdfk_oracle.c", "sdfk_oracle_ray.c", "sdfk_oracle.h", "lewiner_luts.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libsdfk_oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -63,6 +63,14 @@ def lib():
         L.orc_resolve_tiling.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_resolve_tiling.restype = C.c_int
         L.orc_hardware_threads.restype = C.c_int
+        L.orc_mat_look_at.argtypes = [fp, fp, fp, fp]
+        L.orc_mat_perspective_fov.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, fp]
+        L.orc_mat_mul.argtypes = [fp, fp, fp]
+        L.orc_mat_invert.argtypes = [fp, fp]
+        L.orc_mat_invert.restype = C.c_int
+        L.orc_ray_camera.argtypes = [fp, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]
+        L.orc_raymarch.argtypes = [C.POINTER(_Node), C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, C.c_float, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -220,3 +228,35 @@ def resolve_tiling(v8):
 
 def hardware_threads():
     return lib().orc_hardware_threads()
+
+
+# ---- RayMarcher (RayMarcher.cs:45-211) -------------------------------------------------
+def _f16(m):
+    return (C.c_float * 16)(*[float(np.float32(x)) for x in np.asarray(m, np.float32).ravel()])
+
+
+def look_at(pos, target, up):
+    """Matrix4x4.CreateLookAt, row-major 4x4 float32."""
+    out = (C.c_float * 16)()
+    lib().orc_mat_look_at(_f3(pos), _f3(target), _f3(up), out)
+    return np.array(out[:], np.float32).reshape(4, 4)
+
+
+def ray_camera(view, fov_degrees, width, height, near, far):
+    """Host part of RayMarcher.GetCameraRays: (camera position, inverse view-projection)."""
+    cam, vpi = (C.c_float * 3)(), (C.c_float * 16)()
+    lib().orc_ray_camera(_f16(view), fov_degrees, width, height, near, far, cam, vpi)
+    return np.array(cam[:], np.float32), np.array(vpi[:], np.float32).reshape(4, 4)
+
+
+def raymarch(scene, width, height, view=None, fov_degrees=60.0, near=1.0, far=100.0, iterations=40,
+             want_depth=True, want_rgb=True, threads=0):
+    """RayMarcher.RenderDepth / Render.  Returns (depth [h, w] or None, rgb [h, w, 3] or None)."""
+    if view is None:
+        view = look_at((0, 0, 5), (0, 0, 0), (0, 1, 0))   # RayMarcher.cs:22-23
+    cam, vpi = ray_camera(view, fov_degrees, width, height, near, far)
+    depth = np.empty((height, width), np.float32) if want_depth else None
+    rgb = np.empty((height, width, 3), np.float32) if want_rgb else None
+    lib().orc_raymarch(scene.carray(), scene.root, width, height, _f3(cam), _f16(vpi), near, far, iterations,
+                       depth.ctypes.data if want_depth else None, rgb.ctypes.data if want_rgb else None, threads)
+    return depth, rgb

@@ -111,6 +111,16 @@ void orc_mesh_free(orc_mesh*);
 int orc_resolve_tiling(const double v[8], int* lut_offset, int* nt); /* returns case index */
 
 int orc_hardware_threads(void);
+
+/* ---- RayMarcher (sdfk_oracle_ray.c: pinning status in its header) --- */
+void orc_mat_look_at(const float pos[3], const float target[3], const float up[3], float m[16]);
+void orc_mat_perspective_fov(float fov, float aspect, float nearp, float farp, float m[16]);
+void orc_mat_mul(const float a[16], const float b[16], float out[16]);
+int orc_mat_invert(const float m[16], float out[16]);
+void orc_ray_camera(const float view[16], float fov_degrees, int width, int height, float nearp, float farp,
+                    float cam_pos[3], float vp_inverse[16]);
+void orc_raymarch(const osc_node* nodes, int root, int width, int height, const float cam_pos[3],
+                  const float vp_inverse[16], float nearp, float farp, int iters, float* depth, float* rgb, int threads);
 #ifdef __cplusplus
 }
 #endif

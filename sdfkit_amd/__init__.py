@@ -6,6 +6,7 @@ MarchingCubes.CreateMesh hot path behind the reference's Sdf / Voxels / Mesh API
 """
 from .api import (DefaultBatchSize, MarchingCubes, Mesh, Sdf, SdfExprs, SdfFunc, SdfFuncs, Sdfs, Voxels)
 from .expr import MathF, Mod, VMax, Vec3, Vec4
+from .raymarch import FloatData, Matrix4x4, RayMarcher, Vec3Data
 
 __all__ = ["DefaultBatchSize", "MarchingCubes", "Mesh", "Sdf", "SdfExprs", "SdfFunc", "SdfFuncs", "Sdfs",
-           "Voxels", "MathF", "Mod", "VMax", "Vec3", "Vec4"]
+           "Voxels", "MathF", "Mod", "VMax", "Vec3", "Vec4", "FloatData", "Matrix4x4", "RayMarcher", "Vec3Data"]

@@ -68,6 +68,8 @@ SIGNATURES = {
     "sdfk_mesh_free": (None, [_vp]),
     "sdfk_profile_enable": (C.c_int, [_i32]),
     "sdfk_profile_reset": (C.c_int, []),
+    "sdfk_raymarch": (C.c_int, [_vp, _i32, _i32, _fp, _fp, C.c_float, C.c_float, _i32, _vp, _vp]),
+    "sdfk_raymarch_device": (C.c_int, [_vp, _i32, _i32, _fp, _fp, C.c_float, C.c_float, _i32, _vp, _vp]),
     "sdfk_profile_count": (C.c_int, []),
     "sdfk_profile_get": (C.c_int, [_i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),
 }

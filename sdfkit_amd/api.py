@@ -85,6 +85,11 @@ class Sdf:
         v._sample(self, clip=clipToBounds)
         return v
 
+    def ToImage(self, width, height, *camera, **kw):
+        """SdfEx.ToImage (Sdf.cs:65-99): camera = viewTransform, or position, target, up."""
+        from .raymarch import to_image
+        return to_image(self, width, height, *camera, **kw)
+
     def ToMesh(self, min, max, nx, ny, nz, batchSize=DefaultBatchSize, maxDegreeOfParallelism=-1,
                clipToBounds=True, isoValue=0.0, step=1, progress=None):
         """SdfEx.ToMesh (Sdf.cs:59-63): device-resident sample -> mesh."""

@@ -19,6 +19,7 @@
     int clip; float outside; int nzu; int row_stride; unsigned char* bits8; int nx8; float iso;
 
 struct SampleArgs { SDFK_SAMPLE_ARGS_BODY };
+struct RayArgs { float* depth; float* rgb; float cam[3]; float m[16]; int width, height; float nearp, farp; int iters; };
 
 namespace sdfk {
 
@@ -197,6 +198,76 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A
         o[0] = make_float4(c0, c1, c2, c3);
         o[1] = make_float4(c4, c5, c6, c7);
     }
+}
+
+// RayMarcher.RenderDepth / Render (RayMarcher.cs:45-95, 134-169): sphere tracing, one lane per
+// pixel.  The reference runs every step as a whole-image batch operation (VectorData.cs); per
+// pixel that is the same float32 arithmetic, reproduced op for op (mul then add, never fused;
+// Vector3.Normalize = v / length for the rays, NormalizeInplace = v * (1 / length) for the
+// shading vectors).  The camera position and the inverse view-projection are derived by the
+// caller from ViewTransform (GetCameraRays, RayMarcher.cs:97-112).
+struct RayArgs { float* depth; float* rgb; float cam[3]; float m[16]; int width, height; float nearp, farp; int iters; };
+
+__device__ __forceinline__ float sdfk_scene_w(float x, float y, float z, float& r, float& g, float& b)
+{
+    float w;
+    sdf_eval(x, y, z, r, g, b, w);
+    return w;
+}
+
+__device__ __forceinline__ void sdfk_normalize_inplace(float& x, float& y, float& z)   // VectorData.cs:490-508
+{
+    const float len = __builtin_sqrtf((x * x + y * y) + z * z);
+    if (len > 0.0f) {
+        const float r = 1.0f / len;
+        x = x * r; y = y * r; z = z * r;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
+{
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (long)A.width * A.height) return;
+    const int j = (int)(k / A.width), i = (int)(k - (long)j * A.width);
+    // GetCameraRays, RayMarcher.cs:113-128
+    const float y = 1.0f - 2.0f * (float)j / (float)(A.height - 1);
+    const float x = -1.0f + 2.0f * (float)i / (float)(A.width - 1);
+    float v4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v4[q] = ((x * A.m[q] + y * A.m[4 + q]) + 0.0f * A.m[8 + q]) + 1.0f * A.m[12 + q];
+    const float dx = v4[0] / v4[3] - A.cam[0], dy = v4[1] / v4[3] - A.cam[1], dz = v4[2] / v4[3] - A.cam[2];
+    const float dl = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float rx = dx / dl, ry = dy / dl, rz = dz / dl;
+    float depth = A.nearp - 0.1f;
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    for (int it = 0; it < A.iters; it++) {
+        const float w = sdfk_scene_w(rx * depth + A.cam[0], ry * depth + A.cam[1], rz * depth + A.cam[2], cr, cg, cb);
+        depth = depth + w;
+    }
+    if (A.depth) A.depth[k] = depth;
+    if (!A.rgb) return;
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+    if (A.iters > 0) { d0 = 0.0f + cr; d1 = 0.0f + cg; d2 = 0.0f + cb; }
+    const float sx = A.cam[0] + rx * depth, sy = A.cam[1] + ry * depth, sz = A.cam[2] + rz * depth;
+    const float go = 1e-5f;
+    float t0, t1, t2;
+    const float wpx = sdfk_scene_w(sx + go * 1.0f, sy + go * 0.0f, sz + go * 0.0f, t0, t1, t2);
+    const float wpy = sdfk_scene_w(sx + go * 0.0f, sy + go * 1.0f, sz + go * 0.0f, t0, t1, t2);
+    const float wpz = sdfk_scene_w(sx + go * 0.0f, sy + go * 0.0f, sz + go * 1.0f, t0, t1, t2);
+    const float wnx = sdfk_scene_w(sx + -go * 1.0f, sy + -go * 0.0f, sz + -go * 0.0f, t0, t1, t2);
+    const float wny = sdfk_scene_w(sx + -go * 0.0f, sy + -go * 1.0f, sz + -go * 0.0f, t0, t1, t2);
+    const float wnz = sdfk_scene_w(sx + -go * 0.0f, sy + -go * 0.0f, sz + -go * 1.0f, t0, t1, t2);
+    float nx = wpx - wnx, ny = wpy - wny, nz = wpz - wnz;
+    sdfk_normalize_inplace(nx, ny, nz);
+    float lx = 5.0f - sx, ly = 5.0f - sy, lz = 10.0f - sz;
+    sdfk_normalize_inplace(lx, ly, lz);
+    const float dv = sdfk_max_ieee((nx * lx + ny * ly) + nz * lz, 0.0f);
+    const float bgm = depth > A.farp ? 1.0f : 0.0f;
+    const float fgm = bgm == 0.0f ? 1.0f : 0.0f;
+    float* o = A.rgb + 3 * k;
+    o[0] = 0.0f + ((dv * d0 + 0.1f) * fgm + bgm * 0.5f);
+    o[1] = 0.0f + ((dv * d1 + 0.1f) * fgm + bgm * 0.75f);
+    o[2] = 0.0f + ((dv * d2 + 0.1f) * fgm + bgm * 1.0f);
 }
 
 // same, one voxel per lane-iteration (nz not a multiple of 4)

@@ -241,6 +241,7 @@ struct sdfk_program {
     hipFunction_t fn_bits_clip = nullptr;
     hipFunction_t fn_scalar = nullptr;
     hipFunction_t fn_corners = nullptr;
+    hipFunction_t fn_raymarch = nullptr;
     int writes_color = 0;
     int refs = 1;   // the caller's handle + volumes it has sampled + queued jobs that launch from its module
 };
@@ -473,6 +474,7 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_vec4, p->module, "sdfk_sample_vec4");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_scalar, p->module, "sdfk_sample_scalar");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_corners, p->module, "sdfk_corners_eval");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_raymarch, p->module, "sdfk_raymarch");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip, p->module, "sdfk_sample_bits_clip");
     if (e != hipSuccess) {
@@ -1349,6 +1351,64 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     if (!r) r = sdfk_march(v, iso_value, step, out);
     if (!r && (*out)->pending && (*out)->src == v) (*out)->owns_src = true;   // freed when the mesh is resolved
     else sdfk_volume_free(v);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// RayMarcher
+// ---------------------------------------------------------------------------
+static int raymarch_launch(const sdfk_program* p, int32_t width, int32_t height, const float cam[3], const float vpi[16],
+                           float nearp, float farp, int32_t iters, float* depth_dev, float* rgb_dev)
+{
+    RayArgs A;
+    memset(&A, 0, sizeof A);
+    A.depth = depth_dev; A.rgb = rgb_dev;
+    memcpy(A.cam, cam, sizeof A.cam);
+    memcpy(A.m, vpi, sizeof A.m);
+    A.width = width; A.height = height; A.nearp = nearp; A.farp = farp; A.iters = iters;
+    void* params[] = {&A};
+    const size_t n = (size_t)width * height;
+    ProfScope ps("sdfk_raymarch");
+    HIPCHK(hipModuleLaunchKernel(p->fn_raymarch, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, g.stream, params, nullptr));
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_raymarch_device(const sdfk_program* p, int32_t width, int32_t height, const float camera_position[3],
+                                    const float view_projection_inverse[16], float near_plane, float far_plane,
+                                    int32_t depth_iterations, void* depth_dev, void* rgb_dev)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !camera_position || !view_projection_inverse) return fail(SDFK_ERR_INVALID, "sdfk_raymarch: null argument");
+    if (width < 1 || height < 1 || depth_iterations < 0 || (size_t)width * height > (size_t(1) << 31))
+        return fail(SDFK_ERR_INVALID, "sdfk_raymarch: bad image size %d x %d or iteration count %d", width, height, depth_iterations);
+    if (int r = require_init()) return r;
+    if (!depth_dev && !rgb_dev) return SDFK_OK;
+    return raymarch_launch(p, width, height, camera_position, view_projection_inverse, near_plane, far_plane, depth_iterations,
+                           (float*)depth_dev, (float*)rgb_dev);
+}
+
+extern "C" int sdfk_raymarch(const sdfk_program* p, int32_t width, int32_t height, const float camera_position[3],
+                             const float view_projection_inverse[16], float near_plane, float far_plane,
+                             int32_t depth_iterations, float* depth, float* rgb)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !camera_position || !view_projection_inverse) return fail(SDFK_ERR_INVALID, "sdfk_raymarch: null argument");
+    if (width < 1 || height < 1 || depth_iterations < 0 || (size_t)width * height > (size_t(1) << 31))
+        return fail(SDFK_ERR_INVALID, "sdfk_raymarch: bad image size %d x %d or iteration count %d", width, height, depth_iterations);
+    if (int r = require_init()) return r;
+    if (!depth && !rgb) return SDFK_OK;
+    const size_t n = (size_t)width * height;
+    float* d = nullptr;
+    float* c = nullptr;
+    int r = SDFK_OK;
+    if (depth) r = dev_alloc((void**)&d, n * sizeof(float));
+    if (!r && rgb) r = dev_alloc((void**)&c, n * 3 * sizeof(float));
+    if (!r) r = raymarch_launch(p, width, height, camera_position, view_projection_inverse, near_plane, far_plane, depth_iterations, d, c);
+    if (!r && depth && hipMemcpyAsync(depth, d, n * sizeof(float), hipMemcpyDeviceToHost, g.stream) != hipSuccess) r = fail(SDFK_ERR_HIP, "copy of the depth image failed");
+    if (!r && rgb && hipMemcpyAsync(rgb, c, n * 3 * sizeof(float), hipMemcpyDeviceToHost, g.stream) != hipSuccess) r = fail(SDFK_ERR_HIP, "copy of the colour image failed");
+    if (hipStreamSynchronize(g.stream) != hipSuccess && !r) r = fail(SDFK_ERR_HIP, "hipStreamSynchronize failed");
+    dev_free(d);
+    dev_free(c);
     return r;
 }
 
