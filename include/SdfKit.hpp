@@ -408,4 +408,105 @@ inline Mesh Sdf::ToMesh(Vector3 min, Vector3 max, int nx, int ny, int nz, int, i
     return Mesh::FromHandle(m);
 }
 
+// ---------------------------------------------------------------------------------------
+// RayMarcher (RayMarcher.cs) + the image containers it returns (VectorData.cs)
+// ---------------------------------------------------------------------------------------
+// The members of System.Numerics.Matrix4x4 the RayMarcher uses, software float32 forms
+// (row-major M[r][c] = M(r+1)(c+1)); compile with -ffp-contract=off.
+struct Matrix4x4 {
+    float M[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    static Vector3 Normalize(Vector3 v) { const float l = std::sqrt((v.X * v.X + v.Y * v.Y) + v.Z * v.Z); return {v.X / l, v.Y / l, v.Z / l}; }
+    static Vector3 Cross(Vector3 a, Vector3 b) { return {a.Y * b.Z - a.Z * b.Y, a.Z * b.X - a.X * b.Z, a.X * b.Y - a.Y * b.X}; }
+    static float Dot(Vector3 a, Vector3 b) { return (a.X * b.X + a.Y * b.Y) + a.Z * b.Z; }
+    static Matrix4x4 CreateLookAt(Vector3 pos, Vector3 target, Vector3 up)
+    {
+        const Vector3 z = Normalize(pos - target), x = Normalize(Cross(up, z)), y = Cross(z, x);
+        Matrix4x4 r;
+        const float m[4][4] = {{x.X, y.X, z.X, 0}, {x.Y, y.Y, z.Y, 0}, {x.Z, y.Z, z.Z, 0}, {-Dot(x, pos), -Dot(y, pos), -Dot(z, pos), 1}};
+        std::memcpy(r.M, m, sizeof m);
+        return r;
+    }
+    static Matrix4x4 CreatePerspectiveFieldOfView(float fov, float aspect, float nearp, float farp)
+    {
+        const float ys = 1.0f / std::tan(fov * 0.5f), xs = ys / aspect;
+        const float nfr = (std::isinf(farp) && farp > 0) ? -1.0f : farp / (nearp - farp);
+        Matrix4x4 r;
+        std::memset(r.M, 0, sizeof r.M);
+        r.M[0][0] = xs; r.M[1][1] = ys; r.M[2][2] = nfr; r.M[2][3] = -1.0f; r.M[3][2] = nearp * nfr;
+        return r;
+    }
+    friend Matrix4x4 operator*(const Matrix4x4& a, const Matrix4x4& b)
+    {
+        Matrix4x4 r;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++)
+                r.M[i][j] = ((a.M[i][0] * b.M[0][j] + a.M[i][1] * b.M[1][j]) + a.M[i][2] * b.M[2][j]) + a.M[i][3] * b.M[3][j];
+        return r;
+    }
+    static bool Invert(const Matrix4x4& s, Matrix4x4& out)
+    {
+        const float a = s.M[0][0], b = s.M[0][1], c = s.M[0][2], d = s.M[0][3], e = s.M[1][0], f = s.M[1][1], g = s.M[1][2], h = s.M[1][3];
+        const float i = s.M[2][0], j = s.M[2][1], k = s.M[2][2], l = s.M[2][3], m = s.M[3][0], n = s.M[3][1], o = s.M[3][2], p = s.M[3][3];
+        const float kp_lo = k * p - l * o, jp_ln = j * p - l * n, jo_kn = j * o - k * n, ip_lm = i * p - l * m, io_km = i * o - k * m, in_jm = i * n - j * m;
+        const float a11 = +(f * kp_lo - g * jp_ln + h * jo_kn), a12 = -(e * kp_lo - g * ip_lm + h * io_km);
+        const float a13 = +(e * jp_ln - f * ip_lm + h * in_jm), a14 = -(e * jo_kn - f * io_km + g * in_jm);
+        const float det = a * a11 + b * a12 + c * a13 + d * a14;
+        if (std::fabs(det) < 1.1920929e-07f) { for (auto& row : out.M) for (float& v : row) v = NAN; return false; }
+        const float inv = 1.0f / det;
+        float (*R)[4] = out.M;
+        R[0][0] = a11 * inv; R[1][0] = a12 * inv; R[2][0] = a13 * inv; R[3][0] = a14 * inv;
+        R[0][1] = -(b * kp_lo - c * jp_ln + d * jo_kn) * inv; R[1][1] = +(a * kp_lo - c * ip_lm + d * io_km) * inv;
+        R[2][1] = -(a * jp_ln - b * ip_lm + d * in_jm) * inv; R[3][1] = +(a * jo_kn - b * io_km + c * in_jm) * inv;
+        const float gp_ho = g * p - h * o, fp_hn = f * p - h * n, fo_gn = f * o - g * n, ep_hm = e * p - h * m, eo_gm = e * o - g * m, en_fm = e * n - f * m;
+        R[0][2] = +(b * gp_ho - c * fp_hn + d * fo_gn) * inv; R[1][2] = -(a * gp_ho - c * ep_hm + d * eo_gm) * inv;
+        R[2][2] = +(a * fp_hn - b * ep_hm + d * en_fm) * inv; R[3][2] = -(a * fo_gn - b * eo_gm + c * en_fm) * inv;
+        const float gl_hk = g * l - h * k, fl_hj = f * l - h * j, fk_gj = f * k - g * j, el_hi = e * l - h * i, ek_gi = e * k - g * i, ej_fi = e * j - f * i;
+        R[0][3] = -(b * gl_hk - c * fl_hj + d * fk_gj) * inv; R[1][3] = +(a * gl_hk - c * el_hi + d * ek_gi) * inv;
+        R[2][3] = -(a * fl_hj - b * el_hi + d * ej_fi) * inv; R[3][3] = +(a * fk_gj - b * ek_gi + c * ej_fi) * inv;
+        return true;
+    }
+};
+
+struct FloatData {   // VectorData.cs:137-280; indexer is (x, y)
+    int Width = 0, Height = 0;
+    std::vector<float> Values;
+    float operator()(int x, int y) const { return Values[(size_t)y * Width + x]; }
+};
+struct Vec3Data {    // VectorData.cs:343-620
+    int Width = 0, Height = 0;
+    std::vector<float> Values;   // 3 per pixel
+    Vector3 operator()(int x, int y) const { const float* p = &Values[((size_t)y * Width + x) * 3]; return {p[0], p[1], p[2]}; }
+};
+
+class RayMarcher {   // RayMarcher.cs:7-43: same constructor, properties and defaults
+public:
+    static constexpr float DefaultNearPlaneDistance = 1.0f, DefaultFarPlaneDistance = 100.0f, DefaultVerticalFieldOfViewDegrees = 60.0f;
+    static constexpr int DefaultDepthIterations = 40;
+    Matrix4x4 ViewTransform = Matrix4x4::CreateLookAt(Vector3(0, 0, 5), Vector3(0, 0, 0), Vector3(0, 1, 0));
+    float NearPlaneDistance = DefaultNearPlaneDistance, FarPlaneDistance = DefaultFarPlaneDistance;
+    float VerticalFieldOfViewDegrees = DefaultVerticalFieldOfViewDegrees;
+    int DepthIterations = DefaultDepthIterations;
+    RayMarcher(int width, int height, Sdf sdf, int /*batchSize*/ = 2048, int /*maxDegreeOfParallelism*/ = -1) : w_(width), h_(height), sdf_(std::move(sdf)) {}
+    Vec3Data Render() const { Vec3Data d; d.Width = w_; d.Height = h_; d.Values.resize((size_t)w_ * h_ * 3); Run(nullptr, d.Values.data()); return d; }
+    FloatData RenderDepth() const { FloatData d; d.Width = w_; d.Height = h_; d.Values.resize((size_t)w_ * h_); Run(d.Values.data(), nullptr); return d; }
+
+private:
+    void Run(float* depth, float* rgb) const
+    {
+        // host part of GetCameraRays (RayMarcher.cs:97-112)
+        Matrix4x4 cam, vpi;
+        Matrix4x4::Invert(ViewTransform, cam);
+        const float pos[3] = {((0.0f * cam.M[0][0] + 0.0f * cam.M[1][0]) + 0.0f * cam.M[2][0]) + cam.M[3][0],
+                              ((0.0f * cam.M[0][1] + 0.0f * cam.M[1][1]) + 0.0f * cam.M[2][1]) + cam.M[3][1],
+                              ((0.0f * cam.M[0][2] + 0.0f * cam.M[1][2]) + 0.0f * cam.M[2][2]) + cam.M[3][2]};
+        const Matrix4x4 proj = Matrix4x4::CreatePerspectiveFieldOfView(VerticalFieldOfViewDegrees * 3.14159274f / 180.0f, (float)w_ / (float)h_,
+                                                                       NearPlaneDistance, FarPlaneDistance);
+        Matrix4x4::Invert(ViewTransform * proj, vpi);
+        EnsureInit();
+        Check(sdfk_raymarch(sdf_.Program(), w_, h_, pos, &vpi.M[0][0], NearPlaneDistance, FarPlaneDistance, DepthIterations, depth, rgb));
+    }
+    int w_, h_;
+    Sdf sdf_;
+};
+
 }  // namespace SdfKit

@@ -160,8 +160,58 @@ TEST(ReadmeSceneRepeatXY)   // README.md:24-30 scene through the expression API,
     for (auto& c : mesh.Colors) { if (!(c.X >= 0.9f - 0.5f - 1e-5f && c.X <= 0.9f + 1e-5f)) { IS_TRUE(false); break; } }
 }
 
+TEST(RayMarcherSphereDepth)   // RayMarcherTests.cs:10-24
+{
+    const int w = 50, h = 30;
+    RayMarcher rt(w, h, Sdfs::Sphere(1.0f));
+    auto img = rt.RenderDepth();
+    ARE_EQUAL(w, img.Width);
+    ARE_EQUAL(h, img.Height);
+    ARE_EQUAL_TOL(4.0f, img(w / 2, h / 2), 1.0e-2f);
+    IS_TRUE(img(0, 0) > 9.0f);
+}
+
+TEST(RayMarcherBoxDepth)   // RayMarcherTests.cs:27-41
+{
+    const int w = 50, h = 30;
+    auto img = RayMarcher(w, h, Sdfs::Box(1.0f)).RenderDepth();
+    ARE_EQUAL_TOL(4.0f, img(w / 2, h / 2), 1.0e-2f);
+    IS_TRUE(img(0, 0) > 9.0f);
+}
+
+TEST(RayMarcherCylinderDepth)   // RayMarcherTests.cs:44-62
+{
+    const int w = 50, h = 30;
+    const float r = 0.25f;
+    auto img = RayMarcher(w, h, SdfExprs::Cylinder(r, r * 2).RepeatX(4 * r).ToSdf()).RenderDepth();
+    ARE_EQUAL_TOL(5 - r, img(w / 2, h / 2 - 2), 1.0e-1f);
+    IS_TRUE(img(0, 0) > 9.0f);
+}
+
+TEST(RayMarcherPlaneDepth)   // RayMarcherTests.cs:65-78
+{
+    const int w = 50, h = 30;
+    auto img = RayMarcher(w, h, Sdfs::PlaneXY()).RenderDepth();
+    ARE_EQUAL_TOL(5.0f, img(w / 2, h / 2), 1.0e-2f);
+    IS_TRUE(img(0, 0) < 9.0f);
+}
+
+TEST(RayMarcherSphereRepeat)   // RayMarcherTests.cs:96-108 (192 x 108, camera (-2,2,4) -> origin)
+{
+    const float r = 0.5f;
+    auto sdf = SdfExprs::Sphere(r).RepeatXY(2.25f * r, 2.25f * r, [](Vec3 i, Vec3, Vec4) { return Val(0.9f) * Vec3(Vector3::One()) - Vec3::Abs(i) / Val(6.0f); }).ToSdf();
+    RayMarcher rm(192, 108, sdf);
+    rm.ViewTransform = Matrix4x4::CreateLookAt(Vector3(-2, 2, 4), Vector3(0, 0, 0), Vector3(0, 1, 0));
+    auto img = rm.Render();
+    ARE_EQUAL(192, img.Width);
+    ARE_EQUAL(108, img.Height);
+    const Vector3 c = img(96, 54);
+    IS_TRUE(c.X > 0.1f && c.X <= 1.0f);
+}
+
 int main()
 {
+    run_RayMarcherSphereDepth(); run_RayMarcherBoxDepth(); run_RayMarcherCylinderDepth(); run_RayMarcherPlaneDepth(); run_RayMarcherSphereRepeat();
     run_ColoredSpheres(); run_Sphere5(); run_Sphere10(); run_UnclippedSphere10(); run_ClippedSphere10(); run_Box10();
     run_Cylinder50(); run_Sphere128Progress(); run_CreateVolumeSphere(); run_CreateMeshSphere(); run_SolidSphere();
     run_EmptyVolumeDims(); run_SphereCenterValue(); run_ReadmeSceneRepeatXY();
