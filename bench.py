@@ -138,11 +138,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # SDFK_BENCH_ONE_GPU=1 (testing only): every rank uses GPU 0 and the exchange goes over gloo --
+    # lets the whole multi-rank path run on a single-GPU box (RCCL refuses two ranks on one device)
+    one_gpu = os.environ.get("SDFK_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     N.init(local_rank)
     L = N.lib()
     stream = torch.cuda.current_stream()
