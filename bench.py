@@ -260,6 +260,34 @@ def main():
     prof = N.profile_snapshot()
     kern = {k: {"avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "launches": v[1]} for k, v in prof.items() if v[1]}
 
+    # context figures, outside the timed region, rank 0 only: what this box
+    # reaches with a plain device fill / copy, and one step including the mesh copy to the host
+    extra = {}
+    if rank == 0:
+        x = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        y = torch.empty_like(x)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        x.fill_(1); y.copy_(x)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            x.fill_(0)
+        e1.record()
+        for _ in range(10):
+            y.copy_(x)
+        e2.record()
+        torch.cuda.synchronize()
+        extra["hbm_measured"] = {"fill_gbs": round(x.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1),
+                                 "copy_gbs_read_plus_write": round(2 * x.numel() * 10 / (e1.elapsed_time(e2) * 1e-3) / 1e9, 1),
+                                 "what": "torch fill_ / copy_ of 512 MiB, 10 launches each"}
+        del x, y
+        if world == 1 and not force_dist:
+            from sdfkit_amd.api import Mesh
+            t1 = time.perf_counter()
+            m = C.c_void_p()
+            N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+            Mesh._from_handle(m)   # counts + the four arrays into host memory + bounds
+            extra["one_step_incl_mesh_d2h_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
     if rank == 0:
         nvox_rank = n * n * (D.slab_planes(*D.slab_layers(n - 1, world, rank), n)[1] if world > 1 else n)
         colors = bool(sdf.writes_color)
@@ -303,6 +331,7 @@ def main():
             "kernels_us": kern,
             "roofline": roof,
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_n)
         print(json.dumps(out), flush=True)
