@@ -124,3 +124,58 @@ CATALOGUE = {
     "union8": union8,
     "sdf_with_color": sdf_with_color,
 }
+
+
+def random_scene(seed, depth=3):
+    """A random composition of the per-point catalogue (SdfExprs primitives, Translate, RepeatX /
+    RepeatY / RepeatXY, RepeatXY with the README colour lambda, WithColor, Union), built twice --
+    oracle graph and product program -- from the same draws.  Parameters are dyadic-ish float32
+    values so that both sides see exactly the same constants."""
+    rng = np.random.default_rng(seed)
+    s = O.Scene()
+
+    def f(lo, hi):
+        return float(np.float32(rng.integers(int(lo * 16), int(hi * 16) + 1) / 16.0))
+
+    def prim():
+        k = int(rng.integers(0, 3))
+        col = (f(0, 1), f(0, 1), f(0, 1))
+        if k == 0:
+            r = f(0.25, 0.75)
+            return s.f_sphere(r, col), SdfExprs.Sphere(r, col)
+        if k == 1:
+            b = f(0.25, 0.625)
+            return s.f_box(b), SdfExprs.Box(b)
+        r, h = f(0.25, 0.5), f(0.25, 0.75)
+        return s.f_cylinder(r, h, col), SdfExprs.Cylinder(r, h, col)
+
+    def node(d):
+        if d == 0:
+            return prim()
+        k = int(rng.integers(0, 7))
+        if k == 0:
+            a, pa = node(d - 1)
+            b, pb = node(d - 1)
+            return s.f_union(a, b), SdfExprs.Union(pa, pb)
+        c, pc = node(d - 1)
+        if k == 1:
+            t = (f(-1.5, 1.5), f(-1.5, 1.5), f(-1.5, 1.5))
+            return s.f_translate(c, *t), pc.Translate(*t)
+        if k == 2:
+            sx = f(0.75, 2.0)
+            return s.f_repeat_x(c, sx), pc.RepeatX(sx)
+        if k == 3:
+            sy = f(0.75, 2.0)
+            return s.f_repeat_y(c, sy), pc.RepeatY(sy)
+        if k == 4:
+            sx, sy = f(0.75, 2.0), f(0.75, 2.0)
+            return s.f_repeat_xy(c, sx, sy), pc.RepeatXY(sx, sy)
+        if k == 5:
+            sx, sy = f(0.75, 2.0), f(0.75, 2.0)
+            return s.f_repeat_xy_idx(c, sx, sy, O.CF_README), pc.RepeatXY(sx, sy, _readme_color)
+        col = (f(0, 1), f(0, 1), f(0, 1))
+        return s.f_with_color(c, *col), pc.WithColor(*col)
+
+    root, prod = node(depth)
+    s.root = root
+    return s, prod.ToSdf()

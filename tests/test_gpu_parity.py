@@ -434,3 +434,20 @@ def test_slab_one_call_pack_and_rebase(gpu, world):
             assert np.array_equal(bmin, whole.Min) and np.array_equal(bmax, whole.Max)
     finally:
         N.check(N.lib().sdfk_set_stream(None))
+
+
+# ---------------------------------------------------------------------------
+# random compositions of the SDF catalogue: lowering + JIT against the oracle's interpreter
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scene_compositions(gpu, seed):
+    scene, sdf = S.random_scene(seed, depth=3 + seed % 2)
+    mn, mx, dims = [-2.8125, -2.5, -2.25], [2.8125, 2.75, 2.5], (28, 24, 32)
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    O.clip_to_bounds(ov, mn, mx)
+    v = sdf.ToVoxels(mn, mx, *dims)
+    assert np.array_equal(v.Values, ov, equal_nan=True), f"seed {seed}: values differ"
+    assert np.array_equal(v.Colors, oc, equal_nan=True), f"seed {seed}: colours differ"
+    om = O.march(ov, oc, mn, mx)
+    assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), om)
+    assert_mesh_equal(MarchingCubes.CreateMesh(v), om)
