@@ -43,50 +43,16 @@ static const char* const kSampleKernels = R"SRC(
 // Voxels.SampleSdf (Voxels.cs:72-125): sample point of voxel (ix,iy,iz) is
 //   p = (min + 0.5*D) + (float)i * D   per axis (Voxels.cs:81,104-106),
 // value -> Values[ix,iy,iz] (z fastest), colour -> Colors[ix,iy,iz].
-// blockDim = (TZ, TR): TZ lanes walk z (4 voxels each, one 16-byte store), TR rows per
-// workgroup; rows (ix*ny+iy) are contiguous in memory so a wave stores >= 1 KiB contiguous.
-extern "C" __global__ __launch_bounds__(256) void sdfk_sample_vec4(SampleArgs A)
-{
-    const int tz = blockDim.x, tr = blockDim.y;
-    long row = (long)blockIdx.x * tr + threadIdx.y;
-    const long nrows = (long)A.nx * A.ny;
-    if (row >= nrows) return;
-    int ix = (int)(row / A.ny), iy = (int)(row % A.ny);
-    const int sq = A.row_stride / A.ny, sr = A.row_stride % A.ny;
-    for (; row < nrows; row += A.row_stride) {
-        const float px = A.mx + (float)ix * A.dx;
-        const float py = A.my + (float)iy * A.dy;
-        const bool edge_xy = (ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1);
-        float* vrow = A.values + row * A.nz;
-        for (int u = threadIdx.x; u < A.nzu; u += tz) {
-            const int z = 4 * u;
-            float w[4], r[4], g[4], b[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int zg = A.z0 + z + k;
-                const float pz = A.mz + (float)zg * A.dz;
-                sdf_eval(px, py, pz, r[k], g[k], b[k], w[k]);
-                if (A.clip && (edge_xy || zg == 0 || zg == A.nz_global - 1)) w[k] = A.outside;
-            }
-            *reinterpret_cast<float4*>(vrow + z) = make_float4(w[0], w[1], w[2], w[3]);
-            if (A.colors) {
-                float4* c = reinterpret_cast<float4*>(A.colors + (row * A.nz + z) * 3);
-                c[0] = make_float4(r[0], g[0], b[0], r[1]);
-                c[1] = make_float4(g[1], b[1], r[2], g[2]);
-                c[2] = make_float4(b[2], r[3], g[3], b[3]);
-            }
-        }
-        ix += sq; iy += sr;
-        if (iy >= A.ny) { iy -= A.ny; ix++; }
-    }
-}
-
+//
 // Fused form (nz % 4 == 0): sampling AND the marching-cubes sign bits in one pass over the grid.
-// A workgroup = 8 wavefronts = 8 consecutive x rows x 256 z of one y.  Every lane evaluates 4
-// consecutive z and issues exactly ONE 16-byte nontemporal store (1 KiB contiguous per
-// wavefront): the shape that reaches the plain-fill store rate of the MI355X -- more stores per
-// lane, or other workgroup sizes, measurably lose bandwidth (tools/ubench/ub_store.hip).
-// Sign bits (value > iso): each lane leaves a nibble in LDS; wavefront 0 turns the 8 rows'
+// A workgroup owns 8 consecutive x rows x 256 z of one y: 8 / RPW wavefronts, RPW rows each
+// (default RPW = 2: 256 lanes).  A lane evaluates 4 consecutive z of a row and issues one 16-byte
+// nontemporal store for it (1 KiB contiguous per wavefront instruction).  Few stores per lane
+// and 4..8-wavefront workgroups are what reaches the plain-fill store rate of the MI355X
+// (tools/ubench/ub_store.hip: one store per lane 80 us, two 83 us, sixteen 100+ us for 512 MiB);
+// two rows per lane halve the per-lane address / coordinate arithmetic, which matters once the
+// SDF itself costs some ALU (sphere: 112 us with RPW = 1, 98 us with RPW = 2).
+// Sign bits (value > iso): each lane leaves a nibble per row in LDS; wavefront 0 turns the 8 rows'
 // nibbles into 4 bytes per lane (bit r of byte k = row r at z + k) and stores 256 contiguous
 // bytes of bits8[y][x/8][z].  k_bits_transpose (mc_kernels.hip) regroups those bytes into the
 // X-packed words the marching-cubes classifier reads; the volume is never re-read densely.

@@ -236,7 +236,6 @@ int grid_for(size_t work_items, int per_block = 256, int max_blocks = 256 * 8)
 struct sdfk_program {
     std::string source;
     hipModule_t module = nullptr;
-    hipFunction_t fn_vec4 = nullptr;
     hipFunction_t fn_bits = nullptr;
     hipFunction_t fn_bits_clip = nullptr;
     hipFunction_t fn_scalar = nullptr;
@@ -471,7 +470,6 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     p->source = src;
     p->writes_color = writes_color;
     hipError_t e = hipModuleLoadData(&p->module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_vec4, p->module, "sdfk_sample_vec4");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_scalar, p->module, "sdfk_sample_scalar");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_corners, p->module, "sdfk_corners_eval");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_raymarch, p->module, "sdfk_raymarch");
