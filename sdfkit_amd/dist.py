@@ -248,8 +248,9 @@ class SlabSession:
     A step, per rank, is queued without waiting for the GPU: sample + mesh the slab with
     slab-local ids (buffers sized from the previous step), pack a self-describing payload ON THE
     DEVICE (header = counts + bounds, written from the job's own counters), ONE padded all-gather
-    over RCCL, one kernel that rebases the gathered indices from the headers, and an asynchronous
-    copy of the `world` headers to pinned host memory.  `submit()` queues a step into the next of
+    over RCCL -- launched asynchronously, so that it travels while the NEXT step's kernels run --
+    one kernel that rebases the gathered indices from the headers, and an asynchronous copy of
+    the `world` headers to pinned host memory.  `submit()` queues a step into the next of
     `depth` slots (own slab volume, send and gather buffers each); `collect()` waits for the
     OLDEST queued step only, reads its headers and returns this rank's counts -- so with
     depth > 1 the host never idles the GPU or the links between steps.  `step()` = submit +
@@ -294,6 +295,8 @@ class SlabSession:
         self.gathered_slots = [None] * self.depth
         self.hdr_host = [None] * self.depth
         self.ready = [None] * self.depth
+        self.work = [None] * self.depth
+        self.unfinished = None   # slot whose all-gather has been launched but not yet waited for / rebased
         self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
         self.queue = []          # slots in submission order
         self.next_slot = 0
@@ -301,14 +304,40 @@ class SlabSession:
         self.redone = 0          # steps that had to be redone on the exact path
 
     # -- helpers ----------------------------------------------------------------
-    def _all_gather(self, slot):
+    def _start_gather(self, slot):
+        """Launch the all-gather of a slot WITHOUT making the compute stream wait for it: the
+        next step's kernels are queued behind the pack of this one, not behind its exchange."""
         import torch.distributed as dist
         g, b = self.gathered_slots[slot], self.buf[slot]
         if dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(g.view(-1), b, group=self.group)
+            self.work[slot] = dist.all_gather_into_tensor(g.view(-1), b, group=self.group, async_op=True)
         else:
-            dist.all_gather([g[r] for r in range(self.world)], b, group=self.group)
-        self.rebase(g, self.world, self.stride)
+            self.work[slot] = dist.all_gather([g[r] for r in range(self.world)], b, group=self.group, async_op=True)
+        self.unfinished = slot
+
+    def _finish_gather(self, slot=None):
+        """Second half of an exchange (default: the newest one): the compute stream waits for it,
+        indices are rebased, the headers start their way to the host."""
+        if slot is None:
+            slot = self.unfinished
+        if slot is None or self.work[slot] is None:
+            return
+        if self.unfinished == slot:
+            self.unfinished = None
+        self.work[slot].wait()
+        self.work[slot] = None
+        self.rebase(self.gathered_slots[slot], self.world, self.stride)
+        if self.on_gpu:
+            import torch
+            cur = torch.cuda.current_stream(self.device)
+            done = torch.cuda.Event()
+            done.record(cur)
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(done)
+                self.hdr_host[slot].copy_(self.gathered_slots[slot][:, :SLAB_HEADER_BYTES], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self.ready[slot] = ev
 
     def _agree_stride(self, need):
         import torch
@@ -326,6 +355,7 @@ class SlabSession:
 
     def _exact_step(self, slot):
         """Synchronous, exact form of a step (first step, and the redo of a failed one)."""
+        self._finish_gather()
         w = self.workers[slot]
         nv, ni = w.run_local()
         need = SLAB_HEADER_BYTES + 36 * nv + 4 * ni
@@ -334,7 +364,8 @@ class SlabSession:
         if need > self.stride:
             raise RuntimeError(f"slab payload grew to {need} B (> agreed stride {self.stride} B)")
         w.pack_self_describing(self.buf[slot])
-        self._all_gather(slot)
+        self._start_gather(slot)
+        self._finish_gather()
         return nv, ni
 
     def _headers(self, slot):
@@ -349,8 +380,7 @@ class SlabSession:
 
     # -- pipeline ---------------------------------------------------------------
     def submit(self):
-        """Queue one step into the next slot (collect()s the oldest one first when all slots are taken)."""
-        import torch
+        """Queue one step into the next slot."""
         if len(self.queue) == self.depth:
             raise RuntimeError("all slots are in flight: collect() first")
         slot = self.next_slot
@@ -359,24 +389,19 @@ class SlabSession:
             counts = self._exact_step(slot)        # bootstrap: sizes, stride, hints
             self.queue.append((slot, counts))
             return
+        # compute of this step first, then the second half of the PREVIOUS step's exchange: the
+        # all-gather of step i travels while the kernels of step i+1 run
         self.workers[slot].enqueue(self.buf[slot])
-        self._all_gather(slot)
-        if self.on_gpu:
-            cur = torch.cuda.current_stream(self.device)
-            done = torch.cuda.Event()
-            done.record(cur)
-            with torch.cuda.stream(self.copy_stream):
-                self.copy_stream.wait_event(done)
-                self.hdr_host[slot].copy_(self.gathered_slots[slot][:, :SLAB_HEADER_BYTES], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.copy_stream)
-            self.ready[slot] = ev
+        prev = self.unfinished
+        self._start_gather(slot)
+        self._finish_gather(prev)
         self.queue.append((slot, None))
 
     def collect(self):
         """Wait for the oldest queued step; returns this rank's (n_vertices, n_indices)."""
         slot, counts = self.queue.pop(0)
         if counts is None:
+            self._finish_gather(slot)
             hdr = self._headers(slot)
             if (hdr < 0).any():                     # some rank's guess was too small: everybody redoes the step
                 self.redone += 1
