@@ -74,6 +74,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
     __shared__ unsigned char nib[8][64];
+    __shared__ __attribute__((aligned(16))) float cbuf[8 / RPW][768];   // colour staging, one slice per wavefront
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iy = blockIdx.y, x8 = blockIdx.z;
     const int z = blockIdx.x * 256 + 4 * lane;
@@ -104,15 +105,34 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             }
             const long o = ((long)ix * A.ny + iy) * A.nz + z;
             sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
-            if (A.colors) {   // 48 contiguous bytes per lane: plain stores (nontemporal ones are far slower here)
-                float4* c = reinterpret_cast<float4*>(A.colors + o * 3);
-                c[0] = make_float4(cr[0], cg[0], cb[0], cr[1]);
-                c[1] = make_float4(cg[1], cb[1], cr[2], cg[2]);
-                c[2] = make_float4(cb[2], cr[3], cg[3], cb[3]);
+            if (A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
+                sdfk_f4* mine = reinterpret_cast<sdfk_f4*>(cbuf[wave] + 12 * lane);
+                mine[0] = sdfk_f4{cr[0], cg[0], cb[0], cr[1]};
+                mine[1] = sdfk_f4{cg[1], cb[1], cr[2], cg[2]};
+                mine[2] = sdfk_f4{cb[2], cr[3], cg[3], cb[3]};
             }
             n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
         }
         nib[r][lane] = (unsigned char)n;
+        if (A.colors && ix < A.nx) {
+            // A lane produced 48 contiguous bytes (4 voxels x rgb) of the wavefront's 3 KiB run.
+            // Stored as they are, every instruction would touch a third of every line; through
+            // the LDS slice they become three full 1 KiB nontemporal stores (lane L writes
+            // floats 4 L .. 4 L + 3 of each KiB) -- ALL lanes store, also those whose own
+            // voxels lie beyond nz: what they store belongs to the lanes before them.
+            const int z0 = blockIdx.x * 256;
+            const int run = (A.nz - z0 < 256 ? A.nz - z0 : 256) * 3;   // floats of the run that exist (nz % 4 == 0)
+            __builtin_amdgcn_wave_barrier();
+            const float* cw = cbuf[wave];
+            const sdfk_f4 t0 = *reinterpret_cast<const sdfk_f4*>(cw + 4 * lane);
+            const sdfk_f4 t1 = *reinterpret_cast<const sdfk_f4*>(cw + 256 + 4 * lane);
+            const sdfk_f4 t2 = *reinterpret_cast<const sdfk_f4*>(cw + 512 + 4 * lane);
+            __builtin_amdgcn_wave_barrier();
+            float* c = A.colors + (((long)ix * A.ny + iy) * A.nz + z0) * 3;
+            if (4 * lane + 3 < run) sdfk_store4_nt(c + 4 * lane, t0.x, t0.y, t0.z, t0.w);
+            if (256 + 4 * lane + 3 < run) sdfk_store4_nt(c + 256 + 4 * lane, t1.x, t1.y, t1.z, t1.w);
+            if (512 + 4 * lane + 3 < run) sdfk_store4_nt(c + 512 + 4 * lane, t2.x, t2.y, t2.z, t2.w);
+        }
     }
     __syncthreads();
     if (wave == 0 && zok) {
