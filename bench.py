@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="grid edge")
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=512, help="grid edge (--grid under torch.distributed.run, whose own parser claims --n)")
     ap.add_argument("--scene", default="sphere", choices=["sphere", "repeatxy", "union8"])
     ap.add_argument("--cpu-n", type=int, default=256, help="grid edge of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")

@@ -71,6 +71,19 @@ void sdfk_shutdown(void);
 int sdfk_set_stream(void* hip_stream);
 /* Waits for everything the library has queued (the caller's stream and the internal ones). */
 int sdfk_synchronize(void);
+/* Lane sections.  The calls made between sdfk_lane_begin(lane, ...) and sdfk_lane_end(...) are
+ * queued on internal stream `lane` (1..4) instead of the caller's stream, buffers they allocate
+ * come from that lane's pool: independent call sequences issued in sections of different lanes
+ * overlap on the GPU (what sdfk_sample_march does by itself; a sharded step -- sample a slab,
+ * mesh it, pack it -- is such a sequence too).  begin: the lane first waits for
+ * `wait_hip_event` (a hipEvent_t the caller recorded, or NULL) -- e.g. "the collective that read
+ * this section's output buffer last time has finished".  end(1): the caller's stream waits for
+ * everything the section queued, so work the caller queues next (a collective on the packed
+ * buffer) sees its results.  Objects created inside a section are used inside sections of the
+ * same lane, or after one of their accessors has returned (that waits on the host).  One
+ * section at a time per process. */
+int sdfk_lane_begin(int32_t lane, void* wait_hip_event);
+int sdfk_lane_end(int32_t caller_stream_waits);
 const char* sdfk_last_error(void);
 
 /* out_rgbw = value ids of (colour.X, colour.Y, colour.Z, distance W) -- the Vector4 the
@@ -171,6 +184,10 @@ int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_
  * all-gather of sdfk_mesh_pack buffers with slab-local indices): adds to the indices of slab r
  * the vertex counts of slabs 0..r-1, in one launch, reading the counts from the headers. */
 int sdfk_slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes);
+/* Same, and the `world` 64-byte headers are also written to `headers_mirror`: device-accessible
+ * (pinned, mapped) HOST memory, so that the host can read the counts after waiting for one event
+ * on the stream, without a copy of its own. */
+int sdfk_slabs_rebase_mirror(void* gathered, int32_t world, int64_t stride_bytes, void* headers_mirror);
 
 /* ---- RayMarcher (RayMarcher.cs:45-211) ---------------------------------------
  * RenderDepth (depth != NULL) and / or Render (rgb != NULL) of the program's SDF by sphere

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sdfk_sample_march_slab": (C.c_int, [_vp, _vp, _i32, _f, _i32, _i32, _i64, _vpp]),
     "sdfk_mesh_pack": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "sdfk_slabs_rebase": (C.c_int, [_vp, _i32, _i64]),
+    "sdfk_slabs_rebase_mirror": (C.c_int, [_vp, _i32, _i64, _vp]),
     "sdfk_mesh_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_mesh_bounds": (C.c_int, [_vp, _fp, _fp]),
     "sdfk_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -68,6 +69,8 @@ SIGNATURES = {
     "sdfk_mesh_free": (None, [_vp]),
     "sdfk_profile_enable": (C.c_int, [_i32]),
     "sdfk_profile_reset": (C.c_int, []),
+    "sdfk_lane_begin": (C.c_int, [_i32, _vp]),
+    "sdfk_lane_end": (C.c_int, [_i32]),
     "sdfk_raymarch": (C.c_int, [_vp, _i32, _i32, _fp, _fp, C.c_float, C.c_float, _i32, _vp, _vp]),
     "sdfk_raymarch_device": (C.c_int, [_vp, _i32, _i32, _fp, _fp, C.c_float, C.c_float, _i32, _vp, _vp]),
     "sdfk_profile_count": (C.c_int, []),

@@ -1151,9 +1151,12 @@ __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
 
 // slab r of the gathered buffer: indices += sum of the vertex counts of slabs 0..r-1
 // (nothing is touched when a header is marked invalid: that step is redone by the host)
-__global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathered, int world, int64_t stride)
+__global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathered, int world, int64_t stride, SlabHeader* mirror)
 {
     const int r = blockIdx.y;
+    if (mirror && blockIdx.x == 0 && threadIdx.x < sizeof(SlabHeader) / 4)   // header r -> the host's (mapped) copy
+        reinterpret_cast<uint32_t*>(mirror + r)[threadIdx.x] =
+            reinterpret_cast<const uint32_t*>(gathered + (size_t)r * stride)[threadIdx.x];
     int64_t base = 0;
     for (int q = 0; q < world; q++) {
         const int64_t nvq = reinterpret_cast<const SlabHeader*>(gathered + (size_t)q * stride)->nv;

@@ -68,6 +68,7 @@ struct Context {
     static constexpr int NSIDE = 4;
     struct Lane { hipStream_t stream = nullptr; std::multimap<size_t, void*> free_blocks; };
     Lane lanes[1 + NSIDE];
+    hipEvent_t lane_done[1 + NSIDE] = {};   // reused by sdfk_lane_end
     int cur_lane = 0;
     int side_lanes = 2;         // SDFK_LANES=0 disables the side lanes (everything on lane 0)
     int next_side = 0;
@@ -398,6 +399,40 @@ extern "C" int sdfk_set_stream(void* hip_stream)
     g.user_stream = hip_stream ? (hipStream_t)hip_stream : g.own_stream;
     g.lanes[0].stream = g.user_stream;
     g.stream = g.lanes[g.cur_lane].stream;
+    return SDFK_OK;
+}
+
+// Lane sections: the calls between begin and end are queued on internal stream `lane`.
+extern "C" int sdfk_lane_begin(int32_t lane, void* wait_hip_event)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (int r = require_init()) return r;
+    if (lane < 1 || lane > Context::NSIDE) return fail(SDFK_ERR_INVALID, "sdfk_lane_begin: lane %d out of range 1..%d", lane, Context::NSIDE);
+    if (g.cur_lane != 0) return fail(SDFK_ERR_INVALID, "sdfk_lane_begin: already inside a lane section");
+    if (wait_hip_event) HIPCHK(hipStreamWaitEvent(g.lanes[lane].stream, (hipEvent_t)wait_hip_event, 0));
+    g.cur_lane = lane;
+    g.stream = g.lanes[lane].stream;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_lane_end(int32_t caller_stream_waits)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (int r = require_init()) return r;
+    if (g.cur_lane == 0) return fail(SDFK_ERR_INVALID, "sdfk_lane_end: not inside a lane section");
+    const int lane = g.cur_lane;
+    g.cur_lane = 0;
+    g.stream = g.lanes[0].stream;
+    if (caller_stream_waits) {
+        hipEvent_t ev = g.lane_done[lane];
+        if (!ev) {
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            g.lane_done[lane] = ev;
+        }
+        hipError_t e = hipEventRecord(ev, g.lanes[lane].stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(g.lanes[0].stream, ev, 0);
+        if (e != hipSuccess) return fail(SDFK_ERR_HIP, "sdfk_lane_end: %s", hipGetErrorString(e));
+    }
     return SDFK_OK;
 }
 
@@ -1255,7 +1290,7 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m || !dst) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: null argument");
     if (int r = require_init()) return r;
-    const_cast<sdfk_mesh*>(m)->used_on_main = true;
+    if (m->lane != g.cur_lane) const_cast<sdfk_mesh*>(m)->used_on_main = true;
     if (m->pending && !m->status) {
         // the job is still queued: the device packs from the job's own counters, the host is
         // not involved (needed_bytes is unknown here: -1; the header carries the counts)
@@ -1293,15 +1328,27 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
     return SDFK_OK;
 }
 
-extern "C" int sdfk_slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes)
+static int slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes, void* headers_mirror)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!gathered || world < 1 || stride_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_slabs_rebase: bad argument");
     if (int r = require_init()) return r;
-    if (world == 1) return SDFK_OK;
-    hipLaunchKernelGGL(k_slabs_rebase, dim3(64, world), dim3(256), 0, g.stream, (char*)gathered, (int)world, (int64_t)stride_bytes);
+    if (world == 1 && !headers_mirror) return SDFK_OK;
+    hipLaunchKernelGGL(k_slabs_rebase, dim3(64, world), dim3(256), 0, g.stream, (char*)gathered, (int)world, (int64_t)stride_bytes,
+                       (SlabHeader*)headers_mirror);
     HIPCHK(hipGetLastError());
     return SDFK_OK;
+}
+
+extern "C" int sdfk_slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes)
+{
+    return slabs_rebase(gathered, world, stride_bytes, nullptr);
+}
+
+extern "C" int sdfk_slabs_rebase_mirror(void* gathered, int32_t world, int64_t stride_bytes, void* headers_mirror)
+{
+    if (!headers_mirror) return fail(SDFK_ERR_INVALID, "sdfk_slabs_rebase_mirror: null mirror");
+    return slabs_rebase(gathered, world, stride_bytes, headers_mirror);
 }
 
 extern "C" int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32_t ny, int32_t nz,

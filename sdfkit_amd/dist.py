@@ -281,11 +281,15 @@ class SlabSession:
         if make_worker is None:
             def make_worker(slot):
                 return GpuSlabWorker(sdf, mn, mx, nx, ny, nz, self.rank, self.world, clip_to_bounds, iso)
+        self.mirror_headers = rebase is None and self.on_gpu   # product path: the rebase kernel also mirrors the headers to the host
         if rebase is None:
             from . import _native as N
 
-            def rebase(gathered, world, stride):
-                N.check(N.lib().sdfk_slabs_rebase(C.c_void_p(gathered.data_ptr()), world, stride))
+            def rebase(gathered, world, stride, mirror=None):
+                if mirror is not None:
+                    N.check(N.lib().sdfk_slabs_rebase_mirror(C.c_void_p(gathered.data_ptr()), world, stride, C.c_void_p(mirror.data_ptr())))
+                else:
+                    N.check(N.lib().sdfk_slabs_rebase(C.c_void_p(gathered.data_ptr()), world, stride))
         self.rebase = rebase
         self.depth = max(int(depth), 1)
         self.workers = [make_worker(k) for k in range(self.depth)]
@@ -296,6 +300,10 @@ class SlabSession:
         self.hdr_host = [None] * self.depth
         self.ready = [None] * self.depth
         self.work = [None] * self.depth
+        self.buf_free = [None] * self.depth
+        self.nsub = 0
+        import os
+        self.lanes = 2 if (self.mirror_headers and os.environ.get("SDFK_LANES", "2") != "0") else 0
         self.unfinished = None   # slot whose all-gather has been launched but not yet waited for / rebased
         self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
         self.queue = []          # slots in submission order
@@ -326,6 +334,15 @@ class SlabSession:
             self.unfinished = None
         self.work[slot].wait()
         self.work[slot] = None
+        if self.mirror_headers:
+            # the rebase kernel writes the headers straight into pinned host memory: one event, no
+            # copy; the same event says "this slot's send buffer has been read by the collective"
+            import torch
+            self.rebase(self.gathered_slots[slot], self.world, self.stride, self.hdr_host[slot])
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.ready[slot] = self.buf_free[slot] = ev
+            return
         self.rebase(self.gathered_slots[slot], self.world, self.stride)
         if self.on_gpu:
             import torch
@@ -391,7 +408,20 @@ class SlabSession:
             return
         # compute of this step first, then the second half of the PREVIOUS step's exchange: the
         # all-gather of step i travels while the kernels of step i+1 run
-        self.workers[slot].enqueue(self.buf[slot])
+        if self.lanes:
+            # the step's kernels go to an internal stream of the library (alternating between two):
+            # the launch-latency-bound kernel chains of consecutive steps overlap on the GPU.  The
+            # lane only waits for the collective that read this slot's send buffer last time.
+            from . import _native as N
+            ev = self.buf_free[slot]
+            self.nsub += 1   # (lanes alternate per step, not per slot: consecutive steps never share one)
+            N.check(N.lib().sdfk_lane_begin(1 + self.nsub % self.lanes, C.c_void_p(ev.cuda_event) if ev is not None else None))
+            try:
+                self.workers[slot].enqueue(self.buf[slot])
+            finally:
+                N.check(N.lib().sdfk_lane_end(1))
+        else:
+            self.workers[slot].enqueue(self.buf[slot])
         prev = self.unfinished
         self._start_gather(slot)
         self._finish_gather(prev)
