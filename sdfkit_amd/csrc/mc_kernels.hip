@@ -1076,17 +1076,48 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 // ---------------------------------------------------------------------------
 // auxiliary volume kernels
 // ---------------------------------------------------------------------------
-// Voxels.ClipToBounds, Voxels.cs:133-167 (all six faces get Size.X/NX)
+// Voxels.ClipToBounds, Voxels.cs:133-167 (all six faces get Size.X/NX): one lane per element of
+// the largest face, two opposite faces per axis (the z faces only where the slab holds them).
 __global__ __launch_bounds__(256) void k_clip(float* __restrict__ values, int nx, int ny, int nz, int z0, int nz_global, float outside)
 {
-    const size_t n = (size_t)nx * ny * nz;
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
-        const int z = (int)(i % nz);
-        const size_t t = i / nz;
-        const int y = (int)(t % ny);
-        const int x = (int)(t / ny);
-        const int zg = z + z0;
-        if (x == 0 || y == 0 || zg == 0 || x == nx - 1 || y == ny - 1 || zg == nz_global - 1) values[i] = outside;
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const size_t sx = (size_t)ny * nz;
+    if (i < (size_t)ny * nz) {                      // x = 0 and x = nx-1: (y, z) = i, contiguous
+        values[i] = outside;
+        values[(size_t)(nx - 1) * sx + i] = outside;
+    }
+    if (i < (size_t)nx * nz) {                      // y = 0 and y = ny-1
+        const size_t x = i / nz, z = i % nz;
+        values[x * sx + z] = outside;
+        values[x * sx + (size_t)(ny - 1) * nz + z] = outside;
+    }
+    if (i < (size_t)nx * ny) {                      // global z = 0 and z = nz_global-1
+        if (z0 == 0) values[i * nz] = outside;
+        if (z0 + nz == nz_global) values[i * nz + (nz - 1)] = outside;
+    }
+}
+
+// The same on the cached sign bits (bits[z][y][xw]): boundary voxels all become `bit`
+// (= outside > iso); one lane per (z, y) row.  Bits of x >= nx stay 0.
+__global__ __launch_bounds__(256) void k_clip_bits(uint64_t* __restrict__ bits, int nx, int ny, int nz, int z0, int nz_global, int nxw, int bit)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)nz * ny) return;
+    const int z = (int)(i / ny), y = (int)(i % ny), zg = z + z0;
+    uint64_t* row = bits + i * nxw;
+    const int last = nxw - 1, lastbit = (nx - 1) & 63;
+    const uint64_t lastvalid = lastbit == 63 ? ~0ull : ((1ull << (lastbit + 1)) - 1ull);
+    if (y == 0 || y == ny - 1 || zg == 0 || zg == nz_global - 1) {
+        for (int w = 0; w < nxw; w++) row[w] = bit ? (w == last ? lastvalid : ~0ull) : 0ull;
+    } else {
+        uint64_t w0 = row[0];
+        w0 = bit ? (w0 | 1ull) : (w0 & ~1ull);
+        if (last == 0) w0 = bit ? (w0 | (1ull << lastbit)) : (w0 & ~(1ull << lastbit));
+        row[0] = w0;
+        if (last > 0) {
+            const uint64_t wl = row[last];
+            row[last] = bit ? (wl | (1ull << lastbit)) : (wl & ~(1ull << lastbit));
+        }
     }
 }
 

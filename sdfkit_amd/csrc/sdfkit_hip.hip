@@ -730,9 +730,17 @@ extern "C" int sdfk_volume_clip_to_bounds(sdfk_volume* v)
     float d[3], m[3], outside;
     grid_constants(v, d, m, &outside);
     resolve_dependents(v);
-    volume_values_changed(v);
+    // The clip rule is known: the cached views of the values are patched instead of dropped.
+    // Sign bits: the six faces become (outside > iso); the sampling program that produced the
+    // values (if any) is remembered with clip = 1, so re-evaluated cell corners see the same faces.
+    const size_t face = std::max({(size_t)v->ny * v->nz, (size_t)v->nx * v->nz, (size_t)v->nx * v->ny});
     ProfScope ps("k_clip");
-    hipLaunchKernelGGL(k_clip, dim3(grid_for(v->nvox())), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->z0, v->nz_global, outside);
+    hipLaunchKernelGGL(k_clip, dim3((unsigned)((face + 255) / 256)), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->z0,
+                       v->nz_global, outside);
+    if (v->bits && v->bits_valid)
+        hipLaunchKernelGGL(k_clip_bits, dim3((unsigned)(((size_t)v->nz * v->ny + 255) / 256)), dim3(256), 0, g.stream, v->bits, v->nx, v->ny,
+                           v->nz, v->z0, v->nz_global, v->nxw(), outside > v->bits_iso ? 1 : 0);
+    if (v->sampled_by) v->sampled_args.clip = 1;
     HIPCHK(hipGetLastError());
     return SDFK_OK;
 }

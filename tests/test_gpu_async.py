@@ -210,3 +210,29 @@ def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
         assert np.array_equal(bmin, whole.Min) and np.array_equal(bmax, whole.Max)
     finally:
         N.check(L.sdfk_set_stream(None))
+
+
+@pytest.mark.parametrize("dims", [(32, 32, 32), (40, 12, 36), (65, 7, 8), (1, 9, 12), (70, 3, 4), (130, 5, 64)])
+@pytest.mark.parametrize("name", ["readme_repeat_xy", "sphere_w", "union8"])
+def test_explicit_clip_keeps_the_cached_views(gpu, name, dims):
+    """SampleSdf -> ClipToBounds() -> CreateMesh: the clip patches the cached sign bits and the
+    remembered sampling program instead of dropping them, so the mesh must still equal the
+    oracle's -- and no dense pass over the volume (k_signbits) or corner gather may run."""
+    scene, sdf = S.CATALOGUE[name]()
+    ov, oc = O.sample(scene, MN, MX, *dims)
+    O.clip_to_bounds(ov, MN, MX)
+    om = O.march(ov, oc, MN, MX)
+    L = N.lib()
+    vol = Voxels.SampleSdf(sdf, MN, MX, *dims)
+    vol.ClipToBounds()
+    N.check(L.sdfk_profile_reset())
+    N.check(L.sdfk_profile_enable(1))
+    m = MarchingCubes.CreateMesh(vol)
+    N.check(L.sdfk_profile_enable(0))
+    ran = set(N.profile_snapshot())
+    assert_mesh_equal(m, om)
+    assert np.array_equal(vol.Values, ov)
+    if dims[2] % 4 == 0 and min(dims) > 1:      # (the fused sampler needs nz % 4 == 0)
+        assert "k_signbits" not in ran and "k_gather_corners" not in ran, ran
+    m2 = MarchingCubes.CreateMesh(vol, 0.25)    # another iso value: bits are recomputed, corners still re-evaluated
+    assert_mesh_equal(m2, O.march(ov, oc, MN, MX, iso=0.25))
