@@ -377,9 +377,12 @@ extern "C" void sdfk_shutdown(void)
     for (auto& kv : g.live_blocks) (void)hipFree(kv.first);
     g.live_blocks.clear();
     for (int k = 1; k <= Context::NSIDE; k++) {
+        if (g.lane_done[k]) (void)hipEventDestroy(g.lane_done[k]);
+        g.lane_done[k] = nullptr;
         if (g.lanes[k].stream) (void)hipStreamDestroy(g.lanes[k].stream);
         g.lanes[k].stream = nullptr;
     }
+    g.cur_lane = 0;
     g.lanes[0].stream = nullptr;
     if (g.slots) (void)hipHostFree(g.slots);
     g.slots = nullptr;
