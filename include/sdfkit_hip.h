@@ -170,8 +170,9 @@ int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t cli
                            int32_t layer_begin, int32_t layer_end, int64_t vertex_base, sdfk_mesh** out);
 
 /* Self-describing slab payload for a single padded all-gather: 64-byte header
- * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; pad } followed by
- * Vertices | Colors | Normals (3 floats per vertex each) | Triangles (int32).  Written device
+ * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; int32 vertex_bytes; pad }
+ * followed by Vertices | Colors | Normals (3 floats per vertex each) | Triangles (int32).
+ * vertex_bytes = 36, or 24 when the volume had no colours: Colors (all zero) is then left out.  Written device
  * to device into `dst` (capacity_bytes); *needed_bytes = header + arrays.  If it does not fit,
  * only the header is written and SDFK_OK is still returned (the caller sees needed > capacity).
  * For a mesh whose job is still queued (deferred completion) nothing waits: the device packs

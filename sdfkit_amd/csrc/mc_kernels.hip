@@ -1122,16 +1122,17 @@ __global__ __launch_bounds__(256) void k_clip_bits(uint64_t* __restrict__ bits, 
 }
 
 // ---- Z-slab exchange helpers (sdfkit_amd/dist.py) ------------------------------------------
-struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; float pad[6]; };
+// vbytes = bytes per vertex in the payload: 36 (V, C, N) or 24 (V, N: colours are all zero and left out)
+struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; int32_t vbytes; float pad[5]; };
 static_assert(sizeof(SlabHeader) == 64, "SDFK_SLAB_HEADER_BYTES");
 
-__global__ void k_slab_header(SlabHeader* dst, int64_t nv, int64_t ni, const float* __restrict__ bounds)
+__global__ void k_slab_header(SlabHeader* dst, int64_t nv, int64_t ni, const float* __restrict__ bounds, int vbytes)
 {
     if (threadIdx.x == 0) {
         SlabHeader h;
-        h.nv = nv; h.ni = ni;
+        h.nv = nv; h.ni = ni; h.vbytes = vbytes;
         for (int k = 0; k < 3; k++) { h.bmin[k] = nv ? bounds[k] : 0.0f; h.bmax[k] = nv ? bounds[3 + k] : 0.0f; }
-        for (int k = 0; k < 6; k++) h.pad[k] = 0.0f;
+        for (int k = 0; k < 5; k++) h.pad[k] = 0.0f;
         *dst = h;
     }
 }
@@ -1151,6 +1152,7 @@ struct PackArgs {
     const float* bounds;          // device float[6], written by k_triangles
     char* dst;
     int64_t capacity;
+    int vbytes;                   // 36, or 24 = colours left out
 };
 
 __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
@@ -1161,21 +1163,22 @@ __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
     const int64_t nv = ok ? (int64_t)(c.total_v - c.nghost) : -1, ni = ok ? (int64_t)c.total_t * 3 : -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         SlabHeader h;
-        h.nv = nv; h.ni = ni;
+        h.nv = nv; h.ni = ni; h.vbytes = A.vbytes;
         for (int k = 0; k < 3; k++) { h.bmin[k] = nv > 0 ? A.bounds[k] : 0.0f; h.bmax[k] = nv > 0 ? A.bounds[3 + k] : 0.0f; }
-        for (int k = 0; k < 6; k++) h.pad[k] = 0.0f;
+        for (int k = 0; k < 5; k++) h.pad[k] = 0.0f;
         *reinterpret_cast<SlabHeader*>(A.dst) = h;
     }
-    if (!ok || (int64_t)sizeof(SlabHeader) + 36 * nv + 4 * ni > A.capacity) return;
-    // [V | C | N | T] as one run of 4-byte words
-    const int64_t nf = nv * 3, total = 3 * nf + ni;
+    if (!ok || (int64_t)sizeof(SlabHeader) + A.vbytes * nv + 4 * ni > A.capacity) return;
+    // [V | (C) | N | T] as one run of 4-byte words
+    const bool wc = A.vbytes == 36;
+    const int64_t nf = nv * 3, c0 = nf, n0 = wc ? 2 * nf : nf, t0 = n0 + nf, total = t0 + ni;
     uint32_t* out = reinterpret_cast<uint32_t*>(A.dst + sizeof(SlabHeader));
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         uint32_t w;
         if (i < nf) w = __float_as_uint(A.vertices[i]);
-        else if (i < 2 * nf) w = __float_as_uint(A.colors[i - nf]);
-        else if (i < 3 * nf) w = __float_as_uint(A.normals[i - 2 * nf]);
-        else w = (uint32_t)A.triangles[i - 3 * nf];
+        else if (i < n0) w = __float_as_uint(A.colors[i - c0]);
+        else if (i < t0) w = __float_as_uint(A.normals[i - n0]);
+        else w = (uint32_t)A.triangles[i - t0];
         out[i] = w;
     }
 }
@@ -1196,8 +1199,8 @@ __global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathere
     }
     if (r == 0 || base == 0) return;
     const SlabHeader* h = reinterpret_cast<const SlabHeader*>(gathered + (size_t)r * stride);
-    if ((int64_t)sizeof(SlabHeader) + 36 * h->nv + 4 * h->ni > stride) return;   // header-only payload
-    int32_t* t = reinterpret_cast<int32_t*>(gathered + (size_t)r * stride + sizeof(SlabHeader) + (size_t)h->nv * 36);
+    if ((int64_t)sizeof(SlabHeader) + h->vbytes * h->nv + 4 * h->ni > stride) return;   // header-only payload
+    int32_t* t = reinterpret_cast<int32_t*>(gathered + (size_t)r * stride + sizeof(SlabHeader) + (size_t)h->nv * h->vbytes);
     const int64_t n = h->ni;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) t[i] += (int32_t)base;
 }

@@ -293,6 +293,7 @@ struct sdfk_mesh {
     uint64_t key = 0;
     int status = 0;                     // sticky error of a failed resolution
     std::string error;
+    bool has_colors = true;             // false: the source volume had no colours (Colors are all zero)
     int lane = 0;                       // lane the buffers belong to
     bool used_on_main = false;          // lane-0 work (copies, packing, the caller) may still be reading them
 };
@@ -980,6 +981,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     McMeshOut M;
     memset(&M, 0, sizeof M);
     M.vertices = m->vertices; M.colors = m->colors; M.normals = m->normals; M.triangles = m->triangles;
+    m->has_colors = j->P.colors != nullptr;
     M.cap_vertices = (uint32_t)m->cap_v;
     M.cap_indices = m->cap_i;
     M.vertex_base = vertex_base;
@@ -1138,6 +1140,7 @@ int mesh_resolve(sdfk_mesh* m)
             m->bounds_valid = x->bounds_valid;
             m->n_active = x->n_active; m->n_case13 = x->n_case13;
             m->cap_v = x->cap_v; m->cap_i = x->cap_i;
+            m->has_colors = x->has_colors;
             delete x;
         }
     }
@@ -1315,6 +1318,7 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
         A.bounds = m->bounds;
         A.dst = (char*)dst;
         A.capacity = capacity_bytes;
+        A.vbytes = m->has_colors ? 36 : 24;
         if (m->lane != g.cur_lane) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: queued mesh belongs to another stream");
         ProfScope ps("k_pack");
         hipLaunchKernelGGL(k_pack_pending, dim3(grid_for(m->cap_v * 9 + m->cap_i, 256, 1024)), dim3(256), 0, g.stream, A);
@@ -1323,19 +1327,26 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
         return SDFK_OK;
     }
     if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
-    const int64_t vb = m->nv * 12, need = SDFK_SLAB_HEADER_BYTES + 3 * vb + m->ni * 4;
+    const int vbytes = m->has_colors ? 36 : 24;
+    const int64_t vb = m->nv * 12, need = SDFK_SLAB_HEADER_BYTES + (int64_t)vbytes * m->nv + m->ni * 4;
     if (needed_bytes) *needed_bytes = need;
     if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: capacity below the header size");
-    hipLaunchKernelGGL(k_slab_header, dim3(1), dim3(64), 0, g.stream, (SlabHeader*)dst, (int64_t)m->nv, (int64_t)m->ni, (const float*)m->bounds);
+    hipLaunchKernelGGL(k_slab_header, dim3(1), dim3(64), 0, g.stream, (SlabHeader*)dst, (int64_t)m->nv, (int64_t)m->ni,
+                       (const float*)m->bounds, vbytes);
     HIPCHK(hipGetLastError());
     if (need > capacity_bytes) return SDFK_OK;
     char* q = (char*)dst + SDFK_SLAB_HEADER_BYTES;
     if (vb) {
         HIPCHK(hipMemcpyAsync(q, m->vertices, vb, hipMemcpyDeviceToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(q + vb, m->colors, vb, hipMemcpyDeviceToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(q + 2 * vb, m->normals, vb, hipMemcpyDeviceToDevice, g.stream));
+        q += vb;
+        if (m->has_colors) {
+            HIPCHK(hipMemcpyAsync(q, m->colors, vb, hipMemcpyDeviceToDevice, g.stream));
+            q += vb;
+        }
+        HIPCHK(hipMemcpyAsync(q, m->normals, vb, hipMemcpyDeviceToDevice, g.stream));
+        q += vb;
     }
-    if (m->ni) HIPCHK(hipMemcpyAsync(q + 3 * vb, m->triangles, m->ni * 4, hipMemcpyDeviceToDevice, g.stream));
+    if (m->ni) HIPCHK(hipMemcpyAsync(q, m->triangles, m->ni * 4, hipMemcpyDeviceToDevice, g.stream));
     return SDFK_OK;
 }
 

@@ -64,6 +64,7 @@ class GpuSlabWorker:
         N.check(N.lib().sdfk_volume_create_slab(nx, ny, nz, N.f3(mn), N.f3(mx), self.z0, max(self.nzl, 1),
                                                 1 if sdf.writes_color else 0, C.byref(self.vol)))
         self.prog = sdf.program()
+        self.vertex_bytes = 36 if sdf.writes_color else 24   # payload bytes per vertex (sdfk_mesh_pack)
         self.job = None
         self.mesh = None
 
@@ -375,7 +376,7 @@ class SlabSession:
         self._finish_gather()
         w = self.workers[slot]
         nv, ni = w.run_local()
-        need = SLAB_HEADER_BYTES + 36 * nv + 4 * ni
+        need = SLAB_HEADER_BYTES + getattr(w, "vertex_bytes", 36) * nv + 4 * ni
         if self.stride is None:   # first step only (every rank takes this branch together)
             self._agree_stride(need)
         if need > self.stride:
@@ -437,7 +438,7 @@ class SlabSession:
                 self.redone += 1
                 counts = self._exact_step(slot)
             else:
-                need = SLAB_HEADER_BYTES + 36 * hdr[:, 0] + 4 * hdr[:, 1]
+                need = SLAB_HEADER_BYTES + getattr(self.workers[slot], "vertex_bytes", 36) * hdr[:, 0] + 4 * hdr[:, 1]
                 if int(need.max()) > self.stride:
                     raise RuntimeError(f"slab payload grew to {int(need.max())} B (> agreed stride {self.stride} B)")
                 counts = (int(hdr[self.rank, 0]), int(hdr[self.rank, 1]))
@@ -475,11 +476,18 @@ def unpack_self_describing(g):
     for row in g:
         nv, ni = (int(x) for x in row[:16].view(np.int64))
         b = row[16:40].view(np.float32)
+        vbytes = int(row[40:44].view(np.int32)[0])   # 36, or 24: colours (all zero) left out
         o, vb = SLAB_HEADER_BYTES, nv * 12
         V.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
-        Cc.append(row[o + vb:o + 2 * vb].view(np.float32).reshape(-1, 3))
-        Nn.append(row[o + 2 * vb:o + 3 * vb].view(np.float32).reshape(-1, 3))
-        T.append(row[o + 3 * vb:o + 3 * vb + 4 * ni].view(np.int32))
+        o += vb
+        if vbytes == 36:
+            Cc.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
+            o += vb
+        else:
+            Cc.append(np.zeros((nv, 3), np.float32))
+        Nn.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
+        o += vb
+        T.append(row[o:o + 4 * ni].view(np.int32))
         if nv:
             mins.append(b[0:3]); maxs.append(b[3:6])
     mn = np.min(np.stack(mins), axis=0) if mins else np.zeros(3, np.float32)

@@ -127,6 +127,7 @@ class FixtureSessionWorker:
         v = m.vertices[f.v0:f.v1]
         hdr = np.zeros(64, np.uint8)
         hdr[:16] = np.array([nv, ni], np.int64).view(np.uint8)
+        hdr[40:44] = np.array([36], np.int32).view(np.uint8)      # bytes per vertex: V, C, N
         if nv:
             hdr[16:28] = v.min(axis=0).astype(np.float32).view(np.uint8)
             hdr[28:40] = v.max(axis=0).astype(np.float32).view(np.uint8)
@@ -164,7 +165,7 @@ def _rebase_host(gathered, world, stride):
     base = 0
     for r in range(world):
         ni = int(g[r, 8:16].view(np.int64)[0])
-        o = 64 + 36 * nvs[r]
+        o = 64 + int(g[r, 40:44].view(np.int32)[0]) * nvs[r]
         if o + 4 * ni <= stride and base:
             g[r, o:o + 4 * ni].view(np.int32)[:] += base
         base += nvs[r]
