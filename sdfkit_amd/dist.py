@@ -257,8 +257,9 @@ class SlabSession:
     depth > 1 the host never idles the GPU or the links between steps.  `step()` = submit +
     collect (one step in flight).
 
-    The payload stride is agreed once, on the first step, with a count all-gather (+50 %
-    head-room); a later slab that outgrows it raises (use sharded_to_mesh for one-off meshes).
+    The payload stride is agreed once, on the first step, with a count all-gather (+12.5 %
+    head-room: the padding travels too); a later slab that outgrows it raises (make a new
+    session, or use sharded_to_mesh for one-off meshes).
     A step whose speculative buffers were too small on ANY rank is marked in that rank's
     header; every rank sees it after the gather and all of them redo that step on the exact
     (synchronising) path -- same decision everywhere, so the collectives stay matched.
@@ -364,7 +365,8 @@ class SlabSession:
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
         mx = max(int(x.item()) for x in out)
-        self.stride = ((mx + mx // 2 + 4096) + 255) // 256 * 256
+        # every rank sends `stride` bytes in every step, used or not: keep the head-room modest
+        self.stride = ((mx + mx // 8 + 4096) + 255) // 256 * 256
         for k in range(self.depth):
             self.buf[k] = torch.zeros(self.stride, dtype=torch.uint8, device=self.device)
             self.gathered_slots[k] = torch.zeros((self.world, self.stride), dtype=torch.uint8, device=self.device)
