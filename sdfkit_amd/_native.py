@@ -129,6 +129,23 @@ def init(device=None):
     return _inited_device
 
 
+def bind_torch_stream(device=None):
+    """Put torch and this library on ONE explicit stream and return it.
+
+    torch's default stream has the null handle, which sdfk_set_stream reads as "the library's own
+    stream" -- a non-blocking stream that nothing orders against the null stream.  Code that mixes
+    torch work (collectives, copies, events) with library calls must not rely on that pair: this
+    creates a stream (unless torch's current one is already a real one), makes it torch's current
+    stream and hands it to the library."""
+    import torch
+    s = torch.cuda.current_stream(device)
+    if s.cuda_stream == 0:
+        s = torch.cuda.Stream(device)
+        torch.cuda.set_stream(s)
+    check(lib().sdfk_set_stream(C.c_void_p(s.cuda_stream)))
+    return s
+
+
 def shutdown():
     global _inited_device
     if _lib is not None:

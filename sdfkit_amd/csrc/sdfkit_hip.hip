@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ... -lhiprtc
 // (see sdfkit_amd/build.py).  gfx950 only; there is no CPU path in this library.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
 
 #include <algorithm>
@@ -686,10 +687,23 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.nx8 = v->nx8();
         A.iso = iso_hint;
         {
-            ProfScope ps("sdfk_sample_bits");
-            HIPCHK(hipModuleLaunchKernel(clip_to_bounds ? p->fn_bits_clip : p->fn_bits, (unsigned)((v->nz + 255) / 256),
-                                         (unsigned)v->ny, (unsigned)v->nx8(), 512u / (unsigned)g_sample_rpw, 1, 1, 0, g.stream,
-                                         params, nullptr));
+            // The roofline kernel: when profiling is on, its start / stop events are attached to
+            // the dispatch itself (hipExtModuleLaunchKernel), so the measured span is the kernel's
+            // own execution -- an event pair recorded around a launch also contains the packet
+            // processing on either side (~10 us here) and any wait for the host to queue the launch.
+            const unsigned tpb = 512u / (unsigned)g_sample_rpw;
+            const unsigned gx = (unsigned)((v->nz + 255) / 256), gy = (unsigned)v->ny, gz = (unsigned)v->nx8();
+            hipFunction_t fn = clip_to_bounds ? p->fn_bits_clip : p->fn_bits;
+            if (g.prof_on) {
+                ProfSpan sp;
+                sp.name_id = prof_name_id("sdfk_sample_bits");
+                sp.a = prof_event();
+                sp.b = prof_event();
+                HIPCHK(hipExtModuleLaunchKernel(fn, gx * tpb, gy, gz, tpb, 1, 1, 0, g.stream, params, nullptr, sp.a, sp.b, 0));
+                g.prof_pending.push_back(sp);
+            } else {
+                HIPCHK(hipModuleLaunchKernel(fn, gx, gy, gz, tpb, 1, 1, 0, g.stream, params, nullptr));
+            }
         }
         {
             ProfScope ps("k_bits_transpose");

@@ -226,7 +226,7 @@ def sharded_to_mesh(sdf, mn, mx, nx, ny, nz, clip_to_bounds=True, iso=0.0, group
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = torch.device("cuda", torch.cuda.current_device())
     N.init(torch.cuda.current_device())
-    N.check(N.lib().sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    N.bind_torch_stream(dev)
     w = GpuSlabWorker(sdf, mn, mx, nx, ny, nz, rank, world, clip_to_bounds, iso)
     try:
         gathered, nvs, nis = sharded_step(w, group, dev)
@@ -284,6 +284,10 @@ class SlabSession:
             def make_worker(slot):
                 return GpuSlabWorker(sdf, mn, mx, nx, ny, nz, self.rank, self.world, clip_to_bounds, iso)
         self.mirror_headers = rebase is None and self.on_gpu   # product path: the rebase kernel also mirrors the headers to the host
+        if self.mirror_headers:
+            from . import _native as N
+            N.init(self.device.index if self.device.index is not None else None)
+            N.bind_torch_stream(self.device)   # the collectives must be ordered against the library's kernels
         if rebase is None:
             from . import _native as N
 

@@ -124,7 +124,7 @@ def test_queued_slabs_are_packed_by_the_device(gpu, world):
     dims = (44, 40, 48)
     whole = sdf.ToMesh(MN, MX, *dims)
     L = N.lib()
-    N.check(L.sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    N.bind_torch_stream()
     try:
         workers = [D.GpuSlabWorker(sdf, MN, MX, *dims, r, world, True, 0.0) for r in range(world)]
         counts = [w.run_local() for w in workers]                       # exact path: sets the hints
@@ -166,7 +166,9 @@ def test_queued_slabs_are_packed_by_the_device(gpu, world):
         for w in big_dims_workers:
             w.close()
     finally:
+        torch.cuda.synchronize()
         N.check(L.sdfk_set_stream(None))
+        torch.cuda.set_stream(torch.cuda.default_stream())
 
 
 def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
@@ -178,7 +180,7 @@ def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
     scene, sdf = S.CATALOGUE["union8"]()
     n, world = 1024, 8
     L = N.lib()
-    N.check(L.sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    N.bind_torch_stream()
     try:
         whole = sdf.ToMesh(MN, MX, n, n, n)
         nv, t = len(whole.Vertices), whole.Triangles
@@ -209,7 +211,9 @@ def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
         assert np.array_equal(Cc, whole.Colors) and np.array_equal(Nn, whole.Normals, equal_nan=True)
         assert np.array_equal(bmin, whole.Min) and np.array_equal(bmax, whole.Max)
     finally:
+        torch.cuda.synchronize()
         N.check(L.sdfk_set_stream(None))
+        torch.cuda.set_stream(torch.cuda.default_stream())
 
 
 @pytest.mark.parametrize("dims", [(32, 32, 32), (40, 12, 36), (65, 7, 8), (1, 9, 12), (70, 3, 4), (130, 5, 64)])

@@ -414,7 +414,7 @@ def test_slab_one_call_pack_and_rebase(gpu, world):
     scene, sdf = S.readme_repeat_xy()
     mn, mx, dims = [-2.8125] * 3, [2.8125] * 3, (44, 40, 48)
     whole = sdf.ToMesh(mn, mx, *dims)
-    N.check(N.lib().sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    N.bind_torch_stream()
     try:
         for _ in range(2):   # second round runs on the speculative (hinted) path
             workers = [D.GpuSlabWorker(sdf, mn, mx, *dims, r, world, True, 0.0) for r in range(world)]
@@ -433,7 +433,9 @@ def test_slab_one_call_pack_and_rebase(gpu, world):
             assert np.array_equal(Nn, whole.Normals, equal_nan=True)
             assert np.array_equal(bmin, whole.Min) and np.array_equal(bmax, whole.Max)
     finally:
+        torch.cuda.synchronize()
         N.check(N.lib().sdfk_set_stream(None))
+        torch.cuda.set_stream(torch.cuda.default_stream())
 
 
 # ---------------------------------------------------------------------------

@@ -24,7 +24,7 @@ pos, vpi = rm.camera()
 N.init()
 L = N.lib()
 rgb = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
-N.check(L.sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+N.bind_torch_stream()
 args = (sdf.program(), w, h, N.f3(pos), (C.c_float * 16)(*[float(x) for x in vpi.ravel()]), C.c_float(1.0), C.c_float(100.0), iters,
         None, C.c_void_p(rgb.data_ptr()))
 N.check(L.sdfk_raymarch_device(*args))

@@ -8,7 +8,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 torch.cuda.set_device(0); dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 N.init(0); L = N.lib()
-N.check(L.sdfk_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+N.bind_torch_stream()
 n = 64
 ses = D.SlabSession(Sdfs.Sphere(1.0), [-1.5]*3, [1.5]*3, n, n, n, False, 0.0, None, dev, depth=3)
 for _ in range(10):
