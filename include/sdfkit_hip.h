@@ -67,7 +67,11 @@ int sdfk_abi_version(void);
 /* Select HIP device `device` (ordinal) and create the library stream. Idempotent. */
 int sdfk_init(int device);
 void sdfk_shutdown(void);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+/* Run on a caller-owned hipStream_t; NULL = the library's own (non-blocking) stream.  NB: the
+ * legacy default stream IS the null handle (torch's default stream, for one): passing it selects
+ * the library's own stream, which nothing orders against the default stream -- callers that mix
+ * their own stream work with library calls create a real stream and pass that
+ * (sdfkit_amd/_native.py: bind_torch_stream). */
 int sdfk_set_stream(void* hip_stream);
 /* Waits for everything the library has queued (the caller's stream and the internal ones). */
 int sdfk_synchronize(void);
