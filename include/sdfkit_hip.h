@@ -231,7 +231,10 @@ int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case
 void sdfk_mesh_free(sdfk_mesh* m);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------
- * When enabled, every kernel launch is bracketed by hipEvents on the launch stream. */
+ * on = 1: every kernel launch is bracketed by hipEvents on the launch stream (sdfk_profile_get).
+ * on = 2: sdfk_sample launches the fused sampling kernel ONLY (no sign-bit transposition, cached
+ *         views left invalid), so that the caller can time K back-to-back launches of that one
+ *         kernel between two events of its own.  on = 0: normal operation. */
 int sdfk_profile_enable(int32_t on);
 int sdfk_profile_reset(void);
 /* number of distinct kernels recorded; fills name/total milliseconds/launch count */

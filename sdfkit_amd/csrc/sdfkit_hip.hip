@@ -3,7 +3,6 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ... -lhiprtc
 // (see sdfkit_amd/build.py).  gfx950 only; there is no CPU path in this library.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
 
 #include <algorithm>
@@ -77,6 +76,7 @@ struct Context {
     std::map<void*, Block> live_blocks;
     // profiling
     bool prof_on = false;
+    bool sampler_only = false;   // sdfk_profile_enable(2): sdfk_sample launches the fused sampling kernel only
     std::vector<std::string> prof_names;
     std::vector<double> prof_ms;
     std::vector<int64_t> prof_n;
@@ -687,23 +687,14 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.nx8 = v->nx8();
         A.iso = iso_hint;
         {
-            // The roofline kernel: when profiling is on, its start / stop events are attached to
-            // the dispatch itself (hipExtModuleLaunchKernel), so the measured span is the kernel's
-            // own execution -- an event pair recorded around a launch also contains the packet
-            // processing on either side (~10 us here) and any wait for the host to queue the launch.
             const unsigned tpb = 512u / (unsigned)g_sample_rpw;
-            const unsigned gx = (unsigned)((v->nz + 255) / 256), gy = (unsigned)v->ny, gz = (unsigned)v->nx8();
-            hipFunction_t fn = clip_to_bounds ? p->fn_bits_clip : p->fn_bits;
-            if (g.prof_on) {
-                ProfSpan sp;
-                sp.name_id = prof_name_id("sdfk_sample_bits");
-                sp.a = prof_event();
-                sp.b = prof_event();
-                HIPCHK(hipExtModuleLaunchKernel(fn, gx * tpb, gy, gz, tpb, 1, 1, 0, g.stream, params, nullptr, sp.a, sp.b, 0));
-                g.prof_pending.push_back(sp);
-            } else {
-                HIPCHK(hipModuleLaunchKernel(fn, gx, gy, gz, tpb, 1, 1, 0, g.stream, params, nullptr));
-            }
+            ProfScope ps("sdfk_sample_bits");
+            HIPCHK(hipModuleLaunchKernel(clip_to_bounds ? p->fn_bits_clip : p->fn_bits, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
+                                         (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
+        }
+        if (g.sampler_only) {   // measurement mode (sdfk_profile_enable(2)): the sampling kernel alone, back to back
+            v->bits_valid = false;
+            return SDFK_OK;
         }
         {
             ProfScope ps("k_bits_transpose");
@@ -1612,7 +1603,8 @@ extern "C" int sdfk_profile_enable(int32_t on)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (int r = require_init()) return r;
     if (!on) prof_drain();
-    g.prof_on = on != 0;
+    g.prof_on = on == 1;
+    g.sampler_only = on == 2;
     return SDFK_OK;
 }
 
