@@ -89,6 +89,12 @@ struct Context {
     HostSlot* slots = nullptr;      // host view
     HostSlot* slots_dev = nullptr;  // device view
     int slot_next = 0;
+    // A result slot belongs to ONE job from its creation until the job is released; a slot whose
+    // job was dropped with kernels still queued (an unread mesh was freed) is handed out again
+    // only after a full synchronisation (those kernels still write their counters into it).
+    struct SlotState { bool busy = false; uint64_t free_epoch = 0; };
+    SlotState slot_state[NSLOTS];
+    uint64_t epoch = 1;
     // sizes seen last time for a (shape, iso-independent) key: lets a repeat call launch the
     // whole pipeline speculatively and synchronise once
     struct Hint { uint32_t n_active, nv, ni; };
@@ -96,7 +102,6 @@ struct Context {
     // meshes returned by the speculative path whose kernels may still be queued (oldest first)
     std::deque<sdfk_mesh*> pending;
     static constexpr size_t MAX_PENDING = 6;
-    int jobs_since_sync = 0;   // bounds the queue depth when nobody ever reads a result
 };
 
 Context g;
@@ -312,7 +317,7 @@ struct sdfk_march_job {
     bool have_bits = false;
     sdfk_program* eval_prog = nullptr;   // corners by re-evaluation (holds a reference)
     SampleArgs eval_args;
-    int slot = 0;                  // index of the pinned result slot
+    int slot = -1;                 // index of the pinned result slot (owned until job_release)
     size_t rec_first = 0;          // first entry of `owned` that belongs to the record arrays
 };
 
@@ -321,7 +326,7 @@ int mesh_resolve(sdfk_mesh* m);
 void resolve_dependents(const sdfk_volume* v);
 void free_mesh_buffers(sdfk_mesh* m);
 void drop_source(sdfk_mesh* m);
-void job_release(sdfk_march_job* j);
+void job_release(sdfk_march_job* j, bool kernels_may_be_queued = false);
 void program_release(sdfk_program* p);
 void volume_values_changed(sdfk_volume* v);
 }
@@ -447,7 +452,7 @@ extern "C" int sdfk_synchronize(void)
     if (int r = require_init()) return r;
     HIPCHK(hipStreamSynchronize(g.stream));
     sync_all_lanes();
-    g.jobs_since_sync = 0;
+    g.epoch++;   // nothing is queued any more: dropped jobs' slots are reusable
     return SDFK_OK;
 }
 
@@ -769,8 +774,32 @@ int job_alloc(sdfk_march_job* j, T** p, size_t count)
     return SDFK_OK;
 }
 
-void job_release(sdfk_march_job* j)
+int acquire_slot()
 {
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = 0; i < Context::NSLOTS; i++) {
+            const int s = (g.slot_next + i) % Context::NSLOTS;
+            Context::SlotState& st = g.slot_state[s];
+            if (!st.busy && st.free_epoch < g.epoch) {
+                st.busy = true;
+                g.slot_next = (s + 1) % Context::NSLOTS;
+                memset(&g.slots[s], 0, sizeof(Context::HostSlot));
+                return s;
+            }
+        }
+        sync_all_lanes();   // every free slot is waiting for queued kernels of dropped jobs: drain them
+        g.epoch++;
+    }
+    return -1;
+}
+
+void job_release(sdfk_march_job* j, bool kernels_may_be_queued)
+{
+    if (j->slot >= 0) {
+        g.slot_state[j->slot].busy = false;
+        g.slot_state[j->slot].free_epoch = kernels_may_be_queued ? g.epoch : 0;
+        j->slot = -1;
+    }
     for (void* p : j->owned) dev_free(p);
     j->owned.clear();
     if (j->eval_prog) program_release(j->eval_prog);
@@ -863,7 +892,6 @@ int launch_classify(sdfk_march_job* j, bool publish)
 int wait_counters(sdfk_march_job* j)
 {
     HIPCHK(hipStreamSynchronize(g.stream));
-    if (g.cur_lane == 0 && g.side_lanes == 0) g.jobs_since_sync = 0;
     j->c = g.slots[j->slot].c;
     return SDFK_OK;
 }
@@ -881,13 +909,8 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     j->gnx = v->nx; j->gny = v->ny; j->gnz = v->nz_global;
     memcpy(j->gmin, v->gmin, sizeof j->gmin);
     memcpy(j->gmax, v->gmax, sizeof j->gmax);
-    if (++g.jobs_since_sync >= Context::NSLOTS / 2) {   // a result slot is never reused while its job may still run
-        sync_all_lanes();
-        g.jobs_since_sync = 0;
-    }
-    j->slot = g.slot_next;
-    g.slot_next = (g.slot_next + 1) % Context::NSLOTS;
-    memset(&g.slots[j->slot], 0, sizeof(Context::HostSlot));
+    j->slot = acquire_slot();
+    if (j->slot < 0) { delete j; return fail(SDFK_ERR_NOMEM, "more than %d marching-cubes jobs are alive", Context::NSLOTS); }
     const sdfk_volume* w = v;
     if (step > 1) {
         // MarchingCubes.cs:49-80 touches only voxels at multiples of step
@@ -1576,7 +1599,7 @@ extern "C" void sdfk_mesh_free(sdfk_mesh* m)
     if (m->pending) {   // never read: drop the queued job's workspace (stream-ordered, no wait)
         for (auto it = g.pending.begin(); it != g.pending.end(); ++it)
             if (*it == m) { g.pending.erase(it); break; }
-        job_release(m->pending);
+        job_release(m->pending, true);   // its kernels may still be queued (and will still write the result slot)
         delete m->pending;
         m->pending = nullptr;
         if (m->done) (void)hipEventDestroy(m->done);

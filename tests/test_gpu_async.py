@@ -240,3 +240,26 @@ def test_explicit_clip_keeps_the_cached_views(gpu, name, dims):
         assert "k_signbits" not in ran and "k_gather_corners" not in ran, ran
     m2 = MarchingCubes.CreateMesh(vol, 0.25)    # another iso value: bits are recomputed, corners still re-evaluated
     assert_mesh_equal(m2, O.march(ov, oc, MN, MX, iso=0.25))
+
+
+def test_held_mesh_survives_many_other_jobs(gpu):
+    """A queued mesh that is read only after far more other jobs than there are result slots (64):
+    its slot must not have been handed to anyone else in the meantime (found by tools/stress.py)."""
+    scene, sdf = S.CATALOGUE["union8"]()
+    dims = (24, 52, 28)
+    om = oracle_mesh(scene, MN, MX, dims, True)
+    assert_mesh_equal(sdf.ToMesh(MN, MX, *dims), om)                 # size hint for this shape
+    held = raw_sample_march(sdf, MN, MX, dims, True)
+    other_scene, other = S.CATALOGUE["readme_repeat_xy"]()
+    oo = oracle_mesh(other_scene, MN, MX, (40, 36, 44), True)
+    L = N.lib()
+    for k in range(150):                                             # resolved, dropped and two-stage jobs in between
+        if k % 3 == 0:
+            L.sdfk_mesh_free(raw_sample_march(other, MN, MX, (40, 36, 44), True))
+        elif k % 3 == 1:
+            assert_mesh_equal(other.ToMesh(MN, MX, 40, 36, 44), oo)
+        else:
+            vol = Voxels.SampleSdf(other, MN, MX, 40, 36, 44)
+            vol.ClipToBounds()
+            assert_mesh_equal(MarchingCubes.CreateMesh(vol), oo)
+    assert_mesh_equal(Mesh._from_handle(held), om)

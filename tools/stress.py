@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""GPU soak test: a random interleaving of the API (fused ToMesh jobs read late / never read,
+two-stage volumes with explicit clip and edits, other iso values and steps, ray-marched frames)
+for SECONDS (default 60), every result checked against oracle results computed up front."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from oracle import oracle as O
+from sdfkit_amd import MarchingCubes, Mesh, RayMarcher, Voxels
+from sdfkit_amd import _native as N
+from tests import scenes as S
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MN, MX = [-2.8125] * 3, [2.8125] * 3
+CASES = []
+for name in ("readme_repeat_xy", "union8", "sphere_w", "sdf_with_color", "repeat_xz_box"):
+    for dims in ((40, 36, 44), (64, 64, 64), (33, 30, 26), (24, 52, 28)):
+        scene, sdf = S.CATALOGUE[name]()
+        v, c = O.sample(scene, MN, MX, *dims)
+        O.clip_to_bounds(v, MN, MX)
+        CASES.append(dict(name=name, dims=dims, sdf=sdf, scene=scene, v=v, c=c, m=O.march(v, c, MN, MX), m25=None, ray=None))
+N.init()
+L = N.lib()
+
+
+def same(m, o):
+    return (np.array_equal(m.Triangles, o.triangles) and np.array_equal(m.Vertices, o.vertices) and np.array_equal(m.Colors, o.colors)
+            and np.array_equal(m.Normals, o.normals, equal_nan=True) and np.array_equal(m.Min, o.min) and np.array_equal(m.Max, o.max))
+
+
+def raw(case):
+    h = C.c_void_p()
+    N.check(L.sdfk_sample_march(case["sdf"].program(), N.f3(MN), N.f3(MX), *case["dims"], 1, C.c_float(0.0), 1, C.byref(h)))
+    return h
+
+
+held, ops, t0 = [], 0, time.time()
+while time.time() - t0 < secs:
+    k = int(rng.integers(0, 8))
+    case = CASES[int(rng.integers(0, len(CASES)))]
+    if k <= 2:                                   # queue a fused job, read it later (or never)
+        held.append((case, raw(case)))
+    elif k == 3 and held:                        # read one of the held meshes, out of order
+        case2, h = held.pop(int(rng.integers(0, len(held))))
+        assert same(Mesh._from_handle(h), case2["m"]), ("late read", case2["name"], case2["dims"])
+    elif k == 4 and held:                        # drop one unread
+        L.sdfk_mesh_free(held.pop(int(rng.integers(0, len(held))))[1])
+    elif k == 5:                                 # two-stage: sample, explicit clip, mesh; then another iso
+        vol = Voxels.SampleSdf(case["sdf"], MN, MX, *case["dims"])
+        vol.ClipToBounds()
+        assert same(MarchingCubes.CreateMesh(vol), case["m"]), ("two-stage", case["name"], case["dims"])
+        if case["m25"] is None:
+            case["m25"] = O.march(case["v"], case["c"], MN, MX, iso=0.25)
+        assert same(MarchingCubes.CreateMesh(vol, 0.25), case["m25"]), ("iso", case["name"], case["dims"])
+    elif k == 6:                                 # host-array volume (uploaded), edited in place
+        v = case["v"].copy()
+        v[3, 4, 5] = -v[3, 4, 5]
+        assert same(MarchingCubes.CreateMesh(Voxels(v, case["c"], MN, MX)), O.march(v, case["c"], MN, MX)), ("edited", case["name"])
+    else:                                        # a small ray-marched frame
+        if case["ray"] is None:
+            case["ray"] = O.raymarch(case["scene"], 48, 27, iterations=24)
+        rm = RayMarcher(48, 27, case["sdf"])
+        rm.DepthIterations = 24
+        assert np.array_equal(rm.RenderDepth().Values, case["ray"][0], equal_nan=True)
+        assert np.array_equal(rm.Render().Values, case["ray"][1], equal_nan=True)
+    while len(held) > 12:
+        case2, h = held.pop(0)
+        assert same(Mesh._from_handle(h), case2["m"]), ("overflow read", case2["name"], case2["dims"])
+    ops += 1
+for case2, h in held:
+    assert same(Mesh._from_handle(h), case2["m"])
+print(f"stress ok: {ops} operations in {time.time() - t0:.1f} s")
