@@ -1,0 +1,47 @@
+"""The multi-rank benchmark path end to end on ONE GPU: `bench.py --gpus N` under
+torch.distributed.run with SDFK_BENCH_ONE_GPU=1 (every rank on GPU 0, exchange over gloo instead
+of RCCL, which refuses two ranks on one device).  Everything else is the production code: Z-slab
+partition, speculative slab jobs on the library's lanes, device-side pack, pipelined SlabSession,
+rebase, header mirror.  The merged mesh must have the single-GPU vertex / triangle counts."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench(extra, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(extra, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:] + out.stderr[-4000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_bench_on_one_gpu(gpu, world):
+    args = ["--steps", "6", "--warmup", "2", "--no-cpu", "--scene", "repeatxy", "--grid", "160"]
+    one = _bench([sys.executable, "bench.py"] + args)
+    many = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), "bench.py", "--gpus", str(world)] + args, {"SDFK_BENCH_ONE_GPU": "1"})
+    assert many["n_gpus"] == world and one["n_gpus"] == 1
+    assert many["config"]["vertices"] == one["config"]["vertices"] > 10000
+    assert many["config"]["triangles"] == one["config"]["triangles"]
+    for d in (one, many):
+        for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
+            assert k in d
+    assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1.2
