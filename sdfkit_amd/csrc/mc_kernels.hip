@@ -5,9 +5,10 @@
 // depends on that sweep.  This pipeline reproduces the same output in parallel:
 //
 //   K1  signbits  volume[x][y][z] (z fastest) -> 1 bit per voxel packed along X:
-//                 bits[z][y][xw], bit b = (value(64*xw+b, y, z) > iso).  The only dense pass
-//                 over the volume (4 B/voxel read).  Skipped when the fused sampling kernel
-//                 (sample_codegen.h, sdfk_sample_bits) already produced the bits.
+//                 bits[z][y][xw], bit b = (value(64*xw+b, y, z) > iso), via the byte form
+//                 bits8[y][x/8][z] (k_signbits8 -> k_bits_transpose).  The only dense pass over
+//                 the volume (4 B/voxel read); skipped when the fused sampling kernel
+//                 (sample_codegen.h, sdfk_sample_bits) already produced the bytes.
 //   K2  compact   workgroups own chunks of 64-cell X-runs in sweep order; "8 corners not all
 //                 equal" is 64-bit-parallel on the sign words.  Count pass -> one-workgroup
 //                 scan of the per-chunk counts -> write pass (wave-shuffle prefix inside the
@@ -42,46 +43,43 @@ constexpr int K4_RMAX = 288;   // k_vertices: rowstart entries staged per window
 // ---------------------------------------------------------------------------
 // K1: sign bits
 // ---------------------------------------------------------------------------
-// Fast path (nz % 4 == 0): a workgroup stages a tile of 64*WX rows (X) x 64 voxels (Z)
-// of one Y.  Each lane loads a float4 (4 consecutive z), reduces it to a 4-bit nibble in
-// LDS; then, with lane = x, four __ballot()s per nibble column give the four 64-bit
-// X-words of z..z+3.  Loads are 256-B contiguous per row, 1 KiB per wave instruction.
-template <int WX>
-__global__ __launch_bounds__(256) void k_signbits_tile(const float* __restrict__ values,
-                                                       uint64_t* __restrict__ bits, int nx, int ny,
-                                                       int nz, int nxw, float iso)
+// Fast path (nz % 4 == 0), for volumes that did not come from the fused sampling kernel
+// (uploaded arrays, another iso value, sub-sampled steps): the same shape as that kernel with
+// loads in place of stores.  A workgroup owns 8 consecutive x rows x 256 z of one y (4 wavefronts,
+// 2 rows each); a lane loads 4 consecutive z of a row with one 16-byte load (1 KiB contiguous per
+// wavefront instruction), leaves a sign nibble in LDS; wavefront 0 turns the 8 rows' nibbles
+// into 4 bytes per lane and stores 256 contiguous bytes of bits8[y][x/8][z].  k_bits_transpose
+// then regroups the bytes into the X-packed words.
+__global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ values, uint8_t* __restrict__ bits8, int nx, int ny,
+                                                   int nz, int nx8, float iso)
 {
-    constexpr int ROWS = 64 * WX;
-    constexpr int PITCH = 20;  // bytes per LDS row: 16 nibbles + 4 pad (5 dwords: odd bank stride)
-    __shared__ uint8_t nib[ROWS * PITCH];
-    const int z0 = blockIdx.x * 64;
-    const int y = blockIdx.y;
-    const int x0 = blockIdx.z * ROWS;
-    const size_t row_stride = (size_t)ny * nz;
-    const float* base = values + (size_t)y * nz;
-#pragma unroll 8
-    for (int s = threadIdx.x; s < ROWS * 16; s += 256) {
-        const int row = s >> 4, q = s & 15;
-        const int x = x0 + row, z = z0 + 4 * q;
+    __shared__ unsigned char nib[8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int iy = blockIdx.y, x8 = blockIdx.z;
+    const int z = blockIdx.x * 256 + 4 * lane;
+    const bool zok = z < nz;
+    float4 v[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int ix = x8 * 8 + wave * 2 + rr;
+        v[rr] = (ix < nx && zok) ? *reinterpret_cast<const float4*>(values + ((size_t)ix * ny + iy) * nz + z) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int ix = x8 * 8 + wave * 2 + rr;
         unsigned n = 0;
-        if (x < nx && z < nz) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)x * row_stride + z);
-            n = (v.x > iso ? 1u : 0u) | (v.y > iso ? 2u : 0u) | (v.z > iso ? 4u : 0u) | (v.w > iso ? 8u : 0u);
-        }
-        nib[row * PITCH + q] = (uint8_t)n;
+        if (ix < nx && zok) n = (v[rr].x > iso ? 1u : 0u) | (v[rr].y > iso ? 2u : 0u) | (v[rr].z > iso ? 4u : 0u) | (v[rr].w > iso ? 8u : 0u);
+        nib[wave * 2 + rr][lane] = (unsigned char)n;
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int pr = wave; pr < WX * 16; pr += 4) {
-        const int xw = pr >> 4, q = pr & 15;
-        const unsigned n = nib[(xw * 64 + lane) * PITCH + q];
-        const uint64_t b0 = __ballot(n & 1u), b1 = __ballot(n & 2u), b2 = __ballot(n & 4u), b3 = __ballot(n & 8u);
-        const int z = z0 + 4 * q;
-        const int gxw = blockIdx.z * WX + xw;
-        if (lane < 4 && z < nz && gxw < nxw) {
-            const uint64_t w = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-            bits[((size_t)(z + lane) * ny + y) * nxw + gxw] = w;
+    if (wave == 0 && zok) {
+        unsigned out = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned q = nib[r][lane];
+            out |= ((q & 1u) << r) | (((q >> 1) & 1u) << (8 + r)) | (((q >> 2) & 1u) << (16 + r)) | (((q >> 3) & 1u) << (24 + r));
         }
+        *reinterpret_cast<unsigned*>(bits8 + ((size_t)iy * nx8 + x8) * nz + z) = out;
     }
 }
 

@@ -315,6 +315,7 @@ struct sdfk_march_job {
     bool finished = false;
     bool empty = false;
     bool have_bits = false;
+    uint8_t* bits8 = nullptr;            // byte form of the sign bits (k_signbits8 -> k_bits_transpose), job-owned
     sdfk_program* eval_prog = nullptr;   // corners by re-evaluation (holds a reference)
     SampleArgs eval_args;
     int slot = -1;                 // index of the pinned result slot (owned until job_release)
@@ -842,15 +843,12 @@ int launch_classify(sdfk_march_job* j, bool publish)
     if (!j->have_bits) {
         uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
-        if (P.nz % 4 == 0) {
-            const int wx = P.nxw >= 8 ? 8 : (P.nxw >= 4 ? 4 : (P.nxw >= 2 ? 2 : 1));
-            const dim3 grid((P.nz + 63) / 64, P.ny, (P.nxw + wx - 1) / wx);
-            switch (wx) {
-            case 8: hipLaunchKernelGGL(k_signbits_tile<8>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
-            case 4: hipLaunchKernelGGL(k_signbits_tile<4>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
-            case 2: hipLaunchKernelGGL(k_signbits_tile<2>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
-            default: hipLaunchKernelGGL(k_signbits_tile<1>, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso); break;
-            }
+        if (P.nz % 4 == 0 && j->bits8) {
+            const int nx8 = (P.nx + 7) / 8;
+            hipLaunchKernelGGL(k_signbits8, dim3((P.nz + 255) / 256, P.ny, nx8), dim3(256), 0, g.stream, P.values, j->bits8, P.nx, P.ny,
+                               P.nz, nx8, P.iso);
+            hipLaunchKernelGGL(k_bits_transpose, dim3((P.nz + 127) / 128, P.ny, (P.nxw + 7) / 8), dim3(256), 0, g.stream, j->bits8, bits,
+                               nx8, P.ny, P.nz, P.nxw);
         } else {
             const dim3 grid((P.nz + 63) / 64, P.ny, P.nxw);
             hipLaunchKernelGGL(k_signbits_generic, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso);
@@ -974,6 +972,7 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
         uint64_t* bits = nullptr;
         r = r ? r : job_alloc(j, &bits, (size_t)P.nz * P.ny * P.nxw + 8);   // k_compact reads 4 words past a row pair
         P.bits = bits;
+        if (P.nz % 4 == 0) r = r ? r : job_alloc(j, &j->bits8, (size_t)P.ny * ((P.nx + 7) / 8) * P.nz + 64);
     }
     r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl + 1);
     r = r ? r : job_alloc(j, &P.wavecnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl * 4 + 4);
