@@ -466,6 +466,9 @@ static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_
     std::string err;
     if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err))
         return fail(SDFK_ERR_INVALID, "SDF program: %s", err.c_str());
+    if (const char* dump = getenv("SDFK_DUMP_SOURCE")) {   // debugging aid: the generated HIP source of the last program
+        if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
+    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_sample.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail(SDFK_ERR_COMPILE, "hiprtcCreateProgram failed");

@@ -453,3 +453,22 @@ def test_random_scene_compositions(gpu, seed):
     om = O.march(ov, oc, mn, mx)
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), om)
     assert_mesh_equal(MarchingCubes.CreateMesh(v), om)
+
+
+def test_ieee_min_max_semantics(gpu):
+    """Math.Max / Math.Min (SDFK_OP_MAX_IEEE / MIN_IEEE): -0 < +0 and NaN propagates from either side."""
+    from sdfkit_amd import MathF, Sdf, Vec4
+    def run(fn):
+        v = Sdf(lambda p: Vec4.of((0.0, 0.0, 0.0), fn(p)), False).ToVoxels([-1] * 3, [1] * 3, 8, 4, 4, clipToBounds=False)
+        return v.Values[:, 0, 0]
+    xs_negative = np.arange(8) < 4                      # sample x < 0 for the first half of the row
+    z = lambda p: p.x * 0.0                             # -0 where x < 0, +0 elsewhere
+    mx, mn = run(lambda p: MathF.Max(z(p), -z(p))), run(lambda p: MathF.Min(z(p), -z(p)))
+    assert np.all(mx == 0) and not np.signbit(mx).any()                 # max(-0, +0) = max(+0, -0) = +0
+    assert np.all(mn == 0) and np.signbit(mn).all()                     # min = -0
+    assert np.array_equal(np.signbit(run(z)), xs_negative)              # (the inputs really were -0 / +0)
+    nan = lambda p: z(p) / z(p)
+    for f in (lambda p: MathF.Max(nan(p), p.x), lambda p: MathF.Max(p.x, nan(p)),
+              lambda p: MathF.Min(nan(p), p.x), lambda p: MathF.Min(p.x, nan(p))):
+        assert np.isnan(run(f)).all()
+    assert np.array_equal(run(lambda p: MathF.Max(p.x, 0.25)), np.maximum(run(lambda p: p.x), np.float32(0.25)))
