@@ -10,11 +10,15 @@
 // SdfKit::Val records float32 SSA instructions (the role LINQ expression trees play in the
 // reference, GlobalUsings.cs:16), lowered by sdfk_program_create (JIT, like SdfExpr.cs:225-273).
 #pragma once
+#include <charconv>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <functional>
 #include <memory>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -280,6 +284,50 @@ public:
     Vector3 Center() const { return (Min + Max) * 0.5f; }
     Vector3 Size() const { return Max - Min; }
     float Radius() const { return (Max - Min).Length() * 0.5f; }
+    // Mesh.WriteObj (Mesh.cs:66-97): `v` lines, then `vn`, then `f a//a b//b c//c`, 1-based
+    void WriteObj(std::ostream& w) const
+    {
+        for (const auto& v : Vertices) w << "v " << FormatSingle(v.X) << ' ' << FormatSingle(v.Y) << ' ' << FormatSingle(v.Z) << '\n';
+        for (const auto& v : Normals) w << "vn " << FormatSingle(v.X) << ' ' << FormatSingle(v.Y) << ' ' << FormatSingle(v.Z) << '\n';
+        for (size_t i = 0; i + 2 < Triangles.size(); i += 3) {
+            const int a = Triangles[i] + 1, b = Triangles[i + 1] + 1, c = Triangles[i + 2] + 1;
+            w << "f " << a << "//" << a << ' ' << b << "//" << b << ' ' << c << "//" << c << '\n';
+        }
+    }
+    void WriteObj(const std::string& path) const { std::ofstream f(path); WriteObj(f); }
+    // invariant-culture System.Single.ToString(): shortest round-trip digits, scientific
+    // ("d.dddE+XX") when the decimal exponent is < -4 or >= 7
+    static std::string FormatSingle(float x)
+    {
+        if (std::isnan(x)) return "NaN";
+        if (std::isinf(x)) return x > 0 ? "Infinity" : "-Infinity";
+        if (x == 0) return std::signbit(x) ? "-0" : "0";
+        char buf[64];
+        auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);   // shortest round-trip: d.ddde±XX
+        std::string s(buf, r.ptr);
+        const size_t ep = s.find('e');
+        std::string mant = s.substr(0, ep);
+        const int e = std::stoi(s.substr(ep + 1));
+        const bool neg = mant[0] == '-';
+        std::string digits;
+        for (char c : mant) if (c >= '0' && c <= '9') digits.push_back(c);
+        std::string out;
+        if (e > -5 && e < 7) {
+            if (e >= 0) {
+                std::string ip = digits.substr(0, std::min(digits.size(), (size_t)e + 1));
+                ip.append((size_t)e + 1 - ip.size(), '0');
+                const std::string fp = digits.size() > (size_t)e + 1 ? digits.substr(e + 1) : "";
+                out = ip + (fp.empty() ? "" : "." + fp);
+            } else {
+                out = "0." + std::string((size_t)(-e - 1), '0') + digits;
+            }
+        } else {
+            char eb[16];
+            snprintf(eb, sizeof eb, "%02d", e < 0 ? -e : e);
+            out = digits.substr(0, 1) + (digits.size() > 1 ? "." + digits.substr(1) : "") + "E" + (e >= 0 ? "+" : "-") + eb;
+        }
+        return neg ? "-" + out : out;
+    }
     static Mesh FromHandle(sdfk_mesh* h)
     {
         Mesh m;
@@ -467,15 +515,40 @@ struct Matrix4x4 {
     }
 };
 
+inline void WriteTgaHeader(std::ostream& w, int imageType, int width, int height, int bpp)
+{   // VectorData.cs:246-261: 18-byte header, top-down
+    const unsigned char h[18] = {0, 0, (unsigned char)imageType, 0, 0, 0, 0, 0, 0, 0, 0, 0, (unsigned char)(width & 255), (unsigned char)(width >> 8),
+                                 (unsigned char)(height & 255), (unsigned char)(height >> 8), (unsigned char)bpp, 0x20};
+    w.write(reinterpret_cast<const char*>(h), 18);
+}
 struct FloatData {   // VectorData.cs:137-280; indexer is (x, y)
     int Width = 0, Height = 0;
     std::vector<float> Values;
     float operator()(int x, int y) const { return Values[(size_t)y * Width + x]; }
+    void SaveDepthTga(const std::string& path, float nearv, float farv) const   // VectorData.cs:244-279
+    {
+        std::ofstream w(path, std::ios::binary);
+        WriteTgaHeader(w, 3, Width, Height, 8);
+        for (float v : Values) {
+            const unsigned char b = v >= farv ? 0 : (v <= nearv ? 255 : (unsigned char)(255.0f * (farv - v) / (farv - nearv)));
+            w.put((char)b);
+        }
+    }
 };
 struct Vec3Data {    // VectorData.cs:343-620
     int Width = 0, Height = 0;
     std::vector<float> Values;   // 3 per pixel
     Vector3 operator()(int x, int y) const { const float* p = &Values[((size_t)y * Width + x) * 3]; return {p[0], p[1], p[2]}; }
+    void SaveTga(const std::string& path) const   // VectorData.cs:570-619: 24-bit B, G, R, channel * 255 truncated and clamped
+    {
+        std::ofstream w(path, std::ios::binary);
+        WriteTgaHeader(w, 2, Width, Height, 24);
+        for (size_t k = 0; k + 2 < Values.size(); k += 3)
+            for (int c = 2; c >= 0; c--) {
+                const float v = Values[k + c] * 255.0f;
+                w.put((char)(v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (unsigned char)v)));
+            }
+    }
 };
 
 class RayMarcher {   // RayMarcher.cs:7-43: same constructor, properties and defaults

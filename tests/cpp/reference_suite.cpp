@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <sstream>
 
 #include "SdfKit.hpp"
 
@@ -209,8 +210,30 @@ TEST(RayMarcherSphereRepeat)   // RayMarcherTests.cs:96-108 (192 x 108, camera (
     IS_TRUE(c.X > 0.1f && c.X <= 1.0f);
 }
 
+TEST(MeshWriteObjFormat)   // Mesh.cs:66-97 + invariant-culture Single.ToString()
+{
+    ARE_EQUAL(true, Mesh::FormatSingle(1.5f) == "1.5");
+    ARE_EQUAL(true, Mesh::FormatSingle(-0.1f) == "-0.1");
+    ARE_EQUAL(true, Mesh::FormatSingle(1e-5f) == "1E-05");
+    ARE_EQUAL(true, Mesh::FormatSingle(0.0001f) == "0.0001");
+    ARE_EQUAL(true, Mesh::FormatSingle(1234567.0f) == "1234567");
+    ARE_EQUAL(true, Mesh::FormatSingle(12345678.0f) == "1.2345678E+07");
+    ARE_EQUAL(true, Mesh::FormatSingle(0.33333334f) == "0.33333334");
+    ARE_EQUAL(true, Mesh::FormatSingle(100.0f) == "100");
+    auto mesh = Sdfs::Sphere(1.0f).ToMesh(Vector3(-1.5f, -1.5f, -1.5f), Vector3(1.5f, 1.5f, 1.5f), 5, 5, 5, 2048, -1, false);
+    std::ostringstream os;
+    mesh.WriteObj(os);
+    const std::string txt = os.str();
+    size_t lines = 0;
+    for (char c : txt) lines += c == '\n';
+    ARE_EQUAL(mesh.Vertices.size() * 2 + mesh.Triangles.size() / 3, lines);
+    IS_TRUE(txt.rfind("v ", 0) == 0);
+    IS_TRUE(txt.find("\nvn ") != std::string::npos && txt.find("\nf 1//1 ") != std::string::npos);
+}
+
 int main()
 {
+    run_MeshWriteObjFormat();
     run_RayMarcherSphereDepth(); run_RayMarcherBoxDepth(); run_RayMarcherCylinderDepth(); run_RayMarcherPlaneDepth(); run_RayMarcherSphereRepeat();
     run_ColoredSpheres(); run_Sphere5(); run_Sphere10(); run_UnclippedSphere10(); run_ClippedSphere10(); run_Box10();
     run_Cylinder50(); run_Sphere128Progress(); run_CreateVolumeSphere(); run_CreateMeshSphere(); run_SolidSphere();
