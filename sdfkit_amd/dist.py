@@ -34,9 +34,16 @@ def slab_layers(n_layers, world, rank):
 
 
 def slab_planes(lb, le, nz):
-    """Voxel planes [z0, z0+n) a slab must hold for layers [lb, le) (include/sdfkit_hip.h)."""
+    """Voxel planes [z0, z0+n) a slab holds for layers [lb, le): the context the C ABI asks for
+    ([lb-2, le+2) clipped to the grid, include/sdfkit_hip.h), widened to a multiple of 4 planes
+    where the grid allows -- the fused sampling kernel (one 16-byte store per 4 z) needs that, and
+    a few extra planes cost far less than falling back to the one-voxel-per-lane kernel."""
     z0 = max(lb - 2, 0)
     z1 = min(le + 2, nz)
+    pad = (-(z1 - z0)) % 4
+    up = min(pad, nz - z1)
+    z1 += up
+    z0 -= min(pad - up, z0)
     return z0, z1 - z0
 
 

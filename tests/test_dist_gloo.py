@@ -247,7 +247,15 @@ def test_slab_partition_covers_all_layers():
                 got.append(le - lb)
                 prev = le
             assert prev == n_layers and max(got) - min(got) <= 1
-    assert D.slab_planes(0, 64, 512) == (0, 66)       # one plane above the top layer's far face + context
-    assert D.slab_planes(64, 128, 512) == (62, 68)    # two context planes below, one extra above
-    assert D.slab_planes(448, 511, 512) == (446, 66)  # clipped at the last plane
+    assert D.slab_planes(0, 64, 512) == (0, 68)       # context [0, 66) widened upwards to a multiple of 4 planes
+    assert D.slab_planes(64, 128, 512) == (62, 68)    # two context planes below, two above: already a multiple of 4
+    assert D.slab_planes(448, 511, 512) == (444, 68)  # clipped at the last plane: widened downwards
+    assert D.slab_planes(0, 4, 5) == (0, 5)           # nowhere to widen to: stays as it is
+    for nz in (5, 64, 511, 512, 1024):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lb, le = D.slab_layers(nz - 1, world, r)
+                z0, n = D.slab_planes(lb, le, nz)
+                assert z0 <= max(lb - 2, 0) and z0 + n >= min(le + 2, nz) and z0 >= 0 and z0 + n <= nz
+                assert n % 4 == 0 or n == nz or nz < 8
     assert D.exclusive_prefix([3, 0, 5]) == ([0, 3, 3], 8)
