@@ -43,32 +43,42 @@ constexpr int K4_RMAX = 288;   // k_vertices: rowstart entries staged per window
 // ---------------------------------------------------------------------------
 // K1: sign bits
 // ---------------------------------------------------------------------------
-// Fast path (nz % 4 == 0), for volumes that did not come from the fused sampling kernel
+// For volumes that did not come from the fused sampling kernel (any nz; byte rows are pitch8 =
+// nz rounded up to a multiple of 4 bytes long)
 // (uploaded arrays, another iso value, sub-sampled steps): the same shape as that kernel with
 // loads in place of stores.  A workgroup owns 8 consecutive x rows x 256 z of one y (4 wavefronts,
 // 2 rows each); a lane loads 4 consecutive z of a row with one 16-byte load (1 KiB contiguous per
 // wavefront instruction), leaves a sign nibble in LDS; wavefront 0 turns the 8 rows' nibbles
 // into 4 bytes per lane and stores 256 contiguous bytes of bits8[y][x/8][z].  k_bits_transpose
 // then regroups the bytes into the X-packed words.
+typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (gfx950 unaligned mode)
+
 __global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ values, uint8_t* __restrict__ bits8, int nx, int ny,
-                                                   int nz, int nx8, float iso)
+                                                   int nz, int nx8, int pitch8, float iso)
 {
     __shared__ unsigned char nib[8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int iy = blockIdx.y, x8 = blockIdx.z;
     const int z = blockIdx.x * 256 + 4 * lane;
     const bool zok = z < nz;
-    float4 v[2];
+    float v[2][4];
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int ix = x8 * 8 + wave * 2 + rr;
-        v[rr] = (ix < nx && zok) ? *reinterpret_cast<const float4*>(values + ((size_t)ix * ny + iy) * nz + z) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[rr][0] = v[rr][1] = v[rr][2] = v[rr][3] = -INFINITY;   // (never > iso: voxels beyond the row end give 0 bits)
+        if (ix < nx && zok) {
+            const float* p = values + ((size_t)ix * ny + iy) * nz + z;
+            if (z + 3 < nz) {   // any nz: rows start at 4-byte alignment only
+                const f4a4 q = *reinterpret_cast<const f4a4*>(p);
+                v[rr][0] = q.x; v[rr][1] = q.y; v[rr][2] = q.z; v[rr][3] = q.w;
+            } else {
+                for (int k = 0; k < 4; k++) if (z + k < nz) v[rr][k] = p[k];
+            }
+        }
     }
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
-        const int ix = x8 * 8 + wave * 2 + rr;
-        unsigned n = 0;
-        if (ix < nx && zok) n = (v[rr].x > iso ? 1u : 0u) | (v[rr].y > iso ? 2u : 0u) | (v[rr].z > iso ? 4u : 0u) | (v[rr].w > iso ? 8u : 0u);
+        const unsigned n = (v[rr][0] > iso ? 1u : 0u) | (v[rr][1] > iso ? 2u : 0u) | (v[rr][2] > iso ? 4u : 0u) | (v[rr][3] > iso ? 8u : 0u);
         nib[wave * 2 + rr][lane] = (unsigned char)n;
     }
     __syncthreads();
@@ -79,27 +89,7 @@ __global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ val
             const unsigned q = nib[r][lane];
             out |= ((q & 1u) << r) | (((q >> 1) & 1u) << (8 + r)) | (((q >> 2) & 1u) << (16 + r)) | (((q >> 3) & 1u) << (24 + r));
         }
-        *reinterpret_cast<unsigned*>(bits8 + ((size_t)iy * nx8 + x8) * nz + z) = out;
-    }
-}
-
-// Generic path (any nz): lane = x, one ballot per (z, y, xw).  Each lane walks 16
-// consecutive z of its own row so its cache line is reused; only used for odd sizes.
-__global__ __launch_bounds__(256) void k_signbits_generic(const float* __restrict__ values,
-                                                          uint64_t* __restrict__ bits, int nx, int ny,
-                                                          int nz, int nxw, float iso)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int zrun = (blockIdx.x * 4 + wave) * 16;
-    const int y = blockIdx.y;
-    const int xw = blockIdx.z;
-    const int x = xw * 64 + lane;
-    if (zrun >= nz) return;
-    const float* p = values + ((size_t)(x < nx ? x : 0) * ny + y) * nz;
-    for (int z = zrun; z < zrun + 16 && z < nz; z++) {
-        const bool s = (x < nx) && (p[z] > iso);
-        const uint64_t w = __ballot(s);
-        if (lane == 0) bits[((size_t)z * ny + y) * nxw + xw] = w;
+        *reinterpret_cast<unsigned*>(bits8 + ((size_t)iy * nx8 + x8) * pitch8 + z) = out;   // pitch8 % 4 == 0
     }
 }
 
@@ -108,15 +98,15 @@ __global__ __launch_bounds__(256) void k_signbits_generic(const float* __restric
 // Workgroup = (128 z, one y, 8 words): 64 byte-rows x 128 B go through LDS, every z then
 // leaves as 64 contiguous bytes.
 __global__ __launch_bounds__(256) void k_bits_transpose(const uint8_t* __restrict__ bits8, uint64_t* __restrict__ bits,
-                                                        int nx8, int ny, int nz, int nxw)
+                                                        int nx8, int ny, int nz, int nxw, int pitch8)
 {
     __shared__ __attribute__((aligned(4))) uint8_t t[64][132];
     const int iy = blockIdx.y, z0 = blockIdx.x * 128, xw0 = blockIdx.z * 8, row0 = xw0 * 8;
     for (int k = threadIdx.x; k < 64 * 32; k += 256) {
         const int row = k >> 5, c = (k & 31) * 4;
-        unsigned v = 0;   // (nz % 4 == 0: a 4-byte group is all inside or all outside)
+        unsigned v = 0;   // (byte rows are pitch8 long, a multiple of 4: a 4-byte group never straddles a row)
         if (row0 + row < nx8 && z0 + c < nz)
-            v = *reinterpret_cast<const unsigned*>(bits8 + ((size_t)iy * nx8 + row0 + row) * nz + z0 + c);
+            v = *reinterpret_cast<const unsigned*>(bits8 + ((size_t)iy * nx8 + row0 + row) * pitch8 + z0 + c);
         *reinterpret_cast<unsigned*>(&t[row][c]) = v;
     }
     __syncthreads();

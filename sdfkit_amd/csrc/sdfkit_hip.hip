@@ -708,7 +708,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         {
             ProfScope ps("k_bits_transpose");
             hipLaunchKernelGGL(k_bits_transpose, dim3((v->nz + 127) / 128, v->ny, (v->nxw() + 7) / 8), dim3(256), 0, g.stream,
-                               v->bits8, v->bits, v->nx8(), v->ny, v->nz, v->nxw());
+                               v->bits8, v->bits, v->nx8(), v->ny, v->nz, v->nxw(), v->nz);
             HIPCHK(hipGetLastError());
         }
         v->bits_iso = iso_hint;
@@ -846,16 +846,11 @@ int launch_classify(sdfk_march_job* j, bool publish)
     if (!j->have_bits) {
         uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
-        if (P.nz % 4 == 0 && j->bits8) {
-            const int nx8 = (P.nx + 7) / 8;
-            hipLaunchKernelGGL(k_signbits8, dim3((P.nz + 255) / 256, P.ny, nx8), dim3(256), 0, g.stream, P.values, j->bits8, P.nx, P.ny,
-                               P.nz, nx8, P.iso);
-            hipLaunchKernelGGL(k_bits_transpose, dim3((P.nz + 127) / 128, P.ny, (P.nxw + 7) / 8), dim3(256), 0, g.stream, j->bits8, bits,
-                               nx8, P.ny, P.nz, P.nxw);
-        } else {
-            const dim3 grid((P.nz + 63) / 64, P.ny, P.nxw);
-            hipLaunchKernelGGL(k_signbits_generic, grid, dim3(256), 0, g.stream, P.values, bits, P.nx, P.ny, P.nz, P.nxw, P.iso);
-        }
+        const int nx8 = (P.nx + 7) / 8, pitch8 = (P.nz + 3) & ~3;
+        hipLaunchKernelGGL(k_signbits8, dim3((P.nz + 255) / 256, P.ny, nx8), dim3(256), 0, g.stream, P.values, j->bits8, P.nx, P.ny,
+                           P.nz, nx8, pitch8, P.iso);
+        hipLaunchKernelGGL(k_bits_transpose, dim3((P.nz + 127) / 128, P.ny, (P.nxw + 7) / 8), dim3(256), 0, g.stream, j->bits8, bits,
+                           nx8, P.ny, P.nz, P.nxw, pitch8);
         HIPCHK(hipGetLastError());
         j->have_bits = true;
     }
@@ -975,7 +970,7 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
         uint64_t* bits = nullptr;
         r = r ? r : job_alloc(j, &bits, (size_t)P.nz * P.ny * P.nxw + 8);   // k_compact reads 4 words past a row pair
         P.bits = bits;
-        if (P.nz % 4 == 0) r = r ? r : job_alloc(j, &j->bits8, (size_t)P.ny * ((P.nx + 7) / 8) * P.nz + 64);
+        r = r ? r : job_alloc(j, &j->bits8, (size_t)P.ny * ((P.nx + 7) / 8) * ((P.nz + 3) & ~3) + 64);
     }
     r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl + 1);
     r = r ? r : job_alloc(j, &P.wavecnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl * 4 + 4);
