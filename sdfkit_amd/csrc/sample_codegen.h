@@ -16,7 +16,7 @@
 // One definition, used both by the host (below) and pasted into the generated source.
 #define SDFK_SAMPLE_ARGS_BODY                                                                   \
     float* values; float* colors; float mx, my, mz, dx, dy, dz; int nx, ny, nz; int z0, nz_global; \
-    int clip; float outside; int nzu; int row_stride; unsigned char* bits8; int nx8; float iso;
+    int clip; float outside; int pitch8; int pad0; unsigned char* bits8; int nx8; float iso;
 
 struct SampleArgs { SDFK_SAMPLE_ARGS_BODY };
 struct RayArgs { float* depth; float* rgb; float cam[3]; float m[16]; int width, height; float nearp, farp; int iters; };
@@ -37,7 +37,7 @@ static const char* const kSampleKernels = R"SRC(
 //   p = (min + 0.5*D) + (float)i * D   per axis (Voxels.cs:81,104-106),
 // value -> Values[ix,iy,iz] (z fastest), colour -> Colors[ix,iy,iz].
 //
-// Fused form (nz % 4 == 0): sampling AND the marching-cubes sign bits in one pass over the grid.
+// Fused form: sampling AND the marching-cubes sign bits in one pass over the grid.
 // A workgroup owns 8 consecutive x rows x 256 z of one y: 8 / RPW wavefronts, RPW rows each
 // (default RPW = 2: 256 lanes).  A lane evaluates 4 consecutive z of a row and issues one 16-byte
 // nontemporal store for it (1 KiB contiguous per wavefront instruction).  Few stores per lane
@@ -50,13 +50,14 @@ static const char* const kSampleKernels = R"SRC(
 // bytes of bits8[y][x/8][z].  k_bits_transpose (mc_kernels.hip) regroups those bytes into the
 // X-packed words the marching-cubes classifier reads; the volume is never re-read densely.
 typedef float sdfk_f4 __attribute__((ext_vector_type(4)));
+typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));   // rows start at 4-byte alignment when nz % 4 != 0
 __device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float c, float d)
 {
-    const sdfk_f4 t = {a, b, c, d};
+    const sdfk_f4u t = {a, b, c, d};
 #if SDFK_SAMPLE_NT
-    __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(p));
+    __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4u*>(p));
 #else
-    *reinterpret_cast<sdfk_f4*>(p) = t;
+    *reinterpret_cast<sdfk_f4u*>(p) = t;
 #endif
 }
 #ifndef SDFK_SAMPLE_RPW
@@ -97,7 +98,11 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
                 if (CLIP && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
             const long o = ((long)ix * A.ny + iy) * A.nz + z;
-            sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
+            if (z + 3 < A.nz) sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
+            else {   // last lane of a row whose length is not a multiple of 4
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (z + k < A.nz) A.values[o + k] = w[k];
+            }
             if (A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
                 sdfk_f4* mine = reinterpret_cast<sdfk_f4*>(cbuf[wave] + 12 * lane);
                 mine[0] = sdfk_f4{cr[0], cg[0], cb[0], cr[1]};
@@ -105,6 +110,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
                 mine[2] = sdfk_f4{cb[2], cr[3], cg[3], cb[3]};
             }
             n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
+            if (z + 3 >= A.nz) n &= (1u << (A.nz - z)) - 1u;   // voxels past the row end: 0 bits
         }
         nib[r][lane] = (unsigned char)n;
         if (A.colors && ix < A.nx) {
@@ -114,7 +120,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             // floats 4 L .. 4 L + 3 of each KiB) -- ALL lanes store, also those whose own
             // voxels lie beyond nz: what they store belongs to the lanes before them.
             const int z0 = blockIdx.x * 256;
-            const int run = (A.nz - z0 < 256 ? A.nz - z0 : 256) * 3;   // floats of the run that exist (nz % 4 == 0)
+            const int run = (A.nz - z0 < 256 ? A.nz - z0 : 256) * 3;   // floats of the run that exist
             __builtin_amdgcn_wave_barrier();
             const float* cw = cbuf[wave];
             const sdfk_f4 t0 = *reinterpret_cast<const sdfk_f4*>(cw + 4 * lane);
@@ -122,9 +128,17 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             const sdfk_f4 t2 = *reinterpret_cast<const sdfk_f4*>(cw + 512 + 4 * lane);
             __builtin_amdgcn_wave_barrier();
             float* c = A.colors + (((long)ix * A.ny + iy) * A.nz + z0) * 3;
-            if (4 * lane + 3 < run) sdfk_store4_nt(c + 4 * lane, t0.x, t0.y, t0.z, t0.w);
-            if (256 + 4 * lane + 3 < run) sdfk_store4_nt(c + 256 + 4 * lane, t1.x, t1.y, t1.z, t1.w);
-            if (512 + 4 * lane + 3 < run) sdfk_store4_nt(c + 512 + 4 * lane, t2.x, t2.y, t2.z, t2.w);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const sdfk_f4 t = q == 0 ? t0 : (q == 1 ? t1 : t2);
+                const int e = 256 * q + 4 * lane;   // first float of this lane's piece
+                if (e + 3 < run) sdfk_store4_nt(c + e, t.x, t.y, t.z, t.w);
+                else {           // the run ends inside the piece
+                    if (e < run) c[e] = t.x;
+                    if (e + 1 < run) c[e + 1] = t.y;
+                    if (e + 2 < run) c[e + 2] = t.z;
+                }
+            }
         }
     }
     __syncthreads();
@@ -135,7 +149,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             const unsigned q = nib[r][lane];
             out |= ((q & 1u) << r) | (((q >> 1) & 1u) << (8 + r)) | (((q >> 2) & 1u) << (16 + r)) | (((q >> 3) & 1u) << (24 + r));
         }
-        *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * A.nz + z) = out;
+        *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * A.pitch8 + z) = out;   // pitch8 = nz rounded up to 4
     }
 }
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false>(A); }
@@ -249,33 +263,6 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
     o[2] = 0.0f + ((dv * d2 + 0.1f) * fgm + bgm * 1.0f);
 }
 
-// same, one voxel per lane-iteration (nz not a multiple of 4)
-extern "C" __global__ __launch_bounds__(256) void sdfk_sample_scalar(SampleArgs A)
-{
-    const int tz = blockDim.x, tr = blockDim.y;
-    long row = (long)blockIdx.x * tr + threadIdx.y;
-    const long nrows = (long)A.nx * A.ny;
-    if (row >= nrows) return;
-    int ix = (int)(row / A.ny), iy = (int)(row % A.ny);
-    const int sq = A.row_stride / A.ny, sr = A.row_stride % A.ny;
-    for (; row < nrows; row += A.row_stride) {
-        const float px = A.mx + (float)ix * A.dx;
-        const float py = A.my + (float)iy * A.dy;
-        const bool edge_xy = (ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1);
-        for (int z = threadIdx.x; z < A.nzu; z += tz) {
-            const int zg = A.z0 + z;
-            const float pz = A.mz + (float)zg * A.dz;
-            float w, r, g, b;
-            sdf_eval(px, py, pz, r, g, b, w);
-            if (A.clip && (edge_xy || zg == 0 || zg == A.nz_global - 1)) w = A.outside;
-            const long o = row * A.nz + z;
-            A.values[o] = w;
-            if (A.colors) { A.colors[o * 3] = r; A.colors[o * 3 + 1] = g; A.colors[o * 3 + 2] = b; }
-        }
-        ix += sq; iy += sr;
-        if (iy >= A.ny) { iy -= A.ny; ix++; }
-    }
-}
 )SRC";
 
 inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t out_rgbw[4], int writes_color,

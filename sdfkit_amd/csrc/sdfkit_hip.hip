@@ -245,7 +245,6 @@ struct sdfk_program {
     hipModule_t module = nullptr;
     hipFunction_t fn_bits = nullptr;
     hipFunction_t fn_bits_clip = nullptr;
-    hipFunction_t fn_scalar = nullptr;
     hipFunction_t fn_corners = nullptr;
     hipFunction_t fn_raymarch = nullptr;
     int writes_color = 0;
@@ -272,6 +271,7 @@ struct sdfk_volume {
     size_t nvox() const { return (size_t)nx * ny * nz; }
     int nxw() const { return (nx + 63) / 64; }
     int nx8() const { return (nx + 7) / 8; }
+    int pitch8() const { return (nz + 3) & ~3; }   // bytes per row of bits8
     size_t nbitwords() const { return (size_t)nz * ny * nxw() + 8; }   // k_compact reads 4 words past a row pair
 };
 
@@ -519,7 +519,6 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     p->source = src;
     p->writes_color = writes_color;
     hipError_t e = hipModuleLoadData(&p->module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_scalar, p->module, "sdfk_sample_scalar");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_corners, p->module, "sdfk_corners_eval");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_raymarch, p->module, "sdfk_raymarch");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
@@ -683,17 +682,18 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         v->sampled_args = A;
     };
     void* params[] = {&A};
-    if ((v->nz % 4) == 0) {
+    {
         // fused sampling + sign bits (iso known or guessed 0): marching cubes then skips its
         // dense pass over the volume
         if (!v->bits) {
             if (int r = dev_alloc((void**)&v->bits, v->nbitwords() * sizeof(uint64_t))) return r;
         }
         if (!v->bits8) {
-            if (int r = dev_alloc((void**)&v->bits8, (size_t)v->ny * v->nx8() * v->nz + 64)) return r;
+            if (int r = dev_alloc((void**)&v->bits8, (size_t)v->ny * v->nx8() * v->pitch8() + 64)) return r;
         }
         A.bits8 = v->bits8;
         A.nx8 = v->nx8();
+        A.pitch8 = v->pitch8();
         A.iso = iso_hint;
         {
             const unsigned tpb = 512u / (unsigned)g_sample_rpw;
@@ -708,7 +708,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         {
             ProfScope ps("k_bits_transpose");
             hipLaunchKernelGGL(k_bits_transpose, dim3((v->nz + 127) / 128, v->ny, (v->nxw() + 7) / 8), dim3(256), 0, g.stream,
-                               v->bits8, v->bits, v->nx8(), v->ny, v->nz, v->nxw(), v->nz);
+                               v->bits8, v->bits, v->nx8(), v->ny, v->nz, v->nxw(), v->pitch8());
             HIPCHK(hipGetLastError());
         }
         v->bits_iso = iso_hint;
@@ -716,20 +716,6 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         sampled();
         return SDFK_OK;
     }
-    const int nzu = v->nz;      // one voxel per lane-iteration
-    int tz = 1;
-    while (tz < nzu && tz < 256) tz *= 2;
-    const int tr = 256 / tz;
-    const long nrows = (long)v->nx * v->ny;
-    long nblk = (nrows + tr - 1) / tr;
-    const long maxblk = 256L * 16;
-    if (nblk > maxblk) nblk = maxblk;
-    A.nzu = nzu;
-    A.row_stride = (int)(nblk * tr);
-    ProfScope ps("sdfk_sample_scalar");
-    HIPCHK(hipModuleLaunchKernel(p->fn_scalar, (unsigned)nblk, 1, 1, (unsigned)tz, (unsigned)tr, 1, 0, g.stream, params, nullptr));
-    sampled();
-    return SDFK_OK;
 }
 
 extern "C" int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds)
