@@ -51,19 +51,30 @@ static const char* const kSampleKernels = R"SRC(
 // X-packed words the marching-cubes classifier reads; the volume is never re-read densely.
 typedef float sdfk_f4 __attribute__((ext_vector_type(4)));
 typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));   // rows start at 4-byte alignment when nz % 4 != 0
+template <bool ALIGNED>
 __device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float c, float d)
 {
-    const sdfk_f4u t = {a, b, c, d};
+    if (ALIGNED) {
+        const sdfk_f4 t = {a, b, c, d};
 #if SDFK_SAMPLE_NT
-    __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4u*>(p));
+        __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(p));
 #else
-    *reinterpret_cast<sdfk_f4u*>(p) = t;
+        *reinterpret_cast<sdfk_f4*>(p) = t;
 #endif
+    } else {
+        const sdfk_f4u t = {a, b, c, d};
+#if SDFK_SAMPLE_NT
+        __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4u*>(p));
+#else
+        *reinterpret_cast<sdfk_f4u*>(p) = t;
+#endif
+    }
 }
 #ifndef SDFK_SAMPLE_RPW
 #define SDFK_SAMPLE_RPW 2   // x rows per wavefront (stores per lane); workgroup = 8 / RPW wavefronts
 #endif
-template <bool CLIP>
+// ALIGNED: nz % 4 == 0 (16-byte aligned rows, no row tails); the other instantiation handles any nz
+template <bool CLIP, bool ALIGNED>
 __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
@@ -98,7 +109,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
                 if (CLIP && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
             const long o = ((long)ix * A.ny + iy) * A.nz + z;
-            if (z + 3 < A.nz) sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
+            if (ALIGNED || z + 3 < A.nz) sdfk_store4_nt<ALIGNED>(A.values + o, w[0], w[1], w[2], w[3]);
             else {   // last lane of a row whose length is not a multiple of 4
 #pragma unroll
                 for (int k = 0; k < 4; k++) if (z + k < A.nz) A.values[o + k] = w[k];
@@ -110,7 +121,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
                 mine[2] = sdfk_f4{cb[2], cr[3], cg[3], cb[3]};
             }
             n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
-            if (z + 3 >= A.nz) n &= (1u << (A.nz - z)) - 1u;   // voxels past the row end: 0 bits
+            if (!ALIGNED && z + 3 >= A.nz) n &= (1u << (A.nz - z)) - 1u;   // voxels past the row end: 0 bits
         }
         nib[r][lane] = (unsigned char)n;
         if (A.colors && ix < A.nx) {
@@ -132,7 +143,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             for (int q = 0; q < 3; q++) {
                 const sdfk_f4 t = q == 0 ? t0 : (q == 1 ? t1 : t2);
                 const int e = 256 * q + 4 * lane;   // first float of this lane's piece
-                if (e + 3 < run) sdfk_store4_nt(c + e, t.x, t.y, t.z, t.w);
+                if (e + 3 < run) sdfk_store4_nt<ALIGNED>(c + e, t.x, t.y, t.z, t.w);
                 else {           // the run ends inside the piece
                     if (e < run) c[e] = t.x;
                     if (e + 1 < run) c[e + 1] = t.y;
@@ -152,8 +163,10 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
         *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * A.pitch8 + z) = out;   // pitch8 = nz rounded up to 4
     }
 }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false>(A); }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false, true>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true, true>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_anynz(SampleArgs A) { sdfk_sample_bits_body<false, false>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_anynz(SampleArgs A) { sdfk_sample_bits_body<true, false>(A); }
 
 // Corner values of the active cells, RE-EVALUATED instead of gathered: for a volume this very
 // program has just sampled, the 8 corners of cell (x,y,z) are 8 more evaluations of the same

@@ -245,6 +245,7 @@ struct sdfk_program {
     hipModule_t module = nullptr;
     hipFunction_t fn_bits = nullptr;
     hipFunction_t fn_bits_clip = nullptr;
+    hipFunction_t fn_bits_any = nullptr, fn_bits_clip_any = nullptr;   // rows of any length (nz % 4 != 0)
     hipFunction_t fn_corners = nullptr;
     hipFunction_t fn_raymarch = nullptr;
     int writes_color = 0;
@@ -523,6 +524,8 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_raymarch, p->module, "sdfk_raymarch");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip, p->module, "sdfk_sample_bits_clip");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_any, p->module, "sdfk_sample_bits_anynz");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip_any, p->module, "sdfk_sample_bits_clip_anynz");
     if (e != hipSuccess) {
         if (p->module) (void)hipModuleUnload(p->module);
         delete p;
@@ -698,7 +701,9 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         {
             const unsigned tpb = 512u / (unsigned)g_sample_rpw;
             ProfScope ps("sdfk_sample_bits");
-            HIPCHK(hipModuleLaunchKernel(clip_to_bounds ? p->fn_bits_clip : p->fn_bits, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
+            const bool aligned = (v->nz & 3) == 0;
+            hipFunction_t fn = aligned ? (clip_to_bounds ? p->fn_bits_clip : p->fn_bits) : (clip_to_bounds ? p->fn_bits_clip_any : p->fn_bits_any);
+            HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
                                          (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
         }
         if (g.sampler_only) {   // measurement mode (sdfk_profile_enable(2)): the sampling kernel alone, back to back
