@@ -45,3 +45,37 @@ def test_sharded_bench_on_one_gpu(gpu, world):
         for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
             assert k in d
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1.2
+
+
+def test_sharded_to_mesh_exact_protocol_single_rank(gpu):
+    """The one-off form (two exact collectives: counts, then payloads) on a single-rank group."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from sdfkit_amd import dist as D
+    from sdfkit_amd import _native as N
+    from tests import scenes as S
+    from tests.test_gpu_parity import assert_mesh_equal
+    scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
+    mn, mx, dims = [-2.8125] * 3, [2.8125] * 3, (40, 36, 44)
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    O.clip_to_bounds(ov, mn, mx)
+    om = O.march(ov, oc, mn, mx)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        m = D.sharded_to_mesh(sdf, mn, mx, *dims)
+        assert_mesh_equal(m, om)
+        ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, None, torch.device("cuda", 0), depth=2)
+        for _ in range(5):
+            if len(ses.queue) == ses.depth:
+                ses.collect()
+            ses.submit()
+        ses.drain()
+        assert_mesh_equal(ses.mesh(), om)
+        ses.close()
+    finally:
+        dist.destroy_process_group()
+        torch.cuda.synchronize()
+        N.check(N.lib().sdfk_set_stream(None))
+        torch.cuda.set_stream(torch.cuda.default_stream())
