@@ -79,3 +79,13 @@ def test_sharded_to_mesh_exact_protocol_single_rank(gpu):
         torch.cuda.synchronize()
         N.check(N.lib().sdfk_set_stream(None))
         torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+@pytest.mark.parametrize("world,name,dims", [(2, "readme_repeat_xy", (40, 36, 44)), (3, "union8", (36, 40, 50)), (4, "sphere_w", (64, 64, 64))])
+def test_pipelined_session_full_parity_multi_rank(gpu, world, name, dims):
+    """2-4 ranks (one GPU, gloo), real kernels: every rank's gathered mesh == the oracle's, bit for bit."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join("tests", "multirank_worker.py"), name] + [str(d) for d in dims]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("identical") == world
