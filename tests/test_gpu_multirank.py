@@ -89,3 +89,19 @@ def test_pipelined_session_full_parity_multi_rank(gpu, world, name, dims):
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("identical") == world
+
+
+def test_bench_contract_fields(gpu):
+    """One default-shaped bench run (smaller grid, tiny CPU-baseline sample): the JSON line carries
+    every field of the contract, the roofline and the cpu_baseline objects."""
+    d = _bench([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--grid", "256", "--cpu-n", "64"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["vertices"] == 137232 and "workload" in d["config"]            # SURVEY C2
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - 256 ** 3 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
