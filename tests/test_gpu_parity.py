@@ -506,3 +506,36 @@ def test_random_programs_match_ir_interpreter(gpu, seed):
             assert np.array_equal(np.signbit(v[finite]), np.signbit(ev[finite]))       # -0 / +0 too
     finally:
         L.sdfk_program_destroy(prog)
+
+
+# ---------------------------------------------------------------------------
+# isolated cells covering every sign word with wildly different corner magnitudes: reaches the rare
+# face-test / interior-test sub-tilings that uniform random volumes seldom produce
+# ---------------------------------------------------------------------------
+_CORNERS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+
+
+def _cell_lattice(seed, reps=40):
+    rng = np.random.default_rng(5000 + seed)
+    n = 256 * reps
+    side = int(np.ceil(n ** (1 / 3)))
+    v = np.full((3 * side + 1,) * 3, -1.0, np.float32)
+    w = np.arange(n) % 256
+    mag = (10.0 ** rng.uniform(-3, 1.5, (n, 8))).astype(np.float32)
+    vals = mag * np.where((w[:, None] >> np.arange(8)) & 1, 1.0, -1.0).astype(np.float32)
+    ii, jj, kk = np.unravel_index(np.arange(n), (side, side, side))
+    for c, (dx, dy, dz) in enumerate(_CORNERS):
+        v[3 * ii + 1 + dx, 3 * jj + 1 + dy, 3 * kk + 1 + dz] = vals[:, c]
+    return v
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_cell_lattice_rare_subtilings(gpu, seed):
+    v = _cell_lattice(seed)
+    c = np.random.default_rng(seed).uniform(0, 1, v.shape + (3,)).astype(np.float32)
+    mn, mx = [-1, -2, -3], [1.5, 2.5, 3.5]
+    om = O.march(v, c, mn, mx)
+    assert len({tuple(r) for r in om.cells[:, 2:4].tolist()}) > 560      # distinct tiling rows in ONE volume
+    m = MarchingCubes.CreateMesh(Voxels(v, c, mn, mx))
+    assert_mesh_equal(m, om)
+    assert m.ActiveCells == len(om.cells)
