@@ -100,14 +100,14 @@ def cpu_baseline(scene, n):
             "mtris_per_s": round(tris / best[0] / 1e6, 3)}
 
 
-def load_pmc_traffic(kernel, n):
+def load_pmc_traffic(kernel, scene, n):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), if present."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(p):
         return None
     try:
         d = json.load(open(p))
-        return d.get(f"{kernel}@{n}")  # bytes per launch, or None when that kernel/size was not profiled
+        return d.get(f"{kernel}@{scene}@{n}")  # bytes per launch, or None when that kernel/scene/size was not profiled
     except Exception:
         return None
 
@@ -320,19 +320,17 @@ def main():
         # algorithmic bytes per launch: sample stores 4 B/voxel (+12 B colour),
         # signbits loads 4 B/voxel; candidates for "dominant kernel"
         cands = {}
-        for k in ("sdfk_sample_bits", "sdfk_sample_scalar"):
-            if k in kern:  # stores: 4 B/voxel distance (+12 B colour) + 1/8 B/voxel sign bits
+        for k in kern:  # sdfk_sample_bits[_clip][_anynz]: whichever entry point of the fused sampler ran
+            if k.startswith("sdfk_sample_bits"):  # stores: 4 B/voxel distance (+12 B colour) + 1/8 B/voxel sign bits
                 cands[k] = nvox_rank * (16 if colors else 4) + nvox_rank // 8
-        if "k_signbits" in kern:
-            cands["k_signbits"] = nvox_rank * 4
         dom = max(cands, key=lambda k: kern[k]["avg_us"]) if cands else None
         roof = None
         if dom:
-            own = roof_us is not None and dom == "sdfk_sample_bits"
+            own = roof_us is not None
             us = roof_us if own else kern[dom]["avg_us"]
             ach = cands[dom] / (us * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(dom, n),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(dom, args.scene, n),
                     "algorithmic_bytes_per_launch": cands[dom], "avg_launch_us": round(us, 2),
                     "method": ("one HIP event pair on the launch stream around K back-to-back launches of the kernel alone (four resident "
                                "volumes in turn), divided by K" if own else

@@ -735,6 +735,9 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     if (blockIdx.x == 0) publish_totals(P);   // k_resolve has completed (stream order)
     uint64_t chunk_prefix = 0;
     uint32_t prefix_upto = 0;
+#if SDFK_K4_ABLATE == 1
+    if (n) return;
+#endif
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t cnt = min(256u, n - base);
         const uint32_t irec = base + threadIdx.x;
@@ -794,6 +797,9 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         if (threadIdx.x == 0) P.chunkpre[base >> 8] = chunk_prefix;
         const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs: LDS is complete)
         const uint32_t chunk_vbase = (uint32_t)(chunk_prefix >> 31);
+#if SDFK_K4_ABLATE == 2
+        if (n) continue;
+#endif
         // ---- per created vertex
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {
             const int rr = find_owner_256(s_pre, j);   // = window slot of the creator (W1 starts at the chunk)
@@ -843,15 +849,21 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             } else {
                 sl[3] = rr;
             }
+#if SDFK_K4_ABLATE == 3
+            if (n) { if (sl[0] + sl[1] + sl[2] + sl[3] == 123456789) P.rec_vid[0] = vi; continue; }
+#endif
             // push this vertex's id into every live cell around the edge (K5 reads only its own record)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (sl[s] == -1) continue;
                 const uint32_t g = sl[s] >= 0 ? ((uint32_t)sl[s] < w1_cnt ? w1_start + (uint32_t)sl[s] : w2_start + ((uint32_t)sl[s] - w1_cnt))
                                               : (uint32_t)(-2 - sl[s]);
-                P.rec_vid[(size_t)g * 16 + (e == 12 ? 12 : mc_share_edge(dir, s))] = vi;
+                P.rec_vid[(size_t)(e == 12 ? 12 : mc_share_edge(dir, s)) * P.cap_active + g] = vi;
             }
             if (!emit) continue;
+#if SDFK_K4_ABLATE == 4
+            if (n) continue;
+#endif
             const int own_row = (int)(info >> 22);
             float pos[3], colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
@@ -944,6 +956,9 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     }
                 }
             }
+#if SDFK_K4_ABLATE == 5
+            if (n) { if (nrm[0] + nrm[1] + nrm[2] + pos[0] + pos[1] + pos[2] + colr[0] == 1.2345e30f) M.vertices[0] = 1.0f; continue; }
+#endif
             // Cell.NegativeNormals (Cell.cs:97-109), then Mesh.Transform (Mesh.cs:47-64)
             const float len = v3len(nrm[0], nrm[1], nrm[2]);
             const float q0 = -(nrm[0] / len), q1 = -(nrm[1] / len), q2 = -(nrm[2] / len);
@@ -1055,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             const int rr = find_owner_256(s_pre, j);
             const uint32_t k = j - s_pre[rr];
             const int e = s_lut[s_lo[rr] + k];
-            const uint32_t vi = P.rec_vid[(size_t)(base + (uint32_t)rr) * 16 + e];   // pushed by the creator (K4)
+            const uint32_t vi = P.rec_vid[(size_t)e * P.cap_active + (base + (uint32_t)rr)];   // pushed by the creator (K4)
             M.triangles[o] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
         }
     }

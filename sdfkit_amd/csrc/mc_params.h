@@ -47,7 +47,8 @@ struct McParams {
     uint64_t* rec_own;     // created edge ids, 4 bits each, creation order
     uint32_t* rec_pre;     // in-chunk exclusive prefix: created vertices | triangles << 16
     float* rec_corners;    // 8 corner voxel values (v0..v7), 32 bytes per record
-    uint32_t* rec_vid;     // [record][16]: vertex id of the cell's edge e (0..12), pushed by the creator
+    uint32_t* rec_vid;     // [edge 0..12][cap_active]: vertex id of the cell's edge e, pushed by the creator (edge-major:
+                           // consecutive vertices push into consecutive records of the same few edge planes)
     uint32_t* chunkdead;   // "impossible case 13" cells per 256-cell chunk
     uint4* chunkwin;       // per chunk: (first row, last row, end of window 1, start of window 2) (K4 set-up)
     uint32_t* chunkwin2;   // per chunk: end of window 2

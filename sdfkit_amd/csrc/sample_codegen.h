@@ -30,6 +30,26 @@ static const char* const kSamplePrelude =
 // operand is NaN, -0 < +0) -- on gfx950 one instruction each (v_maximum3_f32 / v_minimum3_f32).
 __device__ __forceinline__ float sdfk_max_ieee(float a, float b) { return __builtin_elementwise_maximum(a, b); }
 __device__ __forceinline__ float sdfk_min_ieee(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+// MathF.Sqrt, correctly rounded.  The general expansion (operand scaling for results near the
+// denormal range, pass-through of 0 / inf / NaN) costs 17 instructions per call, and the sampling
+// kernel of a cheap SDF is bound by its VALU work as much as by its stores.  When EVERY lane's
+// operand is a normal number in [2^-96, inf) -- any sample point that is not within 1e-14 of a
+// primitive's centre -- the hardware estimate (<= 1 ulp) plus the same one-ulp correction by two
+// exact FMA residuals gives the same result in 11; a wavefront with any other operand takes the
+// general expansion as a whole (wave-uniform branch).
+__device__ __forceinline__ float sdfk_sqrt(float x)
+{
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    const bool easy = (b - 0x0f800000u) < (0x7f800000u - 0x0f800000u);   // 2^-96 <= x < inf (false for NaN, x <= 0)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!easy) != 0, 0)) return __builtin_sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    if (rm <= 0.0f) s = sm;
+    if (rp > 0.0f) s = sp;
+    return s;
+}
 )SRC";
 
 static const char* const kSampleKernels = R"SRC(
@@ -80,7 +100,8 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
     constexpr int RPW = SDFK_SAMPLE_RPW;
     __shared__ unsigned char nib[8][64];
     __shared__ __attribute__((aligned(16))) float cbuf[8 / RPW][768];   // colour staging, one slice per wavefront
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wavefront index as a scalar: row index, row base address and x coordinate stay off the VALU)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int iy = blockIdx.y, x8 = blockIdx.z;
     const int z = blockIdx.x * 256 + 4 * lane;
     const bool zok = z < A.nz;
@@ -314,7 +335,7 @@ inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t 
         case SDFK_OP_DIV: arity = 2; fmt = "v%d / v%d"; break;
         case SDFK_OP_NEG: arity = 1; fmt = "-v%d"; break;
         case SDFK_OP_ABS: arity = 1; fmt = "__builtin_fabsf(v%d)"; break;
-        case SDFK_OP_SQRT: arity = 1; fmt = "__builtin_sqrtf(v%d)"; break;
+        case SDFK_OP_SQRT: arity = 1; fmt = "sdfk_sqrt(v%d)"; break;
         case SDFK_OP_FLOOR: arity = 1; fmt = "__builtin_floorf(v%d)"; break;
         case SDFK_OP_MIN_SEL: arity = 3; fmt = "(v%d < v%d) ? v%d : v%d"; break;
         case SDFK_OP_MAX_SEL: arity = 3; fmt = "(v%d > v%d) ? v%d : v%d"; break;

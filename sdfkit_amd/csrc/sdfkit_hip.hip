@@ -700,8 +700,10 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.iso = iso_hint;
         {
             const unsigned tpb = 512u / (unsigned)g_sample_rpw;
-            ProfScope ps("sdfk_sample_bits");
             const bool aligned = (v->nz & 3) == 0;
+            // (the name rocprofv3 shows for the entry point launched)
+            ProfScope ps(aligned ? (clip_to_bounds ? "sdfk_sample_bits_clip" : "sdfk_sample_bits")
+                                 : (clip_to_bounds ? "sdfk_sample_bits_clip_anynz" : "sdfk_sample_bits_anynz"));
             hipFunction_t fn = aligned ? (clip_to_bounds ? p->fn_bits_clip : p->fn_bits) : (clip_to_bounds ? p->fn_bits_clip_any : p->fn_bits_any);
             HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
                                          (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
@@ -819,7 +821,7 @@ int alloc_records(sdfk_march_job* j, size_t c)
     rr = rr ? rr : job_alloc(j, &P.rec_own, c);
     rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
     rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
-    rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 16);
+    rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 13);
     rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkpre, c / 256 + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkdead, c / 256 + 2);

@@ -84,6 +84,39 @@ def test_sqrt_div_correctly_rounded(gpu):
     assert np.array_equal(v.Colors[..., 2], Y / (Z * Z))
 
 
+def test_sqrt_whole_float_range(gpu):
+    """The JIT's sqrt takes a short path when every lane of a wavefront has a normal operand >= 2^-96 and the
+    general expansion otherwise: operands from negative / zero / denormal to overflow, mixed within wavefronts
+    (lanes run along z)."""
+    from sdfkit_amd import Sdf, Vec4, MathF
+
+    def f(p):
+        y2 = p.y * p.y; y4 = y2 * y2; y8 = y4 * y4
+        z2 = p.z * p.z; z4 = z2 * z2; z8 = z4 * z4
+        return Vec4(MathF.Sqrt(p.x * y8), MathF.Sqrt((y8 * 1e30) * (z8 * 1e12)), MathF.Sqrt(((y8 * y8) * z8) * abs(p.x)),
+                    MathF.Sqrt((p.x * y8) * z8))
+    sdf = Sdf(f, True)
+    mn, mx, n = [-0.5, 0.0, 0.0], [7.5, 2.56, 0.512], (16, 128, 512)
+    v = sdf.ToVoxels(mn, mx, *n, clipToBounds=False)
+    D = [np.float32((np.float32(mx[a]) - np.float32(mn[a])) / np.float32(n[a])) for a in range(3)]
+    g = [(np.float32(mn[a]) + np.float32(0.5) * D[a]) + np.arange(n[a], dtype=np.float32) * D[a] for a in range(3)]
+    assert all(np.array_equal(g[a], [O.sample_position(mn, mx, *n, i * (1, n[0], n[0] * n[1])[a])[a] for i in range(n[a])]) for a in range(3))
+    X, Y, Z = np.meshgrid(*g, indexing="ij")
+    with np.errstate(all="ignore"):
+        y8 = ((Y * Y) * (Y * Y)) * ((Y * Y) * (Y * Y))
+        z8 = ((Z * Z) * (Z * Z)) * ((Z * Z) * (Z * Z))
+        ops = [X * y8, (y8 * np.float32(1e30)) * (z8 * np.float32(1e12)), ((y8 * y8) * z8) * np.abs(X), (X * y8) * z8]
+        want = [np.sqrt(o) for o in ops]
+    allops = np.concatenate([o.ravel() for o in ops])
+    tiny = np.float32(2.0) ** -96
+    assert (allops == 0).any() and np.isinf(allops).any() and (allops < 0).any()
+    assert ((allops > 0) & (allops < 1e-38)).any() and ((allops >= 1e-38) & (allops < tiny)).any() and (allops > 1e30).any()
+    mixed = ((ops[3] > 0) & (ops[3] < tiny)).any(axis=2) & (ops[3] >= tiny).any(axis=2)
+    assert mixed.any()                                     # rows (= wavefronts) holding both kinds of operand
+    for w_, g_ in zip(want, [v.Colors[..., 0], v.Colors[..., 1], v.Colors[..., 2], v.Values]):
+        np.testing.assert_array_equal(g_, w_)              # (NaN == NaN here)
+
+
 # ---------------------------------------------------------------------------
 # marching cubes on the reference's own test scenes (golden counts + full oracle parity)
 # ---------------------------------------------------------------------------
