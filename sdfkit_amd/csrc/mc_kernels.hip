@@ -708,6 +708,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_own[256];
     __shared__ uint32_t s_z[256];
+    __shared__ uint8_t s_creator[256 * 13];   // creator record (slot in the chunk) of each vertex of the chunk
     __shared__ float s_red[6][4];
     {   // per-row reference counts -> LDS (independent loads per lane)
         const int t = (int)threadIdx.x;
@@ -796,13 +797,18 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         prefix_upto = base >> 8;
         if (threadIdx.x == 0) P.chunkpre[base >> 8] = chunk_prefix;
         const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs: LDS is complete)
+        {   // vertex -> creator table (a cell creates at most 13): one LDS read per vertex instead of a search
+            const uint32_t p0 = s_pre[threadIdx.x];
+            for (uint32_t k = 0; k < my_nown; k++) s_creator[p0 + k] = (uint8_t)threadIdx.x;
+        }
+        __syncthreads();
         const uint32_t chunk_vbase = (uint32_t)(chunk_prefix >> 31);
 #if SDFK_K4_ABLATE == 2
         if (n) continue;
 #endif
         // ---- per created vertex
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {
-            const int rr = find_owner_256(s_pre, j);   // = window slot of the creator (W1 starts at the chunk)
+            const int rr = (int)s_creator[j];          // = window slot of the creator (W1 starts at the chunk)
             const int r = (int)(j - s_pre[rr]);
             const uint32_t info = s_winfo[rr];
             const int x = (int)(s_wxy[rr] & 0xffffu), y = (int)(s_wxy[rr] >> 16);
@@ -837,8 +843,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                                 const uint32_t mid = (lo + hi) >> 1;
                                 if ((int)(s_wxy[mid] & 0xffffu) <= cx) lo = mid; else hi = mid;
                             }
-                            for (uint32_t q = lo; q < hi; q++)
-                                if ((int)(s_wxy[q] & 0xffffu) == cx) sl[s] = (int)q;
+                            // (four independent probes: one LDS round trip instead of a dependent scan)
+#pragma unroll
+                            for (uint32_t q = 0; q < 4u; q++) {
+                                const uint32_t idx = min(lo + q, (uint32_t)K4_WMAX - 1u);
+                                const int wx = (int)(s_wxy[idx] & 0xffffu);
+                                if (lo + q < hi && wx == cx) sl[s] = (int)idx;
+                            }
                         }
                     }
                     if (!in_window) {

@@ -33,14 +33,14 @@ __device__ __forceinline__ float sdfk_min_ieee(float a, float b) { return __buil
 // MathF.Sqrt, correctly rounded.  The general expansion (operand scaling for results near the
 // denormal range, pass-through of 0 / inf / NaN) costs 17 instructions per call, and the sampling
 // kernel of a cheap SDF is bound by its VALU work as much as by its stores.  When EVERY lane's
-// operand is a normal number in [2^-96, inf) -- any sample point that is not within 1e-14 of a
-// primitive's centre -- the hardware estimate (<= 1 ulp) plus the same one-ulp correction by two
-// exact FMA residuals gives the same result in 11; a wavefront with any other operand takes the
+// operand is at least 2^-96 -- any sample point that is not within 4e-15 of a primitive's
+// centre -- the hardware estimate (<= 1 ulp) plus the same one-ulp correction by two exact FMA
+// residuals gives the same result in 10; a wavefront with any other operand takes the
 // general expansion as a whole (wave-uniform branch).
 __device__ __forceinline__ float sdfk_sqrt(float x)
 {
-    const unsigned b = __builtin_bit_cast(unsigned, x);
-    const bool easy = (b - 0x0f800000u) < (0x7f800000u - 0x0f800000u);   // 2^-96 <= x < inf (false for NaN, x <= 0)
+    // (false for NaN, zero, negatives; +inf takes the short path too: both residuals are NaN there and leave inf)
+    const bool easy = x >= 0x1p-96f;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!easy) != 0, 0)) return __builtin_sqrtf(x);
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
