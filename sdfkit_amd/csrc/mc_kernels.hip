@@ -590,8 +590,9 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
 // K4 / K5 helpers
 // ---------------------------------------------------------------------------
 // Workgroup-level re-balancing: a chunk of 256 cells owns a variable number of output items
-// each (created vertices / triangle indices).  An exclusive prefix in LDS plus a binary
-// search turns "one lane per cell" into "one lane per output item".
+// each (created vertices / triangle indices).  An exclusive prefix in LDS plus a small
+// item -> cell table (filled by the cells' own lanes) turns "one lane per cell" into "one lane
+// per output item".
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* s_pre /*[257]*/, uint32_t* s_wave /*[4]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -610,17 +611,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     if (threadIdx.x == 255) s_pre[256] = pre + v;
     __syncthreads();
     return s_pre[256];
-}
-
-__device__ __forceinline__ int find_owner_256(const uint32_t* s_pre, uint32_t j)
-{
-    int lo = 0, hi = 255;   // largest r with s_pre[r] <= j
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (s_pre[mid] <= j) lo = mid; else hi = mid - 1;
-    }
-    return lo;
 }
 
 // Record index of active cell (cx,cy,cz), or -1.  Records are sorted by (z, y, x) and
@@ -1060,6 +1050,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
     __shared__ uint32_t s_pre[257];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_lo[256];
+    __shared__ uint8_t s_cell[256 * 36];   // record (slot in the chunk) of each triangle index of the chunk (<= 12 triangles a cell)
     mc_load_lut_to_lds(s_lut);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
@@ -1074,11 +1065,18 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             s_lo[threadIdx.x] = info & 0x3fffu;
         }
         const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
+        {   // index -> cell table: one LDS read per index instead of a search over the prefix
+            const uint32_t p0 = s_pre[threadIdx.x];
+            for (uint32_t k = 0; k < my_ni; k += 3u) {
+                s_cell[p0 + k] = (uint8_t)threadIdx.x; s_cell[p0 + k + 1u] = (uint8_t)threadIdx.x; s_cell[p0 + k + 2u] = (uint8_t)threadIdx.x;
+            }
+        }
+        __syncthreads();
         const size_t chunk_ibase = (size_t)(P.chunkpre[base >> 8] & 0x7fffffffull) * 3;   // left by k_vertices
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
             const size_t o = chunk_ibase + j;   // serial position of this triangle index
             if (o >= M.cap_indices) { P.host_counters->overflow = 1u; continue; }
-            const int rr = find_owner_256(s_pre, j);
+            const int rr = (int)s_cell[j];
             const uint32_t k = j - s_pre[rr];
             const int e = s_lut[s_lo[rr] + k];
             const uint32_t vi = P.rec_vid[(size_t)e * P.cap_active + (base + (uint32_t)rr)];   // pushed by the creator (K4)
