@@ -531,14 +531,22 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
             corners_to_column(*reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8),
                               *reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8 + 4), col);
             const CornersLds v{col, 256, (double)P.iso};
+#if SDFK_K3_ABLATE == 1
+            Tiling t; t.nt = (int)(col[0] > 1e30f); t.lut_off = 0; t.row = 0; t.index = 1;
+#else
             const Tiling t = mc_resolve(s_lut, v);
+#endif
             const bool counted = z < P.lay_emit_end;     // the layer above is context only
             const bool emit = counted && z >= P.lay_emit_begin;
             if (t.nt > 0) {
                 if (counted) {
                     const unsigned pmask = positional_own_mask(x > 0, y > 0, P.z0 + z > 0) | (1u << 12);
                     uint32_t seen = 0;
+#if SDFK_K3_ABLATE == 2
+                    for (int k = 0; k < (int)(col[0] > 1e30f); k++) {
+#else
                     for (int k = 0; k < 3 * t.nt; k++) {   // creation order = first reference in the row
+#endif
                         const int e = s_lut[t.lut_off + k];
                         if (seen & (1u << e)) continue;
                         seen |= 1u << e;
