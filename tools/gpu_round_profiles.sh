@@ -10,9 +10,19 @@ SDFK_LANES=0 rocprofv3 --kernel-trace --stats -d $R/$O/stats_serial -o s --outpu
 SDFK_LANES=0 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 SDFK_LANES=0 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_w/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv > $O/pmc_hbm_traffic.txt
+# config C3 (RepeatXY with colours, clipToBounds): serial kernel stats + the two PMC passes
+python3 bench.py --no-cpu --scene repeatxy > $O/bench_repeatxy.json 2>/dev/null
+SDFK_LANES=0 rocprofv3 --kernel-trace --stats -d $R/$O/stats_c3 -o s --output-format csv -- python3 bench.py --no-cpu --scene repeatxy > /dev/null 2>&1
+SDFK_LANES=0 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --scene repeatxy > /dev/null 2>&1
+SDFK_LANES=0 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --scene repeatxy > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/pmc_w3/p_counter_collection.csv $O/pmc_f3/p_counter_collection.csv > $O/pmc_hbm_traffic_repeatxy.txt
+cp $O/stats_c3/s_kernel_stats.csv $O/kernel_stats_serial_repeatxy.csv
+rm -rf $O/stats_c3 $O/pmc_w3 $O/pmc_f3
 cp $O/stats/s_kernel_stats.csv $O/kernel_stats.csv
 cp $O/stats_serial/s_kernel_stats.csv $O/kernel_stats_serial.csv
 rm -rf $O/stats $O/stats_serial $O/pmc_w $O/pmc_f
 grep "^{" $O/bench.json | cut -c1-400
 cut -d, -f1,2,4 $O/kernel_stats_serial.csv | cut -c1-100
 cat $O/pmc_hbm_traffic.txt | head -12
+grep "^{" $O/bench_repeatxy.json | cut -c1-300
+head -4 $O/pmc_hbm_traffic_repeatxy.txt

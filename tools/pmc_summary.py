@@ -22,4 +22,4 @@ if __name__ == "__main__":
         print(k)
         for c in names:
             if c in d:
-                print("    %-22s %.4g" % (c, d[c]))
+                print("    %-22s %.6g" % (c, d[c]))
