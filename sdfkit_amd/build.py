@@ -23,11 +23,24 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lhiprtc"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    import fcntl
+    # one builder at a time (the ranks of a multi-process launch all come through here), and the
+    # library appears atomically: nobody ever loads a half-written file
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():   # another process built it while we waited
+            return LIB
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        tmp = f"{LIB}.tmp.{os.getpid()}"
+        cmd = [hipcc] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lhiprtc"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB
 
 
