@@ -480,8 +480,17 @@ static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_
     if (g_sample_rpw != 1 && g_sample_rpw != 2 && g_sample_rpw != 4) g_sample_rpw = 2;
     const std::string dn = std::string("-DSDFK_SAMPLE_NT=") + (en && !atoi(en) ? "0" : "1");
     const std::string dr = "-DSDFK_SAMPLE_RPW=" + std::to_string(g_sample_rpw);
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dn.c_str(), dr.c_str()};
-    hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dn.c_str(), dr.c_str()};
+    std::vector<std::string> extra;   // experiment knob: SDFK_JIT_FLAGS="-fno-slp-vectorize ..." (space separated)
+    if (const char* ex = getenv("SDFK_JIT_FLAGS")) {
+        std::string t;
+        for (const char* q = ex;; q++) {
+            if (*q == ' ' || *q == 0) { if (!t.empty()) extra.push_back(t); t.clear(); if (!*q) break; }
+            else t += *q;
+        }
+        for (auto& e : extra) opts.push_back(e.c_str());
+    }
+    hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);

@@ -117,6 +117,36 @@ def test_sqrt_whole_float_range(gpu):
         np.testing.assert_array_equal(g_, w_)              # (NaN == NaN here)
 
 
+@pytest.mark.parametrize("consts", [(1.125, 6.0, 0.1), (3.0, -7.0, 1e-3), (12345.678, 0.3, 255.0)])
+def test_division_by_constants_correctly_rounded(gpu, consts):
+    """x / c must be the correctly rounded quotient, signed zeros included: operands from zero / denormal to
+    overflow, both signs, mixed within wavefronts (also the regression test for any future short form of the
+    division by a program constant: DESIGN.md 5, "tried and dropped")."""
+    from sdfkit_amd import Sdf, Vec4
+    c0, c1, c2 = (np.float32(c) for c in consts)
+
+    def f(p):
+        z2 = p.z * p.z; z4 = z2 * z2; z8 = z4 * z4
+        big = (p.y * z8) * 1e30
+        return Vec4(((p.x - p.x) * p.y) / float(c0), (p.y * z8) / float(c1), big / float(c2), ((p.x * z8) * z8) / float(c0))
+    sdf = Sdf(f, True)
+    mn, mx, n = [-4.0, -0.5, 0.0], [4.0, 7.5, 0.512 * 40], (16, 16, 512)
+    v = sdf.ToVoxels(mn, mx, *n, clipToBounds=False)
+    D = [np.float32((np.float32(mx[a]) - np.float32(mn[a])) / np.float32(n[a])) for a in range(3)]
+    g = [(np.float32(mn[a]) + np.float32(0.5) * D[a]) + np.arange(n[a], dtype=np.float32) * D[a] for a in range(3)]
+    X, Y, Z = np.meshgrid(*g, indexing="ij")
+    with np.errstate(all="ignore"):
+        z8 = ((Z * Z) * (Z * Z)) * ((Z * Z) * (Z * Z))
+        nums = [(X - X) * Y, Y * z8, (Y * z8) * np.float32(1e30), (X * z8) * z8]   # [0]: zeros of both signs
+        want = [nums[0] / c0, nums[1] / c1, nums[2] / c2, nums[3] / c0]
+    allx = np.abs(np.concatenate([x.ravel() for x in nums]))
+    assert np.isinf(allx).any() and (allx > 2.0 ** 32).any() and ((allx > 0) & (allx < 2.0 ** -32)).any()
+    assert ((allx >= 2.0 ** -32) & (allx <= 2.0 ** 32)).mean() > 0.2 and np.signbit(nums[0]).any() and not np.signbit(nums[0]).all()
+    for w_, g_ in zip(want, [v.Colors[..., 0], v.Colors[..., 1], v.Colors[..., 2], v.Values]):
+        np.testing.assert_array_equal(g_, w_)
+        assert np.array_equal(np.signbit(g_), np.signbit(w_))   # signed zeros too
+
+
 # ---------------------------------------------------------------------------
 # marching cubes on the reference's own test scenes (golden counts + full oracle parity)
 # ---------------------------------------------------------------------------
