@@ -93,18 +93,45 @@ __device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float
 #ifndef SDFK_SAMPLE_RPW
 #define SDFK_SAMPLE_RPW 2   // x rows per wavefront (stores per lane); workgroup = 8 / RPW wavefronts
 #endif
-// ALIGNED: nz % 4 == 0 (16-byte aligned rows, no row tails); the other instantiation handles any nz
-template <bool CLIP, bool ALIGNED>
+// Three shapes of the 256 voxels a wavefront covers per x row (MODE):
+//   SDFK_ROWS  nz % 256 == 0: z in [256 b, 256 b + 256) of ONE y (blockIdx = (b, y, x/8)); y is a scalar
+//   SDFK_FLAT  nz % 4 == 0:   voxels [256 b, 256 b + 256) of the whole (y, z) PLANE of the x row, which is
+//              contiguous in memory (blockIdx = (b, 0, x/8)): a wavefront's 1 KiB store is line-aligned
+//              whatever nz is (when ny nz % 16 == 0), may span two y rows, and only the last chunk of the
+//              plane has idle lanes.  With z tiles per row instead, rows of 500 voxels make every store
+//              end in two partial lines (139 instead of 85 us at 500^3) and rows of 520 use a third tile
+//              for 8 planes.
+//   SDFK_ANY   any nz: rows start at 4-byte alignment only, the last lane of a row stores 1..3 voxels
+#define SDFK_ROWS 0
+#define SDFK_FLAT 1
+#define SDFK_ANY 2
+template <bool CLIP, int MODE>
 __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
+    constexpr bool ALIGNED = MODE != SDFK_ANY;
     __shared__ unsigned char nib[8][64];
     __shared__ __attribute__((aligned(16))) float cbuf[8 / RPW][768];   // colour staging, one slice per wavefront
     // (the wavefront index as a scalar: row index, row base address and x coordinate stay off the VALU)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int iy = blockIdx.y, x8 = blockIdx.z;
-    const int z = blockIdx.x * 256 + 4 * lane;
-    const bool zok = z < A.nz;
+    const int x8 = blockIdx.z;
+    const int plane = A.ny * A.nz;              // voxels per x row (< 2^31: Voxels.cs:82)
+    const int f0 = blockIdx.x * 256;            // SDFK_FLAT: first voxel of the chunk within the plane
+    int iy = blockIdx.y, z = blockIdx.x * 256 + 4 * lane;
+    bool zok = z < A.nz;
+    if (MODE == SDFK_FLAT) {
+        const int iy0 = f0 / A.nz;              // (scalar)
+        iy = iy0;
+        z = (f0 - iy0 * A.nz) + 4 * lane;
+        if (A.nz >= 256) {                      // a chunk spans at most two rows
+            if (z >= A.nz) { z -= A.nz; iy++; }
+        } else {
+            const int q = z / A.nz;
+            z -= q * A.nz;
+            iy += q;
+        }
+        zok = f0 + 4 * lane < plane;
+    }
     const float py = A.my + (float)iy * A.dy;
     const bool edge_y = (iy == 0) | (iy == A.ny - 1);
     float pz[4];
@@ -129,7 +156,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
                 sdf_eval(px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
                 if (CLIP && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
-            const long o = ((long)ix * A.ny + iy) * A.nz + z;
+            const long o = MODE == SDFK_FLAT ? (long)ix * plane + (f0 + 4 * lane) : ((long)ix * A.ny + iy) * A.nz + z;
             if (ALIGNED || z + 3 < A.nz) sdfk_store4_nt<ALIGNED>(A.values + o, w[0], w[1], w[2], w[3]);
             else {   // last lane of a row whose length is not a multiple of 4
 #pragma unroll
@@ -152,14 +179,15 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             // floats 4 L .. 4 L + 3 of each KiB) -- ALL lanes store, also those whose own
             // voxels lie beyond nz: what they store belongs to the lanes before them.
             const int z0 = blockIdx.x * 256;
-            const int run = (A.nz - z0 < 256 ? A.nz - z0 : 256) * 3;   // floats of the run that exist
+            const int left = MODE == SDFK_FLAT ? plane - f0 : A.nz - z0;
+            const int run = (left < 256 ? left : 256) * 3;   // floats of the run that exist
             __builtin_amdgcn_wave_barrier();
             const float* cw = cbuf[wave];
             const sdfk_f4 t0 = *reinterpret_cast<const sdfk_f4*>(cw + 4 * lane);
             const sdfk_f4 t1 = *reinterpret_cast<const sdfk_f4*>(cw + 256 + 4 * lane);
             const sdfk_f4 t2 = *reinterpret_cast<const sdfk_f4*>(cw + 512 + 4 * lane);
             __builtin_amdgcn_wave_barrier();
-            float* c = A.colors + (((long)ix * A.ny + iy) * A.nz + z0) * 3;
+            float* c = A.colors + (MODE == SDFK_FLAT ? (long)ix * plane + f0 : ((long)ix * A.ny + blockIdx.y) * A.nz + z0) * 3;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const sdfk_f4 t = q == 0 ? t0 : (q == 1 ? t1 : t2);
@@ -184,10 +212,12 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
         *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * A.pitch8 + z) = out;   // pitch8 = nz rounded up to 4
     }
 }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false, true>(A); }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true, true>(A); }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_anynz(SampleArgs A) { sdfk_sample_bits_body<false, false>(A); }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_anynz(SampleArgs A) { sdfk_sample_bits_body<true, false>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_ROWS>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ROWS>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_flat(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_FLAT>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_FLAT>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_anynz(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_ANY>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_anynz(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ANY>(A); }
 
 // Corner values of the active cells, RE-EVALUATED instead of gathered: for a volume this very
 // program has just sampled, the 8 corners of cell (x,y,z) are 8 more evaluations of the same

@@ -245,6 +245,7 @@ struct sdfk_program {
     hipModule_t module = nullptr;
     hipFunction_t fn_bits = nullptr;
     hipFunction_t fn_bits_clip = nullptr;
+    hipFunction_t fn_bits_flat = nullptr, fn_bits_clip_flat = nullptr; // nz % 4 == 0 but not a multiple of 256: chunks of the (y, z) plane
     hipFunction_t fn_bits_any = nullptr, fn_bits_clip_any = nullptr;   // rows of any length (nz % 4 != 0)
     hipFunction_t fn_corners = nullptr;
     hipFunction_t fn_raymarch = nullptr;
@@ -533,6 +534,8 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_raymarch, p->module, "sdfk_raymarch");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip, p->module, "sdfk_sample_bits_clip");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_flat, p->module, "sdfk_sample_bits_flat");
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip_flat, p->module, "sdfk_sample_bits_clip_flat");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_any, p->module, "sdfk_sample_bits_anynz");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip_any, p->module, "sdfk_sample_bits_clip_anynz");
     if (e != hipSuccess) {
@@ -709,13 +712,23 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.iso = iso_hint;
         {
             const unsigned tpb = 512u / (unsigned)g_sample_rpw;
-            const bool aligned = (v->nz & 3) == 0;
-            // (the name rocprofv3 shows for the entry point launched)
-            ProfScope ps(aligned ? (clip_to_bounds ? "sdfk_sample_bits_clip" : "sdfk_sample_bits")
-                                 : (clip_to_bounds ? "sdfk_sample_bits_clip_anynz" : "sdfk_sample_bits_anynz"));
-            hipFunction_t fn = aligned ? (clip_to_bounds ? p->fn_bits_clip : p->fn_bits) : (clip_to_bounds ? p->fn_bits_clip_any : p->fn_bits_any);
-            HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
-                                         (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
+            // 0: z tiles of one y row (nz % 256 == 0); 1: 256-voxel chunks of the (y, z) plane of an x row
+            // (nz % 4 == 0); 2: rows of any length
+            static const int force = getenv("SDFK_SAMPLE_MODE") ? atoi(getenv("SDFK_SAMPLE_MODE")) : -1;   // experiment knob
+            int mode = (v->nz % 256) == 0 ? 0 : ((v->nz & 3) == 0 ? 1 : 2);
+            if (force == 0 && (v->nz & 3) == 0) mode = 0;
+            if (force == 1 && (v->nz & 3) == 0) mode = 1;
+            static const char* const names[2][3] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_bits_anynz"},
+                                                    {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat", "sdfk_sample_bits_clip_anynz"}};
+            ProfScope ps(names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
+            const hipFunction_t fns[2][3] = {{p->fn_bits, p->fn_bits_flat, p->fn_bits_any}, {p->fn_bits_clip, p->fn_bits_clip_flat, p->fn_bits_clip_any}};
+            const hipFunction_t fn = fns[clip_to_bounds ? 1 : 0][mode];
+            const size_t plane = (size_t)v->ny * v->nz;
+            if (mode == 1)
+                HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((plane + 255) / 256), 1, (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
+            else
+                HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
+                                             (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
         }
         if (g.sampler_only) {   // measurement mode (sdfk_profile_enable(2)): the sampling kernel alone, back to back
             v->bits_valid = false;
