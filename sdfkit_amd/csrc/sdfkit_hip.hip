@@ -1443,7 +1443,9 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
         g.side_lanes = std::max(0, std::min(Context::NSIDE, atoi(e)));
         if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
     } else {
-        g.side_lanes = 2;
+        // small grids are launch-latency bound (9 dependent launches): a third job in flight fills the gaps
+        // (256^3: 39 instead of 48 us per step); from 512^3 up two lanes are as good or 1 % better
+        g.side_lanes = (int64_t)nx * ny * nz <= (int64_t(1) << 25) ? 3 : 2;
     }
     if (g.side_lanes > 0 && g.cur_lane == 0) {
         lane = 1 + g.next_side;
