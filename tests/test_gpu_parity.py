@@ -58,6 +58,24 @@ def test_sample_bit_exact(gpu, name, dims, clip):
     assert np.array_equal(np.array([v.DX, v.DY, v.DZ]), O.cell_size(mn, mx, *dims))
 
 
+@pytest.mark.parametrize("name", ["readme_repeat_xy", "sphere_w", "union8"])
+@pytest.mark.parametrize("dims,clip", [((10, 12, 260), True), ((9, 7, 516), False), ((16, 5, 256), True), ((8, 6, 768), False),
+                                       ((12, 9, 100), True), ((11, 3, 262), True)])
+def test_sample_long_rows_every_kernel_shape(gpu, name, dims, clip):
+    """The fused sampler has three shapes: z tiles of one row (nz % 256 == 0), 256-voxel chunks of the
+    (y, z) plane (nz % 4 == 0; a chunk spans two rows when nz >= 256, several when nz < 256), rows of any length.
+    Values, colours and the mesh built from the kernel's own sign bits must not depend on the shape."""
+    scene, sdf = S.CATALOGUE[name]()
+    mn, mx = [-2.8125, -2.5, -2.25], [2.8125, 2.75, 2.5]
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    if clip:
+        O.clip_to_bounds(ov, mn, mx)
+    v = sdf.ToVoxels(mn, mx, *dims, clipToBounds=clip)
+    assert np.array_equal(v.Values, ov) and np.array_equal(v.Colors, oc)
+    assert_mesh_equal(v.ToMesh(), O.march(ov, oc, mn, mx))
+    assert_mesh_equal(sdf.ToMesh(mn, mx, *dims, clipToBounds=clip), O.march(ov, oc, mn, mx))
+
+
 def test_sample_instance_then_clip(gpu):
     scene, sdf = S.sphere_w(2.0)
     v = Voxels.SampleSdf(sdf, [-1] * 3, [1] * 3, 10, 10, 10)
