@@ -60,7 +60,8 @@ def test_sample_bit_exact(gpu, name, dims, clip):
 
 @pytest.mark.parametrize("name", ["readme_repeat_xy", "sphere_w", "union8"])
 @pytest.mark.parametrize("dims,clip", [((10, 12, 260), True), ((9, 7, 516), False), ((16, 5, 256), True), ((8, 6, 768), False),
-                                       ((12, 9, 100), True), ((11, 3, 262), True)])
+                                       ((12, 9, 100), True), ((11, 3, 262), True), ((10, 12, 250), True), ((7, 6, 510), False),
+                                       ((9, 4, 7), True), ((8, 8, 5), False), ((6, 2, 258), True), ((5, 3, 257), True)])
 def test_sample_long_rows_every_kernel_shape(gpu, name, dims, clip):
     """The fused sampler has three shapes: z tiles of one row (nz % 256 == 0), 256-voxel chunks of the
     (y, z) plane (nz % 4 == 0; a chunk spans two rows when nz >= 256, several when nz < 256), rows of any length.
