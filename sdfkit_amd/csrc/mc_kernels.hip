@@ -53,14 +53,27 @@ constexpr int K4_RMAX = 288;   // k_vertices: rowstart entries staged per window
 // then regroups the bytes into the X-packed words.
 typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (gfx950 unaligned mode)
 
+// FLAT (nz % 4 == 0 but not a multiple of 256; blockIdx = (chunk, 0, x/8)): a wavefront covers voxels
+// [256 b, 256 b + 256) of the contiguous (y, z) plane of an x row instead of a z tile of one row, exactly
+// like the sampling kernel (sample_codegen.h): no idle z tile, line-aligned loads.
+template <bool FLAT>
 __global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ values, uint8_t* __restrict__ bits8, int nx, int ny,
                                                    int nz, int nx8, int pitch8, float iso)
 {
     __shared__ unsigned char nib[8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int iy = blockIdx.y, x8 = blockIdx.z;
-    const int z = blockIdx.x * 256 + 4 * lane;
-    const bool zok = z < nz;
+    const int x8 = blockIdx.z;
+    int iy = blockIdx.y, z = blockIdx.x * 256 + 4 * lane;
+    bool zok = z < nz;
+    if (FLAT) {
+        const int f0 = blockIdx.x * 256, iy0 = f0 / nz;
+        iy = iy0;
+        z = (f0 - iy0 * nz) + 4 * lane;
+        const int q = z / nz;
+        z -= q * nz;
+        iy += q;
+        zok = f0 + 4 * lane < ny * nz;
+    }
     float v[2][4];
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {

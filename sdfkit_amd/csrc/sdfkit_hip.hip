@@ -862,8 +862,12 @@ int launch_classify(sdfk_march_job* j, bool publish)
         uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
         const int nx8 = (P.nx + 7) / 8, pitch8 = (P.nz + 3) & ~3;
-        hipLaunchKernelGGL(k_signbits8, dim3((P.nz + 255) / 256, P.ny, nx8), dim3(256), 0, g.stream, P.values, j->bits8, P.nx, P.ny,
-                           P.nz, nx8, pitch8, P.iso);
+        if ((P.nz & 3) == 0 && (P.nz % 256) != 0)   // chunks of the (y, z) plane: rows shorter or longer than a z tile
+            hipLaunchKernelGGL(k_signbits8<true>, dim3((unsigned)(((size_t)P.ny * P.nz + 255) / 256), 1, nx8), dim3(256), 0, g.stream,
+                               P.values, j->bits8, P.nx, P.ny, P.nz, nx8, pitch8, P.iso);
+        else
+            hipLaunchKernelGGL(k_signbits8<false>, dim3((P.nz + 255) / 256, P.ny, nx8), dim3(256), 0, g.stream, P.values, j->bits8, P.nx, P.ny,
+                               P.nz, nx8, pitch8, P.iso);
         hipLaunchKernelGGL(k_bits_transpose, dim3((P.nz + 127) / 128, P.ny, (P.nxw + 7) / 8), dim3(256), 0, g.stream, j->bits8, bits,
                            nx8, P.ny, P.nz, P.nxw, pitch8);
         HIPCHK(hipGetLastError());

@@ -75,7 +75,7 @@ int main()
     CK(hipMalloc(&P.rec_xy, P.cap_active * 4)); CK(hipMalloc(&P.rec_z, P.cap_active * 4));
     CK(hipMalloc(&P.counters, sizeof(McCounters)));
     uint8_t* bits8; CK(hipMalloc(&bits8, (size_t)n * (n / 8) * n + 64));
-    hipLaunchKernelGGL(k_signbits8, dim3((n + 255) / 256, n, n / 8), dim3(256), 0, 0, values, bits8, n, n, n, n / 8, n, 0.0f);
+    hipLaunchKernelGGL(k_signbits8<false>, dim3((n + 255) / 256, n, n / 8), dim3(256), 0, 0, values, bits8, n, n, n, n / 8, n, 0.0f);
     hipLaunchKernelGGL(k_bits_transpose, dim3((n + 127) / 128, n, (P.nxw + 7) / 8), dim3(256), 0, 0, bits8, bits, n / 8, n, n, P.nxw, n);
     CK(hipDeviceSynchronize());
     printf("blocks %d\n", nlog);
