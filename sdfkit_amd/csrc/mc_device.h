@@ -58,6 +58,9 @@ struct Tiling {
 // visits every entry) when only the NUMBER of references to one edge is needed.
 __constant__ uint64_t c_rowocc[MCLUT_NROWS] = {MCLUT_ROWOCC_VALUES};
 __constant__ uint8_t c_rownt[MCLUT_NROWS] = {MCLUT_ROWNT_VALUES};   // triangles of each row
+// distinct vertex ids of each row in the order of their first reference (4 bits each from bit 0, their
+// number in bits 60..63): the order in which a cell creates the vertices it owns (Cell.cs:272-359)
+__constant__ uint64_t c_roword[MCLUT_NROWS] = {MCLUT_ROWORD_VALUES};
 
 // Corner accessors.  The Lewiner tables index the eight corners with run-time indices; a
 // per-thread register array indexed that way is demoted to scratch memory by the compiler,

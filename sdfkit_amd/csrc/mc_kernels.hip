@@ -528,7 +528,17 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
     __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
     __shared__ uint64_t s_wave[4];
+    __shared__ uint64_t s_ord[MCLUT_NROWS];
     mc_load_lut_to_lds(s_lut);
+    {   // per-row creation order -> LDS (independent loads per lane)
+        const int t = (int)threadIdx.x;
+        static_assert(MCLUT_NROWS <= 768, "row table copy assumes <= 3 rounds");
+        const uint64_t a0 = c_roword[min(t, MCLUT_NROWS - 1)], a1 = c_roword[min(t + 256, MCLUT_NROWS - 1)];
+        const uint64_t a2 = c_roword[min(t + 512, MCLUT_NROWS - 1)];
+        if (t < MCLUT_NROWS) s_ord[t] = a0;
+        if (t + 256 < MCLUT_NROWS) s_ord[t + 256] = a1;
+        if (t + 512 < MCLUT_NROWS) s_ord[t + 512] = a2;
+    }
     __syncthreads();
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const bool check_dead = P.counters->n_case13 != 0;
@@ -554,15 +564,14 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
             if (t.nt > 0) {
                 if (counted) {
                     const unsigned pmask = positional_own_mask(x > 0, y > 0, P.z0 + z > 0) | (1u << 12);
-                    uint32_t seen = 0;
+                    const uint64_t ord = s_ord[t.row];   // the row's vertex ids in the order of their first reference = creation order
 #if SDFK_K3_ABLATE == 2
-                    for (int k = 0; k < (int)(col[0] > 1e30f); k++) {
+                    const int nd = (int)(col[0] > 1e30f);
 #else
-                    for (int k = 0; k < 3 * t.nt; k++) {   // creation order = first reference in the row
+                    const int nd = (int)(ord >> 60);
 #endif
-                        const int e = s_lut[t.lut_off + k];
-                        if (seen & (1u << e)) continue;
-                        seen |= 1u << e;
+                    for (int k = 0; k < nd; k++) {
+                        const int e = (int)((ord >> (4 * k)) & 15ull);
                         bool mine = (pmask >> e) & 1u;
                         if (check_dead && !mine)   // an earlier sharer exists: is any of them alive?
                             mine = !edge_has_live_predecessor(P, s_lut, e, x, y, z, true, col);

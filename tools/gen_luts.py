@@ -139,7 +139,17 @@ def row_table(tables):
                     c = row.count(e)
                     assert c < 16
                     occ |= c << (4 * e)
-                rows.append((off + r * rowlen, nt, occ))
+                # distinct vertex ids in the order of their first reference (= creation order of the
+                # vertices a cell owns, Cell.cs:272-359): 4 bits each from bit 0, their number in bits 60..63
+                order = []
+                for e in row:
+                    if e not in order:
+                        order.append(e)
+                assert len(order) <= 13
+                ord_word = len(order) << 60
+                for k, e in enumerate(order):
+                    ord_word |= e << (4 * k)
+                rows.append((off + r * rowlen, nt, occ, ord_word))
         off += len(vals)
     return rows, bases
 
@@ -169,6 +179,7 @@ def emit_header(path, guard, prefix, tables, note):
     lines.append(f"#define {prefix}ROWOFF_VALUES " + ",".join(str(r[0]) for r in rows))
     lines.append(f"#define {prefix}ROWNT_VALUES " + ",".join(str(r[1]) for r in rows))
     lines.append(f"#define {prefix}ROWOCC_VALUES " + ",".join("0x%xull" % r[2] for r in rows))
+    lines.append(f"#define {prefix}ROWORD_VALUES " + ",".join("0x%xull" % r[3] for r in rows))
     lines.append(f"#define {prefix}BLOB_VALUES \\")
     row = []
     chunks = []
