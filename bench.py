@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# RCCL / device-memory sharing between the ranks of a node needs dmabuf IPC on this driver stack; the
+# launcher's environment normally carries this already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
