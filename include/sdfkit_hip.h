@@ -185,6 +185,14 @@ int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t cli
  * of that job were too small (complete the mesh with any accessor and pack again). */
 #define SDFK_SLAB_HEADER_BYTES 64
 int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_t* needed_bytes);
+/* One sharded step of a rank in ONE call (what a pipelined driver queues per step; no host wait):
+ * [sdfk_lane_begin(lane, wait_hip_event) if lane > 0] sdfk_sample_march_slab -> sdfk_mesh_pack into dst ->
+ * sdfk_mesh_free [sdfk_lane_end(1)].  The payload header tells the counts (-1: speculative buffers too small,
+ * redo the step on the exact path).  Exists to keep the host out of the way: at 8 ranks a step is bound by
+ * host time, and five foreign-function transitions per step are part of it. */
+int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
+                      int32_t layer_begin, int32_t layer_end, void* dst, int64_t capacity_bytes,
+                      int32_t lane, void* wait_hip_event);
 /* `gathered` = world payloads of stride_bytes each (device memory, as produced by an
  * all-gather of sdfk_mesh_pack buffers with slab-local indices): adds to the indices of slab r
  * the vertex counts of slabs 0..r-1, in one launch, reading the counts from the headers. */

@@ -58,6 +58,7 @@ SIGNATURES = {
     "sdfk_march_slab": (C.c_int, [_vp, _f, _i32, _i32, _i64, _vpp]),
     "sdfk_sample_march_slab": (C.c_int, [_vp, _vp, _i32, _f, _i32, _i32, _i64, _vpp]),
     "sdfk_mesh_pack": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64)]),
+    "sdfk_slab_enqueue": (C.c_int, [_vp, _vp, _i32, _f, _i32, _i32, _vp, _i64, _i32, _vp]),
     "sdfk_slabs_rebase": (C.c_int, [_vp, _i32, _i64]),
     "sdfk_slabs_rebase_mirror": (C.c_int, [_vp, _i32, _i64, _vp]),
     "sdfk_mesh_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -449,6 +449,25 @@ extern "C" int sdfk_lane_end(int32_t caller_stream_waits)
     return SDFK_OK;
 }
 
+extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
+                                 int32_t layer_begin, int32_t layer_end, void* dst, int64_t capacity_bytes,
+                                 int32_t lane, void* wait_hip_event)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    int r = lane > 0 ? sdfk_lane_begin(lane, wait_hip_event) : SDFK_OK;
+    if (r) return r;
+    sdfk_mesh* m = nullptr;
+    r = sdfk_sample_march_slab(p, slab, clip_to_bounds, iso_value, layer_begin, layer_end, 0, &m);
+    int64_t need = 0;
+    if (!r) r = sdfk_mesh_pack(m, dst, capacity_bytes, &need);
+    if (m) sdfk_mesh_free(m);   // stream-ordered: the pack above still reads it
+    if (lane > 0) {
+        const int r2 = sdfk_lane_end(1);
+        if (!r) r = r2;
+    }
+    return r;
+}
+
 extern "C" int sdfk_synchronize(void)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);

@@ -74,6 +74,7 @@ class GpuSlabWorker:
         self.vertex_bytes = 36 if sdf.writes_color else 24   # payload bytes per vertex (sdfk_mesh_pack)
         self.job = None
         self.mesh = None
+        self._clip_i = None
 
     def begin(self):
         N = self.N
@@ -118,18 +119,18 @@ class GpuSlabWorker:
         N.check(N.lib().sdfk_mesh_counts(m, C.byref(nv), C.byref(ni)))
         return nv.value, ni.value
 
-    def enqueue(self, buf):
+    def enqueue(self, buf, lane=0, wait_event=None):
         """Asynchronous form of run_local + pack_self_describing: queues sample, mesh and the
         device-side pack into the uint8 torch tensor `buf` and returns without waiting; the
-        counts are in the payload header (-1 = this job's speculative buffers were too small)."""
+        counts are in the payload header (-1 = this job's speculative buffers were too small).
+        lane > 0: inside a lane section of the library (sdfk_lane_begin/end), after `wait_event`.
+        One foreign call (sdfk_slab_enqueue) instead of five."""
         N = self.N
         self.release()
-        m = C.c_void_p()
-        N.check(N.lib().sdfk_sample_march_slab(self.prog, self.vol, 1 if self.clip else 0, C.c_float(self.iso),
-                                               self.lb, self.le, 0, C.byref(m)))
-        need = C.c_int64()
-        N.check(N.lib().sdfk_mesh_pack(m, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(need)))
-        N.lib().sdfk_mesh_free(m)   # stream-ordered: the pack above still reads it
+        if self._clip_i is None:
+            self._clip_i, self._iso_f = (1 if self.clip else 0), C.c_float(self.iso)
+        N.check(N.lib().sdfk_slab_enqueue(self.prog, self.vol, self._clip_i, self._iso_f, self.lb, self.le,
+                                          buf.data_ptr(), buf.numel(), lane, wait_event))
 
     def pack_self_describing(self, buf):
         """sdfk_mesh_pack into the uint8 torch tensor `buf`; returns the bytes needed."""
@@ -314,6 +315,13 @@ class SlabSession:
         self.ready = [None] * self.depth
         self.work = [None] * self.depth
         self.buf_free = [None] * self.depth
+        # per-step host time matters (at 8 ranks a step is bound by it): everything that can be made once
+        # per slot is -- events, the flat view of the gather buffer, an int64 view of the pinned headers
+        self.slot_event = [None] * self.depth
+        self.gathered_flat = [None] * self.depth
+        self.hdr_np = [None] * self.depth
+        self._nccl = None
+        self._cur_stream = None
         self.nsub = 0
         import os
         self.lanes = 2 if (self.mirror_headers and os.environ.get("SDFK_LANES", "2") != "0") else 0
@@ -330,8 +338,10 @@ class SlabSession:
         next step's kernels are queued behind the pack of this one, not behind its exchange."""
         import torch.distributed as dist
         g, b = self.gathered_slots[slot], self.buf[slot]
-        if dist.get_backend(self.group) == "nccl":
-            self.work[slot] = dist.all_gather_into_tensor(g.view(-1), b, group=self.group, async_op=True)
+        if self._nccl is None:
+            self._nccl = dist.get_backend(self.group) == "nccl"
+        if self._nccl:
+            self.work[slot] = dist.all_gather_into_tensor(self.gathered_flat[slot], b, group=self.group, async_op=True)
         else:
             self.work[slot] = dist.all_gather([g[r] for r in range(self.world)], b, group=self.group, async_op=True)
         self.unfinished = slot
@@ -352,8 +362,12 @@ class SlabSession:
             # copy; the same event says "this slot's send buffer has been read by the collective"
             import torch
             self.rebase(self.gathered_slots[slot], self.world, self.stride, self.hdr_host[slot])
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            ev = self.slot_event[slot]   # (a slot is resubmitted only after it has been collected: its event is free again)
+            if ev is None:
+                ev = self.slot_event[slot] = torch.cuda.Event()
+            if self._cur_stream is None:
+                self._cur_stream = torch.cuda.current_stream(self.device)
+            ev.record(self._cur_stream)
             self.ready[slot] = self.buf_free[slot] = ev
             return
         self.rebase(self.gathered_slots[slot], self.world, self.stride)
@@ -383,6 +397,8 @@ class SlabSession:
             self.gathered_slots[k] = torch.zeros((self.world, self.stride), dtype=torch.uint8, device=self.device)
             h = torch.zeros((self.world, SLAB_HEADER_BYTES), dtype=torch.uint8)
             self.hdr_host[k] = h.pin_memory() if self.on_gpu else h
+            self.gathered_flat[k] = self.gathered_slots[k].view(-1)
+            self.hdr_np[k] = self.hdr_host[k].numpy().view(np.int64) if self.on_gpu else None   # [world, 8]: nv, ni first
 
     def _exact_step(self, slot):
         """Synchronous, exact form of a step (first step, and the redo of a failed one)."""
@@ -400,14 +416,11 @@ class SlabSession:
         return nv, ni
 
     def _headers(self, slot):
-        import torch
         if self.on_gpu:
             self.ready[slot].synchronize()
-            h = self.hdr_host[slot]
-        else:
-            h = self.gathered_slots[slot][:, :SLAB_HEADER_BYTES].contiguous()
-        counts = h.numpy()[:, :16].copy().view(np.int64)   # [world, 2] = (nv, ni)
-        return counts
+            return self.hdr_np[slot][:, :2]   # (read in place: the slot is not rewritten before it is resubmitted)
+        h = self.gathered_slots[slot][:, :SLAB_HEADER_BYTES].contiguous()
+        return h.numpy()[:, :16].copy().view(np.int64)   # [world, 2] = (nv, ni)
 
     # -- pipeline ---------------------------------------------------------------
     def submit(self):
@@ -426,14 +439,9 @@ class SlabSession:
             # the step's kernels go to an internal stream of the library (alternating between two):
             # the launch-latency-bound kernel chains of consecutive steps overlap on the GPU.  The
             # lane only waits for the collective that read this slot's send buffer last time.
-            from . import _native as N
             ev = self.buf_free[slot]
             self.nsub += 1   # (lanes alternate per step, not per slot: consecutive steps never share one)
-            N.check(N.lib().sdfk_lane_begin(1 + self.nsub % self.lanes, C.c_void_p(ev.cuda_event) if ev is not None else None))
-            try:
-                self.workers[slot].enqueue(self.buf[slot])
-            finally:
-                N.check(N.lib().sdfk_lane_end(1))
+            self.workers[slot].enqueue(self.buf[slot], 1 + self.nsub % self.lanes, ev.cuda_event if ev is not None else None)
         else:
             self.workers[slot].enqueue(self.buf[slot])
         prev = self.unfinished
@@ -446,15 +454,16 @@ class SlabSession:
         slot, counts = self.queue.pop(0)
         if counts is None:
             self._finish_gather(slot)
-            hdr = self._headers(slot)
-            if (hdr < 0).any():                     # some rank's guess was too small: everybody redoes the step
+            hdr = self._headers(slot).tolist()      # [[nv, ni]] * world (plain ints: a handful of numpy calls cost more)
+            if any(nv < 0 or ni < 0 for nv, ni in hdr):   # some rank's guess was too small: everybody redoes the step
                 self.redone += 1
                 counts = self._exact_step(slot)
             else:
-                need = SLAB_HEADER_BYTES + getattr(self.workers[slot], "vertex_bytes", 36) * hdr[:, 0] + 4 * hdr[:, 1]
-                if int(need.max()) > self.stride:
-                    raise RuntimeError(f"slab payload grew to {int(need.max())} B (> agreed stride {self.stride} B)")
-                counts = (int(hdr[self.rank, 0]), int(hdr[self.rank, 1]))
+                vb = getattr(self.workers[slot], "vertex_bytes", 36)
+                need = max(SLAB_HEADER_BYTES + vb * nv + 4 * ni for nv, ni in hdr)
+                if need > self.stride:
+                    raise RuntimeError(f"slab payload grew to {need} B (> agreed stride {self.stride} B)")
+                counts = (hdr[self.rank][0], hdr[self.rank][1])
         self.gathered = self.gathered_slots[slot]
         return counts
 
