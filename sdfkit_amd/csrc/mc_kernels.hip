@@ -1001,12 +1001,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             float* ov = M.vertices + (size_t)out * 3;
             float* oc = M.colors + (size_t)out * 3;
             float* on = M.normals + (size_t)out * 3;
-            ov[0] = px; ov[1] = py; ov[2] = pz;
-            oc[0] = colr[0]; oc[1] = colr[1]; oc[2] = colr[2];
-            on[0] = t0 / tl; on[1] = t1 / tl; on[2] = t2 / tl;
+            // (one 12-byte store per array: a third of the store instructions of three dword stores)
+            *reinterpret_cast<f3u*>(ov) = f3u{px, py, pz};
+            *reinterpret_cast<f3u*>(oc) = f3u{colr[0], colr[1], colr[2]};
+            *reinterpret_cast<f3u*>(on) = f3u{t0 / tl, t1 / tl, t2 / tl};
             if (M.grid_vertices) {
                 float* og = M.grid_vertices + (size_t)out * 3;
-                og[0] = pos[0]; og[1] = pos[1]; og[2] = pos[2];
+                *reinterpret_cast<f3u*>(og) = f3u{pos[0], pos[1], pos[2]};
             }
             bmin[0] = fminf(bmin[0], px); bmin[1] = fminf(bmin[1], py); bmin[2] = fminf(bmin[2], pz);
             bmax[0] = fmaxf(bmax[0], px); bmax[1] = fmaxf(bmax[1], py); bmax[2] = fmaxf(bmax[2], pz);
