@@ -12,6 +12,9 @@ writes the volume to HBM, the marching-cubes pipeline reads it and leaves the in
 
 N > 1: the SAME 512^3 grid is sharded by Z slab over the ranks (strong scaling), with an RCCL
 all-gather of the slab meshes (sdfkit_amd/dist.py).  Rank 0 prints ONE JSON line.
+Started as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) it launches
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` itself, as a CHILD process,
+before anything in this process has touched the GPU, and relays rank 0's JSON line.
 """
 import argparse
 import ctypes as C
@@ -33,8 +36,44 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 WORKLOADS = {
     "sphere": "Sdfs.Sphere(1), bounds -1.5..1.5, no clip",
     "repeatxy": "SdfExprs.Sphere(0.5).RepeatXY(1.125,1.125,colour), bounds -2.8125..2.8125, clipToBounds",
-    "union8": "nested SdfExprs.Union of 8 primitives (sphere/box/cylinder) at the octant centres, bounds -2.8125..2.8125, clipToBounds",
+    "union8": "nested SdfExprs.Union of 8 primitives (sphere/box/cylinder) at the octant centres of [-2,2]^3, bounds -2..2, clipToBounds",
 }
+
+
+def launch_ranks(argv, n):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU under
+    torch.distributed.run as a child process (never exec: see the module docstring), forward its
+    output and return its exit code.  Nothing here imports torch or touches HIP."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    tries = [({}, "")]
+    # a second, conservative attempt if the pipelined form fails on this node: one step in flight,
+    # no internal lanes (same protocol, same kernels)
+    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0"}, "retry: one step in flight, no lanes"))
+    rc = 1
+    for extra, note in tries:
+        e = dict(env)
+        e.update(extra)
+        if note:
+            print(f"bench.py: multi-rank run failed (rc {rc}); {note}", file=sys.stderr, flush=True)
+            e["SDFK_BENCH_NOTE"] = note
+        p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, text=True)
+        rc = p.returncode
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if rc == 0 and lines:
+            sys.stdout.write(p.stdout)
+            sys.stdout.flush()
+            return 0
+        sys.stderr.write(p.stdout)
+    return rc or 1
 
 
 def scene_for(name):
@@ -56,14 +95,15 @@ def scene_for(name):
         prod = prims[0]
         for q in prims[1:]:
             prod = SdfExprs.Union(prod, q)
-        return prod.ToSdf(), [-2.8125] * 3, [2.8125] * 3, True
+        return prod.ToSdf(), [-2.0] * 3, [2.0] * 3, True
     raise SystemExit(f"unknown scene {name}")
 
 
-def cpu_baseline(scene, n):
+def cpu_baseline(scene, n, timed=3):
     """Reference-algorithm CPU baseline: the C restatement of the reference (oracle/), sampler
     multi-threaded over 2048-point batches on all host cores, marching cubes single-threaded
-    exactly like the reference.  Bounded sample of the same workload (smaller grid)."""
+    exactly like the reference.  Same scene and (by default) the same grid as the GPU run;
+    1 warm-up + `timed` timed passes, mean of the timed ones (Perf/Program.cs:43-62 convention)."""
     from oracle import oracle as O
     s = O.Scene()
     if scene == "sphere":
@@ -74,21 +114,21 @@ def cpu_baseline(scene, n):
         for sx in (-1, 1):
             for sy in (-1, 1):
                 for sz in (-1, 1):
-                    n = (lambda: s.f_sphere(0.6), lambda: s.f_box(0.5), lambda: s.f_cylinder(0.4, 0.6))[k % 3]()
-                    nodes.append(s.f_translate(n, sx, sy, sz))
+                    prim = (lambda: s.f_sphere(0.6), lambda: s.f_box(0.5), lambda: s.f_cylinder(0.4, 0.6))[k % 3]()
+                    nodes.append(s.f_translate(prim, sx, sy, sz))
                     k += 1
         root = nodes[0]
-        for n in nodes[1:]:
-            root = s.f_union(root, n)
+        for node in nodes[1:]:
+            root = s.f_union(root, node)
         s.root = root
-        mn, mx, clip = [-2.8125] * 3, [2.8125] * 3, True
+        mn, mx, clip = [-2.0] * 3, [2.0] * 3, True
     else:
         s.f_repeat_xy_idx(s.f_sphere(0.5), 1.125, 1.125, O.CF_README)
         mn, mx, clip = [-2.8125] * 3, [2.8125] * 3, True
     cores = O.hardware_threads()
-    best = None
+    tot = smp = mc = 0.0
     tris = 0
-    for it in range(2):  # 1 warm-up + 1 timed (Perf/Program.cs:43-62 convention, bounded)
+    for it in range(1 + timed):
         t0 = time.perf_counter()
         v, c = O.sample(s, mn, mx, n, n, n, threads=cores)
         if clip:
@@ -96,12 +136,17 @@ def cpu_baseline(scene, n):
         t1 = time.perf_counter()
         m = O.march(v, c, mn, mx)
         t2 = time.perf_counter()
-        best = (t2 - t0, t1 - t0, t2 - t1)
         tris = len(m.triangles) // 3
-    return {"value": round(n ** 3 / best[0] / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
-            "sample": f"{n}^3 grid of the same scene, 1 warm-up + 1 timed pass "
-                      f"(sample {best[1]:.2f} s on {cores} threads, marching cubes {best[2]:.2f} s on 1 thread)",
-            "mtris_per_s": round(tris / best[0] / 1e6, 3)}
+        del v, c, m
+        if it:   # (pass 0 is the warm-up)
+            tot += t2 - t0
+            smp += t1 - t0
+            mc += t2 - t1
+    tot, smp, mc = tot / timed, smp / timed, mc / timed
+    return {"value": round(n ** 3 / tot / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": f"{n}^3 grid of the same scene, 1 warm-up + {timed} timed passes, mean "
+                      f"(sample {smp:.2f} s on {cores} threads, marching cubes {mc:.2f} s on 1 thread)",
+            "mtris_per_s": round(tris / tot / 1e6, 3)}
 
 
 def load_pmc_traffic(kernel, scene, n):
@@ -116,6 +161,10 @@ def load_pmc_traffic(kernel, scene, n):
         return None
 
 
+XGMI_LINKS = 7
+XGMI_LINK_GBS_PER_DIRECTION = 76.8   # 153.6 GB/s per link, both directions together
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,9 +172,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", "--grid", dest="n", type=int, default=512, help="grid edge (--grid under torch.distributed.run, whose own parser claims --n)")
     ap.add_argument("--scene", default="sphere", choices=["sphere", "repeatxy", "union8"])
-    ap.add_argument("--cpu-n", type=int, default=256, help="grid edge of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=0, help="grid edge of the CPU-baseline run (default: the same grid as the GPU run)")
+    ap.add_argument("--cpu-passes", type=int, default=3, help="timed passes of the CPU baseline (after 1 warm-up)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has imported torch or
+        # called HIP; the ranks are CHILD processes (a process that has touched the GPU must never exec).
+        argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--grid", str(args.n),
+                "--scene", args.scene, "--cpu-n", str(args.cpu_n), "--cpu-passes", str(args.cpu_passes)] + (["--no-cpu"] if args.no_cpu else [])
+        sys.exit(launch_ranks(argv, args.gpus))
 
     import numpy as np
     import torch
@@ -136,10 +193,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # SDFK_BENCH_ONE_GPU=1 (testing only): every rank uses GPU 0 and the exchange goes over gloo --
@@ -150,8 +204,10 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if one_gpu else "nccl"
         if one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -162,8 +218,37 @@ def main():
 
     n = args.n
     sdf, mn, mx, clip = scene_for(args.scene)
+
+    def sample_march_once():
+        m = C.c_void_p()
+        N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+        a, b = C.c_int64(), C.c_int64()
+        N.check(L.sdfk_mesh_counts(m, C.byref(a), C.byref(b)))
+        L.sdfk_mesh_free(m)
+        return a.value, b.value
+
+    # ---- what a caller sees on the FIRST call: program creation (hiprtc, or the on-disk code-object
+    # cache of an earlier process) + the exact two-phase path (no size hints yet: two host syncs)
+    jit0 = (C.c_int64(), C.c_int64(), C.c_double())
+    L.sdfk_jit_stats(C.byref(jit0[0]), C.byref(jit0[1]), C.byref(jit0[2]))
+    t0 = time.perf_counter()
     prog = sdf.program()
+    t_prog = time.perf_counter() - t0
+    jit1 = (C.c_int64(), C.c_int64(), C.c_double())
+    L.sdfk_jit_stats(C.byref(jit1[0]), C.byref(jit1[1]), C.byref(jit1[2]))
+    first = {"program_ms": round(t_prog * 1e3, 2),
+             "program_from": "hiprtc compile" if jit1[0].value > jit0[0].value else "on-disk code-object cache"}
     nv = ni = 0
+    if world == 1:
+        t0 = time.perf_counter()
+        nv, ni = sample_march_once()
+        first["first_mesh_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        first["what"] = ("sdfk_program_create, then the first sdfk_sample_march + sdfk_mesh_counts of this shape "
+                         "(exact two-phase path, buffers allocated from the driver)")
+        t0 = time.perf_counter()
+        sdf.check()   # sdfk_program_check: always a full hiprtc compile (no cache), no device needed
+        first["hiprtc_compile_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    first_call_ms = round(first["program_ms"] + first.get("first_mesh_ms", 0.0), 2)
 
     def barrier():
         if world > 1:
@@ -175,13 +260,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    if world == 1 and not force_dist:
+        backend = "nccl"
+    sharded = world > 1 or force_dist
+    depth_env = int(os.environ.get("SDFK_BENCH_DEPTH", "3"))
+    if not sharded:
         # sdfk_sample_march returns its mesh handle while the kernels are still queued (the
         # sizes are a guess from the previous mesh of this shape; the first accessor waits and
         # verifies).  Steps are therefore enqueued `depth` ahead of the one whose counts are read
         # back: every step is still checked, but the host never idles the GPU in between, and
         # consecutive steps overlap on the library's two internal streams.
-        depth = [int(os.environ.get("SDFK_BENCH_DEPTH", "3"))]
+        depth = [depth_env]
         inflight, last = [], [0, 0]
 
         def retire(m):
@@ -205,9 +293,9 @@ def main():
                 retire(inflight.pop(0))
             return tuple(last)
     else:
-        # one sync + one RCCL all-gather per step (sdfkit_amd/dist.py: SlabSession)
-        # three steps in flight: no host wait inside a step (sdfkit_amd/dist.py: SlabSession)
-        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev, depth=int(os.environ.get("SDFK_BENCH_DEPTH", "3")) or 1)
+        # three steps in flight, one RCCL all-gather per step, no host wait inside a step
+        # (sdfkit_amd/dist.py: SlabSession)
+        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev, depth=depth_env or 1, headroom=1.0 / 32)
         totals = torch.zeros(2, dtype=torch.int64, device=dev)
         last = [0, 0]
 
@@ -232,15 +320,48 @@ def main():
     nv, ni = drain()   # every queued step has completed and been checked before the clock stops
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1 or force_dist:   # per-rank counts -> totals of the whole mesh (outside the timed region)
-        totals[0], totals[1] = nv, ni
-        dist.all_reduce(totals)
-        nv, ni = int(totals[0].item()), int(totals[1].item())
+    per_rank = None
+    if sharded:   # per-rank counts -> totals of the whole mesh (outside the timed region)
+        mine = torch.tensor([nv, ni], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        allc = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        per_rank = [[int(t[0]), int(t[1])] for t in allc]
+        nv, ni = sum(p[0] for p in per_rank), sum(p[1] for p in per_rank)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_step = dt / args.steps * 1e3
+
+    # ---- the sharded step without its exchange: this rank's slab kernels alone, queued back to back
+    # (what "kernel-only" means at N > 1); max over ranks
+    dist_extra = {}
+    if sharded:
+        w0 = worker.workers[0]
+        for _ in range(3):
+            w0.enqueue(worker.buf[0])
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            w0.enqueue(worker.buf[0])
+        torch.cuda.synchronize()
+        tk = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        barrier()
+        recv = (world - 1) * worker.stride
+        dist_extra = {"world": world, "backend": ("RCCL (torch.distributed nccl)" if backend == "nccl" else backend),
+                      "backend_world_size": dist.get_world_size(), "per_rank_vertices_indices": per_rank,
+                      "slab_kernels_only_ms": round(float(tk.item()) / args.steps * 1e3, 4),
+                      "end_to_end_ms": round(ms_step, 4),
+                      "gather_stride_bytes_per_rank": int(worker.stride), "gather_bytes_received_per_rank": int(recv),
+                      "xgmi": {"links_per_gpu": XGMI_LINKS, "gbs_per_link_per_direction": XGMI_LINK_GBS_PER_DIRECTION,
+                               "receive_bound_ms": round(recv / (min(world - 1, XGMI_LINKS) * XGMI_LINK_GBS_PER_DIRECTION * 1e9) * 1e3, 4) if world > 1 else 0.0,
+                               "what": "every rank must RECEIVE the other ranks' slab meshes each step: bytes received / (links used x per-direction "
+                                       "link rate) is a floor for the step time whatever the kernels do"},
+                      "steps_redone_on_the_exact_path": worker.redone}
+        if os.environ.get("SDFK_BENCH_NOTE"):
+            dist_extra["note"] = os.environ["SDFK_BENCH_NOTE"]
 
     # per-kernel durations: HIP events on the launch stream, same K steps again (events around
     # every launch perturb the un-instrumented timing above, so they get their own pass).  The
@@ -256,19 +377,32 @@ def main():
     drain()
     barrier()
     N.check(L.sdfk_profile_enable(0))
+    prof = N.profile_snapshot()
+    kern = {k: {"avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "launches": v[1]} for k, v in prof.items() if v[1]}
+
+    # ---- latency of ONE call, nothing else in flight, everything on one stream: sdfk_sample_march,
+    # then the accessor that waits for it (what a caller that needs each mesh before it builds the
+    # next one gets; the headline `value` is the pipelined steady state)
+    latency_ms = None
+    if not sharded:
+        for _ in range(3):
+            sample_march_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sample_march_once()
+        latency_ms = (time.perf_counter() - t0) / args.steps * 1e3
     if lanes_env is None:
         del os.environ["SDFK_LANES"]
     else:
         os.environ["SDFK_LANES"] = lanes_env
-    prof = N.profile_snapshot()
-    kern = {k: {"avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "launches": v[1]} for k, v in prof.items() if v[1]}
 
     # The roofline kernel on its own: K back-to-back launches of the fused sampling kernel into a
     # resident volume (sdfk_sample), HIP event pairs around each launch on the launch stream.  In
     # the pipeline pass above the event pair of a job's FIRST kernel also contains the time the
     # stream sat idle waiting for the (event-laden, hence slower) host to queue the job.
     roof_us = None
-    if world == 1 and not force_dist:
+    if not sharded:
         from sdfkit_amd.api import Voxels
         # (four volumes in turn, as the pipeline does: re-writing the SAME 512 MiB back to back is
         # 30 % slower than writing a buffer that was last touched a few launches ago)
@@ -311,13 +445,22 @@ def main():
                                  "copy_gbs_read_plus_write": round(2 * x.numel() * 10 / (e1.elapsed_time(e2) * 1e-3) / 1e9, 1),
                                  "what": "torch fill_ / copy_ of 512 MiB, 10 launches each"}
         del x, y
-        if world == 1 and not force_dist:
+        if not sharded:
+            # what a host-array caller (the C# shim: Mesh.cs:10-13 are managed arrays) gets per call:
+            # sample + mesh + the four mesh arrays copied into FRESHLY allocated host arrays
             from sdfkit_amd.api import Mesh
-            t1 = time.perf_counter()
-            m = C.c_void_p()
-            N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
-            Mesh._from_handle(m)   # counts + the four arrays into host memory + bounds
-            extra["one_step_incl_mesh_d2h_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+            ts = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                m = C.c_void_p()
+                N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+                hm = Mesh._from_handle(m)   # counts + the four arrays into new host arrays + bounds
+                ts.append((time.perf_counter() - t1) * 1e3)
+                del hm
+            extra["one_step_incl_mesh_d2h_ms"] = round(min(ts[1:]), 3)
+            extra["one_step_incl_mesh_d2h_what"] = ("sdfk_sample_march + counts + sdfk_mesh_copy of V/C/N/T into newly allocated (untouched) host "
+                                                    f"arrays + bounds; best of 3 after a warm-up call; all four: {[round(t, 3) for t in ts]}")
     if rank == 0:
         nvox_rank = n * n * (D.slab_planes(*D.slab_layers(n - 1, world, rank), n)[1] if world > 1 else n)
         colors = bool(sdf.writes_color)
@@ -335,12 +478,14 @@ def main():
             ach = cands[dom] / (us * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(dom, args.scene, n),
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command, committed; not re-measured in this run)",
                     "algorithmic_bytes_per_launch": cands[dom], "avg_launch_us": round(us, 2),
                     "method": ("one HIP event pair on the launch stream around K back-to-back launches of the kernel alone (four resident "
                                "volumes in turn), divided by K" if own else
                                "hipEvent pairs around each launch on the launch stream, K-step pipeline pass on ONE in-order stream")
                               + "; the timed pass overlaps consecutive steps on two streams, which stretches every kernel"}
         total_alg = n ** 3 * (32 if colors else 8) + 36 * nv + 4 * ni
+        measured_hbm = load_pmc_traffic("pipeline_step", args.scene, n)
         out = {
             "metric": "Mvoxels/s, 512^3 sphere SDF sample->mesh" if (n == 512 and args.scene == "sphere")
                       else f"Mvoxels/s, {n}^3 {args.scene} SDF sample->mesh",
@@ -357,17 +502,28 @@ def main():
                                    f", {n}^3 voxels, iso 0, step 1; Voxels.SampleSdf -> MarchingCubes.CreateMesh, device-resident",
                        "grid": [n, n, n], "vertices": nv, "triangles": ni // 3,
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, RCCL all-gather of slab meshes"},
+            "value_is": ("throughput of the pipelined steady state: three identical jobs in flight on the library's internal streams, "
+                         "buffers sized from the previous mesh of the shape; see latency_ms_single_stream / first_call_ms for one call"),
             "mtris_per_s": round(ni / 3 / (dt / args.steps) / 1e6, 2),
+            "latency_ms_single_stream": None if latency_ms is None else round(latency_ms, 4),
+            "first_call_ms": first_call_ms,
+            "first_call": first,
             "pipeline_algorithmic_gbs": round(total_alg / (dt / args.steps) / 1e9, 1),
             "pipeline_frac_of_hbm_peak": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "pipeline_frac_is": "contract model: 8 B/voxel (4 stored by sampling + 4 loaded by meshing; 32 with colours) + 36 B/vertex + 4 B/index, "
+                                "divided by the step time and by 8 TB/s -- the fused path never re-reads the volume, so this is NOT achieved bandwidth",
+            "pipeline_measured_hbm_bytes": measured_hbm,
+            "pipeline_measured_hbm_gbs": None if not measured_hbm else round(measured_hbm / (dt / args.steps) / 1e9, 1),
             "kernels_us": kern,
             "roofline": roof,
         }
         out.update(extra)
+        if dist_extra:
+            out["sharded"] = dist_extra
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_n)
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_n or n, max(args.cpu_passes, 1))
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
+    if sharded:
         worker.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -99,6 +99,11 @@ int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgb
  * check the shim can run at build time. */
 int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color);
 const char* sdfk_program_source(const sdfk_program* p);
+/* JIT bookkeeping of this process.  Compiled code objects are kept on disk (see sdfkit_hip.hip,
+ * "on-disk cache": $SDFK_CACHE_DIR | $XDG_CACHE_HOME/sdfkit_hip | ~/.cache/sdfkit_hip; SDFK_NO_CACHE=1
+ * switches it off), so only the first process that sees a program pays for hiprtc -- the counterpart
+ * of SdfExprCompiler.Compile (SdfExpr.cs:234-238) paying the expression JIT once per delegate. */
+int sdfk_jit_stats(int64_t* n_compiled, int64_t* n_cache_hits, double* compile_ms_total);
 void sdfk_program_destroy(sdfk_program* p);
 
 /* ---- Voxels (Voxels.cs:6-65) ------------------------------------------------

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sdfk_program_check": (C.c_int, [C.POINTER(Op), _i32, C.POINTER(_i32), _i32]),
     "sdfk_program_source": (C.c_char_p, [_vp]),
     "sdfk_program_destroy": (None, [_vp]),
+    "sdfk_jit_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "sdfk_volume_create": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _i32, _vpp]),
     "sdfk_volume_create_slab": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _i32, _i32, _i32, _vpp]),
     "sdfk_volume_upload": (C.c_int, [_vp, _vp, _vp]),
@@ -89,11 +90,13 @@ def lib():
     if _lib is None:
         path = library_path()
         if not os.path.exists(path) or _build.needs_build():
+            # sources or the header are newer than the library (or it is missing): rebuild, and never
+            # run a stale binary against the current ctypes table -- a failed build is an error
             try:
                 _build.build()
-            except Exception as e:  # no silent fallback
-                if not os.path.exists(path):
-                    raise RuntimeError(f"libsdfkit_hip.so is missing and could not be built with hipcc: {e}") from e
+            except Exception as e:
+                what = "is missing" if not os.path.exists(path) else "is older than its sources"
+                raise RuntimeError(f"libsdfkit_hip.so {what} and could not be built with hipcc: {e}") from e
         # PyTorch's ROCm wheels bundle their own HIP runtime, and the runtime a process loads
         # FIRST is the one that owns the GPU: loading this library before torch leaves torch
         # without a device ("No HIP GPUs are available").  Where torch is installed, load it

@@ -5,15 +5,24 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sdfkit_hip.h"
@@ -90,11 +99,15 @@ struct Context {
     HostSlot* slots_dev = nullptr;  // device view
     int slot_next = 0;
     // A result slot belongs to ONE job from its creation until the job is released; a slot whose
-    // job was dropped with kernels still queued (an unread mesh was freed) is handed out again
-    // only after a full synchronisation (those kernels still write their counters into it).
-    struct SlotState { bool busy = false; uint64_t free_epoch = 0; };
+    // job was dropped with kernels still queued (an unread mesh was freed, a sharded step retired
+    // its mesh right after packing it) is handed out again once the event recorded on the job's
+    // lane at drop time has completed (those kernels still write their counters into it): no
+    // stream is ever synchronised for that.
+    struct SlotState { bool busy = false; bool drop_pending = false; hipEvent_t dropped = nullptr; };
     SlotState slot_state[NSLOTS];
-    uint64_t epoch = 1;
+    // pinned staging for sdfk_mesh_copy / sdfk_volume_download (grown on demand, kept)
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
     // sizes seen last time for a (shape, iso-independent) key: lets a repeat call launch the
     // whole pipeline speculatively and synchronise once
     struct Hint { uint32_t n_active, nv, ni; };
@@ -221,10 +234,27 @@ struct ProfScope {
     }
 };
 
+// The HIP current device is per THREAD, and the C# shim's callers may sit on thread-pool threads:
+// every entry point that allocates, launches or copies comes through here, and a thread that has
+// not been seen before is bound to the library's device first (otherwise a rank with device != 0
+// would allocate and launch on device 0 against streams and modules of device N).
+thread_local int t_bound_device = -1;
 int require_init()
 {
     if (!g.inited) return fail(SDFK_ERR_NO_DEVICE, "sdfk_init() has not been called or no HIP device is available");
+    if (t_bound_device != g.device) {
+        const hipError_t e = hipSetDevice(g.device);
+        if (e != hipSuccess) return fail(SDFK_ERR_HIP, "hipSetDevice(%d): %s", g.device, hipGetErrorString(e));
+        t_bound_device = g.device;
+    }
     return SDFK_OK;
+}
+
+// entry points that cannot fail for lack of a device (frees, accessors of finished objects)
+// still bind the calling thread: they may queue work (a deferred mesh is completed, an event is recorded)
+void bind_thread()
+{
+    if (g.inited && t_bound_device != g.device && hipSetDevice(g.device) == hipSuccess) t_bound_device = g.device;
 }
 
 int grid_for(size_t work_items, int per_block = 256, int max_blocks = 256 * 8)
@@ -235,6 +265,202 @@ int grid_for(size_t work_items, int per_block = 256, int max_blocks = 256 * 8)
     return (int)b;
 }
 
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host-side copy helpers (sdfk_mesh_copy / sdfk_volume_download)
+// ---------------------------------------------------------------------------
+// What a managed caller hands over are freshly allocated, pageable arrays (Mesh.cs:10-13 are
+// `new Vector3[n]` / `new int[n]`; the Python mirror's are numpy.empty): a device-to-host copy into
+// them is dominated by first-touch page faults on ONE thread (512^3 sphere, 33 MB: 9 ms, against
+// 0.65 ms into memory that has been touched).  Faults scale with threads, so a small persistent
+// pool touches the destination pages (one write per page: the whole range is overwritten right
+// after) while the previous array is still on the wire.
+namespace {
+class HostPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> fn;
+    int ntasks = 0, next = 0, running = 0;
+    uint64_t generation = 0;
+    bool stopping = false;
+
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stopping || (generation != seen && next < ntasks); });
+            if (stopping) return;
+            seen = generation;
+            while (next < ntasks) {
+                const int t = next++;
+                running++;
+                lk.unlock();
+                fn(t);
+                lk.lock();
+                running--;
+            }
+            if (running == 0) cv_done.notify_all();
+        }
+    }
+
+public:
+    int size()
+    {
+        static const int n = [] {
+            int v = 0;
+            if (const char* e = getenv("SDFK_COPY_THREADS")) v = atoi(e);
+            if (v <= 0) v = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+            return std::min(v, 64);
+        }();
+        return n;
+    }
+    // starts `n` tasks fn(0..n-1) on the pool and returns; wait() blocks until they are done
+    void start(int n, std::function<void(int)> f)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (threads.empty())
+            for (int i = 0; i < size(); i++) threads.emplace_back([this] { worker(); });
+        fn = std::move(f);
+        ntasks = n;
+        next = 0;
+        generation++;
+        cv_work.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        while (next < ntasks) {   // the caller works too
+            const int t = next++;
+            running++;
+            lk.unlock();
+            fn(t);
+            lk.lock();
+            running--;
+        }
+        cv_done.wait(lk, [&] { return running == 0; });
+        ntasks = 0;
+    }
+    ~HostPool()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            stopping = true;
+            cv_work.notify_all();
+        }
+        for (auto& t : threads) t.join();
+    }
+};
+HostPool g_pool;
+
+// one write per page of [p, p + n): slices are 2 MiB-aligned so that two threads never fault into
+// the same page-table page (or the same transparent huge page)
+void prefault_start(void* p, size_t n)
+{
+    if (!p || n == 0) { g_pool.start(0, [](int) {}); return; }
+    constexpr size_t kSlice = size_t(2) << 20;
+    char* base = (char*)p;
+    const size_t first = (kSlice - ((uintptr_t)base & (kSlice - 1))) & (kSlice - 1);   // bytes up to the first 2 MiB boundary
+    const size_t nslices = 1 + (n > first ? (n - first + kSlice - 1) / kSlice : 0);
+    g_pool.start((int)nslices, [=](int t) {
+        size_t a = t == 0 ? 0 : first + (size_t)(t - 1) * kSlice;
+        size_t b = t == 0 ? std::min(first, n) : std::min(a + kSlice, n);
+        const long page = 4096;
+        for (size_t o = a; o < b; o += page) *(volatile char*)(base + o) = 0;
+        if (b > a) *(volatile char*)(base + b - 1) = 0;
+    });
+}
+
+int stage_reserve(size_t n)
+{
+    if (g.stage_bytes >= n) return SDFK_OK;
+    if (g.stage) (void)hipHostFree(g.stage);
+    g.stage = nullptr;
+    g.stage_bytes = 0;
+    const size_t want = size_class(n);
+    if (hipHostMalloc(&g.stage, want, hipHostMallocDefault) != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipHostMalloc(%zu) for the copy staging buffer failed", want);
+    memset(g.stage, 0, want);   // touch it once, here
+    g.stage_bytes = want;
+    return SDFK_OK;
+}
+
+struct CopyPiece { const void* src; void* dst; size_t bytes; };
+
+// Device -> caller arrays.  mode 0: the destination of piece k+1 is pre-faulted by the pool while
+// piece k is copied by the runtime (which pins touched pageable memory on the fly and moves it at
+// the link rate); mode 1: everything goes to the pinned staging buffer in 4 MiB chunks and the
+// pool copies the chunks that have arrived into the (concurrently pre-faulted) destination.
+int copy_to_host(const std::vector<CopyPiece>& pieces)
+{
+    const char* em = getenv("SDFK_COPY_MODE");   // (read per call: tests and probes compare the three)
+    const int mode = em ? atoi(em) : 0;
+    size_t total = 0;
+    for (auto& p : pieces) total += p.bytes;
+    if (total == 0) return SDFK_OK;
+    if (total < (size_t(1) << 20) || mode == 2) {   // small: nothing to gain from helpers
+        for (auto& p : pieces)
+            if (p.bytes) HIPCHK(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        return SDFK_OK;
+    }
+    if (mode == 1) {
+        if (int r = stage_reserve(total)) return r;
+        constexpr size_t kChunk = size_t(4) << 20;
+        struct Chunk { char* stage; char* dst; size_t bytes; hipEvent_t ev; };
+        std::vector<Chunk> chunks;
+        size_t off = 0;
+        hipError_t e = hipSuccess;
+        for (auto& p : pieces)
+            for (size_t o = 0; o < p.bytes && e == hipSuccess; o += kChunk) {
+                Chunk c{(char*)g.stage + off, (char*)p.dst + o, std::min(kChunk, p.bytes - o), prof_event()};
+                e = hipMemcpyAsync(c.stage, (const char*)p.src + o, c.bytes, hipMemcpyDeviceToHost, g.stream);
+                if (e == hipSuccess) e = hipEventRecord(c.ev, g.stream);
+                off += c.bytes;
+                chunks.push_back(c);
+            }
+        if (e == hipSuccess) {
+            // pre-fault the whole destination while the first chunks travel
+            for (auto& p : pieces) { prefault_start(p.dst, p.bytes); g_pool.wait(); }
+            const int nt = g_pool.size() + 1;
+            for (auto& c : chunks) {
+                e = hipEventSynchronize(c.ev);
+                if (e != hipSuccess) break;
+                const size_t per = (c.bytes + nt - 1) / nt;
+                g_pool.start(nt, [=](int t) {
+                    const size_t a = std::min((size_t)t * per, c.bytes), b = std::min(a + per, c.bytes);
+                    if (b > a) memcpy(c.dst + a, c.stage + a, b - a);
+                });
+                g_pool.wait();
+            }
+        }
+        if (e != hipSuccess) (void)hipStreamSynchronize(g.stream);
+        for (auto& c : chunks) g.prof_event_pool.push_back(c.ev);
+        if (e != hipSuccess) return fail(SDFK_ERR_HIP, "device-to-host copy: %s", hipGetErrorString(e));
+        return SDFK_OK;
+    }
+    // mode 0
+    size_t k0 = 0;
+    while (k0 < pieces.size() && pieces[k0].bytes == 0) k0++;
+    prefault_start(pieces[k0].dst, pieces[k0].bytes);
+    g_pool.wait();
+    for (size_t k = k0; k < pieces.size(); k++) {
+        size_t kn = k + 1;
+        while (kn < pieces.size() && pieces[kn].bytes == 0) kn++;
+        const bool more = kn < pieces.size();
+        if (more) prefault_start(pieces[kn].dst, pieces[kn].bytes);
+        hipError_t e = hipSuccess;
+        if (pieces[k].bytes) {
+            e = hipMemcpyAsync(pieces[k].dst, pieces[k].src, pieces[k].bytes, hipMemcpyDeviceToHost, g.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        }
+        if (more) g_pool.wait();
+        if (e != hipSuccess) return fail(SDFK_ERR_HIP, "device-to-host copy: %s", hipGetErrorString(e));
+        k = kn - 1;
+    }
+    return SDFK_OK;
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -321,6 +547,7 @@ struct sdfk_march_job {
     sdfk_program* eval_prog = nullptr;   // corners by re-evaluation (holds a reference)
     SampleArgs eval_args;
     int slot = -1;                 // index of the pinned result slot (owned until job_release)
+    int lane = 0;                  // lane the job's kernels are queued on
     size_t rec_first = 0;          // first entry of `owned` that belongs to the record arrays
 };
 
@@ -366,6 +593,7 @@ extern "C" int sdfk_init(int device)
     HIPCHK(hipHostGetDevicePointer((void**)&g.slots_dev, g.slots, 0));
     memset(g.slots, 0, sizeof(Context::HostSlot) * Context::NSLOTS);
     g.device = device;
+    t_bound_device = device;
     g.inited = true;
     return SDFK_OK;
 }
@@ -373,6 +601,7 @@ extern "C" int sdfk_init(int device)
 extern "C" void sdfk_shutdown(void)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!g.inited) return;
     while (!g.pending.empty()) (void)mesh_resolve(g.pending.front());
     (void)hipStreamSynchronize(g.stream);
@@ -394,6 +623,13 @@ extern "C" void sdfk_shutdown(void)
     }
     g.cur_lane = 0;
     g.lanes[0].stream = nullptr;
+    for (auto& st : g.slot_state) {
+        if (st.dropped) (void)hipEventDestroy(st.dropped);
+        st = Context::SlotState();
+    }
+    if (g.stage) (void)hipHostFree(g.stage);
+    g.stage = nullptr;
+    g.stage_bytes = 0;
     if (g.slots) (void)hipHostFree(g.slots);
     g.slots = nullptr;
     g.slots_dev = nullptr;
@@ -474,25 +710,92 @@ extern "C" int sdfk_synchronize(void)
     if (int r = require_init()) return r;
     HIPCHK(hipStreamSynchronize(g.stream));
     sync_all_lanes();
-    g.epoch++;   // nothing is queued any more: dropped jobs' slots are reusable
+    for (auto& st : g.slot_state) st.drop_pending = false;   // nothing is queued any more: dropped jobs' slots are reusable
     return SDFK_OK;
 }
 
 // ---------------------------------------------------------------------------
 // programs (JIT, counterpart of SdfExprCompiler.Compile, SdfExpr.cs:225-273)
 // ---------------------------------------------------------------------------
-static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
-                           std::string& src, std::vector<char>& code)
+// ---- on-disk cache of compiled code objects ------------------------------------------------
+// hiprtc takes 0.3-1 s per program, once per PROCESS without this: the reference's counterpart
+// (SdfExprCompiler.Compile, SdfExpr.cs:234-238) is also a JIT, but what an `sdf.ToMesh()` user sees
+// is the first-call latency.  A compiled code object is stored under
+//   $SDFK_CACHE_DIR | $XDG_CACHE_HOME/sdfkit_hip | $HOME/.cache/sdfkit_hip | /tmp/sdfkit_hip-<uid>
+// as <hash of (flags, hiprtc version, source)>.co = { magic, lengths, the key text itself, code }: a
+// hit compares the whole key text, so a hash collision cannot return foreign code.  Files appear
+// atomically (write to a temporary, rename).  SDFK_NO_CACHE=1 switches it off.
+namespace {
+struct JitStats { int64_t compiled = 0, cache_hits = 0; double compile_ms = 0.0; } g_jit;
+
+uint64_t fnv1a64(const std::string& s, uint64_t h)
 {
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; }
+    return h;
+}
+
+std::string cache_dir()
+{
+    if (const char* e = getenv("SDFK_NO_CACHE")) if (atoi(e)) return std::string();
+    std::string d;
+    if (const char* e = getenv("SDFK_CACHE_DIR")) d = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/sdfkit_hip";
+    else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/sdfkit_hip";
+    else d = "/tmp/sdfkit_hip-" + std::to_string((long)getuid());
+    // mkdir -p
+    for (size_t i = 1; i <= d.size(); i++)
+        if (i == d.size() || d[i] == '/') {
+            const std::string sub = d.substr(0, i);
+            if (mkdir(sub.c_str(), 0700) != 0 && errno != EEXIST) return std::string();
+        }
+    return d;
+}
+
+constexpr uint64_t kCacheMagic = 0x31304f434b464453ull;   // "SDFKCO01"
+
+bool cache_load(const std::string& path, const std::string& key, std::vector<char>& code)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint64_t hdr[3] = {0, 0, 0};
+    bool ok = fread(hdr, sizeof hdr, 1, f) == 1 && hdr[0] == kCacheMagic && hdr[1] == key.size() && hdr[2] > 0 && hdr[2] < (1ull << 31);
+    if (ok) {
+        std::string k(key.size(), '\0');
+        ok = fread(&k[0], 1, k.size(), f) == k.size() && k == key;
+    }
+    if (ok) {
+        code.resize(hdr[2]);
+        ok = fread(code.data(), 1, code.size(), f) == code.size() && fgetc(f) == EOF;
+    }
+    fclose(f);
+    if (!ok) code.clear();
+    return ok;
+}
+
+void cache_store(const std::string& path, const std::string& key, const std::vector<char>& code)
+{
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint64_t hdr[3] = {kCacheMagic, key.size(), code.size()};
+    bool ok = fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(key.data(), 1, key.size(), f) == key.size() &&
+              fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+}  // namespace
+
+static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
+                           std::string& src, std::vector<char>& code, bool use_cache, bool* from_cache = nullptr,
+                           bool refresh = false)
+{
+    if (from_cache) *from_cache = false;
     std::string err;
     if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err))
         return fail(SDFK_ERR_INVALID, "SDF program: %s", err.c_str());
     if (const char* dump = getenv("SDFK_DUMP_SOURCE")) {   // debugging aid: the generated HIP source of the last program
         if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
     }
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_sample.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-        return fail(SDFK_ERR_COMPILE, "hiprtcCreateProgram failed");
     // experiment knobs (the defaults are the tuned values)
     const char* en = getenv("SDFK_SAMPLE_NT");    // 0: plain instead of nontemporal stores of the values
     const char* er = getenv("SDFK_SAMPLE_RPW");   // x rows per wavefront of the fused sampling kernel (1, 2 or 4)
@@ -510,6 +813,32 @@ static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_
         }
         for (auto& e : extra) opts.push_back(e.c_str());
     }
+    // cache key: everything the code object depends on
+    std::string key, path;
+    if (use_cache) {
+        int vmaj = 0, vmin = 0;
+        (void)hiprtcVersion(&vmaj, &vmin);
+        key = "sdfkit_hip abi " + std::to_string(SDFK_ABI_VERSION) + " hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin) + " opts";
+        for (const char* o : opts) { key += ' '; key += o; }
+        key += '\n';
+        key += src;
+        const std::string dir = cache_dir();
+        if (!dir.empty()) {
+            char name[64];
+            snprintf(name, sizeof name, "/%016llx%016llx.co", (unsigned long long)fnv1a64(key, 0xcbf29ce484222325ull),
+                     (unsigned long long)fnv1a64(key, 0x84222325cbf29ce4ull));
+            path = dir + name;
+            if (!refresh && cache_load(path, key, code)) {
+                g_jit.cache_hits++;
+                if (from_cache) *from_cache = true;
+                return SDFK_OK;
+            }
+        }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "sdfk_sample.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(SDFK_ERR_COMPILE, "hiprtcCreateProgram failed");
     hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t ls = 0;
@@ -524,15 +853,28 @@ static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_
     code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    g_jit.compiled++;
+    g_jit.compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!path.empty()) cache_store(path, key, code);
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_jit_stats(int64_t* n_compiled, int64_t* n_cache_hits, double* compile_ms_total)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (n_compiled) *n_compiled = g_jit.compiled;
+    if (n_cache_hits) *n_cache_hits = g_jit.cache_hits;
+    if (compile_ms_total) *compile_ms_total = g_jit.compile_ms;
     return SDFK_OK;
 }
 
 extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color)
 {
     if (!ops || !out_rgbw || n_ops <= 0) return fail(SDFK_ERR_INVALID, "sdfk_program_check: null/empty argument");
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
     std::string src;
     std::vector<char> code;
-    return compile_program(ops, n_ops, out_rgbw, writes_color, src, code);
+    return compile_program(ops, n_ops, out_rgbw, writes_color, src, code, false);   // a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -544,11 +886,17 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     if (int r = require_init()) return r;
     std::string src;
     std::vector<char> code;
-    if (int r = compile_program(ops, n_ops, out_rgbw, writes_color, src, code)) return r;
+    bool cached = false;
+    if (int r = compile_program(ops, n_ops, out_rgbw, writes_color, src, code, true, &cached)) return r;
     sdfk_program* p = new sdfk_program();
     p->source = src;
     p->writes_color = writes_color;
     hipError_t e = hipModuleLoadData(&p->module, code.data());
+    if (e != hipSuccess && cached) {   // a damaged cache entry: compile again and replace it
+        p->module = nullptr;
+        if (int r = compile_program(ops, n_ops, out_rgbw, writes_color, src, code, true, nullptr, true)) { delete p; return r; }
+        e = hipModuleLoadData(&p->module, code.data());
+    }
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_corners, p->module, "sdfk_corners_eval");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_raymarch, p->module, "sdfk_raymarch");
     if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
@@ -571,6 +919,7 @@ extern "C" const char* sdfk_program_source(const sdfk_program* p) { return p ? p
 extern "C" void sdfk_program_destroy(sdfk_program* p)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!p) return;
     program_release(p);
 }
@@ -630,6 +979,7 @@ extern "C" int sdfk_volume_create(int32_t nx, int32_t ny, int32_t nz, const floa
 extern "C" void sdfk_volume_free(sdfk_volume* v)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!v) return;
     resolve_dependents(v);
     volume_values_changed(v);   // (drops the reference to the program that sampled it)
@@ -661,18 +1011,22 @@ extern "C" int sdfk_volume_download(const sdfk_volume* v, float* values, float* 
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!v) return fail(SDFK_ERR_INVALID, "sdfk_volume_download: null volume");
     if (int r = require_init()) return r;
-    if (values) HIPCHK(hipMemcpyAsync(values, v->values, v->nvox() * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-    if (colors3) {
-        if (v->colors) HIPCHK(hipMemcpyAsync(colors3, v->colors, v->nvox() * 3 * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-        else memset(colors3, 0, v->nvox() * 3 * sizeof(float));
+    std::vector<CopyPiece> pieces;
+    if (values) pieces.push_back({v->values, values, v->nvox() * sizeof(float)});
+    if (colors3 && v->colors) pieces.push_back({v->colors, colors3, v->nvox() * 3 * sizeof(float)});
+    if (colors3 && !v->colors) {   // colours that were never written are zero (Voxels.cs:88-92): cleared on the pool
+        const size_t nb = v->nvox() * 3 * sizeof(float), per = size_t(2) << 20;
+        char* c = (char*)colors3;
+        g_pool.start((int)((nb + per - 1) / per), [=](int t) { const size_t a = (size_t)t * per; memset(c + a, 0, std::min(per, nb - a)); });
+        g_pool.wait();
     }
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return SDFK_OK;
+    return copy_to_host(pieces);
 }
 
 extern "C" int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void** colors3)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!v) return fail(SDFK_ERR_INVALID, "null volume");
     resolve_dependents(v);   // the caller may write through these pointers: no cached view of
     volume_values_changed(const_cast<sdfk_volume*>(v));   // the values stays valid
@@ -815,18 +1169,25 @@ int job_alloc(sdfk_march_job* j, T** p, size_t count)
 int acquire_slot()
 {
     for (int pass = 0; pass < 2; pass++) {
+        int oldest = -1;
         for (int i = 0; i < Context::NSLOTS; i++) {
             const int s = (g.slot_next + i) % Context::NSLOTS;
             Context::SlotState& st = g.slot_state[s];
-            if (!st.busy && st.free_epoch < g.epoch) {
-                st.busy = true;
-                g.slot_next = (s + 1) % Context::NSLOTS;
-                memset(&g.slots[s], 0, sizeof(Context::HostSlot));
-                return s;
+            if (st.busy) continue;
+            if (st.drop_pending) {   // the dropped job's kernels may still be queued: has its lane passed them?
+                if (hipEventQuery(st.dropped) != hipSuccess) { if (oldest < 0) oldest = s; continue; }
+                st.drop_pending = false;
             }
+            st.busy = true;
+            g.slot_next = (s + 1) % Context::NSLOTS;
+            memset(&g.slots[s], 0, sizeof(Context::HostSlot));
+            return s;
         }
-        sync_all_lanes();   // every free slot is waiting for queued kernels of dropped jobs: drain them
-        g.epoch++;
+        if (oldest < 0) break;   // every slot belongs to a live job
+        // all free slots still wait for dropped jobs: wait for the one dropped first (slots are
+        // handed out round-robin, so the first candidate after slot_next is the oldest) -- one
+        // event, not a synchronisation of every lane
+        (void)hipEventSynchronize(g.slot_state[oldest].dropped);
     }
     return -1;
 }
@@ -834,8 +1195,16 @@ int acquire_slot()
 void job_release(sdfk_march_job* j, bool kernels_may_be_queued)
 {
     if (j->slot >= 0) {
-        g.slot_state[j->slot].busy = false;
-        g.slot_state[j->slot].free_epoch = kernels_may_be_queued ? g.epoch : 0;
+        Context::SlotState& st = g.slot_state[j->slot];
+        st.busy = false;
+        st.drop_pending = false;
+        if (kernels_may_be_queued) {
+            hipError_t e = hipSuccess;
+            if (!st.dropped) e = hipEventCreateWithFlags(&st.dropped, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(st.dropped, g.lanes[j->lane].stream);
+            if (e == hipSuccess) st.drop_pending = true;
+            else (void)hipStreamSynchronize(g.lanes[j->lane].stream);   // no event: wait here instead
+        }
         j->slot = -1;
     }
     for (void* p : j->owned) dev_free(p);
@@ -943,6 +1312,7 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     j->gnx = v->nx; j->gny = v->ny; j->gnz = v->nz_global;
     memcpy(j->gmin, v->gmin, sizeof j->gmin);
     memcpy(j->gmax, v->gmax, sizeof j->gmax);
+    j->lane = g.cur_lane;
     j->slot = acquire_slot();
     if (j->slot < 0) { delete j; return fail(SDFK_ERR_NOMEM, "more than %d marching-cubes jobs are alive", Context::NSLOTS); }
     const sdfk_volume* w = v;
@@ -1326,6 +1696,7 @@ extern "C" int sdfk_march_finish(sdfk_march_job* j, int64_t vertex_base, sdfk_me
 extern "C" void sdfk_march_job_free(sdfk_march_job* job)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!job) return;
     job_release(job);   // stream-ordered pool: no sync needed
     delete job;
@@ -1550,6 +1921,7 @@ extern "C" int sdfk_raymarch(const sdfk_program* p, int32_t width, int32_t heigh
 extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     if (n_vertices) *n_vertices = m->nv;
@@ -1560,6 +1932,7 @@ extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t
 extern "C" int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case13_cells)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     if (n_active_cells) *n_active_cells = m->n_active;
@@ -1593,12 +1966,22 @@ extern "C" int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* color
     if (int r = require_init()) return r;
     if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;
     const size_t vb = (size_t)m->nv * 3 * sizeof(float);
-    if (vertices3 && vb) HIPCHK(hipMemcpyAsync(vertices3, m->vertices, vb, hipMemcpyDeviceToHost, g.stream));
-    if (colors3 && vb) HIPCHK(hipMemcpyAsync(colors3, m->colors, vb, hipMemcpyDeviceToHost, g.stream));
-    if (normals3 && vb) HIPCHK(hipMemcpyAsync(normals3, m->normals, vb, hipMemcpyDeviceToHost, g.stream));
-    if (triangles && m->ni) HIPCHK(hipMemcpyAsync(triangles, m->triangles, (size_t)m->ni * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return SDFK_OK;
+    std::vector<CopyPiece> pieces;
+    if (vertices3 && vb) pieces.push_back({m->vertices, vertices3, vb});
+    if (colors3 && vb) {
+        // (a volume without colours has all-zero mesh colours: nothing to move, the pool clears the array)
+        if (m->has_colors) pieces.push_back({m->colors, colors3, vb});
+    }
+    if (normals3 && vb) pieces.push_back({m->normals, normals3, vb});
+    if (triangles && m->ni) pieces.push_back({m->triangles, triangles, (size_t)m->ni * sizeof(int32_t)});
+    if (m->lane != g.cur_lane) const_cast<sdfk_mesh*>(m)->used_on_main = true;
+    if (colors3 && vb && !m->has_colors) {   // zero-fill (and first touch) on the pool
+        const size_t per = size_t(2) << 20, nt = (vb + per - 1) / per;
+        char* c = (char*)colors3;
+        g_pool.start((int)nt, [=](int t) { const size_t a = (size_t)t * per; memset(c + a, 0, std::min(per, vb - a)); });
+        g_pool.wait();
+    }
+    return copy_to_host(pieces);
 }
 
 extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* colors3, void* normals3, void* triangles)
@@ -1619,6 +2002,7 @@ extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* 
 extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, void** normals3, void** triangles)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;   // (the buffers may be replaced by an exact re-run)
     const_cast<sdfk_mesh*>(m)->used_on_main = true;
@@ -1632,6 +2016,7 @@ extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void*
 extern "C" void sdfk_mesh_free(sdfk_mesh* m)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     if (!m) return;
     if (m->pending) {   // never read: drop the queued job's workspace (stream-ordered, no wait)
         for (auto it = g.pending.begin(); it != g.pending.end(); ++it)
@@ -1671,6 +2056,7 @@ extern "C" int sdfk_profile_enable(int32_t on)
 extern "C" int sdfk_profile_reset(void)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     prof_drain();
     std::fill(g.prof_ms.begin(), g.prof_ms.end(), 0.0);
     std::fill(g.prof_n.begin(), g.prof_n.end(), 0);
@@ -1680,6 +2066,7 @@ extern "C" int sdfk_profile_reset(void)
 extern "C" int sdfk_profile_count(void)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     prof_drain();
     return (int)g.prof_names.size();
 }
@@ -1687,6 +2074,7 @@ extern "C" int sdfk_profile_count(void)
 extern "C" int sdfk_profile_get(int32_t i, const char** name, double* total_ms, int64_t* launches)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
+    bind_thread();
     prof_drain();
     if (i < 0 || i >= (int)g.prof_names.size()) return fail(SDFK_ERR_INVALID, "profile index out of range");
     if (name) *name = g.prof_names[i].c_str();

@@ -265,8 +265,8 @@ class SlabSession:
     depth > 1 the host never idles the GPU or the links between steps.  `step()` = submit +
     collect (one step in flight).
 
-    The payload stride is agreed once, on the first step, with a count all-gather (+12.5 %
-    head-room: the padding travels too); a later slab that outgrows it raises (make a new
+    The payload stride is agreed once, on the first step, with a count all-gather (+`headroom`,
+    12.5 % by default: the padding travels too); a later slab that outgrows it raises (make a new
     session, or use sharded_to_mesh for one-off meshes).
     A step whose speculative buffers were too small on ANY rank is marked in that rank's
     header; every rank sees it after the gather and all of them redo that step on the exact
@@ -279,7 +279,7 @@ class SlabSession:
     tests/test_dist_gloo.py drives the same protocol on CPU tensors over gloo with fixtures."""
 
     def __init__(self, sdf=None, mn=None, mx=None, nx=0, ny=0, nz=0, clip_to_bounds=True, iso=0.0, group=None,
-                 device=None, depth=1, make_worker=None, rebase=None):
+                 device=None, depth=1, make_worker=None, rebase=None, headroom=0.125):
         import torch
         import torch.distributed as dist
         self.group = group
@@ -306,6 +306,7 @@ class SlabSession:
                     N.check(N.lib().sdfk_slabs_rebase(C.c_void_p(gathered.data_ptr()), world, stride))
         self.rebase = rebase
         self.depth = max(int(depth), 1)
+        self.headroom = float(headroom)   # payload stride = largest first-step payload * (1 + headroom): the padding travels too
         self.workers = [make_worker(k) for k in range(self.depth)]
         self.worker = self.workers[0]
         self.stride = None
@@ -391,7 +392,7 @@ class SlabSession:
         dist.all_gather(out, t, group=self.group)
         mx = max(int(x.item()) for x in out)
         # every rank sends `stride` bytes in every step, used or not: keep the head-room modest
-        self.stride = ((mx + mx // 8 + 4096) + 255) // 256 * 256
+        self.stride = ((mx + int(mx * self.headroom) + 4096) + 255) // 256 * 256
         for k in range(self.depth):
             self.buf[k] = torch.zeros(self.stride, dtype=torch.uint8, device=self.device)
             self.gathered_slots[k] = torch.zeros((self.world, self.stride), dtype=torch.uint8, device=self.device)

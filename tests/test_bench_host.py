@@ -1,0 +1,64 @@
+"""Host-side logic of bench.py that needs no GPU: the `--gpus N` self-launcher (the driver starts the
+multi-GPU leg as plain `python bench.py --gpus N`) and the CPU-baseline leg (oracle, bounded sample)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_cpu_baseline_keeps_the_grid_edge_union8():
+    # (the node ids of the 8-primitive union must not overwrite the grid edge)
+    r = bench.cpu_baseline("union8", 32, timed=1)
+    assert r["sample"].startswith("32^3"), r["sample"]
+    assert r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 0 and r["mtris_per_s"] > 0
+
+
+@pytest.mark.parametrize("scene", ["sphere", "repeatxy"])
+def test_cpu_baseline_scenes(scene):
+    r = bench.cpu_baseline(scene, 24, timed=2)
+    assert r["sample"].startswith("24^3") and "2 timed passes" in r["sample"]
+
+
+def test_launcher_spawns_torchrun_as_a_child(monkeypatch):
+    """WORLD_SIZE unset + --gpus 4: one child `python -m torch.distributed.run --nproc-per-node 4 bench.py ...`
+    whose JSON line is relayed; a failing first attempt is retried conservatively."""
+    calls = []
+
+    class P:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        calls.append((cmd, env))
+        if len(calls) == 1:
+            return P(1, "boom\n")
+        return P(0, '{"metric": "x", "n_gpus": 4}\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    rc = bench.launch_ranks(["--gpus", "4", "--steps", "5"], 4)
+    assert rc == 0 and len(calls) == 2
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    assert "SDFK_BENCH_DEPTH" not in env or env["SDFK_BENCH_DEPTH"] != "1" or "SDFK_BENCH_DEPTH" in os.environ
+    assert calls[1][1]["SDFK_BENCH_DEPTH"] == "1" and calls[1][1]["SDFK_LANES"] == "0" and "SDFK_BENCH_NOTE" in calls[1][1]
+
+
+def test_plain_python_with_gpus_gt_1_launches_before_touching_torch():
+    """`python bench.py --gpus 2` must reach the launcher without importing torch in the parent: run it
+    with a poisoned `torch` on the path of the PARENT only -- the launcher hands the children the same
+    environment, so they fail, which is what this box (no GPU) would do anyway; the parent must exit with
+    the children's failure, not with an ImportError of its own."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--grid", "32"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0                      # no GPU here: the ranks refuse to run
+    assert "bench.py needs an MI355X" in p.stderr or "retry" in p.stderr
+    assert "launch with torch.distributed.run" not in p.stderr

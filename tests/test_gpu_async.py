@@ -179,17 +179,18 @@ def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
     from sdfkit_amd import dist as D
     scene, sdf = S.CATALOGUE["union8"]()
     n, world = 1024, 8
+    MN, MX = [-2.0] * 3, [2.0] * 3        # bounds -2..2 (primitives reach +-1.6), clipToBounds
     L = N.lib()
     N.bind_torch_stream()
     try:
         whole = sdf.ToMesh(MN, MX, n, n, n)
         nv, t = len(whole.Vertices), whole.Triangles
-        assert nv > 1_000_000 and t.min() == 0 and t.max() == nv - 1
+        assert nv > 2_500_000 and t.min() == 0 and t.max() == nv - 1   # (1.6 M on the wider -2.8125..2.8125 box of round 1)
         first = np.full(nv, len(t), np.int64)
         np.minimum.at(first, t, np.arange(len(t)))
         assert np.all(np.diff(first) > 0)                       # numbered in order of first reference
         assert np.abs(np.linalg.norm(whole.Normals.astype(np.float64), axis=1) - 1).max() < 1e-5
-        assert np.all(whole.Min >= np.float32(-2.8125)) and np.all(whole.Max <= np.float32(2.8125))
+        assert np.all(whole.Min >= np.float32(-2.0)) and np.all(whole.Max <= np.float32(2.0))
         tri = t.reshape(-1, 3)
         e = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
         key = e[:, 0].astype(np.int64) * nv + e[:, 1]

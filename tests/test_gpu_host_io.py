@@ -1,0 +1,172 @@
+"""Host-side plumbing of the C ABI on the GPU box: the device-to-host copy strategies of
+sdfk_mesh_copy / sdfk_volume_download (threaded first touch, pinned staging), the on-disk cache of
+JIT-compiled code objects, and calls arriving from threads the library has not seen before."""
+import ctypes as C
+import glob
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdfkit_amd import Mesh, SdfExprs, Sdfs, Voxels
+from sdfkit_amd import _native as N
+from tests import scenes as S
+from tests.test_gpu_parity import assert_mesh_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw(sdf, mn, mx, dims, clip):
+    m = C.c_void_p()
+    N.check(N.lib().sdfk_sample_march(sdf.program(), N.f3(mn), N.f3(mx), *dims, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+    return m
+
+
+@pytest.mark.parametrize("name,clip", [("sphere_w", False), ("readme_repeat_xy", True)])
+def test_mesh_copy_strategies_agree(gpu, name, clip):
+    """SDFK_COPY_MODE 0 (pre-fault on the pool + runtime copy), 1 (pinned staging + pool memcpy) and
+    2 (plain copies) deliver the same bytes; a mesh of > 1 MiB so that the helpers are really used."""
+    scene, sdf = S.CATALOGUE[name]()
+    mn, mx = ([-1.5] * 3, [1.5] * 3) if name == "sphere_w" else ([-2.8125] * 3, [2.8125] * 3)
+    dims = (160, 152, 168)
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    if clip:
+        O.clip_to_bounds(ov, mn, mx)
+    om = O.march(ov, oc, mn, mx)
+    assert len(om.vertices) * 36 + len(om.triangles) * 4 > (1 << 20)
+    got = []
+    try:
+        for mode in ("0", "1", "2", "1", "0"):
+            os.environ["SDFK_COPY_MODE"] = mode
+            m = Mesh._from_handle(_raw(sdf, mn, mx, dims, clip))
+            assert_mesh_equal(m, om)
+            got.append(m)
+    finally:
+        os.environ.pop("SDFK_COPY_MODE", None)
+    for m in got[1:]:
+        for f in ("Vertices", "Colors", "Normals", "Triangles"):
+            assert np.array_equal(getattr(m, f), getattr(got[0], f), equal_nan=True)
+
+
+def test_mesh_copy_partial_and_unaligned_destinations(gpu):
+    """NULL destinations are skipped; destinations need no alignment beyond their element type."""
+    scene, sdf = S.sphere_w(1.0)
+    mn, mx, dims = [-1.5] * 3, [1.5] * 3, (128, 128, 128)
+    ref = Mesh._from_handle(_raw(sdf, mn, mx, dims, False))
+    L = N.lib()
+    for mode in ("0", "1"):
+        os.environ["SDFK_COPY_MODE"] = mode
+        try:
+            h = _raw(sdf, mn, mx, dims, False)
+            nv, ni = C.c_int64(), C.c_int64()
+            N.check(L.sdfk_mesh_counts(h, C.byref(nv), C.byref(ni)))
+            big = np.full(nv.value * 3 + ni.value + 64, -7.0, np.float32)
+            v = big[1:1 + nv.value * 3]                      # 4-byte aligned only
+            t = big[nv.value * 3 + 3:nv.value * 3 + 3 + ni.value].view(np.int32)
+            N.check(L.sdfk_mesh_copy(h, v.ctypes.data, None, None, t.ctypes.data))
+            assert np.array_equal(v.reshape(-1, 3), ref.Vertices) and np.array_equal(t, ref.Triangles)
+            assert big[0] == -7.0 and big[1 + nv.value * 3] == -7.0 and big[-1] == -7.0     # nothing outside the arrays was written
+            c = np.full((nv.value, 3), 5.0, np.float32)
+            N.check(L.sdfk_mesh_copy(h, None, c.ctypes.data, None, None))
+            assert not c.any()                                # W-only SDF: colours are zero (Voxels.cs:88-92)
+            L.sdfk_mesh_free(h)
+        finally:
+            os.environ.pop("SDFK_COPY_MODE", None)
+
+
+def test_volume_download_through_the_pool(gpu):
+    scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
+    mn, mx, dims = [-2.8125] * 3, [2.8125] * 3, (96, 100, 104)
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    for mode in ("0", "1", "2"):
+        os.environ["SDFK_COPY_MODE"] = mode
+        try:
+            vol = Voxels.SampleSdf(sdf, mn, mx, *dims)
+            assert np.array_equal(vol.Values, ov) and np.array_equal(vol.Colors, oc)
+        finally:
+            os.environ.pop("SDFK_COPY_MODE", None)
+    w = Voxels.SampleSdf(Sdfs.Sphere(1.0), mn, mx, *dims)    # no colour array on the device: zeros come from the pool
+    assert not w.Colors.any() and w.Colors.shape == dims + (3,)
+
+
+def _stats():
+    a, b, c = C.c_int64(), C.c_int64(), C.c_double()
+    N.check(N.lib().sdfk_jit_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+def test_code_object_cache_on_disk(gpu, tmp_path):
+    """First creation of a program compiles with hiprtc and leaves a code object in the cache directory; the next
+    creation of the same program (a new process would do the same) loads it; a damaged entry is recompiled."""
+    old = os.environ.get("SDFK_CACHE_DIR")
+    os.environ["SDFK_CACHE_DIR"] = str(tmp_path / "jit")
+    try:
+        mn, mx, dims = [-2.0] * 3, [2.0] * 3, (40, 44, 48)
+
+        def build():
+            return SdfExprs.Sphere(0.8125, (0.25, 0.5, 0.75)).RepeatX(1.5).ToSdf()   # a fresh Sdf: no in-process program yet
+
+        scene = O.Scene()
+        scene.f_repeat_x(scene.f_sphere(0.8125, (0.25, 0.5, 0.75)), 1.5)
+        ov, oc = O.sample(scene, mn, mx, *dims)
+        O.clip_to_bounds(ov, mn, mx)
+        om = O.march(ov, oc, mn, mx)
+        c0, h0, _ = _stats()
+        assert_mesh_equal(build().ToMesh(mn, mx, *dims), om)
+        c1, h1, ms = _stats()
+        assert (c1, h1) == (c0 + 1, h0) and ms > 0
+        files = glob.glob(str(tmp_path / "jit" / "*.co"))
+        assert len(files) == 1 and os.path.getsize(files[0]) > 10000
+        assert_mesh_equal(build().ToMesh(mn, mx, *dims), om)
+        c2, h2, _ = _stats()
+        assert (c2, h2) == (c1, h1 + 1)                      # loaded, not compiled
+        # damage the code object (keep the key): the load fails, the library recompiles and replaces the entry
+        raw = bytearray(open(files[0], "rb").read())
+        raw[-4096:] = b"\\0" * 4096
+        raw[len(raw) // 2:len(raw) // 2 + 4096] = b"\\xff" * 4096
+        open(files[0], "wb").write(bytes(raw))
+        assert_mesh_equal(build().ToMesh(mn, mx, *dims), om)
+        c3, h3, _ = _stats()
+        assert c3 == c2 + 1
+        os.environ["SDFK_NO_CACHE"] = "1"
+        try:
+            assert_mesh_equal(build().ToMesh(mn, mx, *dims), om)
+        finally:
+            del os.environ["SDFK_NO_CACHE"]
+        c4, h4, _ = _stats()
+        assert (c4, h4) == (c3 + 1, h3)
+    finally:
+        if old is None:
+            os.environ.pop("SDFK_CACHE_DIR", None)
+        else:
+            os.environ["SDFK_CACHE_DIR"] = old
+
+
+def test_calls_from_other_threads(gpu):
+    """The HIP current device is per thread; every entry point binds the calling thread to the library's device.
+    Whole meshes built on threads the library has never seen, concurrently (the ABI serialises internally)."""
+    scene, sdf = S.CATALOGUE["union8"]()
+    mn, mx, dims = [-2.0] * 3, [2.0] * 3, (40, 36, 44)
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    O.clip_to_bounds(ov, mn, mx)
+    om = O.march(ov, oc, mn, mx)
+    sdf.program()
+    out, err = [None] * 4, []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                out[k] = sdf.ToMesh(mn, mx, *dims)
+        except Exception as e:   # noqa: BLE001
+            err.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not err, err
+    for m in out:
+        assert_mesh_equal(m, om)

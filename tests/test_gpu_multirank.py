@@ -47,6 +47,32 @@ def test_sharded_bench_on_one_gpu(gpu, world):
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1.2
 
 
+@pytest.mark.parametrize("world", [2])
+def test_bench_gpus_n_started_as_plain_python(gpu, world):
+    """The way the driver starts the multi-GPU leg: `python bench.py --gpus N`, no launcher, no WORLD_SIZE.
+    bench.py must spawn torch.distributed.run itself (as a child, before touching the GPU) and relay rank 0's line."""
+    args = ["--steps", "6", "--warmup", "2", "--no-cpu", "--grid", "128"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SDFK_BENCH_ONE_GPU"] = "1"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(world)] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    many = json.loads(lines[0])
+    one = _bench([sys.executable, "bench.py"] + args)
+    assert many["n_gpus"] == world and one["n_gpus"] == 1
+    assert many["config"]["vertices"] == one["config"]["vertices"] > 10000
+    assert many["config"]["triangles"] == one["config"]["triangles"]
+    sh = many["sharded"]
+    assert sh["world"] == world == sh["backend_world_size"] and len(sh["per_rank_vertices_indices"]) == world
+    assert sum(p[0] for p in sh["per_rank_vertices_indices"]) == many["config"]["vertices"]
+    assert sh["gather_bytes_received_per_rank"] == (world - 1) * sh["gather_stride_bytes_per_rank"]
+    assert 0 < sh["slab_kernels_only_ms"] and sh["xgmi"]["receive_bound_ms"] > 0
+    for k in ("latency_ms_single_stream", "first_call_ms", "first_call", "value_is", "pipeline_frac_is"):
+        assert k in one
+    assert one["latency_ms_single_stream"] >= one["ms_per_step"] * 0.8
+
+
 def test_sharded_to_mesh_exact_protocol_single_rank(gpu):
     """The one-off form (two exact collectives: counts, then payloads) on a single-rank group."""
     import numpy as np

@@ -372,6 +372,22 @@ def _sign_change_edges(v, iso=0.0):
     return int((s[1:] != s[:-1]).sum() + (s[:, 1:] != s[:, :-1]).sum() + (s[:, :, 1:] != s[:, :, :-1]).sum())
 
 
+def test_c3s_sphere_512(gpu):
+    """The headline workload itself (BASELINE C3s: 512^3 `Sdfs.Sphere(1)`, bounds -1.5..1.5, no clip):
+    the mesh bench.py times, compared array by array with the oracle's (CPU marching cubes: ~15 s)."""
+    scene, sdf = S.sphere_w(1.0)
+    mn, mx, n = [-1.5] * 3, [1.5] * 3, 512
+    m = sdf.ToMesh(mn, mx, n, n, n, clipToBounds=False)       # the fused path bench.py drives (sdfk_sample_march)
+    assert len(m.Vertices) == 549144 and len(m.Triangles) == 3 * 1098284   # SURVEY.md 8d / BASELINE.md C3s
+    ov, oc = O.sample(scene, mn, mx, n, n, n)
+    om = O.march(ov, oc, mn, mx)
+    assert_mesh_equal(m, om)
+    # ... and the two-call form through a resident volume (Voxels.SampleSdf -> CreateMesh)
+    vol = Voxels.SampleSdf(sdf, mn, mx, n, n, n)
+    assert_mesh_equal(vol.ToMesh(), om)
+    assert np.array_equal(vol.Values, ov)
+
+
 def test_c2_sphere_256(gpu):
     scene, sdf = S.sphere_w(1.0)
     vol = Voxels.SampleSdf(sdf, [-1.5] * 3, [1.5] * 3, 256, 256, 256)
