@@ -446,21 +446,57 @@ def main():
                                  "what": "torch fill_ / copy_ of 512 MiB, 10 launches each"}
         del x, y
         if not sharded:
-            # what a host-array caller (the C# shim: Mesh.cs:10-13 are managed arrays) gets per call:
-            # sample + mesh + the four mesh arrays copied into FRESHLY allocated host arrays
+            # What a host-array caller gets per call: sample + mesh + counts + the four mesh arrays copied to the
+            # host + bounds.  Three kinds of destination:
+            #   pinned   the Python mirror's Mesh (arrays from the library's pinned arena, sdfk_host_alloc): plain DMA
+            #   managed  FRESH private anonymous 4 KiB-page memory nobody has touched -- what `new Vector3[n]` /
+            #            `new int[n]` of the C# shim are (Mesh.cs:10-13); the library pre-faults it on its thread pool
+            #   numpy    fresh numpy.empty arrays (numpy advises transparent huge pages for them)
+            import mmap
             from sdfkit_amd.api import Mesh
-            ts = []
-            for _ in range(4):
+
+            def fresh_managed(nbytes):
+                mm = mmap.mmap(-1, max(nbytes, 1), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+                try:
+                    mm.madvise(mmap.MADV_NOHUGEPAGE)
+                except (AttributeError, OSError):
+                    pass
+                return mm, np.frombuffer(mm, dtype=np.uint8, count=nbytes)
+
+            def one_call(kind):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 m = C.c_void_p()
                 N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
-                hm = Mesh._from_handle(m)   # counts + the four arrays into new host arrays + bounds
-                ts.append((time.perf_counter() - t1) * 1e3)
-                del hm
-            extra["one_step_incl_mesh_d2h_ms"] = round(min(ts[1:]), 3)
-            extra["one_step_incl_mesh_d2h_what"] = ("sdfk_sample_march + counts + sdfk_mesh_copy of V/C/N/T into newly allocated (untouched) host "
-                                                    f"arrays + bounds; best of 3 after a warm-up call; all four: {[round(t, 3) for t in ts]}")
+                if kind == "pinned":
+                    hm = Mesh._from_handle(m)   # counts + the four arrays + bounds + stats, frees the handle
+                    dt1 = time.perf_counter() - t1
+                    del hm
+                    return dt1 * 1e3
+                a, b = C.c_int64(), C.c_int64()
+                N.check(L.sdfk_mesh_counts(m, C.byref(a), C.byref(b)))
+                if kind == "managed":
+                    keep = [fresh_managed(a.value * 12) for _ in range(3)] + [fresh_managed(b.value * 4)]
+                    arrs = [x for _, x in keep]
+                else:
+                    arrs = [np.empty(a.value * 12, np.uint8) for _ in range(3)] + [np.empty(b.value * 4, np.uint8)]
+                N.check(L.sdfk_mesh_copy(m, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data))
+                lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
+                N.check(L.sdfk_mesh_bounds(m, lo, hi))
+                L.sdfk_mesh_free(m)
+                return (time.perf_counter() - t1) * 1e3
+
+            d2h = {}
+            for kind in ("pinned", "managed", "numpy"):
+                ts = [one_call(kind) for _ in range(5)]
+                d2h[kind] = {"median_ms": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "all_ms": [round(t, 3) for t in ts]}
+            extra["one_step_incl_mesh_d2h_ms"] = d2h["pinned"]["median_ms"]
+            extra["one_step_incl_mesh_d2h"] = {
+                "what": "sdfk_sample_march + sdfk_mesh_counts + sdfk_mesh_copy of V/C/N/T to the host + sdfk_mesh_bounds, one call at a time; "
+                        "median of 4 calls after a warm-up call.  pinned = destination arrays from the library's pinned host arena (the Python "
+                        "mirror's Mesh; the headline figure); managed = freshly mapped, never touched 4 KiB-page memory, as a managed runtime's "
+                        "new arrays are (the library pre-faults it on its thread pool); numpy = fresh numpy.empty arrays (huge-page advised)",
+                **d2h}
     if rank == 0:
         nvox_rank = n * n * (D.slab_planes(*D.slab_layers(n - 1, world, rank), n)[1] if world > 1 else n)
         colors = bool(sdf.writes_color)

@@ -224,6 +224,19 @@ int sdfk_raymarch_device(const sdfk_program* p, int32_t width, int32_t height, c
                          const float view_projection_inverse[16], float near_plane, float far_plane,
                          int32_t depth_iterations, void* depth_dev, void* rgb_dev);
 
+/* ---- pinned host arena -------------------------------------------------------
+ * Host memory the GPU can write directly (hipHostMalloc), recycled through size-class free lists:
+ * destinations inside such a block make sdfk_mesh_copy / sdfk_volume_download / sdfk_raymarch plain
+ * DMA transfers at the link rate (512^3 sphere mesh, 33 MB: 0.6 ms).  Into ordinary pageable
+ * memory (managed arrays pinned by the shim for the call) the same entry points first touch the
+ * destination pages on a small thread pool, which is what a copy into FRESHLY allocated arrays
+ * is otherwise dominated by (SDFK_COPY_THREADS, SDFK_COPY_MODE).  The Python mirror allocates
+ * Mesh.Vertices/Colors/Normals/Triangles here; a C# shim can do the same for Span<T>/Memory<T>
+ * based accessors, while Mesh's public arrays (Mesh.cs:10-13) have to stay managed arrays.
+ * sdfk_host_free returns the block to the arena; a block must not be used after sdfk_shutdown. */
+int sdfk_host_alloc(int64_t n_bytes, void** out);
+void sdfk_host_free(void* p);
+
 /* ---- Mesh (Mesh.cs:8-64) ----------------------------------------------------
  * Vertices/Colors/Normals: 3 floats each per vertex; Triangles: int32 indices
  * (Mesh.cs:10-13).  Vertices/Normals are already transformed to world space

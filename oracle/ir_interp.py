@@ -18,18 +18,12 @@ def _min_ieee(a, b):
         return np.where(a != b, np.where(np.isnan(a), a, np.where(a < b, a, b)), np.where(np.signbit(a), a, b)).astype(f32)
 
 
-def sample(ops, out_rgbw, writes_color, mn, mx, nx, ny, nz):
-    """ops: list of (opcode, a, b, c, d, imm).  Returns (values[nx,ny,nz], colors[nx,ny,nz,3])."""
-    mn, mx = np.asarray(mn, f32), np.asarray(mx, f32)
-    d = (mx - mn) / np.array([nx, ny, nz], f32)
-    m = mn + f32(0.5) * d
-    px = (m[0] + np.arange(nx, dtype=f32) * d[0])[:, None, None] + np.zeros((nx, ny, nz), f32)
-    py = (m[1] + np.arange(ny, dtype=f32) * d[1])[None, :, None] + np.zeros((nx, ny, nz), f32)
-    pz = (m[2] + np.arange(nz, dtype=f32) * d[2])[None, None, :] + np.zeros((nx, ny, nz), f32)
+def _eval(ops, px, py, pz):
+    """every value of the program at the points (px, py, pz) (float32 arrays of one shape)"""
     v = []
     with np.errstate(all="ignore"):
         for (op, a, b, c, dd, imm) in ops:
-            if op == CONST: r = np.full((nx, ny, nz), f32(imm), f32)
+            if op == CONST: r = np.full(px.shape, f32(imm), f32)
             elif op == X: r = px
             elif op == Y: r = py
             elif op == Z: r = pz
@@ -48,9 +42,28 @@ def sample(ops, out_rgbw, writes_color, mn, mx, nx, ny, nz):
             elif op == SEL_LT: r = np.where(v[a] < v[b], v[c], v[dd])
             else: raise ValueError(op)
             v.append(np.asarray(r, f32))
+    return v
+
+
+def sample(ops, out_rgbw, writes_color, mn, mx, nx, ny, nz):
+    """ops: list of (opcode, a, b, c, d, imm).  Returns (values[nx,ny,nz], colors[nx,ny,nz,3])."""
+    mn, mx = np.asarray(mn, f32), np.asarray(mx, f32)
+    d = (mx - mn) / np.array([nx, ny, nz], f32)
+    m = mn + f32(0.5) * d
+    px = (m[0] + np.arange(nx, dtype=f32) * d[0])[:, None, None] + np.zeros((nx, ny, nz), f32)
+    py = (m[1] + np.arange(ny, dtype=f32) * d[1])[None, :, None] + np.zeros((nx, ny, nz), f32)
+    pz = (m[2] + np.arange(nz, dtype=f32) * d[2])[None, None, :] + np.zeros((nx, ny, nz), f32)
+    v = _eval(ops, px, py, pz)
     values = v[out_rgbw[3]]
     colors = np.stack([v[out_rgbw[k]] for k in range(3)], axis=-1) if writes_color else np.zeros((nx, ny, nz, 3), f32)
     return values, colors
+
+
+def run(ops, out_rgbw, points):
+    """The program at arbitrary points [n, 3] (float32): (r, g, b, w) arrays, None for an output id < 0."""
+    pts = np.asarray(points, f32)
+    v = _eval(ops, np.ascontiguousarray(pts[:, 0]), np.ascontiguousarray(pts[:, 1]), np.ascontiguousarray(pts[:, 2]))
+    return [v[k] if k >= 0 else None for k in out_rgbw]
 
 
 def random_program(seed, n_ops=48):

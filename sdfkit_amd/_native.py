@@ -62,6 +62,8 @@ SIGNATURES = {
     "sdfk_slab_enqueue": (C.c_int, [_vp, _vp, _i32, _f, _i32, _i32, _vp, _i64, _i32, _vp]),
     "sdfk_slabs_rebase": (C.c_int, [_vp, _i32, _i64]),
     "sdfk_slabs_rebase_mirror": (C.c_int, [_vp, _i32, _i64, _vp]),
+    "sdfk_host_alloc": (C.c_int, [_i64, _vpp]),
+    "sdfk_host_free": (None, [_vp]),
     "sdfk_mesh_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_mesh_bounds": (C.c_int, [_vp, _fp, _fp]),
     "sdfk_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -148,6 +150,39 @@ def bind_torch_stream(device=None):
         torch.cuda.set_stream(s)
     check(lib().sdfk_set_stream(C.c_void_p(s.cuda_stream)))
     return s
+
+
+class _PinnedBlock:
+    """A block of the library's pinned host arena, exposed to numpy through the array interface; goes
+    back to the arena when the last array viewing it is collected."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().sdfk_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    @property
+    def __array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None and _inited_device is not None:
+                _lib.sdfk_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = 0
+
+
+def pinned_empty(shape, dtype):
+    """numpy.empty in pinned host memory (sdfk_host_alloc): device-to-host copies into it are plain DMA.
+    SDFK_PINNED_ARRAYS=0 falls back to numpy's own allocator (pageable memory, as a managed runtime hands out)."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    if n == 0 or os.environ.get("SDFK_PINNED_ARRAYS") == "0":
+        return np.empty(shape, dt)
+    return np.asarray(_PinnedBlock(n)).view(dt).reshape(shape)
 
 
 def shutdown():

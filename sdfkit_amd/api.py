@@ -503,10 +503,12 @@ class Mesh:
         L = N.lib()
         nv, ni = C.c_int64(), C.c_int64()
         N.check(L.sdfk_mesh_counts(h, C.byref(nv), C.byref(ni)))
-        v = np.empty((nv.value, 3), np.float32)
-        c = np.empty((nv.value, 3), np.float32)
-        n = np.empty((nv.value, 3), np.float32)
-        t = np.empty((ni.value,), np.int32)
+        # (pinned host arena: the copy below is then a plain DMA transfer, and the arrays of a Mesh that has been
+        # collected are recycled instead of being first-touched again; numpy owns nothing here but the views)
+        v = N.pinned_empty((nv.value, 3), np.float32)
+        c = N.pinned_empty((nv.value, 3), np.float32)
+        n = N.pinned_empty((nv.value, 3), np.float32)
+        t = N.pinned_empty((ni.value,), np.int32)
         N.check(L.sdfk_mesh_copy(h, v.ctypes.data, c.ctypes.data, n.ctypes.data, t.ctypes.data))
         mn, mx = (C.c_float * 3)(), (C.c_float * 3)()
         N.check(L.sdfk_mesh_bounds(h, mn, mx))

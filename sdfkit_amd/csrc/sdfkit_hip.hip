@@ -108,6 +108,10 @@ struct Context {
     // pinned staging for sdfk_mesh_copy / sdfk_volume_download (grown on demand, kept)
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    // pinned host arena (sdfk_host_alloc): size-class free lists like the device pool; a block in
+    // `host_live` is in the caller's hands
+    std::multimap<size_t, void*> host_free;
+    std::map<void*, size_t> host_live;
     // sizes seen last time for a (shape, iso-independent) key: lets a repeat call launch the
     // whole pipeline speculatively and synchronise once
     struct Hint { uint32_t n_active, nv, ni; };
@@ -379,6 +383,10 @@ int stage_reserve(size_t n)
     if (g.stage) (void)hipHostFree(g.stage);
     g.stage = nullptr;
     g.stage_bytes = 0;
+    for (auto& kv : g.host_free) (void)hipHostFree(kv.second);
+    g.host_free.clear();
+    for (auto& kv : g.host_live) (void)hipHostFree(kv.first);   // (their owners must not touch them after shutdown)
+    g.host_live.clear();
     const size_t want = size_class(n);
     if (hipHostMalloc(&g.stage, want, hipHostMallocDefault) != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipHostMalloc(%zu) for the copy staging buffer failed", want);
     memset(g.stage, 0, want);   // touch it once, here
@@ -399,7 +407,15 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
     size_t total = 0;
     for (auto& p : pieces) total += p.bytes;
     if (total == 0) return SDFK_OK;
-    if (total < (size_t(1) << 20) || mode == 2) {   // small: nothing to gain from helpers
+    bool pinned = true;   // every destination inside a block of the library's pinned arena: plain DMA, nothing to pre-fault
+    for (auto& p : pieces) {
+        if (!p.bytes) continue;
+        auto it = g.host_live.upper_bound(p.dst);
+        if (it == g.host_live.begin()) { pinned = false; break; }
+        --it;
+        if ((const char*)p.dst + p.bytes > (const char*)it->first + it->second) { pinned = false; break; }
+    }
+    if (total < (size_t(1) << 20) || mode == 2 || pinned) {   // small: nothing to gain from helpers
         for (auto& p : pieces)
             if (p.bytes) HIPCHK(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -630,6 +646,10 @@ extern "C" void sdfk_shutdown(void)
     if (g.stage) (void)hipHostFree(g.stage);
     g.stage = nullptr;
     g.stage_bytes = 0;
+    for (auto& kv : g.host_free) (void)hipHostFree(kv.second);
+    g.host_free.clear();
+    for (auto& kv : g.host_live) (void)hipHostFree(kv.first);   // (their owners must not touch them after shutdown)
+    g.host_live.clear();
     if (g.slots) (void)hipHostFree(g.slots);
     g.slots = nullptr;
     g.slots_dev = nullptr;
@@ -1913,6 +1933,41 @@ extern "C" int sdfk_raymarch(const sdfk_program* p, int32_t width, int32_t heigh
     dev_free(d);
     dev_free(c);
     return r;
+}
+
+// ---------------------------------------------------------------------------
+// pinned host arena
+// ---------------------------------------------------------------------------
+extern "C" int sdfk_host_alloc(int64_t n_bytes, void** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!out || n_bytes < 0) return fail(SDFK_ERR_INVALID, "sdfk_host_alloc: bad argument");
+    *out = nullptr;
+    if (int r = require_init()) return r;
+    const size_t c = size_class((size_t)std::max<int64_t>(n_bytes, 1));
+    auto it = g.host_free.find(c);
+    void* p = nullptr;
+    if (it != g.host_free.end()) {
+        p = it->second;
+        g.host_free.erase(it);
+    } else if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) {
+        for (auto& kv : g.host_free) (void)hipHostFree(kv.second);   // drop the cache and retry once
+        g.host_free.clear();
+        if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipHostMalloc(%zu) failed", c);
+    }
+    g.host_live[p] = c;
+    *out = p;
+    return SDFK_OK;
+}
+
+extern "C" void sdfk_host_free(void* p)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p) return;
+    auto it = g.host_live.find(p);
+    if (it == g.host_live.end()) return;
+    if (g.inited) g.host_free.emplace(it->second, p);   // back to the arena (after shutdown the memory is gone already)
+    g.host_live.erase(it);
 }
 
 // ---------------------------------------------------------------------------

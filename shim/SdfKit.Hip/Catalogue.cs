@@ -1,0 +1,60 @@
+// Catalogue.cs -- where the reference's factories gain their GPU tag.  These are the bodies the patched
+// SdfKit/Sdf.cs and SdfKit/SdfExpr.cs members get (same signatures, same returned delegate -- still callable on the
+// CPU exactly as before -- plus the tag).  UNCOMPILED HERE (no .NET in the build image).
+using System;
+using System.Numerics;
+using SdfKit.Hip;
+
+namespace SdfKit
+{
+    public static partial class Sdfs
+    {
+        // Sdf.cs:202-215: the reference delegate is kept (CPU callers, RayMarcher on CPU, opaque compositions)
+        public static Sdf Sphere(float radius) => GpuSdf.Tag(SphereCpu(radius), GpuSdf.Sphere(radius));
+        // Sdf.cs:125-139
+        public static Sdf Box(Vector3 bounds) => GpuSdf.Tag(BoxCpu(bounds), GpuSdf.Box(bounds));
+        // Sdf.cs:144-156
+        public static Sdf Plane(Vector3 normal, float distanceFromOrigin) => GpuSdf.Tag(PlaneCpu(normal, distanceFromOrigin), GpuSdf.Plane(normal, distanceFromOrigin));
+        // Sdfs.Cylinder (Sdf.cs:141-142) goes through SdfExprs.Cylinder(...).ToSdf() and is tagged there.
+        // Sdfs.Solid(SdfFunc) / Solid(SdfDistFunc) (Sdf.cs:172-200) take COMPILED delegates: opaque, no tag.
+        // (SphereCpu / BoxCpu / PlaneCpu = the reference bodies, renamed.)
+    }
+
+    public static partial class SdfEx
+    {
+        // Sdf.cs:101-110: colour constant, distance of the inner SDF
+        public static Sdf WithColor(this Sdf sdf, Vector3 color)
+        {
+            Sdf cpu = WithColorCpu(sdf, color);                       // the reference body
+            var inner = GpuSdf.ProgramOf(sdf);
+            return inner == null ? cpu : GpuSdf.Tag(cpu, GpuSdf.WithColor(inner, color));
+        }
+
+        // Sdf.cs:59-63.  With a tagged SDF the whole chain stays on the device: ONE native call
+        // (sample + ClipToBounds + sign bits fused, marching cubes, mesh left in HBM), then the copy into the
+        // managed Mesh arrays.  batchSize / maxDegreeOfParallelism have no GPU meaning.
+        public static unsafe Mesh ToMesh(this Sdf sdf, Vector3 min, Vector3 max, int nx, int ny, int nz, int batchSize = SdfConfig.DefaultBatchSize,
+                                         int maxDegreeOfParallelism = -1, bool clipToBounds = true, float isoValue = 0.0f, int step = 1, IProgress<float>? progress = null)
+        {
+            var prog = GpuSdf.ProgramOf(sdf);
+            if (prog == null)   // opaque delegate: the reference's own path (CPU sampler), meshing still on the GPU via the host arrays
+                return ToVoxels(sdf, min, max, nx, ny, nz, batchSize, maxDegreeOfParallelism, clipToBounds).ToMesh(isoValue, step, progress);
+            Native.Check(Native.sdfk_sample_march(prog.Handle, (float*)&min, (float*)&max, nx, ny, nz, clipToBounds ? 1 : 0, isoValue, step, out var h));
+            MarchingCubes.ReportProgress(progress, nz, step);
+            try { return Mesh.FromNative(h); } finally { Native.sdfk_mesh_free(h); }
+        }
+    }
+
+    public static partial class SdfExprEx
+    {
+        // SdfExpr.cs:208-211.  The CPU delegate is still produced (SdfExprCompiler.Compile) so that the result can be
+        // called like any Sdf; the GPU program is lowered from the same tree.  A tree with a node the lowering does
+        // not know (NotSupportedException) simply stays untagged = CPU only.
+        public static Sdf ToSdf(this SdfExpr sdf)
+        {
+            Sdf cpu = SdfExprCompiler.Compile(sdf);
+            try { return GpuSdf.Tag(cpu, Lowering.Lower(sdf)); }
+            catch (NotSupportedException) { return cpu; }
+        }
+    }
+}

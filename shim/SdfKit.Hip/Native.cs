@@ -1,0 +1,83 @@
+// Native.cs -- P/Invoke surface of libsdfkit_hip.so (include/sdfkit_hip.h), one [DllImport] per entry point the
+// shim uses.  UNCOMPILED IN THIS REPOSITORY: the build image has no .NET toolchain (DESIGN.md section 1); the same
+// ABI is driven end to end by the ctypes mirror sdfkit_amd/_native.py, whose SIGNATURES table this file follows
+// entry for entry (tests/test_abi.py checks header <-> exports <-> ctypes table).
+using System;
+using System.Numerics;
+using System.Runtime.InteropServices;
+
+namespace SdfKit.Hip
+{
+    /// <summary>struct sdfk_op (include/sdfkit_hip.h): one float32 SSA instruction; value id = index.</summary>
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SdfkOp
+    {
+        public int Opcode, A, B, C, D;
+        public float Imm;
+    }
+
+    /// <summary>enum sdfk_opcode</summary>
+    public enum Op
+    {
+        Const = 0, X = 1, Y = 2, Z = 3, Add = 4, Sub = 5, Mul = 6, Div = 7, Neg = 8, Abs = 9, Sqrt = 10, Floor = 11,
+        MinSel = 12, MaxSel = 13, MinIeee = 14, MaxIeee = 15, SelLt = 16,
+    }
+
+    static unsafe class Native
+    {
+        const string Lib = "sdfkit_hip";   // libsdfkit_hip.so next to the assembly or on LD_LIBRARY_PATH
+
+        // lifetime
+        [DllImport(Lib)] public static extern int sdfk_abi_version();
+        [DllImport(Lib)] public static extern int sdfk_init(int device);
+        [DllImport(Lib)] public static extern void sdfk_shutdown();
+        [DllImport(Lib)] public static extern int sdfk_synchronize();
+        [DllImport(Lib)] public static extern IntPtr sdfk_last_error();
+        // programs (Sdf delegate / SdfExprCompiler.Compile, Sdf.cs:8, SdfExpr.cs:225-273)
+        [DllImport(Lib)] public static extern int sdfk_program_create(SdfkOp* ops, int nOps, int* outRgbw, int writesColor, out IntPtr program);
+        [DllImport(Lib)] public static extern int sdfk_program_check(SdfkOp* ops, int nOps, int* outRgbw, int writesColor);
+        [DllImport(Lib)] public static extern void sdfk_program_destroy(IntPtr program);
+        // Voxels (Voxels.cs)
+        [DllImport(Lib)] public static extern int sdfk_volume_create(int nx, int ny, int nz, float* min, float* max, int withColors, out IntPtr volume);
+        [DllImport(Lib)] public static extern int sdfk_volume_upload(IntPtr volume, float* values, float* colors3);
+        [DllImport(Lib)] public static extern int sdfk_volume_download(IntPtr volume, float* values, float* colors3);
+        [DllImport(Lib)] public static extern int sdfk_volume_clip_to_bounds(IntPtr volume);
+        [DllImport(Lib)] public static extern void sdfk_volume_free(IntPtr volume);
+        [DllImport(Lib)] public static extern int sdfk_sample(IntPtr program, IntPtr volume, int clipToBounds);
+        // MarchingCubes.CreateMesh (MarchingCubes.cs:39-92), SdfEx.ToMesh (Sdf.cs:59-63)
+        [DllImport(Lib)] public static extern int sdfk_march(IntPtr volume, float iso, int step, out IntPtr mesh);
+        [DllImport(Lib)] public static extern int sdfk_march_host(float* values, float* colors3, int nx, int ny, int nz, float* min, float* max, float iso, int step, out IntPtr mesh);
+        [DllImport(Lib)] public static extern int sdfk_sample_march(IntPtr program, float* min, float* max, int nx, int ny, int nz, int clip, float iso, int step, out IntPtr mesh);
+        // Mesh (Mesh.cs)
+        [DllImport(Lib)] public static extern int sdfk_mesh_counts(IntPtr mesh, out long nVertices, out long nIndices);
+        [DllImport(Lib)] public static extern int sdfk_mesh_bounds(IntPtr mesh, float* min, float* max);
+        [DllImport(Lib)] public static extern int sdfk_mesh_copy(IntPtr mesh, float* v, float* c, float* n, int* tri);
+        [DllImport(Lib)] public static extern void sdfk_mesh_free(IntPtr mesh);
+        // RayMarcher (RayMarcher.cs:45-211)
+        [DllImport(Lib)] public static extern int sdfk_raymarch(IntPtr program, int width, int height, float* cameraPosition, float* viewProjectionInverse,
+                                                                float near, float far, int depthIterations, float* depth, float* rgb);
+
+        static readonly object initLock = new object();
+        static bool inited;
+
+        /// <summary>sdfk_init once per process; device = LOCAL_RANK (one process per GPU) or 0.</summary>
+        public static void EnsureInit()
+        {
+            if (inited) return;
+            lock (initLock) {
+                if (inited) return;
+                if (sdfk_abi_version() < 2) throw new InvalidOperationException("libsdfkit_hip.so is older than this shim");
+                int device = int.TryParse(Environment.GetEnvironmentVariable("LOCAL_RANK"), out var r) ? r : 0;
+                Check(sdfk_init(device));
+                inited = true;
+            }
+        }
+
+        /// <summary>The reference throws nothing on this path; a native failure becomes InvalidOperationException.</summary>
+        public static void Check(int status)
+        {
+            if (status != 0)
+                throw new InvalidOperationException($"sdfkit_hip status {status}: {Marshal.PtrToStringAnsi(sdfk_last_error())}");
+        }
+    }
+}

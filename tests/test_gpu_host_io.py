@@ -170,3 +170,35 @@ def test_calls_from_other_threads(gpu):
     assert not err, err
     for m in out:
         assert_mesh_equal(m, om)
+
+
+def test_mesh_arrays_come_from_the_pinned_arena(gpu):
+    """Mesh._from_handle allocates V/C/N/T in the library's pinned host arena (plain DMA, recycled blocks);
+    SDFK_PINNED_ARRAYS=0 gives ordinary numpy arrays with the same contents."""
+    scene, sdf = S.sphere_w(1.0)
+    mn, mx, dims = [-1.5] * 3, [1.5] * 3, (96, 96, 96)
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    om = O.march(ov, oc, mn, mx)
+    L = N.lib()
+    ptrs = set()
+    for _ in range(4):
+        m = Mesh._from_handle(_raw(sdf, mn, mx, dims, False))
+        assert_mesh_equal(m, om)
+        assert m.Vertices.flags.writeable and m.Vertices.base is not None
+        ptrs.add(m.Vertices.ctypes.data)
+        del m
+    assert len(ptrs) <= 2          # blocks of collected meshes are handed out again
+    os.environ["SDFK_PINNED_ARRAYS"] = "0"
+    try:
+        assert_mesh_equal(Mesh._from_handle(_raw(sdf, mn, mx, dims, False)), om)
+    finally:
+        del os.environ["SDFK_PINNED_ARRAYS"]
+    p = C.c_void_p()
+    N.check(L.sdfk_host_alloc(1 << 20, C.byref(p)))
+    assert p.value
+    L.sdfk_host_free(p)
+    L.sdfk_host_free(p)            # double free of an arena block is ignored
+    q = C.c_void_p()
+    N.check(L.sdfk_host_alloc(1 << 20, C.byref(q)))
+    assert q.value == p.value      # recycled
+    L.sdfk_host_free(q)

@@ -25,7 +25,11 @@ except OSError:
 
 def fresh(nbytes):
     """an anonymous mapping nobody has touched (what a brand-new managed / numpy array is)"""
-    mm = mmap.mmap(-1, nbytes + 4096)
+    mm = mmap.mmap(-1, nbytes + 4096, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)   # (Python's default is MAP_SHARED: shmem pages)
+    if os.environ.get("PROBE_HUGE") == "1":
+        mm.madvise(mmap.MADV_HUGEPAGE)      # what numpy does for its large arrays
+    else:
+        mm.madvise(mmap.MADV_NOHUGEPAGE)
     return mm, np.frombuffer(mm, dtype=np.uint8, count=nbytes)
 
 
