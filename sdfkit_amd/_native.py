@@ -83,7 +83,8 @@ SIGNATURES = {
 
 
 def library_path():
-    return os.path.join(_HERE, "libsdfkit_hip.so")
+    # SDFKIT_HIP_LIBRARY: an experiment build of the same sources (tools/variants.sh), never a different product
+    return os.environ.get("SDFKIT_HIP_LIBRARY") or os.path.join(_HERE, "libsdfkit_hip.so")
 
 
 def lib():
@@ -91,7 +92,7 @@ def lib():
     global _lib
     if _lib is None:
         path = library_path()
-        if not os.path.exists(path) or _build.needs_build():
+        if not os.environ.get("SDFKIT_HIP_LIBRARY") and (not os.path.exists(path) or _build.needs_build()):
             # sources or the header are newer than the library (or it is missing): rebuild, and never
             # run a stale binary against the current ctypes table -- a failed build is an error
             try:

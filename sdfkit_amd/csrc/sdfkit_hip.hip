@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -261,6 +262,15 @@ void bind_thread()
     if (g.inited && t_bound_device != g.device && hipSetDevice(g.device) == hipSuccess) t_bound_device = g.device;
 }
 
+// experiment knob: SDFK_GRID_<NAME>=n caps the grid of the marching-cubes kernel NAME (RESOLVE, VERT, TRI)
+int grid_cap(const char* name, int dflt)
+{
+    const std::string key = std::string("SDFK_GRID_") + name;
+    const char* e = getenv(key.c_str());
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
+
 int grid_for(size_t work_items, int per_block = 256, int max_blocks = 256 * 8)
 {
     size_t b = (work_items + per_block - 1) / per_block;
@@ -359,8 +369,14 @@ public:
 };
 HostPool g_pool;
 
-// one write per page of [p, p + n): slices are 2 MiB-aligned so that two threads never fault into
-// the same page-table page (or the same transparent huge page)
+// Makes the pages of [p, p + n) present and writable before the copy lands in them: slices are
+// 2 MiB-aligned so that two threads never fault into the same page-table page (or the same
+// transparent huge page).  MADV_POPULATE_WRITE (Linux 5.14+) faults a whole slice in one system call
+// and does not modify the pages, so it may cover the partial first / last page; without it, one
+// byte per page is written (inside the destination only: the whole range is overwritten right after).
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 void prefault_start(void* p, size_t n)
 {
     if (!p || n == 0) { g_pool.start(0, [](int) {}); return; }
@@ -369,11 +385,17 @@ void prefault_start(void* p, size_t n)
     const size_t first = (kSlice - ((uintptr_t)base & (kSlice - 1))) & (kSlice - 1);   // bytes up to the first 2 MiB boundary
     const size_t nslices = 1 + (n > first ? (n - first + kSlice - 1) / kSlice : 0);
     g_pool.start((int)nslices, [=](int t) {
-        size_t a = t == 0 ? 0 : first + (size_t)(t - 1) * kSlice;
-        size_t b = t == 0 ? std::min(first, n) : std::min(a + kSlice, n);
-        const long page = 4096;
+        const size_t a = t == 0 ? 0 : first + (size_t)(t - 1) * kSlice;
+        const size_t b = t == 0 ? std::min(first, n) : std::min(a + kSlice, n);
+        if (b <= a) return;
+        const uintptr_t page = 4096, lo = ((uintptr_t)base + a) & ~(page - 1), hi = ((uintptr_t)base + b + page - 1) & ~(page - 1);
+        static std::atomic<int> have_populate{1};
+        if (have_populate.load(std::memory_order_relaxed)) {
+            if (madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+            if (errno == EINVAL) have_populate.store(0, std::memory_order_relaxed);   // older kernel: touch instead
+        }
         for (size_t o = a; o < b; o += page) *(volatile char*)(base + o) = 0;
-        if (b > a) *(volatile char*)(base + b - 1) = 0;
+        *(volatile char*)(base + b - 1) = 0;
     });
 }
 
@@ -383,10 +405,6 @@ int stage_reserve(size_t n)
     if (g.stage) (void)hipHostFree(g.stage);
     g.stage = nullptr;
     g.stage_bytes = 0;
-    for (auto& kv : g.host_free) (void)hipHostFree(kv.second);
-    g.host_free.clear();
-    for (auto& kv : g.host_live) (void)hipHostFree(kv.first);   // (their owners must not touch them after shutdown)
-    g.host_live.clear();
     const size_t want = size_class(n);
     if (hipHostMalloc(&g.stage, want, hipHostMallocDefault) != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipHostMalloc(%zu) for the copy staging buffer failed", want);
     memset(g.stage, 0, want);   // touch it once, here
@@ -396,14 +414,16 @@ int stage_reserve(size_t n)
 
 struct CopyPiece { const void* src; void* dst; size_t bytes; };
 
-// Device -> caller arrays.  mode 0: the destination of piece k+1 is pre-faulted by the pool while
-// piece k is copied by the runtime (which pins touched pageable memory on the fly and moves it at
-// the link rate); mode 1: everything goes to the pinned staging buffer in 4 MiB chunks and the
-// pool copies the chunks that have arrived into the (concurrently pre-faulted) destination.
+// Device -> caller arrays.  Default (mode 1): everything goes to the pinned staging buffer in 4 MiB
+// chunks (plain DMA at the link rate) and the pool copies the chunks that have arrived into the
+// destination, which it has pre-faulted while the first chunks were on the wire.  The caller's
+// pageable memory is never handed to the HIP runtime: its pin-on-the-fly path measured anywhere
+// between 0.8 and 26 ms for the same 33 MB, depending on page size and history (tools/host_io_probe.py).
+// mode 0: pre-fault on the pool, then the runtime's own copy; mode 2: the runtime's copy alone.
 int copy_to_host(const std::vector<CopyPiece>& pieces)
 {
     const char* em = getenv("SDFK_COPY_MODE");   // (read per call: tests and probes compare the three)
-    const int mode = em ? atoi(em) : 0;
+    const int mode = em ? atoi(em) : 1;
     size_t total = 0;
     for (auto& p : pieces) total += p.bytes;
     if (total == 0) return SDFK_OK;
@@ -1302,7 +1322,8 @@ int launch_classify(sdfk_march_job* j, bool publish)
     }
     {
         ProfScope ps("k_resolve");
-        hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, 256 * 12)), dim3(256), 0, g.stream, P);
+        static const int cap = grid_cap("RESOLVE", 256 * 12);
+        hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, cap)), dim3(256), 0, g.stream, P);
         // totals for the host: workgroup 0 of k_vertices publishes them, unless the caller
         // needs the counts before (or without) emitting
         if (publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, g.stream, P);
@@ -1455,7 +1476,8 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
         const float inv_det = 1.0f / det;
         M.inv[0] = yz * inv_det; M.inv[1] = xz * inv_det; M.inv[2] = xy * inv_det;
     }
-    const int vgrid = grid_for(j->P.cap_active, 256, 256 * 8);
+    static const int vcap = grid_cap("VERT", 256 * 8), tcap = grid_cap("TRI", 256 * 8);
+    const int vgrid = grid_for(j->P.cap_active, 256, vcap);
     if (int rr = job_alloc(j, &M.bounds_partial, (size_t)vgrid * 6)) return rr;
     M.bounds_blocks = vgrid;
     M.bounds = m->bounds;
@@ -1467,7 +1489,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     }
     {
         ProfScope ps("k_triangles");
-        hipLaunchKernelGGL(k_triangles, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
+        hipLaunchKernelGGL(k_triangles, dim3(grid_for(j->P.cap_active, 256, tcap)), dim3(256), 0, g.stream, j->P, M);
         HIPCHK(hipGetLastError());
     }
     return SDFK_OK;
