@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDFK_ABI_VERSION 1
+#define SDFK_ABI_VERSION 2   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free */
 
 typedef enum sdfk_status {
     SDFK_OK = 0,

@@ -1,6 +1,6 @@
 #!/bin/bash
-# On the GPU box: everything profiles/ needs for a round.  usage: tools/gpu_round_profiles.sh r01
-tag=${1:-r01}
+# On the GPU box: everything profiles/ needs for a round.  usage: tools/gpu_round_profiles.sh r02
+tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; export TMPDIR=/tmp
 O=gpurun_out/profiles_$tag; mkdir -p $O
@@ -10,19 +10,26 @@ SDFK_LANES=0 rocprofv3 --kernel-trace --stats -d $R/$O/stats_serial -o s --outpu
 SDFK_LANES=0 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 SDFK_LANES=0 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_w/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv > $O/pmc_hbm_traffic.txt
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+python3 tools/pmc_to_json.py $O/pmc_w/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv sphere 512 $O/pmc_traffic.json
 # config C3 (RepeatXY with colours, clipToBounds): serial kernel stats + the two PMC passes
 python3 bench.py --no-cpu --scene repeatxy > $O/bench_repeatxy.json 2>/dev/null
 SDFK_LANES=0 rocprofv3 --kernel-trace --stats -d $R/$O/stats_c3 -o s --output-format csv -- python3 bench.py --no-cpu --scene repeatxy > /dev/null 2>&1
 SDFK_LANES=0 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --scene repeatxy > /dev/null 2>&1
 SDFK_LANES=0 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --scene repeatxy > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_w3/p_counter_collection.csv $O/pmc_f3/p_counter_collection.csv > $O/pmc_hbm_traffic_repeatxy.txt
+python3 tools/pmc_to_json.py $O/pmc_w3/p_counter_collection.csv $O/pmc_f3/p_counter_collection.csv repeatxy 512 $O/pmc_traffic.json
 cp $O/stats_c3/s_kernel_stats.csv $O/kernel_stats_serial_repeatxy.csv
 rm -rf $O/stats_c3 $O/pmc_w3 $O/pmc_f3
 cp $O/stats/s_kernel_stats.csv $O/kernel_stats.csv
 cp $O/stats_serial/s_kernel_stats.csv $O/kernel_stats_serial.csv
 rm -rf $O/stats $O/stats_serial $O/pmc_w $O/pmc_f
+# C4 at its full size on one GPU, and the sharded path as the driver starts it (every rank on this one GPU, gloo)
+python3 bench.py --no-cpu --scene union8 --grid 1024 --steps 5 --warmup 2 > $O/bench_c4_1024.json 2>/dev/null
+SDFK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --no-cpu > $O/bench_two_ranks_one_gpu.json 2>/dev/null
 grep "^{" $O/bench.json | cut -c1-400
 cut -d, -f1,2,4 $O/kernel_stats_serial.csv | cut -c1-100
 cat $O/pmc_hbm_traffic.txt | head -12
 grep "^{" $O/bench_repeatxy.json | cut -c1-300
+grep "^{" $O/bench_c4_1024.json | cut -c1-300
 head -4 $O/pmc_hbm_traffic_repeatxy.txt

@@ -9,7 +9,7 @@ def summarise(paths):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in paths:
         for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].split("(")[0][-64:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
