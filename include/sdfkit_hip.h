@@ -36,9 +36,12 @@ typedef enum sdfk_status {
  * Replaces the `Sdf` delegate (Sdf.cs:8) for SDFs that can run on the GPU: the shim
  * lowers an SdfExpr tree (SdfExpr.cs:16-212) or a tagged Sdfs.* factory (Sdf.cs:118-215)
  * to a flat SSA list of scalar float32 operations.  Value id = instruction index.
- * sdfk_program_create JIT-compiles it with hiprtc into a grid-sampling kernel -- the
- * counterpart of SdfExprCompiler.Compile (SdfExpr.cs:225-273).  All arithmetic is IEEE
- * binary32, one rounding per op, no FMA contraction. */
+ * sdfk_program_create validates the list and generates the HIP source of the program's kernels
+ * (grid sampler in its row-length instantiations, cell-corner evaluator, ray marcher); each kernel is
+ * JIT-compiled with hiprtc -- or loaded from the on-disk code-object cache -- the first time a call
+ * needs it (SDFK_ERR_COMPILE is then reported by that call).  The counterpart of
+ * SdfExprCompiler.Compile (SdfExpr.cs:225-273).  All arithmetic is IEEE binary32, one rounding
+ * per op, no FMA contraction. */
 typedef enum sdfk_opcode {
     SDFK_OP_CONST = 0,   /* imm */
     SDFK_OP_X = 1, SDFK_OP_Y = 2, SDFK_OP_Z = 3,   /* sample point (Voxels.cs:104-106) */
@@ -95,8 +98,8 @@ const char* sdfk_last_error(void);
  * (Sdfs.Sphere/Box/Plane, Sdf.cs:134,153,211): colour stays (0,0,0) (Voxels.cs:88-92). */
 int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
                         int32_t writes_color, sdfk_program** out);
-/* Generate + hiprtc-compile for gfx950 without loading (needs no device): a lowering
- * check the shim can run at build time. */
+/* Generate + hiprtc-compile EVERY kernel of the program for gfx950 without loading (needs no
+ * device, never uses the cache): a lowering check the shim can run at build time. */
 int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color);
 const char* sdfk_program_source(const sdfk_program* p);
 /* JIT bookkeeping of this process.  Compiled code objects are kept on disk (see sdfkit_hip.hip,

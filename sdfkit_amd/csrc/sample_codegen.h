@@ -212,12 +212,29 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
         *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * A.pitch8 + z) = out;   // pitch8 = nz rounded up to 4
     }
 }
+// SDFK_KERNELS: bit mask of the entry points this module contains (the host compiles a program's kernels on demand:
+// bits 0..5 = the six instantiations below in this order, 6 = sdfk_corners_eval, 7 = sdfk_raymarch)
+#ifndef SDFK_KERNELS
+#define SDFK_KERNELS 0xff
+#endif
+#if SDFK_KERNELS & 0x01
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_ROWS>(A); }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ROWS>(A); }
+#endif
+#if SDFK_KERNELS & 0x02
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_flat(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_FLAT>(A); }
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_FLAT>(A); }
+#endif
+#if SDFK_KERNELS & 0x04
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_anynz(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_ANY>(A); }
+#endif
+#if SDFK_KERNELS & 0x08
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ROWS>(A); }
+#endif
+#if SDFK_KERNELS & 0x10
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_FLAT>(A); }
+#endif
+#if SDFK_KERNELS & 0x20
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_anynz(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ANY>(A); }
+#endif
 
 // Corner values of the active cells, RE-EVALUATED instead of gathered: for a volume this very
 // program has just sampled, the 8 corners of cell (x,y,z) are 8 more evaluations of the same
@@ -238,6 +255,7 @@ __device__ __forceinline__ float sdfk_voxel(const SampleArgs& A, int ix, int iy,
     return w;
 }
 
+#if SDFK_KERNELS & 0x40
 extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A, const unsigned* __restrict__ rec_xy,
                                                                      const unsigned* __restrict__ rec_z,
                                                                      float* __restrict__ rec_corners,
@@ -256,6 +274,7 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A
         o[1] = make_float4(c4, c5, c6, c7);
     }
 }
+#endif
 
 // RayMarcher.RenderDepth / Render (RayMarcher.cs:45-95, 134-169): sphere tracing, one lane per
 // pixel.  The reference runs every step as a whole-image batch operation (VectorData.cs); per
@@ -281,6 +300,7 @@ __device__ __forceinline__ void sdfk_normalize_inplace(float& x, float& y, float
     }
 }
 
+#if SDFK_KERNELS & 0x80
 extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
 {
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
@@ -326,6 +346,7 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
     o[1] = 0.0f + ((dv * d1 + 0.1f) * fgm + bgm * 0.75f);
     o[2] = 0.0f + ((dv * d2 + 0.1f) * fgm + bgm * 1.0f);
 }
+#endif
 
 )SRC";
 

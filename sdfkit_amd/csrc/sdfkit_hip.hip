@@ -36,7 +36,16 @@ using namespace sdfk;
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string t_err;
-static int g_sample_rpw = 2;   // x rows per wavefront of sdfk_sample_bits (compiled into the programs)
+// x rows per wavefront of sdfk_sample_bits (compiled into the programs; SDFK_SAMPLE_RPW = 1, 2 or 4 is an experiment knob)
+static int sample_rpw()
+{
+    static const int v = [] {
+        const char* er = getenv("SDFK_SAMPLE_RPW");
+        const int r = er ? atoi(er) : 2;
+        return (r == 1 || r == 2 || r == 4) ? r : 2;
+    }();
+    return v;
+}
 static int fail(int code, const char* fmt, ...)
 {
     char buf[1024];
@@ -502,15 +511,17 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
 // ---------------------------------------------------------------------------
 // opaque objects
 // ---------------------------------------------------------------------------
+// Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
+enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_BITS_ANY = 2, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_BITS_CLIP_ANY = 5,
+                  PK_CORNERS = 6, PK_RAYMARCH = 7, PK_COUNT = 8 };
+
 struct sdfk_program {
     std::string source;
-    hipModule_t module = nullptr;
-    hipFunction_t fn_bits = nullptr;
-    hipFunction_t fn_bits_clip = nullptr;
-    hipFunction_t fn_bits_flat = nullptr, fn_bits_clip_flat = nullptr; // nz % 4 == 0 but not a multiple of 256: chunks of the (y, z) plane
-    hipFunction_t fn_bits_any = nullptr, fn_bits_clip_any = nullptr;   // rows of any length (nz % 4 != 0)
-    hipFunction_t fn_corners = nullptr;
-    hipFunction_t fn_raymarch = nullptr;
+    // The entry points are compiled ON DEMAND, one hiprtc module per kernel set: what a caller pays on the first call
+    // is the sampler instantiation its grid needs + sdfk_corners_eval (they share a module), not all eight kernels
+    // (512^3 sphere on the bench box: 150 instead of 310 ms; an 8-primitive union: a third).
+    std::vector<hipModule_t> modules;
+    hipFunction_t fn[PK_COUNT] = {};
     int writes_color = 0;
     int refs = 1;   // the caller's handle + volumes it has sampled + queued jobs that launch from its module
 };
@@ -825,25 +836,17 @@ void cache_store(const std::string& path, const std::string& key, const std::vec
 }
 }  // namespace
 
-static int compile_program(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
-                           std::string& src, std::vector<char>& code, bool use_cache, bool* from_cache = nullptr,
-                           bool refresh = false)
+// hiprtc (or the on-disk cache) for the kernels `mask` of a generated source
+static int compile_source(const std::string& src, unsigned mask, std::vector<char>& code, bool use_cache, bool* from_cache = nullptr,
+                          bool refresh = false)
 {
     if (from_cache) *from_cache = false;
-    std::string err;
-    if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err))
-        return fail(SDFK_ERR_INVALID, "SDF program: %s", err.c_str());
-    if (const char* dump = getenv("SDFK_DUMP_SOURCE")) {   // debugging aid: the generated HIP source of the last program
-        if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
-    }
     // experiment knobs (the defaults are the tuned values)
     const char* en = getenv("SDFK_SAMPLE_NT");    // 0: plain instead of nontemporal stores of the values
-    const char* er = getenv("SDFK_SAMPLE_RPW");   // x rows per wavefront of the fused sampling kernel (1, 2 or 4)
-    g_sample_rpw = er ? atoi(er) : 2;
-    if (g_sample_rpw != 1 && g_sample_rpw != 2 && g_sample_rpw != 4) g_sample_rpw = 2;
     const std::string dn = std::string("-DSDFK_SAMPLE_NT=") + (en && !atoi(en) ? "0" : "1");
-    const std::string dr = "-DSDFK_SAMPLE_RPW=" + std::to_string(g_sample_rpw);
-    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dn.c_str(), dr.c_str()};
+    const std::string dr = "-DSDFK_SAMPLE_RPW=" + std::to_string(sample_rpw());
+    const std::string dk = "-DSDFK_KERNELS=" + std::to_string(mask);
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dn.c_str(), dr.c_str(), dk.c_str()};
     std::vector<std::string> extra;   // experiment knob: SDFK_JIT_FLAGS="-fno-slp-vectorize ..." (space separated)
     if (const char* ex = getenv("SDFK_JIT_FLAGS")) {
         std::string t;
@@ -908,13 +911,25 @@ extern "C" int sdfk_jit_stats(int64_t* n_compiled, int64_t* n_cache_hits, double
     return SDFK_OK;
 }
 
+static int generate_source(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color, std::string& src)
+{
+    std::string err;
+    if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err))
+        return fail(SDFK_ERR_INVALID, "SDF program: %s", err.c_str());
+    if (const char* dump = getenv("SDFK_DUMP_SOURCE")) {   // debugging aid: the generated HIP source of the last program
+        if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
+    }
+    return SDFK_OK;
+}
+
 extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color)
 {
     if (!ops || !out_rgbw || n_ops <= 0) return fail(SDFK_ERR_INVALID, "sdfk_program_check: null/empty argument");
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     std::string src;
     std::vector<char> code;
-    return compile_program(ops, n_ops, out_rgbw, writes_color, src, code, false);   // a real compile: this IS the check
+    if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
+    return compile_source(src, 0xffu, code, false);   // every kernel, a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -924,35 +939,45 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     if (!out || !ops || !out_rgbw || n_ops <= 0) return fail(SDFK_ERR_INVALID, "sdfk_program_create: null/empty argument");
     *out = nullptr;
     if (int r = require_init()) return r;
-    std::string src;
-    std::vector<char> code;
-    bool cached = false;
-    if (int r = compile_program(ops, n_ops, out_rgbw, writes_color, src, code, true, &cached)) return r;
     sdfk_program* p = new sdfk_program();
-    p->source = src;
+    if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, p->source)) { delete p; return r; }   // validates the op list
     p->writes_color = writes_color;
-    hipError_t e = hipModuleLoadData(&p->module, code.data());
-    if (e != hipSuccess && cached) {   // a damaged cache entry: compile again and replace it
-        p->module = nullptr;
-        if (int r = compile_program(ops, n_ops, out_rgbw, writes_color, src, code, true, nullptr, true)) { delete p; return r; }
-        e = hipModuleLoadData(&p->module, code.data());
-    }
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_corners, p->module, "sdfk_corners_eval");
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_raymarch, p->module, "sdfk_raymarch");
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits, p->module, "sdfk_sample_bits");
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip, p->module, "sdfk_sample_bits_clip");
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_flat, p->module, "sdfk_sample_bits_flat");
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip_flat, p->module, "sdfk_sample_bits_clip_flat");
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_any, p->module, "sdfk_sample_bits_anynz");
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_bits_clip_any, p->module, "sdfk_sample_bits_clip_anynz");
-    if (e != hipSuccess) {
-        if (p->module) (void)hipModuleUnload(p->module);
-        delete p;
-        return fail(SDFK_ERR_HIP, "loading JIT module: %s", hipGetErrorString(e));
-    }
     *out = p;
     return SDFK_OK;
 }
+
+namespace {
+// The device function of kernel `k` of a program, compiled and loaded on first use.  A sampler instantiation brings
+// sdfk_corners_eval along (same module): marching cubes on the volume it sampled re-evaluates cell corners with it.
+int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
+{
+    sdfk_program* p = const_cast<sdfk_program*>(cp);
+    if (!p->fn[k]) {
+        static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_bits_anynz", "sdfk_sample_bits_clip",
+                                                    "sdfk_sample_bits_clip_flat", "sdfk_sample_bits_clip_anynz", "sdfk_corners_eval", "sdfk_raymarch"};
+        unsigned mask = 1u << k;
+        if (k <= PK_BITS_CLIP_ANY && !p->fn[PK_CORNERS]) mask |= 1u << PK_CORNERS;
+        std::vector<char> code;
+        bool cached = false;
+        if (int r = compile_source(p->source, mask, code, true, &cached)) return r;
+        hipModule_t mod = nullptr;
+        hipError_t e = hipModuleLoadData(&mod, code.data());
+        if (e != hipSuccess && cached) {   // a damaged cache entry: compile again and replace it
+            if (int r = compile_source(p->source, mask, code, true, nullptr, true)) return r;
+            e = hipModuleLoadData(&mod, code.data());
+        }
+        if (e != hipSuccess) return fail(SDFK_ERR_HIP, "loading JIT module: %s", hipGetErrorString(e));
+        p->modules.push_back(mod);
+        for (int q = 0; q < PK_COUNT; q++)
+            if ((mask >> q) & 1u) {
+                e = hipModuleGetFunction(&p->fn[q], mod, names[q]);
+                if (e != hipSuccess) { p->fn[q] = nullptr; return fail(SDFK_ERR_HIP, "JIT module lacks %s: %s", names[q], hipGetErrorString(e)); }
+            }
+    }
+    *fn = p->fn[k];
+    return SDFK_OK;
+}
+}  // namespace
 
 extern "C" const char* sdfk_program_source(const sdfk_program* p) { return p ? p->source.c_str() : ""; }
 
@@ -968,8 +993,8 @@ namespace {
 void program_release(sdfk_program* p)
 {
     if (!p || --p->refs > 0) return;
-    if (g.inited) sync_all_lanes();   // kernels of this module may still be queued
-    if (p->module) (void)hipModuleUnload(p->module);
+    if (g.inited) sync_all_lanes();   // kernels of these modules may still be queued
+    for (hipModule_t m : p->modules) (void)hipModuleUnload(m);
     delete p;
 }
 
@@ -1124,7 +1149,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.pitch8 = v->pitch8();
         A.iso = iso_hint;
         {
-            const unsigned tpb = 512u / (unsigned)g_sample_rpw;
+            const unsigned tpb = 512u / (unsigned)sample_rpw();
             // 0: z tiles of one y row (nz % 256 == 0); 1: 256-voxel chunks of the (y, z) plane of an x row
             // (nz % 4 == 0); 2: rows of any length
             static const int force = getenv("SDFK_SAMPLE_MODE") ? atoi(getenv("SDFK_SAMPLE_MODE")) : -1;   // experiment knob
@@ -1133,9 +1158,9 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
             if (force == 1 && (v->nz & 3) == 0) mode = 1;
             static const char* const names[2][3] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_bits_anynz"},
                                                     {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat", "sdfk_sample_bits_clip_anynz"}};
+            hipFunction_t fn = nullptr;   // (compiled on first use)
+            if (int r = program_fn(p, (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode, &fn)) return r;
             ProfScope ps(names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
-            const hipFunction_t fns[2][3] = {{p->fn_bits, p->fn_bits_flat, p->fn_bits_any}, {p->fn_bits_clip, p->fn_bits_clip_flat, p->fn_bits_clip_any}};
-            const hipFunction_t fn = fns[clip_to_bounds ? 1 : 0][mode];
             const size_t plane = (size_t)v->ny * v->nz;
             if (mode == 1)
                 HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((plane + 255) / 256), 1, (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
@@ -1310,10 +1335,12 @@ int launch_classify(sdfk_march_job* j, bool publish)
     }
     const int nchunks = (int)((P.cap_active + 255u) / 256u);
     if (j->eval_prog) {   // the volume still is this program's output: evaluate the corners
+        hipFunction_t fn_corners = nullptr;
+        if (int r = program_fn(j->eval_prog, PK_CORNERS, &fn_corners)) return r;
         ProfScope ps("sdfk_corners_eval");
         const unsigned* n_active = &P.counters->n_active;
         void* params[] = {&j->eval_args, &P.rec_xy, &P.rec_z, &P.rec_corners, &n_active, &P.cap_active};
-        HIPCHK(hipModuleLaunchKernel(j->eval_prog->fn_corners, (unsigned)std::min(nchunks, 256 * 8), 1, 1, 256, 1, 1, 0,
+        HIPCHK(hipModuleLaunchKernel(fn_corners, (unsigned)std::min(nchunks, 256 * 8), 1, 1, 256, 1, 1, 0,
                                      g.stream, params, nullptr));
     } else {
         ProfScope ps("k_gather_corners");
@@ -1914,7 +1941,9 @@ static int raymarch_launch(const sdfk_program* p, int32_t width, int32_t height,
     void* params[] = {&A};
     const size_t n = (size_t)width * height;
     ProfScope ps("sdfk_raymarch");
-    HIPCHK(hipModuleLaunchKernel(p->fn_raymarch, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, g.stream, params, nullptr));
+    hipFunction_t fn_raymarch = nullptr;
+    if (int r = program_fn(p, PK_RAYMARCH, &fn_raymarch)) return r;
+    HIPCHK(hipModuleLaunchKernel(fn_raymarch, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, g.stream, params, nullptr));
     return SDFK_OK;
 }
 
