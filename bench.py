@@ -208,10 +208,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if one_gpu else "nccl"
+        import datetime
+        # (a short collective timeout: a rank that died must fail the run -- and let the launcher retry -- instead of hanging it)
         if one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
     N.init(local_rank)
     L = N.lib()
     stream = N.bind_torch_stream(dev)   # torch (RCCL, events) and the library on one explicit stream

@@ -33,3 +33,5 @@ cat $O/pmc_hbm_traffic.txt | head -12
 grep "^{" $O/bench_repeatxy.json | cut -c1-300
 grep "^{" $O/bench_c4_1024.json | cut -c1-300
 head -4 $O/pmc_hbm_traffic_repeatxy.txt
+# instruction / wait counters per kernel (two more PMC passes)
+bash tools/gpu_pmc.sh 2>&1 | grep -v "^W2026\|^E2026" > $O/pmc_sq_counters.txt
