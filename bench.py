@@ -175,13 +175,16 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=0, help="grid edge of the CPU-baseline run (default: the same grid as the GPU run)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="timed passes of the CPU baseline (after 1 warm-up)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--minimal", action="store_true", help="timed loop + per-kernel pass only (for rocprofv3 counter passes: no cold-call, "
+                    "latency, host-copy or host-Values legs, whose launches would mix into the per-kernel means)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing above has imported torch or
         # called HIP; the ranks are CHILD processes (a process that has touched the GPU must never exec).
         argv = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--grid", str(args.n),
-                "--scene", args.scene, "--cpu-n", str(args.cpu_n), "--cpu-passes", str(args.cpu_passes)] + (["--no-cpu"] if args.no_cpu else [])
+                "--scene", args.scene, "--cpu-n", str(args.cpu_n), "--cpu-passes", str(args.cpu_passes)] + (["--no-cpu"] if args.no_cpu else []) + \
+               (["--minimal"] if args.minimal else [])
         sys.exit(launch_ranks(argv, args.gpus))
 
     import numpy as np
@@ -255,16 +258,17 @@ def main():
         first["what"] = ("sdfk_program_create, then the first sdfk_sample_march + sdfk_mesh_counts of this shape: the sampler instantiation "
                          "the grid needs + sdfk_corners_eval are compiled / loaded here, then the exact two-phase path runs with buffers "
                          "allocated from the driver")
-        # the same first call when the machine has never seen the program: a fresh Sdf object, cache off
-        os.environ["SDFK_NO_CACHE"] = "1"
-        try:
-            cold_sdf = scene_for(args.scene)[0]
-            t0 = time.perf_counter()
-            cold_sdf.ToMesh(mn, mx, 8, 8, n, clipToBounds=clip)     # same sampler instantiation (same row length), tiny grid
-            first["cold_first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
-            del cold_sdf
-        finally:
-            del os.environ["SDFK_NO_CACHE"]
+        if not args.minimal:
+            # the same first call when the machine has never seen the program: a fresh Sdf object, cache off
+            os.environ["SDFK_NO_CACHE"] = "1"
+            try:
+                cold_sdf = scene_for(args.scene)[0]
+                t0 = time.perf_counter()
+                cold_sdf.ToMesh(mn, mx, 8, 8, n, clipToBounds=clip)     # same sampler instantiation (same row length), tiny grid
+                first["cold_first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                del cold_sdf
+            finally:
+                del os.environ["SDFK_NO_CACHE"]
     first_call_ms = round(first["program_ms"] + first.get("first_mesh_ms", 0.0), 2)
 
     def barrier():
@@ -401,7 +405,7 @@ def main():
     # then the accessor that waits for it (what a caller that needs each mesh before it builds the
     # next one gets; the headline `value` is the pipelined steady state)
     latency_ms = None
-    if not sharded:
+    if not sharded and not args.minimal:
         for _ in range(3):
             sample_march_once()
         torch.cuda.synchronize()
@@ -419,7 +423,7 @@ def main():
     # the pipeline pass above the event pair of a job's FIRST kernel also contains the time the
     # stream sat idle waiting for the (event-laden, hence slower) host to queue the job.
     roof_us = None
-    if not sharded:
+    if not sharded and not args.minimal:
         from sdfkit_amd.api import Voxels
         # (four volumes in turn, as the pipeline does: re-writing the SAME 512 MiB back to back is
         # 30 % slower than writing a buffer that was last touched a few launches ago)
@@ -444,7 +448,7 @@ def main():
     # context figures, outside the timed region, rank 0 only: what this box
     # reaches with a plain device fill / copy, and one step including the mesh copy to the host
     extra = {}
-    if rank == 0:
+    if rank == 0 and not args.minimal:
         x = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
         y = torch.empty_like(x)
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))

@@ -22,7 +22,9 @@ for k, c in res.items():
     b = c.get("WRITE_SIZE", 0.0) * 1024 + 2 * c.get("FETCH_SIZE", 0.0) * 1024
     name = k.replace("void ", "").replace("sdfk::", "").split("(")[0].strip()
     d[f"{name}@{scene}@{n}"] = int(round(b))
-    if name != "k_publish":      # (only on the exact path: not part of a steady-state step)
+    # the kernels of a steady-state step of the fused path (k_publish, k_signbits8, k_gather_corners, k_clip* only run on
+    # the exact / host-array / explicit-clip routes)
+    if name.startswith(("sdfk_sample_bits", "k_bits_transpose", "k_compact", "sdfk_corners_eval", "k_resolve", "k_vertices", "k_triangles")):
         step += b
 d[f"pipeline_step@{scene}@{n}"] = int(round(step))
 json.dump(d, open(out, "w"), indent=1, sort_keys=True)
