@@ -182,9 +182,11 @@ int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t cli
                            int32_t layer_begin, int32_t layer_end, int64_t vertex_base, sdfk_mesh** out);
 
 /* Self-describing slab payload for a single padded all-gather: 64-byte header
- * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; int32 vertex_bytes; pad }
+ * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; int32 vertex_bytes; int32 cap_v; pad }
  * followed by Vertices | Colors | Normals (3 floats per vertex each) | Triangles (int32).
- * vertex_bytes = 36, or 24 when the volume had no colours: Colors (all zero) is then left out.  Written device
+ * vertex_bytes = 36, or 24 when the volume had no colours: Colors (all zero) is then left out.
+ * cap_v = vertex slots each section is laid out for (sections at 64, 64 + 12 cap_v, ...; indices at
+ * 64 + vertex_bytes * cap_v); 0 = dense (cap_v = n_vertices), what sdfk_mesh_pack writes.  Written device
  * to device into `dst` (capacity_bytes); *needed_bytes = header + arrays.  If it does not fit,
  * only the header is written and SDFK_OK is still returned (the caller sees needed > capacity).
  * For a mesh whose job is still queued (deferred completion) nothing waits: the device packs
@@ -194,10 +196,12 @@ int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t cli
 #define SDFK_SLAB_HEADER_BYTES 64
 int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_t* needed_bytes);
 /* One sharded step of a rank in ONE call (what a pipelined driver queues per step; no host wait):
- * [sdfk_lane_begin(lane, wait_hip_event) if lane > 0] sdfk_sample_march_slab -> sdfk_mesh_pack into dst ->
- * sdfk_mesh_free [sdfk_lane_end(1)].  The payload header tells the counts (-1: speculative buffers too small,
- * redo the step on the exact path).  Exists to keep the host out of the way: at 8 ranks a step is bound by
- * host time, and five foreign-function transitions per step are part of it. */
+ * [sdfk_lane_begin(lane, wait_hip_event) if lane > 0] sample the slab -> mesh it [sdfk_lane_end(1)].  From the
+ * second call for a slab shape on, the mesh is EMITTED STRAIGHT INTO the payload at dst: its arrays are the
+ * payload's sections, laid out for the capacities guessed from the previous mesh (cap_v in the header), and the
+ * last kernel writes the header -- no pack launch, no second copy.  (The first call, and hints that do not fit
+ * capacity_bytes, mesh into buffers of the library and pack.)  The payload header tells the counts (-1: a
+ * speculative capacity was too small, redo the step on the exact path). */
 int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
                       int32_t layer_begin, int32_t layer_end, void* dst, int64_t capacity_bytes,
                       int32_t lane, void* wait_hip_event);

@@ -999,11 +999,11 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const float py = pos[1] * M.sc[1] + M.tr[1];
             const float pz = pos[2] * M.sc[2] + M.tr[2];
             float* ov = M.vertices + (size_t)out * 3;
-            float* oc = M.colors + (size_t)out * 3;
             float* on = M.normals + (size_t)out * 3;
             // (one 12-byte store per array: a third of the store instructions of three dword stores)
             *reinterpret_cast<f3u*>(ov) = f3u{px, py, pz};
-            *reinterpret_cast<f3u*>(oc) = f3u{colr[0], colr[1], colr[2]};
+            if (M.colors)   // (null: a slab payload without a colour section -- the volume has no colours, they are all zero)
+                *reinterpret_cast<f3u*>(M.colors + (size_t)out * 3) = f3u{colr[0], colr[1], colr[2]};
             *reinterpret_cast<f3u*>(on) = f3u{t0 / tl, t1 / tl, t2 / tl};
             if (M.grid_vertices) {
                 float* og = M.grid_vertices + (size_t)out * 3;
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 
 // Mesh.Measure (Mesh.cs:30-45): reduce the per-workgroup AABB partials of K4.  Run by one
 // workgroup of K5 (K4 is complete by then), so it costs no launch of its own.
-__device__ __forceinline__ void reduce_bounds(const McMeshOut& M)
+__device__ __forceinline__ void reduce_bounds(const McMeshOut& M, float* s_bounds /*[6], LDS*/)
 {
     __shared__ float s_red[6][4];
     float r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -1068,9 +1068,17 @@ __device__ __forceinline__ void reduce_bounds(const McMeshOut& M)
         for (int w = 1; w < 4; w++) a = (j < 3) ? fminf(a, s_red[j][w]) : fmaxf(a, s_red[j][w]);
         M.bounds[j] = a;
         M.host_bounds[j] = a;
+        s_bounds[j] = a;
     }
     __syncthreads();
 }
+
+// ---- Z-slab payload header (sdfkit_amd/dist.py; SDFK_SLAB_HEADER_BYTES) -------------------------------------
+// cap_v: vertex slots each of the V / (C) / N sections is laid out for -- the sections start at 64, 64 + 12 cap_v, ...,
+// the indices at 64 + vbytes * cap_v.  0 (or nv) = dense.  A step that emits straight into the send buffer lays the
+// sections out for the CAPACITIES it guessed, before it knows the counts.
+struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; int32_t vbytes; int32_t cap_v; float pad[4]; };
+static_assert(sizeof(SlabHeader) == 64, "SDFK_SLAB_HEADER_BYTES");
 
 // ---------------------------------------------------------------------------
 // K5: triangles
@@ -1085,7 +1093,26 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
     mc_load_lut_to_lds(s_lut);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
-    if (blockIdx.x == 0) reduce_bounds(M);   // K4 has completed (stream order): finish Mesh.Measure
+    if (blockIdx.x == 0) {   // K4 has completed (stream order): finish Mesh.Measure
+        __shared__ float s_bounds[6];
+        reduce_bounds(M, s_bounds);
+        // A sharded step that emits straight into its all-gather send buffer (the mesh arrays ARE sections of the
+        // payload, laid out for the capacities): the payload header, from the job's own counters -- counts, or
+        // -1/-1 when a speculative capacity was too small (every rank then redoes the step on the exact path).
+        if (M.slab_header && threadIdx.x == 0) {
+            const McCounters c = *P.counters;
+            const bool ok = c.n_active <= P.cap_active && (uint64_t)(c.total_v - c.nghost) <= (uint64_t)M.cap_vertices &&
+                            (uint64_t)c.total_t * 3u <= (uint64_t)M.cap_indices;
+            SlabHeader h;
+            h.nv = ok ? (int64_t)(c.total_v - c.nghost) : -1;
+            h.ni = ok ? (int64_t)c.total_t * 3 : -1;
+            h.vbytes = M.slab_vbytes;
+            h.cap_v = (int32_t)M.cap_vertices;
+            for (int k = 0; k < 3; k++) { h.bmin[k] = h.nv > 0 ? s_bounds[k] : 0.0f; h.bmax[k] = h.nv > 0 ? s_bounds[3 + k] : 0.0f; }
+            for (int k = 0; k < 4; k++) h.pad[k] = 0.0f;
+            *reinterpret_cast<SlabHeader*>(M.slab_header) = h;
+        }
+    }
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_ni = 0;
@@ -1166,16 +1193,16 @@ __global__ __launch_bounds__(256) void k_clip_bits(uint64_t* __restrict__ bits, 
 
 // ---- Z-slab exchange helpers (sdfkit_amd/dist.py) ------------------------------------------
 // vbytes = bytes per vertex in the payload: 36 (V, C, N) or 24 (V, N: colours are all zero and left out)
-struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; int32_t vbytes; float pad[5]; };
-static_assert(sizeof(SlabHeader) == 64, "SDFK_SLAB_HEADER_BYTES");
+// (struct SlabHeader: above k_triangles, whose first workgroup writes it when a step emits into its send buffer)
+
 
 __global__ void k_slab_header(SlabHeader* dst, int64_t nv, int64_t ni, const float* __restrict__ bounds, int vbytes)
 {
     if (threadIdx.x == 0) {
         SlabHeader h;
-        h.nv = nv; h.ni = ni; h.vbytes = vbytes;
+        h.nv = nv; h.ni = ni; h.vbytes = vbytes; h.cap_v = 0;
         for (int k = 0; k < 3; k++) { h.bmin[k] = nv ? bounds[k] : 0.0f; h.bmax[k] = nv ? bounds[3 + k] : 0.0f; }
-        for (int k = 0; k < 5; k++) h.pad[k] = 0.0f;
+        for (int k = 0; k < 4; k++) h.pad[k] = 0.0f;
         *dst = h;
     }
 }
@@ -1206,9 +1233,9 @@ __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
     const int64_t nv = ok ? (int64_t)(c.total_v - c.nghost) : -1, ni = ok ? (int64_t)c.total_t * 3 : -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         SlabHeader h;
-        h.nv = nv; h.ni = ni; h.vbytes = A.vbytes;
+        h.nv = nv; h.ni = ni; h.vbytes = A.vbytes; h.cap_v = 0;
         for (int k = 0; k < 3; k++) { h.bmin[k] = nv > 0 ? A.bounds[k] : 0.0f; h.bmax[k] = nv > 0 ? A.bounds[3 + k] : 0.0f; }
-        for (int k = 0; k < 5; k++) h.pad[k] = 0.0f;
+        for (int k = 0; k < 4; k++) h.pad[k] = 0.0f;
         *reinterpret_cast<SlabHeader*>(A.dst) = h;
     }
     if (!ok || (int64_t)sizeof(SlabHeader) + A.vbytes * nv + 4 * ni > A.capacity) return;
@@ -1242,8 +1269,9 @@ __global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathere
     }
     if (r == 0 || base == 0) return;
     const SlabHeader* h = reinterpret_cast<const SlabHeader*>(gathered + (size_t)r * stride);
-    if ((int64_t)sizeof(SlabHeader) + h->vbytes * h->nv + 4 * h->ni > stride) return;   // header-only payload
-    int32_t* t = reinterpret_cast<int32_t*>(gathered + (size_t)r * stride + sizeof(SlabHeader) + (size_t)h->nv * h->vbytes);
+    const int64_t capv = h->cap_v > 0 ? (int64_t)h->cap_v : h->nv;
+    if ((int64_t)sizeof(SlabHeader) + h->vbytes * capv + 4 * h->ni > stride) return;   // header-only payload
+    int32_t* t = reinterpret_cast<int32_t*>(gathered + (size_t)r * stride + sizeof(SlabHeader) + (size_t)capv * h->vbytes);
     const int64_t n = h->ni;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) t[i] += (int32_t)base;
 }

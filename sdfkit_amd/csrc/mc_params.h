@@ -72,6 +72,8 @@ struct McMeshOut {
     int bounds_blocks;     // number of k_vertices workgroups
     float* bounds;         // device float[6] (Mesh.Min, Mesh.Max)
     float* host_bounds;    // pinned, device-mapped mirror
+    void* slab_header;     // non-null: the mesh arrays are sections of a slab payload; k_triangles writes its 64-byte header here
+    int32_t slab_vbytes;   // 36 or 24 (no colour section)
 };
 
 }  // namespace sdfk

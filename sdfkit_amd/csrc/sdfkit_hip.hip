@@ -575,6 +575,8 @@ struct sdfk_mesh {
     int status = 0;                     // sticky error of a failed resolution
     std::string error;
     bool has_colors = true;             // false: the source volume had no colours (Colors are all zero)
+    bool external = false;              // V / C / N / T are sections of a caller-owned slab payload (not freed here)
+    void* slab_header = nullptr;        // ... whose header k_triangles writes
     int lane = 0;                       // lane the buffers belong to
     bool used_on_main = false;          // lane-0 work (copies, packing, the caller) may still be reading them
 };
@@ -734,25 +736,6 @@ extern "C" int sdfk_lane_end(int32_t caller_stream_waits)
         if (e != hipSuccess) return fail(SDFK_ERR_HIP, "sdfk_lane_end: %s", hipGetErrorString(e));
     }
     return SDFK_OK;
-}
-
-extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
-                                 int32_t layer_begin, int32_t layer_end, void* dst, int64_t capacity_bytes,
-                                 int32_t lane, void* wait_hip_event)
-{
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    int r = lane > 0 ? sdfk_lane_begin(lane, wait_hip_event) : SDFK_OK;
-    if (r) return r;
-    sdfk_mesh* m = nullptr;
-    r = sdfk_sample_march_slab(p, slab, clip_to_bounds, iso_value, layer_begin, layer_end, 0, &m);
-    int64_t need = 0;
-    if (!r) r = sdfk_mesh_pack(m, dst, capacity_bytes, &need);
-    if (m) sdfk_mesh_free(m);   // stream-ordered: the pack above still reads it
-    if (lane > 0) {
-        const int r2 = sdfk_lane_end(1);
-        if (!r) r = r2;
-    }
-    return r;
 }
 
 extern "C" int sdfk_synchronize(void)
@@ -1486,6 +1469,8 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     M.cap_vertices = (uint32_t)m->cap_v;
     M.cap_indices = m->cap_i;
     M.vertex_base = vertex_base;
+    M.slab_header = m->slab_header;
+    M.slab_vbytes = m->has_colors ? 36 : 24;
     // MarchingCubes.cs:85-90 (row-vector T*S*T) and Mesh.cs:49-55, all float32
     const int nn[3] = {j->gnx, j->gny, j->gnz};
     for (int k = 0; k < 3; k++) {
@@ -1585,10 +1570,13 @@ int march_exact(const sdfk_volume* v, float iso, int step, int layer_begin, int 
 
 void free_mesh_buffers(sdfk_mesh* m)
 {
-    dev_free(m->vertices);   // stream-ordered pool: no sync needed
-    dev_free(m->colors);
-    dev_free(m->normals);
-    dev_free(m->triangles);
+    if (!m->external) {
+        dev_free(m->vertices);   // stream-ordered pool: no sync needed
+        dev_free(m->colors);
+        dev_free(m->normals);
+        dev_free(m->triangles);
+    }
+    m->external = false;
     dev_free(m->bounds);
     m->vertices = m->colors = m->normals = m->bounds = nullptr;
     m->triangles = nullptr;
@@ -1663,8 +1651,42 @@ void resolve_dependents(const sdfk_volume* v)
     }
 }
 
-// MarchingCubes.CreateMesh on the cell layers [layer_begin, layer_end) of a volume / slab.
-int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end, int64_t vertex_base, sdfk_mesh** out)
+// A mesh whose arrays are sections of a slab payload at `dst` (64-byte header, then V | (C) | N | T laid out for the
+// capacities): what a sharded step emits into when it writes straight into its all-gather send buffer.  The
+// capacities are the size hints scaled up to what `capacity` bytes hold (at most the usual +25 %); returns false when
+// not even the hints fit (the caller then takes the ordinary path and packs).
+bool external_mesh(char* dst, int64_t capacity, bool colors, uint32_t nv_hint, uint32_t ni_hint, sdfk_mesh** out)
+{
+    const int64_t vb = colors ? 36 : 24, avail = capacity - SDFK_SLAB_HEADER_BYTES;
+    const int64_t min_v = (int64_t)nv_hint + 64, min_i = (int64_t)ni_hint + 192;
+    if (avail < vb * min_v + 4 * min_i) return false;
+    const double scale = std::min(1.25, (double)avail / (double)(vb * min_v + 4 * min_i));
+    int64_t cap_v = std::max<int64_t>(min_v, (int64_t)((double)min_v * scale));
+    int64_t cap_i = (avail - vb * cap_v) / 4;
+    cap_i = std::min<int64_t>(cap_i, (int64_t)ni_hint + ni_hint / 4 + 12288);
+    cap_i -= cap_i % 3;
+    if (cap_i < min_i - 2) return false;
+    sdfk_mesh* m = new sdfk_mesh();
+    if (dev_alloc((void**)&m->bounds, 8 * sizeof(float))) { delete m; return false; }
+    char* q = dst + SDFK_SLAB_HEADER_BYTES;
+    m->vertices = (float*)q; q += 12 * cap_v;
+    if (colors) { m->colors = (float*)q; q += 12 * cap_v; }
+    else m->colors = nullptr;       // no colour section: k_vertices skips the (all-zero) colour stores
+    m->normals = (float*)q; q += 12 * cap_v;
+    m->triangles = (int32_t*)q;
+    m->external = true;
+    m->slab_header = dst;
+    m->has_colors = colors;
+    m->lane = g.cur_lane;
+    m->cap_v = (size_t)cap_v; m->cap_i = (size_t)cap_i;
+    *out = m;
+    return true;
+}
+
+// MarchingCubes.CreateMesh on the cell layers [layer_begin, layer_end) of a volume / slab.  emit_dst != nullptr (sharded
+// step): on the speculative path the mesh is emitted straight into that slab payload (external_mesh).
+int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int layer_end, int64_t vertex_base, sdfk_mesh** out,
+                char* emit_dst = nullptr, int64_t emit_capacity = 0)
 {
     *out = nullptr;
     const uint64_t key = hint_key(v, step, layer_begin, layer_end);
@@ -1679,7 +1701,8 @@ int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int 
         if (r) return r;
         if (!j->empty) {
             sdfk_mesh* m = nullptr;
-            r = alloc_mesh(&m, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
+            if (!(emit_dst && external_mesh(emit_dst, emit_capacity, v->colors != nullptr, h.nv, h.ni, &m)))
+                r = alloc_mesh(&m, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
             r = r ? r : launch_classify(j, false);
             r = r ? r : launch_emit(j, m, vertex_base);
             if (!r) {
@@ -1851,6 +1874,33 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
     }
     if (m->ni) HIPCHK(hipMemcpyAsync(q, m->triangles, m->ni * 4, hipMemcpyDeviceToDevice, g.stream));
     return SDFK_OK;
+}
+
+extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
+                                 int32_t layer_begin, int32_t layer_end, void* dst, int64_t capacity_bytes,
+                                 int32_t lane, void* wait_hip_event)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !slab || !dst) return fail(SDFK_ERR_INVALID, "sdfk_slab_enqueue: null argument");
+    if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_slab_enqueue: capacity below the header size");
+    int r = lane > 0 ? sdfk_lane_begin(lane, wait_hip_event) : SDFK_OK;
+    if (r) return r;
+    sdfk_mesh* m = nullptr;
+    r = require_init();
+    if (!r) r = sample_impl(p, slab, clip_to_bounds, iso_value);
+    // With size hints for this slab shape the mesh is emitted STRAIGHT into the payload at dst (its arrays are the
+    // payload's sections, k_triangles writes the header): no pack launch, no second copy of the mesh.
+    if (!r) r = march_range(slab, iso_value, 1, layer_begin, layer_end, 0, &m, (char*)dst, capacity_bytes);
+    if (!r && !(m->external && m->pending)) {   // first call of a shape (exact path) or hints that do not fit: pack
+        int64_t need = 0;
+        r = sdfk_mesh_pack(m, dst, capacity_bytes, &need);
+    }
+    if (m) sdfk_mesh_free(m);   // stream-ordered: the kernels above still use it
+    if (lane > 0) {
+        const int r2 = sdfk_lane_end(1);
+        if (!r) r = r2;
+    }
+    return r;
 }
 
 static int slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes, void* headers_mirror)

@@ -120,9 +120,10 @@ class GpuSlabWorker:
         return nv.value, ni.value
 
     def enqueue(self, buf, lane=0, wait_event=None):
-        """Asynchronous form of run_local + pack_self_describing: queues sample, mesh and the
-        device-side pack into the uint8 torch tensor `buf` and returns without waiting; the
-        counts are in the payload header (-1 = this job's speculative buffers were too small).
+        """Asynchronous form of run_local + pack_self_describing: queues sample + mesh, EMITTED STRAIGHT INTO the
+        uint8 torch tensor `buf` (the mesh arrays are sections of the payload, laid out for the guessed capacities;
+        the last kernel writes the header), and returns without waiting; the counts are in the payload header
+        (-1 = this job's speculative capacities were too small).
         lane > 0: inside a lane section of the library (sdfk_lane_begin/end), after `wait_event`.
         One foreign call (sdfk_slab_enqueue) instead of five."""
         N = self.N
@@ -494,22 +495,26 @@ class SlabSession:
 
 
 def unpack_self_describing(g):
-    """g: [world, stride] uint8 array of rebased sdfk_mesh_pack payloads -> concatenated arrays."""
+    """g: [world, stride] uint8 array of rebased slab payloads -> concatenated arrays.  Header (64 bytes): int64 nv, ni;
+    float min[3], max[3]; int32 vertex_bytes (36, or 24: colours, all zero, left out); int32 cap_v = vertex slots the
+    V / (C) / N sections are laid out for (0 = dense: nv) -- a step that emits straight into its send buffer lays the
+    sections out for the capacities it guessed."""
     V, Cc, Nn, T, mins, maxs = [], [], [], [], [], []
     for row in g:
         nv, ni = (int(x) for x in row[:16].view(np.int64))
         b = row[16:40].view(np.float32)
-        vbytes = int(row[40:44].view(np.int32)[0])   # 36, or 24: colours (all zero) left out
+        vbytes, cap_v = (int(x) for x in row[40:48].view(np.int32))
+        sec = 12 * (cap_v if cap_v > 0 else nv)      # bytes per section
         o, vb = SLAB_HEADER_BYTES, nv * 12
         V.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
-        o += vb
+        o += sec
         if vbytes == 36:
             Cc.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
-            o += vb
+            o += sec
         else:
             Cc.append(np.zeros((nv, 3), np.float32))
         Nn.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
-        o += vb
+        o += sec
         T.append(row[o:o + 4 * ni].view(np.int32))
         if nv:
             mins.append(b[0:3]); maxs.append(b[3:6])
