@@ -122,8 +122,12 @@ int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global, const flo
 int sdfk_volume_upload(sdfk_volume* v, const float* values, const float* colors3);
 int sdfk_volume_download(const sdfk_volume* v, float* values, float* colors3);
 /* Raw device pointers (the caller may write through them: cached sign bits are dropped and
- * meshes that still depend on the volume are completed first). */
+ * meshes that still depend on the volume are completed first).  The DEVICE arrays pad every z row to
+ * sdfk_volume_row_pitch voxels (nz rounded up to a multiple of 4: 16-byte aligned rows for the sampling
+ * kernel): voxel (x, y, z) is at ((x * ny + y) * pitch + z), its colour at 3x that.  upload / download
+ * convert from / to the dense host layout of Voxels.Values / Voxels.Colors. */
 int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void** colors3);
+int sdfk_volume_row_pitch(const sdfk_volume* v, int32_t* pitch_voxels);
 void sdfk_volume_free(sdfk_volume* v);
 
 /* Voxels.SampleSdf(Sdf, batchSize, maxDegreeOfParallelism) (Voxels.cs:72-125): evaluates

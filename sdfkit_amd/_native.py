@@ -47,6 +47,7 @@ SIGNATURES = {
     "sdfk_volume_upload": (C.c_int, [_vp, _vp, _vp]),
     "sdfk_volume_download": (C.c_int, [_vp, _vp, _vp]),
     "sdfk_volume_device_ptrs": (C.c_int, [_vp, _vpp, _vpp]),
+    "sdfk_volume_row_pitch": (C.c_int, [_vp, C.POINTER(_i32)]),
     "sdfk_volume_free": (None, [_vp]),
     "sdfk_sample": (C.c_int, [_vp, _vp, _i32]),
     "sdfk_volume_clip_to_bounds": (C.c_int, [_vp]),

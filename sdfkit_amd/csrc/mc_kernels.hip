@@ -43,36 +43,34 @@ constexpr int K4_RMAX = 288;   // k_vertices: rowstart entries staged per window
 // ---------------------------------------------------------------------------
 // K1: sign bits
 // ---------------------------------------------------------------------------
-// For volumes that did not come from the fused sampling kernel (any nz; byte rows are pitch8 =
-// nz rounded up to a multiple of 4 bytes long)
-// (uploaded arrays, another iso value, sub-sampled steps): the same shape as that kernel with
-// loads in place of stores.  A workgroup owns 8 consecutive x rows x 256 z of one y (4 wavefronts,
-// 2 rows each); a lane loads 4 consecutive z of a row with one 16-byte load (1 KiB contiguous per
-// wavefront instruction), leaves a sign nibble in LDS; wavefront 0 turns the 8 rows' nibbles
-// into 4 bytes per lane and stores 256 contiguous bytes of bits8[y][x/8][z].  k_bits_transpose
-// then regroups the bytes into the X-packed words.
-typedef float f4a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (gfx950 unaligned mode)
-
-// FLAT (nz % 4 == 0 but not a multiple of 256; blockIdx = (chunk, 0, x/8)): a wavefront covers voxels
-// [256 b, 256 b + 256) of the contiguous (y, z) plane of an x row instead of a z tile of one row, exactly
-// like the sampling kernel (sample_codegen.h): no idle z tile, line-aligned loads.
+// For volumes that did not come from the fused sampling kernel (uploaded arrays, another iso value, sub-sampled
+// steps): the same shape as that kernel with loads in place of stores.  Rows of the volume are `pitch` floats long
+// (nz rounded up to a multiple of 4: every row starts 16-byte aligned; the byte rows of bits8 have the same pitch).
+// A workgroup owns 8 consecutive x rows x 256 z of one y (4 wavefronts, 2 rows each); a lane loads 4 consecutive z of
+// a row with one 16-byte load (1 KiB contiguous per wavefront instruction), leaves a sign nibble in LDS; wavefront 0
+// turns the 8 rows' nibbles into 4 bytes per lane and stores 256 contiguous bytes of bits8[y][x/8][z].
+// k_bits_transpose then regroups the bytes into the X-packed words.
+//
+// FLAT (nz not a multiple of 256; blockIdx = (chunk, 0, x/8)): a wavefront covers voxels [256 b, 256 b + 256) of the
+// contiguous (y, z) plane of an x row (ny * pitch floats) instead of a z tile of one row, exactly like the sampling
+// kernel (sample_codegen.h): no idle z tile, line-aligned loads.  Voxels of the row padding give 0 bits.
 template <bool FLAT>
 __global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ values, uint8_t* __restrict__ bits8, int nx, int ny,
-                                                   int nz, int nx8, int pitch8, float iso)
+                                                   int nz, int nx8, int pitch, float iso)
 {
     __shared__ unsigned char nib[8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x8 = blockIdx.z;
     int iy = blockIdx.y, z = blockIdx.x * 256 + 4 * lane;
-    bool zok = z < nz;
+    bool zok = z < pitch;
     if (FLAT) {
-        const int f0 = blockIdx.x * 256, iy0 = f0 / nz;
+        const int f0 = blockIdx.x * 256, iy0 = f0 / pitch;
         iy = iy0;
-        z = (f0 - iy0 * nz) + 4 * lane;
-        const int q = z / nz;
-        z -= q * nz;
+        z = (f0 - iy0 * pitch) + 4 * lane;
+        const int q = z / pitch;
+        z -= q * pitch;
         iy += q;
-        zok = f0 + 4 * lane < ny * nz;
+        zok = f0 + 4 * lane < ny * pitch;
     }
     float v[2][4];
 #pragma unroll
@@ -80,13 +78,12 @@ __global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ val
         const int ix = x8 * 8 + wave * 2 + rr;
         v[rr][0] = v[rr][1] = v[rr][2] = v[rr][3] = -INFINITY;   // (never > iso: voxels beyond the row end give 0 bits)
         if (ix < nx && zok) {
-            const float* p = values + ((size_t)ix * ny + iy) * nz + z;
-            if (z + 3 < nz) {   // any nz: rows start at 4-byte alignment only
-                const f4a4 q = *reinterpret_cast<const f4a4*>(p);
-                v[rr][0] = q.x; v[rr][1] = q.y; v[rr][2] = q.z; v[rr][3] = q.w;
-            } else {
-                for (int k = 0; k < 4; k++) if (z + k < nz) v[rr][k] = p[k];
-            }
+            const float4 q = *reinterpret_cast<const float4*>(values + ((size_t)ix * ny + iy) * pitch + z);
+            v[rr][0] = q.x;
+            if (z + 1 < nz) v[rr][1] = q.y;
+            if (z + 2 < nz) v[rr][2] = q.z;
+            if (z + 3 < nz) v[rr][3] = q.w;
+            if (z >= nz) v[rr][0] = -INFINITY;
         }
     }
 #pragma unroll
@@ -102,7 +99,7 @@ __global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ val
             const unsigned q = nib[r][lane];
             out |= ((q & 1u) << r) | (((q >> 1) & 1u) << (8 + r)) | (((q >> 2) & 1u) << (16 + r)) | (((q >> 3) & 1u) << (24 + r));
         }
-        *reinterpret_cast<unsigned*>(bits8 + ((size_t)iy * nx8 + x8) * pitch8 + z) = out;   // pitch8 % 4 == 0
+        *reinterpret_cast<unsigned*>(bits8 + ((size_t)iy * nx8 + x8) * pitch + z) = out;   // pitch % 4 == 0
     }
 }
 
@@ -409,7 +406,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
-// the 8 corner voxels of cell (x,y,z) into this thread's LDS column ([corner][thread])
+// the 8 corner voxels of cell (x,y,z) into this thread's LDS column ([corner][thread]); nz = the volume's ROW PITCH
 __device__ __forceinline__ void stage_corners(const float* values, int ny, int nz, int x, int y, int z, float* col, int stride)
 {
     // the two z-neighbours of a corner pair are adjacent in memory: four 8-byte loads
@@ -483,7 +480,7 @@ __device__ __forceinline__ bool edge_has_live_predecessor(const McParams& P, con
             continue;
         }
         if (pz >= P.ncz) continue;
-        if (!check_dead || !cell_is_dead(lut, P.values, P.ny, P.nz, P.iso, px, py, pz, col)) return true;
+        if (!check_dead || !cell_is_dead(lut, P.values, P.ny, P.nzp, P.iso, px, py, pz, col)) return true;
     }
     return false;
 }
@@ -512,7 +509,7 @@ __device__ __forceinline__ unsigned positional_own_mask(bool X, bool Y, bool Z)
 __global__ __launch_bounds__(256) void k_gather_corners(McParams P)
 {
     const uint32_t n = min(P.counters->n_active, P.cap_active);
-    const size_t sx = (size_t)P.ny * P.nz, sy = (size_t)P.nz;
+    const size_t sx = (size_t)P.ny * P.nzp, sy = (size_t)P.nzp;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const uint32_t xy = P.rec_xy[i];
         const float* p = P.values + (size_t)(xy & 0xffffu) * sx + (size_t)(xy >> 16) * sy + P.rec_z[i];
@@ -667,7 +664,7 @@ __device__ __forceinline__ float v3len(float x, float y, float z) { return sqrtf
 
 __device__ __forceinline__ void load_corner_color(const McParams& P, int x, int y, int z, int corner, float* c)
 {
-    const size_t o = ((size_t)(x + mc_corner_dx(corner)) * P.ny + (y + mc_corner_dy(corner))) * P.nz + (z + mc_corner_dz(corner));
+    const size_t o = ((size_t)(x + mc_corner_dx(corner)) * P.ny + (y + mc_corner_dy(corner))) * P.nzp + (z + mc_corner_dz(corner));
     const f3u q = *reinterpret_cast<const f3u*>(P.colors + o * 3);
     c[0] = q.x; c[1] = q.y; c[2] = q.z;
 }
@@ -1147,23 +1144,24 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 // auxiliary volume kernels
 // ---------------------------------------------------------------------------
 // Voxels.ClipToBounds, Voxels.cs:133-167 (all six faces get Size.X/NX): one lane per element of
-// the largest face, two opposite faces per axis (the z faces only where the slab holds them).
-__global__ __launch_bounds__(256) void k_clip(float* __restrict__ values, int nx, int ny, int nz, int z0, int nz_global, float outside)
+// the largest face, two opposite faces per axis (the z faces only where the slab holds them).  Rows are `pitch` long.
+__global__ __launch_bounds__(256) void k_clip(float* __restrict__ values, int nx, int ny, int nz, int pitch, int z0, int nz_global, float outside)
 {
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    const size_t sx = (size_t)ny * nz;
-    if (i < (size_t)ny * nz) {                      // x = 0 and x = nx-1: (y, z) = i, contiguous
-        values[i] = outside;
-        values[(size_t)(nx - 1) * sx + i] = outside;
+    const size_t sx = (size_t)ny * pitch;
+    if (i < (size_t)ny * nz) {                      // x = 0 and x = nx-1
+        const size_t y = i / nz, z = i % nz;
+        values[y * pitch + z] = outside;
+        values[(size_t)(nx - 1) * sx + y * pitch + z] = outside;
     }
     if (i < (size_t)nx * nz) {                      // y = 0 and y = ny-1
         const size_t x = i / nz, z = i % nz;
         values[x * sx + z] = outside;
-        values[x * sx + (size_t)(ny - 1) * nz + z] = outside;
+        values[x * sx + (size_t)(ny - 1) * pitch + z] = outside;
     }
     if (i < (size_t)nx * ny) {                      // global z = 0 and z = nz_global-1
-        if (z0 == 0) values[i * nz] = outside;
-        if (z0 + nz == nz_global) values[i * nz + (nz - 1)] = outside;
+        if (z0 == 0) values[i * pitch] = outside;
+        if (z0 + nz == nz_global) values[i * pitch + (nz - 1)] = outside;
     }
 }
 
@@ -1277,10 +1275,10 @@ __global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathere
 }
 
 // step > 1 (MarchingCubes.cs:49-80): the sweep only ever touches voxels whose indices are
-// multiples of `step`; gather them into a dense volume and mesh that with unit cells.
+// multiples of `step`; gather them into a dense volume and mesh that with unit cells.  sp / dp = row pitches.
 __global__ __launch_bounds__(256) void k_subsample(const float* __restrict__ src, const float* __restrict__ srcc,
                                                    float* __restrict__ dst, float* __restrict__ dstc, int nx, int ny,
-                                                   int nz, int mx, int my, int mz, int step)
+                                                   int sp, int mx, int my, int mz, int dp, int step)
 {
     const size_t n = (size_t)mx * my * mz;
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
@@ -1288,9 +1286,24 @@ __global__ __launch_bounds__(256) void k_subsample(const float* __restrict__ src
         const size_t t = i / mz;
         const int y = (int)(t % my);
         const int x = (int)(t / my);
-        const size_t o = ((size_t)(x * step) * ny + (size_t)(y * step)) * nz + (size_t)(z * step);
-        dst[i] = src[o];
-        if (srcc) { dstc[i * 3] = srcc[o * 3]; dstc[i * 3 + 1] = srcc[o * 3 + 1]; dstc[i * 3 + 2] = srcc[o * 3 + 2]; }
+        const size_t o = ((size_t)(x * step) * ny + (size_t)(y * step)) * sp + (size_t)(z * step);
+        const size_t d = ((size_t)x * my + y) * dp + z;
+        dst[d] = src[o];
+        if (srcc) { dstc[d * 3] = srcc[o * 3]; dstc[d * 3 + 1] = srcc[o * 3 + 1]; dstc[d * 3 + 2] = srcc[o * 3 + 2]; }
+    }
+}
+
+// Rows of `w` floats between a dense array (row stride w) and a pitched one (row stride pw >= w): the host side of
+// Voxels.Values / Voxels.Colors is dense ([nx][ny][nz], Voxels.cs:8-9), the device volume pads its rows to a
+// multiple of 4 voxels.  TO_PITCHED: dense -> pitched; else pitched -> dense.
+template <bool TO_PITCHED>
+__global__ __launch_bounds__(256) void k_repitch(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int w, int pw)
+{
+    const size_t n = rows * (size_t)w;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        const size_t r = i / w, c = i - r * w;
+        if (TO_PITCHED) dst[r * pw + c] = src[i];
+        else dst[i] = src[r * pw + c];
     }
 }
 

@@ -22,6 +22,7 @@ struct McParams {
     const float* values;   // [nx][ny][nz], z fastest (Voxels.cs:8)
     const float* colors;   // [nx][ny][nz][3] or nullptr (= zeros)
     int nx, ny, nz;        // voxel dims of this (slab) volume
+    int nzp;               // row pitch of values / colors in voxels: nz rounded up to a multiple of 4 (16-byte aligned rows)
     int ncx, ncy, ncz;     // cell dims = n-1
     int nxw;               // 64-bit X words per (z,y) row of the sign-bit array
     int z0;                // global z of local plane 0

@@ -16,7 +16,7 @@
 // One definition, used both by the host (below) and pasted into the generated source.
 #define SDFK_SAMPLE_ARGS_BODY                                                                   \
     float* values; float* colors; float mx, my, mz, dx, dy, dz; int nx, ny, nz; int z0, nz_global; \
-    int clip; float outside; int pitch8; int pad0; unsigned char* bits8; int nx8; float iso;
+    int clip; float outside; int pitch8 /* row pitch of values, colors (x3) and bits8 */; int pad0; unsigned char* bits8; int nx8; float iso;
 
 struct SampleArgs { SDFK_SAMPLE_ARGS_BODY };
 struct RayArgs { float* depth; float* rgb; float cam[3]; float m[16]; int width, height; float nearp, farp; int iters; };
@@ -70,64 +70,55 @@ static const char* const kSampleKernels = R"SRC(
 // bytes of bits8[y][x/8][z].  k_bits_transpose (mc_kernels.hip) regroups those bytes into the
 // X-packed words the marching-cubes classifier reads; the volume is never re-read densely.
 typedef float sdfk_f4 __attribute__((ext_vector_type(4)));
-typedef float sdfk_f4u __attribute__((ext_vector_type(4), aligned(4)));   // rows start at 4-byte alignment when nz % 4 != 0
-template <bool ALIGNED>
+// (rows of the volume are A.pitch8 floats long -- nz rounded up to a multiple of 4 -- so every 4-voxel group is 16-byte aligned)
 __device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float c, float d)
 {
-    if (ALIGNED) {
-        const sdfk_f4 t = {a, b, c, d};
+    const sdfk_f4 t = {a, b, c, d};
 #if SDFK_SAMPLE_NT
-        __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(p));
+    __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(p));
 #else
-        *reinterpret_cast<sdfk_f4*>(p) = t;
+    *reinterpret_cast<sdfk_f4*>(p) = t;
 #endif
-    } else {
-        const sdfk_f4u t = {a, b, c, d};
-#if SDFK_SAMPLE_NT
-        __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4u*>(p));
-#else
-        *reinterpret_cast<sdfk_f4u*>(p) = t;
-#endif
-    }
 }
 #ifndef SDFK_SAMPLE_RPW
 #define SDFK_SAMPLE_RPW 2   // x rows per wavefront (stores per lane); workgroup = 8 / RPW wavefronts
 #endif
-// Three shapes of the 256 voxels a wavefront covers per x row (MODE):
-//   SDFK_ROWS  nz % 256 == 0: z in [256 b, 256 b + 256) of ONE y (blockIdx = (b, y, x/8)); y is a scalar
-//   SDFK_FLAT  nz % 4 == 0:   voxels [256 b, 256 b + 256) of the whole (y, z) PLANE of the x row, which is
-//              contiguous in memory (blockIdx = (b, 0, x/8)): a wavefront's 1 KiB store is line-aligned
-//              whatever nz is (when ny nz % 16 == 0), may span two y rows, and only the last chunk of the
+// Two shapes of the 256 voxels a wavefront covers per x row (MODE); P = A.pitch8 = the row pitch of the volume
+// (nz rounded up to a multiple of 4):
+//   SDFK_ROWS  nz % 256 == 0 (P = nz): z in [256 b, 256 b + 256) of ONE y (blockIdx = (b, y, x/8)); y is a scalar
+//   SDFK_FLAT  any nz:        voxels [256 b, 256 b + 256) of the whole (y, z) PLANE of the x row (ny * P floats,
+//              contiguous in memory; blockIdx = (b, 0, x/8)): a wavefront's 1 KiB store is line-aligned
+//              whatever nz is (when ny P % 16 == 0), may span two y rows, and only the last chunk of the
 //              plane has idle lanes.  With z tiles per row instead, rows of 500 voxels make every store
 //              end in two partial lines (139 instead of 85 us at 500^3) and rows of 520 use a third tile
-//              for 8 planes.
-//   SDFK_ANY   any nz: rows start at 4-byte alignment only, the last lane of a row stores 1..3 voxels
+//              for 8 planes.  The up to 3 padding voxels of a row are stored like any other (nobody reads
+//              them) and give 0 sign bits.  (Round 1 stored rows of nz % 4 != 0 unpadded, at 4-byte alignment:
+//              130 instead of 80 us at 510^3.)
 #define SDFK_ROWS 0
 #define SDFK_FLAT 1
-#define SDFK_ANY 2
 template <bool CLIP, int MODE>
 __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
-    constexpr bool ALIGNED = MODE != SDFK_ANY;
     __shared__ unsigned char nib[8][64];
     __shared__ __attribute__((aligned(16))) float cbuf[8 / RPW][768];   // colour staging, one slice per wavefront
     // (the wavefront index as a scalar: row index, row base address and x coordinate stay off the VALU)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x8 = blockIdx.z;
-    const int plane = A.ny * A.nz;              // voxels per x row (< 2^31: Voxels.cs:82)
+    const int P = A.pitch8;                     // floats per row
+    const int plane = A.ny * P;                 // floats per x row (< 2^31: Voxels.cs:82, + <= 3 per row)
     const int f0 = blockIdx.x * 256;            // SDFK_FLAT: first voxel of the chunk within the plane
     int iy = blockIdx.y, z = blockIdx.x * 256 + 4 * lane;
     bool zok = z < A.nz;
     if (MODE == SDFK_FLAT) {
-        const int iy0 = f0 / A.nz;              // (scalar)
+        const int iy0 = f0 / P;                 // (scalar)
         iy = iy0;
-        z = (f0 - iy0 * A.nz) + 4 * lane;
-        if (A.nz >= 256) {                      // a chunk spans at most two rows
-            if (z >= A.nz) { z -= A.nz; iy++; }
+        z = (f0 - iy0 * P) + 4 * lane;
+        if (P >= 256) {                         // a chunk spans at most two rows
+            if (z >= P) { z -= P; iy++; }
         } else {
-            const int q = z / A.nz;
-            z -= q * A.nz;
+            const int q = z / P;
+            z -= q * P;
             iy += q;
         }
         zok = f0 + 4 * lane < plane;
@@ -156,12 +147,8 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
                 sdf_eval(px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
                 if (CLIP && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
-            const long o = MODE == SDFK_FLAT ? (long)ix * plane + (f0 + 4 * lane) : ((long)ix * A.ny + iy) * A.nz + z;
-            if (ALIGNED || z + 3 < A.nz) sdfk_store4_nt<ALIGNED>(A.values + o, w[0], w[1], w[2], w[3]);
-            else {   // last lane of a row whose length is not a multiple of 4
-#pragma unroll
-                for (int k = 0; k < 4; k++) if (z + k < A.nz) A.values[o + k] = w[k];
-            }
+            const long o = MODE == SDFK_FLAT ? (long)ix * plane + (f0 + 4 * lane) : ((long)ix * A.ny + iy) * P + z;
+            sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
             if (A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
                 sdfk_f4* mine = reinterpret_cast<sdfk_f4*>(cbuf[wave] + 12 * lane);
                 mine[0] = sdfk_f4{cr[0], cg[0], cb[0], cr[1]};
@@ -169,7 +156,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
                 mine[2] = sdfk_f4{cb[2], cr[3], cg[3], cb[3]};
             }
             n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
-            if (!ALIGNED && z + 3 >= A.nz) n &= (1u << (A.nz - z)) - 1u;   // voxels past the row end: 0 bits
+            if (MODE == SDFK_FLAT && z + 3 >= A.nz) n &= z < A.nz ? (1u << (A.nz - z)) - 1u : 0u;   // row padding: 0 bits
         }
         nib[r][lane] = (unsigned char)n;
         if (A.colors && ix < A.nx) {
@@ -179,7 +166,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             // floats 4 L .. 4 L + 3 of each KiB) -- ALL lanes store, also those whose own
             // voxels lie beyond nz: what they store belongs to the lanes before them.
             const int z0 = blockIdx.x * 256;
-            const int left = MODE == SDFK_FLAT ? plane - f0 : A.nz - z0;
+            const int left = MODE == SDFK_FLAT ? plane - f0 : P - z0;
             const int run = (left < 256 ? left : 256) * 3;   // floats of the run that exist
             __builtin_amdgcn_wave_barrier();
             const float* cw = cbuf[wave];
@@ -187,12 +174,12 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             const sdfk_f4 t1 = *reinterpret_cast<const sdfk_f4*>(cw + 256 + 4 * lane);
             const sdfk_f4 t2 = *reinterpret_cast<const sdfk_f4*>(cw + 512 + 4 * lane);
             __builtin_amdgcn_wave_barrier();
-            float* c = A.colors + (MODE == SDFK_FLAT ? (long)ix * plane + f0 : ((long)ix * A.ny + blockIdx.y) * A.nz + z0) * 3;
+            float* c = A.colors + (MODE == SDFK_FLAT ? (long)ix * plane + f0 : ((long)ix * A.ny + blockIdx.y) * P + z0) * 3;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const sdfk_f4 t = q == 0 ? t0 : (q == 1 ? t1 : t2);
                 const int e = 256 * q + 4 * lane;   // first float of this lane's piece
-                if (e + 3 < run) sdfk_store4_nt<ALIGNED>(c + e, t.x, t.y, t.z, t.w);
+                if (e + 3 < run) sdfk_store4_nt(c + e, t.x, t.y, t.z, t.w);
                 else {           // the run ends inside the piece
                     if (e < run) c[e] = t.x;
                     if (e + 1 < run) c[e + 1] = t.y;
@@ -209,11 +196,11 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             const unsigned q = nib[r][lane];
             out |= ((q & 1u) << r) | (((q >> 1) & 1u) << (8 + r)) | (((q >> 2) & 1u) << (16 + r)) | (((q >> 3) & 1u) << (24 + r));
         }
-        *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * A.pitch8 + z) = out;   // pitch8 = nz rounded up to 4
+        *reinterpret_cast<unsigned*>(A.bits8 + ((long)iy * A.nx8 + x8) * P + z) = out;   // (the byte rows of bits8 have the same pitch)
     }
 }
 // SDFK_KERNELS: bit mask of the entry points this module contains (the host compiles a program's kernels on demand:
-// bits 0..5 = the six instantiations below in this order, 6 = sdfk_corners_eval, 7 = sdfk_raymarch)
+// bit 0 / 1 = the two instantiations without ClipToBounds, 3 / 4 = with it, 6 = sdfk_corners_eval, 7 = sdfk_raymarch)
 #ifndef SDFK_KERNELS
 #define SDFK_KERNELS 0xff
 #endif
@@ -223,17 +210,11 @@ extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_
 #if SDFK_KERNELS & 0x02
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_flat(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_FLAT>(A); }
 #endif
-#if SDFK_KERNELS & 0x04
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_anynz(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_ANY>(A); }
-#endif
 #if SDFK_KERNELS & 0x08
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ROWS>(A); }
 #endif
 #if SDFK_KERNELS & 0x10
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_FLAT>(A); }
-#endif
-#if SDFK_KERNELS & 0x20
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_anynz(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ANY>(A); }
 #endif
 
 // Corner values of the active cells, RE-EVALUATED instead of gathered: for a volume this very

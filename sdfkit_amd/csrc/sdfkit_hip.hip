@@ -512,8 +512,7 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
 // opaque objects
 // ---------------------------------------------------------------------------
 // Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
-enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_BITS_ANY = 2, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_BITS_CLIP_ANY = 5,
-                  PK_CORNERS = 6, PK_RAYMARCH = 7, PK_COUNT = 8 };
+enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_CORNERS = 6, PK_RAYMARCH = 7, PK_COUNT = 8 };
 
 struct sdfk_program {
     std::string source;
@@ -543,7 +542,11 @@ struct sdfk_volume {
     // gathering them
     sdfk_program* sampled_by = nullptr;
     SampleArgs sampled_args;
-    size_t nvox() const { return (size_t)nx * ny * nz; }
+    // Rows of `values` / `colors` are pitch() voxels long: nz rounded up to a multiple of 4, so that every row -- and
+    // every 4-voxel group a lane of the sampling kernel stores -- is 16-byte aligned whatever nz is.
+    int pitch() const { return (nz + 3) & ~3; }
+    size_t nvox() const { return (size_t)nx * ny * nz; }          // voxels of the grid (what the host arrays hold)
+    size_t nalloc() const { return (size_t)nx * ny * pitch(); }   // voxel slots of the device arrays
     int nxw() const { return (nx + 63) / 64; }
     int nx8() const { return (nx + 7) / 8; }
     int pitch8() const { return (nz + 3) & ~3; }   // bytes per row of bits8
@@ -912,7 +915,7 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::string src;
     std::vector<char> code;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
-    return compile_source(src, 0xffu, code, false);   // every kernel, a real compile: this IS the check
+    return compile_source(src, 0xdbu, code, false);   // every kernel, a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -936,10 +939,10 @@ int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
 {
     sdfk_program* p = const_cast<sdfk_program*>(cp);
     if (!p->fn[k]) {
-        static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_bits_anynz", "sdfk_sample_bits_clip",
-                                                    "sdfk_sample_bits_clip_flat", "sdfk_sample_bits_clip_anynz", "sdfk_corners_eval", "sdfk_raymarch"};
+        static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "", "sdfk_sample_bits_clip",
+                                                    "sdfk_sample_bits_clip_flat", "", "sdfk_corners_eval", "sdfk_raymarch"};
         unsigned mask = 1u << k;
-        if (k <= PK_BITS_CLIP_ANY && !p->fn[PK_CORNERS]) mask |= 1u << PK_CORNERS;
+        if (k <= PK_BITS_CLIP_FLAT && !p->fn[PK_CORNERS]) mask |= 1u << PK_CORNERS;
         std::vector<char> code;
         bool cached = false;
         if (int r = compile_source(p->source, mask, code, true, &cached)) return r;
@@ -1011,8 +1014,8 @@ extern "C" int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global
     v->nx = nx; v->ny = ny; v->nz = nz_local; v->nz_global = nz_global; v->z0 = z0;
     memcpy(v->gmin, min, sizeof v->gmin);
     memcpy(v->gmax, max, sizeof v->gmax);
-    int r = dev_alloc((void**)&v->values, v->nvox() * sizeof(float));
-    if (!r && with_colors) r = dev_alloc((void**)&v->colors, v->nvox() * 3 * sizeof(float));
+    int r = dev_alloc((void**)&v->values, v->nalloc() * sizeof(float));
+    if (!r && with_colors) r = dev_alloc((void**)&v->colors, v->nalloc() * 3 * sizeof(float));
     if (r) { dev_free(v->values); delete v; return r; }
     *out = v;
     return SDFK_OK;
@@ -1048,9 +1051,28 @@ extern "C" int sdfk_volume_upload(sdfk_volume* v, const float* values, const flo
     if (colors3 && !v->colors) return fail(SDFK_ERR_INVALID, "sdfk_volume_upload: volume was created without colours");
     resolve_dependents(v);
     volume_values_changed(v);
-    HIPCHK(hipMemcpyAsync(v->values, values, v->nvox() * sizeof(float), hipMemcpyHostToDevice, g.stream));
-    if (colors3) HIPCHK(hipMemcpyAsync(v->colors, colors3, v->nvox() * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));  // the caller's arrays are not retained
+    if (v->pitch() == v->nz) {
+        HIPCHK(hipMemcpyAsync(v->values, values, v->nvox() * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        if (colors3) HIPCHK(hipMemcpyAsync(v->colors, colors3, v->nvox() * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));  // the caller's arrays are not retained
+        return SDFK_OK;
+    }
+    // rows of nz % 4 != 0 voxels: the dense host layout goes to a temporary device array, a kernel spreads the rows out
+    const size_t rows = (size_t)v->nx * v->ny;
+    float* tmp = nullptr;
+    if (int r = dev_alloc((void**)&tmp, v->nvox() * (colors3 ? 3 : 1) * sizeof(float))) return r;
+    hipError_t e = hipMemcpyAsync(tmp, values, v->nvox() * sizeof(float), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_repitch<true>, dim3(grid_for(v->nvox())), dim3(256), 0, g.stream, tmp, v->values, rows, v->nz, v->pitch());
+        if (colors3) {
+            e = hipMemcpyAsync(tmp, colors3, v->nvox() * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(k_repitch<true>, dim3(grid_for(v->nvox() * 3)), dim3(256), 0, g.stream, tmp, v->colors, rows, v->nz * 3, v->pitch() * 3);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);   // the caller's arrays are not retained
+    dev_free(tmp);
+    if (e != hipSuccess) return fail(SDFK_ERR_HIP, "sdfk_volume_upload: %s", hipGetErrorString(e));
     return SDFK_OK;
 }
 
@@ -1060,8 +1082,22 @@ extern "C" int sdfk_volume_download(const sdfk_volume* v, float* values, float* 
     if (!v) return fail(SDFK_ERR_INVALID, "sdfk_volume_download: null volume");
     if (int r = require_init()) return r;
     std::vector<CopyPiece> pieces;
-    if (values) pieces.push_back({v->values, values, v->nvox() * sizeof(float)});
-    if (colors3 && v->colors) pieces.push_back({v->colors, colors3, v->nvox() * 3 * sizeof(float)});
+    float* dense_v = nullptr;   // rows of nz % 4 != 0 voxels: packed into dense temporaries first
+    float* dense_c = nullptr;
+    if (v->pitch() != v->nz) {
+        const size_t rows = (size_t)v->nx * v->ny;
+        if (values) {
+            if (int r = dev_alloc((void**)&dense_v, v->nvox() * sizeof(float))) return r;
+            hipLaunchKernelGGL(k_repitch<false>, dim3(grid_for(v->nvox())), dim3(256), 0, g.stream, v->values, dense_v, rows, v->nz, v->pitch());
+        }
+        if (colors3 && v->colors) {
+            if (int r = dev_alloc((void**)&dense_c, v->nvox() * 3 * sizeof(float))) { dev_free(dense_v); return r; }
+            hipLaunchKernelGGL(k_repitch<false>, dim3(grid_for(v->nvox() * 3)), dim3(256), 0, g.stream, v->colors, dense_c, rows, v->nz * 3, v->pitch() * 3);
+        }
+    }
+    struct FreeTmp { float *a, *b; ~FreeTmp() { dev_free(a); dev_free(b); } } free_tmp{dense_v, dense_c};   // (stream-ordered pool; the copies below are synchronous)
+    if (values) pieces.push_back({dense_v ? dense_v : v->values, values, v->nvox() * sizeof(float)});
+    if (colors3 && v->colors) pieces.push_back({dense_c ? dense_c : v->colors, colors3, v->nvox() * 3 * sizeof(float)});
     if (colors3 && !v->colors) {   // colours that were never written are zero (Voxels.cs:88-92): cleared on the pool
         const size_t nb = v->nvox() * 3 * sizeof(float), per = size_t(2) << 20;
         char* c = (char*)colors3;
@@ -1069,6 +1105,13 @@ extern "C" int sdfk_volume_download(const sdfk_volume* v, float* values, float* 
         g_pool.wait();
     }
     return copy_to_host(pieces);
+}
+
+extern "C" int sdfk_volume_row_pitch(const sdfk_volume* v, int32_t* pitch_voxels)
+{
+    if (!v || !pitch_voxels) return fail(SDFK_ERR_INVALID, "sdfk_volume_row_pitch: null argument");
+    *pitch_voxels = v->pitch();
+    return SDFK_OK;
 }
 
 extern "C" int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void** colors3)
@@ -1133,18 +1176,17 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.iso = iso_hint;
         {
             const unsigned tpb = 512u / (unsigned)sample_rpw();
-            // 0: z tiles of one y row (nz % 256 == 0); 1: 256-voxel chunks of the (y, z) plane of an x row
-            // (nz % 4 == 0); 2: rows of any length
+            // 0: z tiles of one y row (nz % 256 == 0); 1: 256-voxel chunks of the (y, z) plane of an x row (any nz:
+            // rows are padded to a multiple of 4 voxels)
             static const int force = getenv("SDFK_SAMPLE_MODE") ? atoi(getenv("SDFK_SAMPLE_MODE")) : -1;   // experiment knob
-            int mode = (v->nz % 256) == 0 ? 0 : ((v->nz & 3) == 0 ? 1 : 2);
+            int mode = (v->nz % 256) == 0 ? 0 : 1;
             if (force == 0 && (v->nz & 3) == 0) mode = 0;
-            if (force == 1 && (v->nz & 3) == 0) mode = 1;
-            static const char* const names[2][3] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_bits_anynz"},
-                                                    {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat", "sdfk_sample_bits_clip_anynz"}};
+            if (force == 1) mode = 1;
+            static const char* const names[2][2] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat"}, {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat"}};
             hipFunction_t fn = nullptr;   // (compiled on first use)
             if (int r = program_fn(p, (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode, &fn)) return r;
             ProfScope ps(names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
-            const size_t plane = (size_t)v->ny * v->nz;
+            const size_t plane = (size_t)v->ny * v->pitch();
             if (mode == 1)
                 HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((plane + 255) / 256), 1, (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
             else
@@ -1189,7 +1231,7 @@ extern "C" int sdfk_volume_clip_to_bounds(sdfk_volume* v)
     // values (if any) is remembered with clip = 1, so re-evaluated cell corners see the same faces.
     const size_t face = std::max({(size_t)v->ny * v->nz, (size_t)v->nx * v->nz, (size_t)v->nx * v->ny});
     ProfScope ps("k_clip");
-    hipLaunchKernelGGL(k_clip, dim3((unsigned)((face + 255) / 256)), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->z0,
+    hipLaunchKernelGGL(k_clip, dim3((unsigned)((face + 255) / 256)), dim3(256), 0, g.stream, v->values, v->nx, v->ny, v->nz, v->pitch(), v->z0,
                        v->nz_global, outside);
     if (v->bits && v->bits_valid)
         hipLaunchKernelGGL(k_clip_bits, dim3((unsigned)(((size_t)v->nz * v->ny + 255) / 256)), dim3(256), 0, g.stream, v->bits, v->nx, v->ny,
@@ -1297,9 +1339,9 @@ int launch_classify(sdfk_march_job* j, bool publish)
     if (!j->have_bits) {
         uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
-        const int nx8 = (P.nx + 7) / 8, pitch8 = (P.nz + 3) & ~3;
-        if ((P.nz & 3) == 0 && (P.nz % 256) != 0)   // chunks of the (y, z) plane: rows shorter or longer than a z tile
-            hipLaunchKernelGGL(k_signbits8<true>, dim3((unsigned)(((size_t)P.ny * P.nz + 255) / 256), 1, nx8), dim3(256), 0, g.stream,
+        const int nx8 = (P.nx + 7) / 8, pitch8 = P.nzp;
+        if ((P.nz % 256) != 0)   // chunks of the (y, z) plane: rows shorter or longer than a z tile
+            hipLaunchKernelGGL(k_signbits8<true>, dim3((unsigned)(((size_t)P.ny * pitch8 + 255) / 256), 1, nx8), dim3(256), 0, g.stream,
                                P.values, j->bits8, P.nx, P.ny, P.nz, nx8, pitch8, P.iso);
         else
             hipLaunchKernelGGL(k_signbits8<false>, dim3((P.nz + 255) / 256, P.ny, nx8), dim3(256), 0, g.stream, P.values, j->bits8, P.nx, P.ny,
@@ -1374,12 +1416,12 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
         s->nz_global = s->nz;
         s->values = nullptr; s->colors = nullptr; s->bits = nullptr; s->bits8 = nullptr; s->bits_valid = false; s->sampled_by = nullptr;
         j->sub = s;
-        int r = dev_alloc((void**)&s->values, s->nvox() * sizeof(float));
-        if (!r && v->colors) r = dev_alloc((void**)&s->colors, s->nvox() * 3 * sizeof(float));
+        int r = dev_alloc((void**)&s->values, s->nalloc() * sizeof(float));
+        if (!r && v->colors) r = dev_alloc((void**)&s->colors, s->nalloc() * 3 * sizeof(float));
         if (r) { job_release(j); delete j; return r; }
         ProfScope ps("k_subsample");
         hipLaunchKernelGGL(k_subsample, dim3(grid_for(s->nvox())), dim3(256), 0, g.stream, v->values, v->colors,
-                           s->values, s->colors, v->nx, v->ny, v->nz, s->nx, s->ny, s->nz, step);
+                           s->values, s->colors, v->nx, v->ny, v->pitch(), s->nx, s->ny, s->nz, s->pitch(), step);
         w = s;
         layer_end = s->nz - 1;
     }
@@ -1387,6 +1429,7 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     memset(&P, 0, sizeof P);
     P.values = w->values; P.colors = w->colors;
     P.nx = w->nx; P.ny = w->ny; P.nz = w->nz;
+    P.nzp = w->pitch();
     P.ncx = w->nx - 1; P.ncy = w->ny - 1; P.ncz = w->nz - 1;
     P.nxw = (w->nx + 63) / 64;
     P.z0 = w->z0;
