@@ -207,3 +207,29 @@ def test_mesh_arrays_come_from_the_pinned_arena(gpu):
     assert p.value in seen
     for v in seen:
         L.sdfk_host_free(C.c_void_p(v))
+
+
+@pytest.mark.parametrize("dims", [(9, 7, 13), (12, 10, 250), (6, 5, 64)])
+def test_padded_rows_upload_download_round_trip(gpu, dims):
+    """Device volumes pad their z rows to a multiple of 4 voxels; the host arrays stay dense [nx][ny][nz]
+    (Voxels.cs:8-9): upload -> download is the identity for values and colours, whatever nz is, and meshing an
+    uploaded volume equals the oracle's mesh of the same arrays."""
+    L = N.lib()
+    rng = np.random.default_rng(11)
+    nx, ny, nz = dims
+    vals = rng.uniform(-1, 1, dims).astype(np.float32)
+    cols = rng.uniform(0, 1, dims + (3,)).astype(np.float32)
+    mn, mx = [-1.0, -1.5, -2.0], [1.0, 1.5, 2.0]
+    h = C.c_void_p()
+    N.check(L.sdfk_volume_create(nx, ny, nz, N.f3(mn), N.f3(mx), 1, C.byref(h)))
+    pitch = C.c_int32()
+    N.check(L.sdfk_volume_row_pitch(h, C.byref(pitch)))
+    assert pitch.value == (nz + 3) // 4 * 4
+    N.check(L.sdfk_volume_upload(h, vals.ctypes.data, cols.ctypes.data))
+    v2, c2 = np.full(dims, 9.0, np.float32), np.full(dims + (3,), 9.0, np.float32)
+    N.check(L.sdfk_volume_download(h, v2.ctypes.data, c2.ctypes.data))
+    assert np.array_equal(v2, vals) and np.array_equal(c2, cols)
+    m = C.c_void_p()
+    N.check(L.sdfk_march(h, C.c_float(0.0), 1, C.byref(m)))
+    assert_mesh_equal(Mesh._from_handle(m), O.march(vals, cols, mn, mx))
+    L.sdfk_volume_free(h)
