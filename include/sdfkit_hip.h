@@ -244,7 +244,8 @@ int sdfk_raymarch_device(const sdfk_program* p, int32_t width, int32_t height, c
  * is otherwise dominated by (SDFK_COPY_THREADS, SDFK_COPY_MODE).  The Python mirror allocates
  * Mesh.Vertices/Colors/Normals/Triangles here; a C# shim can do the same for Span<T>/Memory<T>
  * based accessors, while Mesh's public arrays (Mesh.cs:10-13) have to stay managed arrays.
- * sdfk_host_free returns the block to the arena; a block must not be used after sdfk_shutdown. */
+ * sdfk_host_free returns the block to the arena; blocks that are still out at sdfk_shutdown stay valid (they are
+ * not reclaimed: sdfk_host_free after a shutdown ignores them). */
 int sdfk_host_alloc(int64_t n_bytes, void** out);
 void sdfk_host_free(void* p);
 

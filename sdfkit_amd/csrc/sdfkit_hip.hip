@@ -684,8 +684,7 @@ extern "C" void sdfk_shutdown(void)
     g.stage_bytes = 0;
     for (auto& kv : g.host_free) (void)hipHostFree(kv.second);
     g.host_free.clear();
-    for (auto& kv : g.host_live) (void)hipHostFree(kv.first);   // (their owners must not touch them after shutdown)
-    g.host_live.clear();
+    g.host_live.clear();   // blocks still in their owners' hands stay mapped (arrays of the host mirror may outlive the library state): leaked, not freed
     if (g.slots) (void)hipHostFree(g.slots);
     g.slots = nullptr;
     g.slots_dev = nullptr;
@@ -2110,7 +2109,7 @@ extern "C" void sdfk_host_free(void* p)
     if (!p) return;
     auto it = g.host_live.find(p);
     if (it == g.host_live.end()) return;
-    if (g.inited) g.host_free.emplace(it->second, p);   // back to the arena (after shutdown the memory is gone already)
+    g.host_free.emplace(it->second, p);   // back to the arena
     g.host_live.erase(it);
 }
 
