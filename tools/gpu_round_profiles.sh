@@ -5,18 +5,18 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; export TMPDIR=/tmp
 O=gpurun_out/profiles_$tag; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_under_rocprof.json 2>/dev/null
-SDFK_LANES=0 rocprofv3 --kernel-trace --stats -d $R/$O/stats_serial -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_serial_under_rocprof.json 2>/dev/null
-SDFK_LANES=0 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal > /dev/null 2>&1
-SDFK_LANES=0 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_under_rocprof.json 2>/dev/null
+SDFK_LANES=0 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats_serial -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_serial_under_rocprof.json 2>/dev/null
+SDFK_LANES=0 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal > /dev/null 2>&1
+SDFK_LANES=0 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_w/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv > $O/pmc_hbm_traffic.txt
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 python3 tools/pmc_to_json.py $O/pmc_w/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv sphere 512 $O/pmc_traffic.json
 # config C3 (RepeatXY with colours, clipToBounds): serial kernel stats + the two PMC passes
 python3 bench.py --no-cpu --scene repeatxy > $O/bench_repeatxy.json 2>/dev/null
-SDFK_LANES=0 rocprofv3 --kernel-trace --stats -d $R/$O/stats_c3 -o s --output-format csv -- python3 bench.py --no-cpu --scene repeatxy > /dev/null 2>&1
-SDFK_LANES=0 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal --scene repeatxy > /dev/null 2>&1
-SDFK_LANES=0 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal --scene repeatxy > /dev/null 2>&1
+SDFK_LANES=0 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats_c3 -o s --output-format csv -- python3 bench.py --no-cpu --scene repeatxy > /dev/null 2>&1
+SDFK_LANES=0 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal --scene repeatxy > /dev/null 2>&1
+SDFK_LANES=0 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f3 -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal --scene repeatxy > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_w3/p_counter_collection.csv $O/pmc_f3/p_counter_collection.csv > $O/pmc_hbm_traffic_repeatxy.txt
 python3 tools/pmc_to_json.py $O/pmc_w3/p_counter_collection.csv $O/pmc_f3/p_counter_collection.csv repeatxy 512 $O/pmc_traffic.json
 cp $O/stats_c3/s_kernel_stats.csv $O/kernel_stats_serial_repeatxy.csv
