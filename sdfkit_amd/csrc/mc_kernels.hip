@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_signbits8(const float* __restrict__ val
 {
     __shared__ unsigned char nib[8][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x8 = blockIdx.z;
+    const int x8 = FLAT ? (int)(blockIdx.z + blockIdx.y * 65535u) : (int)blockIdx.z;   // (FLAT: x groups beyond 65535 in blockIdx.y)
+    if (x8 >= nx8) return;
     int iy = blockIdx.y, z = blockIdx.x * 256 + 4 * lane;
     bool zok = z < pitch;
     if (FLAT) {
@@ -111,7 +112,11 @@ __global__ __launch_bounds__(256) void k_bits_transpose(const uint8_t* __restric
                                                         int nx8, int ny, int nz, int nxw, int pitch8)
 {
     __shared__ __attribute__((aligned(4))) uint8_t t[64][132];
-    const int iy = blockIdx.y, z0 = blockIdx.x * 128, xw0 = blockIdx.z * 8, row0 = xw0 * 8;
+    // blockIdx.x = (y, z tile) -- ny may exceed what grid dimension y holds --, blockIdx.z (+ 65535 blockIdx.y) = group of 8 words
+    const int ztiles = (nz + 127) / 128;
+    const int iy = (int)(blockIdx.x / (unsigned)ztiles), z0 = (int)(blockIdx.x % (unsigned)ztiles) * 128;
+    const int xw0 = (int)(blockIdx.z + blockIdx.y * 65535u) * 8, row0 = xw0 * 8;
+    if (xw0 >= nxw) return;
     for (int k = threadIdx.x; k < 64 * 32; k += 256) {
         const int row = k >> 5, c = (k & 31) * 4;
         unsigned v = 0;   // (byte rows are pitch8 long, a multiple of 4: a 4-byte group never straddles a row)
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
         for (int k = 0; k < 4; k++) {
             if (i0 + k < nseg) {
                 if (xw == 0) rowstart[y] = pos;   // first record of cell row (z, y)
-                const uint32_t yz = (uint32_t)y << 16;
+                const uint32_t yz = (uint32_t)y << P.xbits;
                 uint64_t mk = m[k];
                 while (mk) {
                     const int bit = __builtin_ctzll(mk);
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(256) void k_gather_corners(McParams P)
     const size_t sx = (size_t)P.ny * P.nzp, sy = (size_t)P.nzp;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const uint32_t xy = P.rec_xy[i];
-        const float* p = P.values + (size_t)(xy & 0xffffu) * sx + (size_t)(xy >> 16) * sy + P.rec_z[i];
+        const float* p = P.values + (size_t)(xy & P.xmask) * sx + (size_t)(xy >> P.xbits) * sy + P.rec_z[i];
         const f2u q0 = *reinterpret_cast<const f2u*>(p), q1 = *reinterpret_cast<const f2u*>(p + sx);
         const f2u q3 = *reinterpret_cast<const f2u*>(p + sy), q2 = *reinterpret_cast<const f2u*>(p + sx + sy);
         *reinterpret_cast<float4*>(P.rec_corners + (size_t)i * 8) = make_float4(q0.x, q1.x, q2.x, q3.x);
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
         uint64_t own = 0;
         if (i < n) {
             const uint32_t xy = P.rec_xy[i];
-            const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), z = (int)P.rec_z[i];
+            const int x = (int)(xy & P.xmask), y = (int)(xy >> P.xbits), z = (int)P.rec_z[i];
             corners_to_column(*reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8),
                               *reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8 + 4), col);
             const CornersLds v{col, 256, (double)P.iso};
@@ -599,8 +604,8 @@ __global__ __launch_bounds__(256) void k_resolve(McParams P)
             P.chunkdead[c] = (uint32_t)ndead;
             // rows spanned by the chunk: lets K4 fetch its windows without first reading records
             const uint32_t first = (uint32_t)c * 256u, last = min(first + 255u, n - 1u);
-            const uint32_t rf = (P.rec_z[first] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[first] >> 16);
-            const uint32_t rl = (P.rec_z[last] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[last] >> 16);
+            const uint32_t rf = (P.rec_z[first] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[first] >> P.xbits);
+            const uint32_t rl = (P.rec_z[last] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[last] >> P.xbits);
             // ... and the record ranges of its two neighbour windows (see k_vertices)
             const uint32_t nrows = (uint32_t)((P.lay_list_end - P.lay_count_begin) * P.ncy);
             const uint32_t nrs = min(rl - rf + 3u, (uint32_t)K4_RMAX);
@@ -653,10 +658,10 @@ __device__ __forceinline__ int find_record(const McParams& P, uint32_t n, int cx
     uint32_t a = min(rs[0], n), b = min(rs[1], n);
     while (b - a > 4u) {   // long rows: bisect
         const uint32_t mid = (a + b) >> 1;
-        if ((int)(P.rec_xy[mid] & 0xffffu) <= cx) a = mid; else b = mid;
+        if ((int)(P.rec_xy[mid] & P.xmask) <= cx) a = mid; else b = mid;
     }
     for (uint32_t k = a; k < b; k++)
-        if ((int)(P.rec_xy[k] & 0xffffu) == cx) return (int)k;
+        if ((int)(P.rec_xy[k] & P.xmask) == cx) return (int)k;
     return -1;
 }
 
@@ -828,7 +833,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int rr = (int)s_creator[j];          // = window slot of the creator (W1 starts at the chunk)
             const int r = (int)(j - s_pre[rr]);
             const uint32_t info = s_winfo[rr];
-            const int x = (int)(s_wxy[rr] & 0xffffu), y = (int)(s_wxy[rr] >> 16);
+            const int x = (int)(s_wxy[rr] & P.xmask), y = (int)(s_wxy[rr] >> P.xbits);
             const int e = (int)((s_own[rr] >> (4 * r)) & 15u);
             const int dir = mc_edge_dir(e);
             const int z = (int)s_z[rr];
@@ -858,13 +863,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                             uint32_t lo = ra - ws + off, hi = rb - ws + off;
                             while (hi - lo > 4u) {
                                 const uint32_t mid = (lo + hi) >> 1;
-                                if ((int)(s_wxy[mid] & 0xffffu) <= cx) lo = mid; else hi = mid;
+                                if ((int)(s_wxy[mid] & P.xmask) <= cx) lo = mid; else hi = mid;
                             }
                             // (four independent probes: one LDS round trip instead of a dependent scan)
 #pragma unroll
                             for (uint32_t q = 0; q < 4u; q++) {
                                 const uint32_t idx = min(lo + q, (uint32_t)K4_WMAX - 1u);
-                                const int wx = (int)(s_wxy[idx] & 0xffffu);
+                                const int wx = (int)(s_wxy[idx] & P.xmask);
                                 if (lo + q < hi && wx == cx) sl[s] = (int)idx;
                             }
                         }

@@ -41,7 +41,9 @@ struct McParams {
     uint64_t* chunkpre;    // exclusive prefix of chunktot, per chunk (k_vertices, read by k_triangles)
     // Active cells ("records") in serial-sweep order.  Everything the emit kernels read is
     // compact (tens of MB, L2/MALL resident): no per-voxel maps.
-    uint32_t* rec_xy;      // x | y << 16
+    uint32_t* rec_xy;      // x | y << xbits
+    int xbits;             // bits of x in rec_xy: 16, or more when nx > 65536 (then ny needs fewer: nx * ny * nz < 2^31, Voxels.cs:82)
+    uint32_t xmask;        // (1 << xbits) - 1
     uint32_t* rec_z;       // z (local layer)
     uint32_t* rowstart;    // [(z - lay_count_begin) * ncy + y] = first record of cell row (z,y); +1 sentinel
     uint32_t* rec_info;    // lut_off | nt_emitted << 14 | n_created << 18 | row_id << 22   (0 = emits nothing)

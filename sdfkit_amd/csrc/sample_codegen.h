@@ -104,7 +104,10 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
     __shared__ __attribute__((aligned(16))) float cbuf[8 / RPW][768];   // colour staging, one slice per wavefront
     // (the wavefront index as a scalar: row index, row base address and x coordinate stay off the VALU)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x8 = blockIdx.z;
+    // (grid dimensions y and z hold at most 65535 workgroups: the plane-chunk form, which has no y in its grid, takes the
+    // groups of 8 x rows beyond that in blockIdx.y -- extreme aspect ratios only)
+    const int x8 = MODE == SDFK_FLAT ? (int)(blockIdx.z + blockIdx.y * 65535u) : (int)blockIdx.z;
+    if (x8 >= A.nx8) return;
     const int P = A.pitch8;                     // floats per row
     const int plane = A.ny * P;                 // floats per x row (< 2^31: Voxels.cs:82, + <= 3 per row)
     const int f0 = blockIdx.x * 256;            // SDFK_FLAT: first voxel of the chunk within the plane
@@ -240,12 +243,12 @@ __device__ __forceinline__ float sdfk_voxel(const SampleArgs& A, int ix, int iy,
 extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A, const unsigned* __restrict__ rec_xy,
                                                                      const unsigned* __restrict__ rec_z,
                                                                      float* __restrict__ rec_corners,
-                                                                     const unsigned* __restrict__ n_active, unsigned cap)
+                                                                     const unsigned* __restrict__ n_active, unsigned cap, int xbits)
 {
     const unsigned n = *n_active < cap ? *n_active : cap;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const unsigned xy = rec_xy[i];
-        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), z = (int)rec_z[i];
+        const int x = (int)(xy & ((1u << xbits) - 1u)), y = (int)(xy >> xbits), z = (int)rec_z[i];
         const float c0 = sdfk_voxel(A, x, y, z), c1 = sdfk_voxel(A, x + 1, y, z);
         const float c2 = sdfk_voxel(A, x + 1, y + 1, z), c3 = sdfk_voxel(A, x, y + 1, z);
         const float c4 = sdfk_voxel(A, x, y, z + 1), c5 = sdfk_voxel(A, x + 1, y, z + 1);

@@ -1006,8 +1006,6 @@ extern "C" int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global
         return fail(SDFK_ERR_INVALID, "sdfk_volume_create: bad dimensions %dx%dx%d (slab z0=%d nz=%d)", nx, ny, nz_global, z0, nz_local);
     if ((int64_t)nx * ny * nz_global >= (int64_t(1) << 31))
         return fail(SDFK_ERR_INVALID, "grid exceeds the reference's int32 linear index (Voxels.cs:82)");
-    if (nx > 65535 || ny > 65535)
-        return fail(SDFK_ERR_UNSUPPORTED, "nx and ny are limited to 65535 (cell coordinates are packed in 16 bits)");
     if (int r = require_init()) return r;
     sdfk_volume* v = new sdfk_volume();
     v->nx = nx; v->ny = ny; v->nz = nz_local; v->nz_global = nz_global; v->z0 = z0;
@@ -1125,6 +1123,17 @@ extern "C" int sdfk_volume_device_ptrs(const sdfk_volume* v, void** values, void
     return SDFK_OK;
 }
 
+// Grid dimensions y and z hold at most 65535 workgroups; extents that may exceed that go to x, or are split over z and y.
+static dim3 transpose_grid(int nz, int ny, int nxw)
+{
+    const unsigned groups = (unsigned)((nxw + 7) / 8);
+    return dim3((unsigned)((nz + 127) / 128) * (unsigned)ny, (groups + 65534u) / 65535u, std::min(groups, 65535u));
+}
+static dim3 flat_grid(size_t plane, int nx8)   // plane-chunk kernels: (chunks of the (y, z) plane, x groups beyond 65535, x groups)
+{
+    return dim3((unsigned)((plane + 255) / 256), ((unsigned)nx8 + 65534u) / 65535u, std::min((unsigned)nx8, 65535u));
+}
+
 // Voxels.cs:32-34,81,139: cell size, first cell centre and ClipToBounds value, in float
 static void grid_constants(const sdfk_volume* v, float d[3], float m[3], float* outside)
 {
@@ -1180,14 +1189,16 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
             static const int force = getenv("SDFK_SAMPLE_MODE") ? atoi(getenv("SDFK_SAMPLE_MODE")) : -1;   // experiment knob
             int mode = (v->nz % 256) == 0 ? 0 : 1;
             if (force == 0 && (v->nz & 3) == 0) mode = 0;
-            if (force == 1) mode = 1;
+            if (force == 1 || v->ny > 65535 || v->nx8() > 65535) mode = 1;   // (the row-tiled form has y and x/8 in 16-bit grid dimensions)
             static const char* const names[2][2] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat"}, {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat"}};
             hipFunction_t fn = nullptr;   // (compiled on first use)
             if (int r = program_fn(p, (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode, &fn)) return r;
             ProfScope ps(names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
             const size_t plane = (size_t)v->ny * v->pitch();
-            if (mode == 1)
-                HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((plane + 255) / 256), 1, (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
+            if (mode == 1) {
+                const dim3 fg = flat_grid(plane, v->nx8());
+                HIPCHK(hipModuleLaunchKernel(fn, fg.x, fg.y, fg.z, tpb, 1, 1, 0, g.stream, params, nullptr));
+            }
             else
                 HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
                                              (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
@@ -1198,7 +1209,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         }
         {
             ProfScope ps("k_bits_transpose");
-            hipLaunchKernelGGL(k_bits_transpose, dim3((v->nz + 127) / 128, v->ny, (v->nxw() + 7) / 8), dim3(256), 0, g.stream,
+            hipLaunchKernelGGL(k_bits_transpose, transpose_grid(v->nz, v->ny, v->nxw()), dim3(256), 0, g.stream,
                                v->bits8, v->bits, v->nx8(), v->ny, v->nz, v->nxw(), v->pitch8());
             HIPCHK(hipGetLastError());
         }
@@ -1339,13 +1350,13 @@ int launch_classify(sdfk_march_job* j, bool publish)
         uint64_t* bits = const_cast<uint64_t*>(P.bits);
         ProfScope ps("k_signbits");
         const int nx8 = (P.nx + 7) / 8, pitch8 = P.nzp;
-        if ((P.nz % 256) != 0)   // chunks of the (y, z) plane: rows shorter or longer than a z tile
-            hipLaunchKernelGGL(k_signbits8<true>, dim3((unsigned)(((size_t)P.ny * pitch8 + 255) / 256), 1, nx8), dim3(256), 0, g.stream,
+        if ((P.nz % 256) != 0 || P.ny > 65535 || nx8 > 65535)   // chunks of the (y, z) plane: rows shorter or longer than a z tile
+            hipLaunchKernelGGL(k_signbits8<true>, flat_grid((size_t)P.ny * pitch8, nx8), dim3(256), 0, g.stream,
                                P.values, j->bits8, P.nx, P.ny, P.nz, nx8, pitch8, P.iso);
         else
             hipLaunchKernelGGL(k_signbits8<false>, dim3((P.nz + 255) / 256, P.ny, nx8), dim3(256), 0, g.stream, P.values, j->bits8, P.nx, P.ny,
                                P.nz, nx8, pitch8, P.iso);
-        hipLaunchKernelGGL(k_bits_transpose, dim3((P.nz + 127) / 128, P.ny, (P.nxw + 7) / 8), dim3(256), 0, g.stream, j->bits8, bits,
+        hipLaunchKernelGGL(k_bits_transpose, transpose_grid(P.nz, P.ny, P.nxw), dim3(256), 0, g.stream, j->bits8, bits,
                            nx8, P.ny, P.nz, P.nxw, pitch8);
         HIPCHK(hipGetLastError());
         j->have_bits = true;
@@ -1363,7 +1374,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
         if (int r = program_fn(j->eval_prog, PK_CORNERS, &fn_corners)) return r;
         ProfScope ps("sdfk_corners_eval");
         const unsigned* n_active = &P.counters->n_active;
-        void* params[] = {&j->eval_args, &P.rec_xy, &P.rec_z, &P.rec_corners, &n_active, &P.cap_active};
+        void* params[] = {&j->eval_args, &P.rec_xy, &P.rec_z, &P.rec_corners, &n_active, &P.cap_active, &P.xbits};
         HIPCHK(hipModuleLaunchKernel(fn_corners, (unsigned)std::min(nchunks, 256 * 8), 1, 1, 256, 1, 1, 0,
                                      g.stream, params, nullptr));
     } else {
@@ -1429,6 +1440,12 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     P.values = w->values; P.colors = w->colors;
     P.nx = w->nx; P.ny = w->ny; P.nz = w->nz;
     P.nzp = w->pitch();
+    {   // bit split of the packed cell coordinates: 16 + 16 unless one of nx, ny needs more (the other then needs fewer)
+        auto bits = [](int n) { int b = 0; while ((1 << b) < n) b++; return b; };
+        const int bx = bits(w->nx), by = bits(w->ny);
+        P.xbits = by > 16 ? 32 - by : std::max(16, bx);
+        P.xmask = P.xbits >= 32 ? 0xffffffffu : ((1u << P.xbits) - 1u);
+    }
     P.ncx = w->nx - 1; P.ncy = w->ny - 1; P.ncz = w->nz - 1;
     P.nxw = (w->nx + 63) / 64;
     P.z0 = w->z0;

@@ -637,3 +637,23 @@ def test_cell_lattice_rare_subtilings(gpu, seed):
     m = MarchingCubes.CreateMesh(Voxels(v, c, mn, mx))
     assert_mesh_equal(m, om)
     assert m.ActiveCells == len(om.cells)
+
+
+@pytest.mark.parametrize("name,dims", [("plane_w", (70001, 3, 5)), ("sphere_w", (3, 66001, 4)), ("readme_repeat_xy", (66000, 4, 3)),
+                                      ("union8", (5, 4, 70003))])
+def test_extents_beyond_16_bits(gpu, name, dims):
+    """The reference only caps nx * ny * nz (int32 linear index, Voxels.cs:82): one extent may well exceed 65535.  Cell
+    coordinates are packed with a variable bit split then, and extents that do not fit a 16-bit grid dimension are
+    folded into another one.  Sampling (values, colours) and the mesh, fused and two-stage, against the oracle."""
+    scene, sdf = S.CATALOGUE[name]()
+    mn, mx = [-2.8125, -2.5, -2.25], [2.8125, 2.75, 2.5]
+    ov, oc = O.sample(scene, mn, mx, *dims)
+    vol = Voxels.SampleSdf(sdf, mn, mx, *dims)
+    assert np.array_equal(vol.Values, ov) and np.array_equal(vol.Colors, oc)
+    om = O.march(ov, oc, mn, mx)
+    assert len(om.vertices) > 1000
+    assert_mesh_equal(vol.ToMesh(), om)
+    O.clip_to_bounds(ov, mn, mx)
+    assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), O.march(ov, oc, mn, mx))
+    # an uploaded volume takes the load-based sign-bit and corner kernels
+    assert_mesh_equal(MarchingCubes.CreateMesh(Voxels(ov, oc, mn, mx)), O.march(ov, oc, mn, mx))
