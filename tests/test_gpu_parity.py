@@ -657,3 +657,26 @@ def test_extents_beyond_16_bits(gpu, name, dims):
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), O.march(ov, oc, mn, mx))
     # an uploaded volume takes the load-based sign-bit and corner kernels
     assert_mesh_equal(MarchingCubes.CreateMesh(Voxels(ov, oc, mn, mx)), O.march(ov, oc, mn, mx))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_special_values_in_host_volumes(gpu, seed):
+    """Garbage in, the reference's garbage out: uploaded volumes with NaN, +-inf, signed zeros, denormals and huge
+    magnitudes sprinkled in (sign test `v - iso > 0` is false for NaN, weights 1 / (1e-7 + |v|) become 0 or NaN,
+    positions and normals go NaN / inf) -- topology, vertex count and every finite or non-finite output bit must
+    still be the oracle's."""
+    rng = np.random.default_rng(100 + seed)
+    dims = (19, 17, 22)
+    v = rng.uniform(-1, 1, dims).astype(np.float32)
+    specials = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-42, -1e-42, 3e38, -3e38, 1e-30], np.float32)
+    idx = rng.integers(0, v.size, v.size // 40)
+    v.ravel()[idx] = specials[rng.integers(0, len(specials), len(idx))]
+    c = rng.uniform(0, 1, dims + (3,)).astype(np.float32)
+    mn, mx = [-1.0, -1.25, -1.5], [1.0, 1.25, 1.5]
+    for iso in (0.0, 0.125):
+        om = O.march(v, c, mn, mx, iso=iso)
+        m = MarchingCubes.CreateMesh(Voxels(v.copy(), c.copy(), mn, mx), iso)
+        assert len(m.Vertices) == len(om.vertices) and np.array_equal(m.Triangles, om.triangles)
+        for a, b in ((m.Vertices, om.vertices), (m.Colors, om.colors), (m.Normals, om.normals)):
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b))
+            assert np.array_equal(a, b, equal_nan=True)
