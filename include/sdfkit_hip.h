@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDFK_ABI_VERSION 2   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free */
+#define SDFK_ABI_VERSION 3   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats */
 
 typedef enum sdfk_status {
     SDFK_OK = 0,
@@ -158,10 +158,19 @@ int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32
  * Self-contained jobs: consecutive calls are queued on two internal streams in turn (not on the
  * sdfk_set_stream stream) and overlap on the GPU; their results are safe to use from any stream
  * once an accessor has returned.  SDFK_LANES=0 in the environment (read per call) keeps them on
- * the caller's stream. */
+ * the caller's stream.
+ * Repeat calls on launch-bound grids (<= 2^24 voxels, step 1): the job of a (program, bounds, grid, clip,
+ * iso) is built once per internal stream -- volume, workspace and mesh arrays sized from the previous
+ * result of that grid shape -- its kernel launches are captured in a hipGraph, and every later call is
+ * ONE hipGraphLaunch; the returned handle borrows the job's arrays until it is freed (up to 3 live
+ * handles per key and stream, further calls take the ordinary path).  Same results, same deferred
+ * completion; a result that outgrows the captured capacities is redone exactly as always.
+ * SDFK_GRAPHS=0 switches this off, =2 applies it to every grid size. */
 int sdfk_sample_march(const sdfk_program* p, const float min[3], const float max[3],
                       int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds,
                       float iso_value, int32_t step, sdfk_mesh** out);
+/* Captured jobs alive, graph launches so far, device bytes the captured jobs hold. */
+int sdfk_graph_stats(int64_t* jobs, int64_t* launches, int64_t* device_bytes);
 
 /* Two-phase form for Z-slab sharding (one process per GPU).  `v` is a slab whose planes
  * cover the cell layers [layer_begin, layer_end) (global layer indices) plus context:

@@ -42,6 +42,7 @@ SIGNATURES = {
     "sdfk_program_source": (C.c_char_p, [_vp]),
     "sdfk_program_destroy": (None, [_vp]),
     "sdfk_jit_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "sdfk_graph_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_volume_create": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _i32, _vpp]),
     "sdfk_volume_create_slab": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _i32, _i32, _i32, _vpp]),
     "sdfk_volume_upload": (C.c_int, [_vp, _vp, _vp]),

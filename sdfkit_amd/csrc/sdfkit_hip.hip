@@ -129,6 +129,11 @@ struct Context {
     // meshes returned by the speculative path whose kernels may still be queued (oldest first)
     std::deque<sdfk_mesh*> pending;
     static constexpr size_t MAX_PENDING = 6;
+    // captured launch graphs of repeat sdfk_sample_march jobs on launch-bound grids (struct GraphJob below)
+    std::vector<struct GraphJob*> graph_jobs;
+    uint64_t graph_clock = 0;
+    size_t graph_bytes = 0;
+    int64_t graph_launches = 0;
 };
 
 Context g;
@@ -579,6 +584,8 @@ struct sdfk_mesh {
     std::string error;
     bool has_colors = true;             // false: the source volume had no colours (Colors are all zero)
     bool external = false;              // V / C / N / T are sections of a caller-owned slab payload (not freed here)
+    struct GraphJob* graph_job = nullptr;   // the job came from a captured launch graph: `pending` and (while `borrowed`) the buffers are its
+    bool borrowed = false;
     void* slab_header = nullptr;        // ... whose header k_triangles writes
     int lane = 0;                       // lane the buffers belong to
     bool used_on_main = false;          // lane-0 work (copies, packing, the caller) may still be reading them
@@ -600,11 +607,15 @@ struct sdfk_march_job {
     SampleArgs eval_args;
     int slot = -1;                 // index of the pinned result slot (owned until job_release)
     int lane = 0;                  // lane the job's kernels are queued on
+    float* bounds_partial = nullptr;   // per-workgroup AABB partials of k_vertices (allocated once per job: launch_emit is allocation-free after)
+    int bounds_blocks = 0;
     size_t rec_first = 0;          // first entry of `owned` that belongs to the record arrays
 };
 
 namespace {
 int mesh_resolve(sdfk_mesh* m);
+void graph_job_retire(sdfk_mesh* m, bool too_small);
+void graph_jobs_destroy_all();
 void resolve_dependents(const sdfk_volume* v);
 void free_mesh_buffers(sdfk_mesh* m);
 void drop_source(sdfk_mesh* m);
@@ -656,6 +667,7 @@ extern "C" void sdfk_shutdown(void)
     bind_thread();
     if (!g.inited) return;
     while (!g.pending.empty()) (void)mesh_resolve(g.pending.front());
+    graph_jobs_destroy_all();
     (void)hipStreamSynchronize(g.stream);
     prof_drain();
     for (auto e : g.prof_event_pool) (void)hipEventDestroy(e);
@@ -1324,6 +1336,7 @@ int alloc_records(sdfk_march_job* j, size_t c)
     McParams& P = j->P;
     for (size_t k = j->rec_first; k < j->owned.size(); k++) dev_free(j->owned[k]);
     j->owned.resize(j->rec_first);
+    j->bounds_partial = nullptr;   // (allocated after the records: freed with them)
     int rr = 0;
     rr = rr ? rr : job_alloc(j, &P.rec_xy, c);
     rr = rr ? rr : job_alloc(j, &P.rec_z, c);
@@ -1549,7 +1562,11 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     }
     static const int vcap = grid_cap("VERT", 256 * 8), tcap = grid_cap("TRI", 256 * 8);
     const int vgrid = grid_for(j->P.cap_active, 256, vcap);
-    if (int rr = job_alloc(j, &M.bounds_partial, (size_t)vgrid * 6)) return rr;
+    if (!j->bounds_partial || j->bounds_blocks != vgrid) {
+        if (int rr = job_alloc(j, &j->bounds_partial, (size_t)vgrid * 6)) return rr;
+        j->bounds_blocks = vgrid;
+    }
+    M.bounds_partial = j->bounds_partial;
     M.bounds_blocks = vgrid;
     M.bounds = m->bounds;
     M.host_bounds = g.slots_dev[j->slot].bounds;
@@ -1629,6 +1646,12 @@ int march_exact(const sdfk_volume* v, float iso, int step, int layer_begin, int 
 
 void free_mesh_buffers(sdfk_mesh* m)
 {
+    if (m->borrowed) {   // the buffers belong to a GraphJob
+        m->borrowed = false;
+        m->vertices = m->colors = m->normals = m->bounds = nullptr;
+        m->triangles = nullptr;
+        return;
+    }
     if (!m->external) {
         dev_free(m->vertices);   // stream-ordered pool: no sync needed
         dev_free(m->colors);
@@ -1674,11 +1697,14 @@ int mesh_resolve(sdfk_mesh* m)
             g.hints[m->key] = Context::Hint{j->c.n_active, (uint32_t)m->nv, (uint32_t)m->ni};
         }
     }
-    job_release(j);
-    delete j;
+    if (!m->graph_job) {   // (a job of a captured launch graph belongs to its GraphJob and is replayed)
+        job_release(j);
+        delete j;
+    }
     if (!r && !fits) {   // the guess was too small: the exact two-phase path, into the same handle
         sdfk_mesh* x = nullptr;
         r = march_exact(m->src, m->iso, m->step, m->layer_begin, m->layer_end, m->vertex_base, m->key, &x);
+        if (m->graph_job) graph_job_retire(m, true);   // its capacities are too small for this scene: rebuilt on a later call
         if (!r) {
             free_mesh_buffers(m);
             m->nv = x->nv; m->ni = x->ni;
@@ -1792,6 +1818,202 @@ int march_range(const sdfk_volume* v, float iso, int step, int layer_begin, int 
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------
+// captured launch graphs for repeat sdfk_sample_march jobs
+// ---------------------------------------------------------------------------
+// On launch-bound grids (<= 2^24 voxels) a job is nine small dependent kernels: queueing them costs the host 23 us, more
+// than the GPU needs for the job next to the others in flight (tools/ubench/ub_graph.hip: 9 launches 23.4 us, one
+// hipGraphLaunch of the captured chain 6.0 us; the chain takes the GPU the same time either way).  So the speculative
+// job of a (program, grid, clip, iso) on a lane is built ONCE -- its own volume, workspace sized from the shape's hints,
+// mesh buffers, result slot -- its launches are captured into a hipGraph, and every later call for that key on that lane
+// is one hipGraphLaunch.  The mesh handle borrows the GraphJob's buffers until it is freed; a result that does not fit the
+// captured capacities is redone on the exact path as always, and the GraphJob is rebuilt with the new hints.
+namespace {
+
+struct GraphJob {
+    const sdfk_program* prog = nullptr;
+    int nx = 0, ny = 0, nz = 0, clip = 0, lane = 0;
+    float mn[3], mx[3], iso = 0.0f;
+    sdfk_volume* vol = nullptr;
+    sdfk_march_job* job = nullptr;
+    sdfk_mesh* proto = nullptr;     // owns the mesh buffers and their capacities
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t key = 0;
+    sdfk_mesh* borrower = nullptr;  // the live handle whose arrays are proto's (at most one)
+    hipEvent_t ran = nullptr;       // after the latest run (a handle dropped unread leaves its run in flight)
+    bool busy = false, stale = false;
+    size_t bytes = 0;
+    uint64_t last_use = 0;
+};
+int g_graph_build_failures = 0;
+
+void graph_job_destroy(GraphJob* q)
+{
+    (void)hipStreamSynchronize(g.lanes[q->lane].stream);   // its kernels may still be queued
+    if (q->exec) (void)hipGraphExecDestroy(q->exec);
+    if (q->graph) (void)hipGraphDestroy(q->graph);
+    if (q->ran) (void)hipEventDestroy(q->ran);
+    if (sdfk_mesh* b = q->borrower) {   // (only at shutdown: a handle that outlives the library reads as failed)
+        b->graph_job = nullptr; b->borrowed = false;
+        b->vertices = b->colors = b->normals = b->bounds = nullptr; b->triangles = nullptr;
+        b->nv = b->ni = 0; b->pending = nullptr; b->src = nullptr;
+        if (!b->status) { b->status = SDFK_ERR_INVALID; b->error = "the library was shut down"; }
+    }
+    LaneScope on_lane(q->lane);
+    if (q->job) { job_release(q->job); delete q->job; }
+    if (q->proto) { q->proto->graph_job = nullptr; q->proto->borrowed = false; sdfk_mesh_free(q->proto); }
+    if (q->vol) sdfk_volume_free(q->vol);
+    if (q->prog) program_release(const_cast<sdfk_program*>(q->prog));
+    g.graph_bytes -= std::min(g.graph_bytes, q->bytes);
+    for (auto it = g.graph_jobs.begin(); it != g.graph_jobs.end(); ++it)
+        if (*it == q) { g.graph_jobs.erase(it); break; }
+    delete q;
+}
+
+void graph_jobs_destroy_all()
+{
+    while (!g.graph_jobs.empty()) graph_job_destroy(g.graph_jobs.back());
+}
+
+// the mesh no longer needs its GraphJob (freed, or redone on the exact path because the captured capacities were too small)
+void graph_job_retire(sdfk_mesh* m, bool too_small)
+{
+    GraphJob* q = m->graph_job;
+    if (!q) return;
+    if (too_small) q->stale = true;
+    q->busy = false;
+    q->borrower = nullptr;
+    m->graph_job = nullptr;
+}
+
+bool graphs_enabled(int64_t nvox)
+{
+    const char* e = getenv("SDFK_GRAPHS");   // (read per call, like SDFK_LANES) 0: never, 1: launch-bound grids, 2: every grid
+    const int mode = e ? atoi(e) : 1;
+    return mode == 2 || (mode == 1 && nvox <= (int64_t(1) << 24));   // (measured: 64^3 35 -> 23.5 us per job, 128^3 33 -> 26, 256^3 42 -> 39; 320^3 and up 0-3 % slower)
+}
+
+// Queue the job of (p, grid, clip, iso) on the current lane from a captured graph.  *out stays null when graphs do not
+// apply (no size hints yet, no free GraphJob and the limits are reached, capture not possible): the caller then takes
+// the ordinary path.
+int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[3], int nx, int ny, int nz, int clip, float iso, sdfk_mesh** out)
+{
+    *out = nullptr;
+    const int lane = g.cur_lane;
+    if (lane == 0 || g.prof_on || g.sampler_only || !mn || !mx || g_graph_build_failures >= 8) return SDFK_OK;
+    GraphJob* q = nullptr;
+    size_t alive = 0;
+    for (size_t i = 0; i < g.graph_jobs.size();) {
+        GraphJob* c = g.graph_jobs[i];
+        const bool same = c->prog == p && c->nx == nx && c->ny == ny && c->nz == nz && c->clip == clip && c->lane == lane &&
+                          memcmp(&c->iso, &iso, 4) == 0 && memcmp(c->mn, mn, 12) == 0 && memcmp(c->mx, mx, 12) == 0;
+        if (same && !c->busy && c->stale) { graph_job_destroy(c); continue; }   // (erases g.graph_jobs[i])
+        if (same) alive++;
+        if (same && !c->busy && !q) q = c;
+        i++;
+    }
+    if (!q) {
+        // build: everything a job needs, allocated up front, sized from the hints of this grid shape
+        sdfk_volume probe;
+        probe.nx = nx; probe.ny = ny; probe.nz = nz; probe.nz_global = nz; probe.z0 = 0;
+        const uint64_t key = hint_key(&probe, 1, 0, std::max(nz - 1, 0));
+        auto hit = g.hints.find(key);
+        if (hit == g.hints.end() || nx < 2 || ny < 2 || nz < 2) return SDFK_OK;
+        if (alive >= 3 || g.graph_jobs.size() >= 24 || g.graph_bytes > (size_t(4) << 30)) {
+            GraphJob* lru = nullptr;   // make room: the least recently used free one, if any
+            for (GraphJob* c : g.graph_jobs)
+                if (!c->busy && (!lru || c->last_use < lru->last_use)) lru = c;
+            if (!lru || alive >= 3) return SDFK_OK;
+            graph_job_destroy(lru);
+        }
+        const Context::Hint h = hit->second;
+        q = new GraphJob();
+        q->prog = p; const_cast<sdfk_program*>(p)->refs++;
+        q->nx = nx; q->ny = ny; q->nz = nz; q->clip = clip; q->lane = lane; q->iso = iso; q->key = key;
+        memcpy(q->mn, mn, 12); memcpy(q->mx, mx, 12);
+        g.graph_jobs.push_back(q);
+        const size_t before = [] { size_t b = 0; for (auto& kv : g.live_blocks) b += kv.second.size; return b; }();
+        int r = sdfk_volume_create(nx, ny, nz, mn, mx, p->writes_color ? 1 : 0, &q->vol);
+        // (first run outside the capture: compiles / loads the kernels, allocates the sign-bit arrays, marks the volume as this program's output)
+        if (!r) r = sample_impl(p, q->vol, clip, iso);
+        if (!r) r = setup_job(q->vol, iso, 1, 0, std::max(nz - 1, 0), (size_t)h.n_active + h.n_active / 4 + 4096, &q->job);
+        if (!r && (q->job->empty || !q->job->have_bits)) r = -1;   // (an iso value that never compares equal, NaN, leaves the sign-bit pass to the job)
+        if (!r) r = alloc_mesh(&q->proto, (size_t)h.nv + h.nv / 4 + 4096, (size_t)h.ni + h.ni / 4 + 12288);
+        if (!r) r = launch_classify(q->job, false);
+        if (!r) r = launch_emit(q->job, q->proto, 0);   // (allocates the AABB partials: the captured run below does not allocate)
+        if (!r) {
+            hipStream_t st = g.lanes[lane].stream;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                int rc = sample_impl(p, q->vol, clip, iso);
+                if (!rc) rc = launch_classify(q->job, false);
+                if (!rc) rc = launch_emit(q->job, q->proto, 0);
+                e = hipStreamEndCapture(st, &q->graph);
+                if (e == hipSuccess && rc) e = hipErrorUnknown;
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&q->exec, q->graph, nullptr, nullptr, 0);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ran, hipEventDisableTiming);
+            if (e != hipSuccess) { (void)hipGetLastError(); r = -1; }
+        }
+        if (r) {   // graphs are an optimisation: any failure here means "take the ordinary path"
+            g_graph_build_failures++;
+            graph_job_destroy(q);
+            return SDFK_OK;
+        }
+        const size_t after = [] { size_t b = 0; for (auto& kv : g.live_blocks) b += kv.second.size; return b; }();
+        q->bytes = after > before ? after - before : 0;
+        g.graph_bytes += q->bytes;
+        // (the un-captured first run above already queued this call's job: no graph launch for it)
+    } else {
+        if (hipEventQuery(q->ran) != hipSuccess) (void)hipEventSynchronize(q->ran);   // the previous run raises `overflow` in the slot itself
+        g.slots[q->job->slot].c.overflow = 0;
+        const hipError_t e = hipGraphLaunch(q->exec, g.lanes[lane].stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); q->stale = true; return SDFK_OK; }
+        g.graph_launches++;
+    }
+    q->busy = true;
+    q->last_use = ++g.graph_clock;
+    sdfk_mesh* m = new sdfk_mesh();
+    const sdfk_mesh* pr = q->proto;
+    m->vertices = pr->vertices; m->colors = pr->colors; m->normals = pr->normals; m->triangles = pr->triangles; m->bounds = pr->bounds;
+    m->cap_v = pr->cap_v; m->cap_i = pr->cap_i; m->has_colors = pr->has_colors; m->lane = lane;
+    m->borrowed = true;
+    m->graph_job = q;
+    q->borrower = m;
+    hipError_t e = hipEventCreateWithFlags(&m->done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(m->done, g.lanes[lane].stream);
+    if (e == hipSuccess) e = hipEventRecord(q->ran, g.lanes[lane].stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(g.lanes[lane].stream);
+        if (m->done) (void)hipEventDestroy(m->done);
+        m->borrowed = false; m->vertices = m->colors = m->normals = m->bounds = nullptr; m->triangles = nullptr;
+        q->busy = false;
+        q->borrower = nullptr;
+        delete m;
+        return fail(SDFK_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+    }
+    m->pending = q->job;
+    m->src = q->vol;
+    m->iso = iso; m->step = 1; m->layer_begin = 0; m->layer_end = std::max(nz - 1, 0);
+    m->vertex_base = 0; m->key = q->key;
+    g.pending.push_back(m);
+    while (g.pending.size() > Context::MAX_PENDING) (void)mesh_resolve(g.pending.front());
+    *out = m;
+    return SDFK_OK;
+}
+
+}  // namespace
+
+extern "C" int sdfk_graph_stats(int64_t* jobs, int64_t* launches, int64_t* device_bytes)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (jobs) *jobs = (int64_t)g.graph_jobs.size();
+    if (launches) *launches = g.graph_launches;
+    if (device_bytes) *device_bytes = (int64_t)g.graph_bytes;
+    return SDFK_OK;
+}
 
 extern "C" int sdfk_march_begin(const sdfk_volume* v, float iso_value, int32_t layer_begin, int32_t layer_end,
                                 sdfk_march_job** job, int64_t* n_vertices, int64_t* n_indices)
@@ -2010,7 +2232,7 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     if (int r = require_init()) return r;
     // self-contained job (no input but the program; the output is only read after a host-side
     // wait): consecutive calls alternate between the side lanes and overlap on the GPU
-    int lane = 0;
+    int lane = g.cur_lane;   // (inside sdfk_lane_begin/end: the caller's lane)
     if (const char* e = getenv("SDFK_LANES")) {   // read per call: measurement passes switch the overlap off and on
         g.side_lanes = std::max(0, std::min(Context::NSIDE, atoi(e)));
         if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
@@ -2024,6 +2246,11 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
         g.next_side = (g.next_side + 1) % g.side_lanes;
     }
     LaneScope on_lane(lane);
+    *out = nullptr;
+    if (step == 1 && graphs_enabled((int64_t)nx * ny * nz)) {   // launch-bound grids: the whole job as one captured graph
+        if (int r = graph_sample_march(p, min, max, nx, ny, nz, clip_to_bounds ? 1 : 0, iso_value, out)) return r;
+        if (*out) return SDFK_OK;
+    }
     sdfk_volume* v = nullptr;
     int r = sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
     if (r) return r;
@@ -2236,11 +2463,14 @@ extern "C" void sdfk_mesh_free(sdfk_mesh* m)
     if (m->pending) {   // never read: drop the queued job's workspace (stream-ordered, no wait)
         for (auto it = g.pending.begin(); it != g.pending.end(); ++it)
             if (*it == m) { g.pending.erase(it); break; }
-        job_release(m->pending, true);   // its kernels may still be queued (and will still write the result slot)
-        delete m->pending;
+        if (!m->graph_job) {
+            job_release(m->pending, true);   // its kernels may still be queued (and will still write the result slot)
+            delete m->pending;
+        }
         m->pending = nullptr;
         if (m->done) (void)hipEventDestroy(m->done);
     }
+    if (m->graph_job) { m->src = nullptr; graph_job_retire(m, false); }   // (the GraphJob is free for the next call on its lane: stream order protects its buffers)
     drop_source(m);
     if (m->lane != 0 && m->used_on_main && g.inited) {
         // lane-0 work may still read the buffers: their lane must not reuse them before that
