@@ -331,7 +331,24 @@ def main():
                 last[0], last[1] = worker.collect()
             return tuple(last)
 
-    for _ in range(max(args.warmup, 1) + 4):   # (the extra steps fill the allocator's pool: untimed set-up)
+    n_warm = max(args.warmup, 1) + 4   # (the extra steps fill the allocator's pool: untimed set-up)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_warm):
+        nv, ni = step()
+    nv, ni = drain()
+    barrier()
+    # Clock warm-up, untimed: after an idle period the GPU needs 10-15 ms of load to reach its sustained clocks
+    # (tools/step_transient_probe.py, 512^3 sphere: 0.20 ms per step over the first 20 steps after >= 20 ms of idling,
+    # 0.169 ms from the 80th step on) -- the W warm-up steps of a default run are 1 ms.  So the same step keeps running
+    # for SDFK_BENCH_CLOCK_WARM_MS (default 80 ms; 0 = off) before the timed region; the count is derived from the
+    # slowest rank's warm-up time so that every rank queues the same number of steps (matched collectives).
+    warm_ms = float(os.environ.get("SDFK_BENCH_CLOCK_WARM_MS", "80"))
+    per_warm = torch.tensor([(time.perf_counter() - t0) / n_warm], dtype=torch.float64, device=dev if (world > 1 and backend == "nccl") else "cpu")
+    if world > 1:
+        dist.all_reduce(per_warm, op=dist.ReduceOp.MAX)
+    n_clock = 0 if warm_ms <= 0 else min(4000, int(warm_ms * 1e-3 / max(float(per_warm.item()), 1e-6)) + 1)
+    for _ in range(n_clock):
         nv, ni = step()
     nv, ni = drain()
     barrier()
@@ -431,8 +448,13 @@ def main():
         for k in range(8):
             vols[k % 4]._sample(sdf, clip=clip)
         N.check(L.sdfk_profile_enable(2))            # the sampling kernel alone
-        for k in range(4):
+        t_w = time.perf_counter()
+        k = 0
+        while k < 4 or (time.perf_counter() - t_w) * 1e3 < warm_ms:   # (sustained clocks, as for the timed region above)
             vols[k % 4]._sample(sdf, clip=clip)
+            k += 1
+            if k % 64 == 0:
+                torch.cuda.synchronize()    # (the host must not run far ahead: wall time stands for GPU time here)
         barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
@@ -590,6 +612,10 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, RCCL all-gather of slab meshes"},
             "value_is": ("throughput of the pipelined steady state: three identical jobs in flight on the library's internal streams, "
                          "buffers sized from the previous mesh of the shape; see latency_ms_single_stream / first_call_ms for one call"),
+            "untimed_steps_before_timing": {"warmup": n_warm, "clock_warmup": n_clock,
+                                            "why": "W + 4 steps fill the allocator's pools; then the same step runs for ~80 ms so that the GPU is at "
+                                                   "its sustained clocks when the K timed steps start (after idling it needs 10-15 ms of load: "
+                                                   "0.20 -> 0.169 ms per step at 512^3, tools/step_transient_probe.py); SDFK_BENCH_CLOCK_WARM_MS=0 switches it off"},
             "mtris_per_s": round(ni / 3 / (dt / args.steps) / 1e6, 2),
             "latency_ms_single_stream": None if latency_ms is None else round(latency_ms, 4),
             "first_call_ms": first_call_ms,
