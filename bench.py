@@ -289,7 +289,7 @@ def main():
         # sizes are a guess from the previous mesh of this shape; the first accessor waits and
         # verifies).  Steps are therefore enqueued `depth` ahead of the one whose counts are read
         # back: every step is still checked, but the host never idles the GPU in between, and
-        # consecutive steps overlap on the library's two internal streams.
+        # consecutive steps overlap on the library's three internal streams.
         depth = [depth_env]
         inflight, last = [], [0, 0]
 
@@ -591,7 +591,7 @@ def main():
                     "method": ("one HIP event pair on the launch stream around K back-to-back launches of the kernel alone (four resident "
                                "volumes in turn), divided by K" if own else
                                "hipEvent pairs around each launch on the launch stream, K-step pipeline pass on ONE in-order stream")
-                              + "; the timed pass overlaps consecutive steps on two streams, which stretches every kernel"}
+                              + "; the timed pass overlaps consecutive steps on three streams, which stretches every kernel"}
         total_alg = n ** 3 * (32 if colors else 8) + 36 * nv + 4 * ni
         measured_hbm = load_pmc_traffic("pipeline_step", args.scene, n)
         out = {

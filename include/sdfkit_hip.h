@@ -155,7 +155,7 @@ int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32
                     const float min[3], const float max[3], float iso_value, int32_t step,
                     sdfk_mesh** out);
 /* SdfEx.ToMesh (Sdf.cs:59-63): sample (+clip) and mesh without leaving the device.
- * Self-contained jobs: consecutive calls are queued on two internal streams in turn (not on the
+ * Self-contained jobs: consecutive calls are queued on three internal streams in turn (not on the
  * sdfk_set_stream stream) and overlap on the GPU; their results are safe to use from any stream
  * once an accessor has returned.  SDFK_LANES=0 in the environment (read per call) keeps them on
  * the caller's stream.

@@ -104,7 +104,12 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
     __shared__ unsigned char nib[8][64];
+#if SDFK_WRITES_COLOR
     __shared__ __attribute__((aligned(16))) float cbuf[8 / RPW][768];   // colour staging, one slice per wavefront
+#endif
+    // (a program that only assigns .W has no staging buffer: 0.5 instead of 12.5 KB of LDS per workgroup -- at 8 wavefronts
+    // per SIMD the sampler would otherwise hold 100 of a CU's 160 KB, and the marching-cubes kernels of the job before it
+    // on the other stream, 28-41 KB per workgroup, could keep only one workgroup per CU next to it)
     // (the wavefront index as a scalar: row index, row base address and x coordinate stay off the VALU)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (grid dimensions y and z hold at most 65535 workgroups: the plane-chunk form, which has no y in its grid, takes the
@@ -155,12 +160,14 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             }
             const long o = MODE == SDFK_FLAT ? (long)ix * plane + (f0 + 4 * lane) : ((long)ix * A.ny + iy) * P + z;
             sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
+#if SDFK_WRITES_COLOR
             if (A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
                 sdfk_f4* mine = reinterpret_cast<sdfk_f4*>(cbuf[wave] + 12 * lane);
                 mine[0] = sdfk_f4{cr[0], cg[0], cb[0], cr[1]};
                 mine[1] = sdfk_f4{cg[1], cb[1], cr[2], cg[2]};
                 mine[2] = sdfk_f4{cb[2], cr[3], cg[3], cb[3]};
             }
+#endif
             n = (w[0] > A.iso ? 1u : 0u) | (w[1] > A.iso ? 2u : 0u) | (w[2] > A.iso ? 4u : 0u) | (w[3] > A.iso ? 8u : 0u);
             if (MODE == SDFK_FLAT && z + 3 >= A.nz) n &= z < A.nz ? (1u << (A.nz - z)) - 1u : 0u;   // row padding: 0 bits
         }
@@ -174,12 +181,16 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             const int z0 = blockIdx.x * 256;
             const int left = MODE == SDFK_FLAT ? plane - f0 : P - z0;
             const int run = (left < 256 ? left : 256) * 3;   // floats of the run that exist
+#if SDFK_WRITES_COLOR
             __builtin_amdgcn_wave_barrier();
             const float* cw = cbuf[wave];
             const sdfk_f4 t0 = *reinterpret_cast<const sdfk_f4*>(cw + 4 * lane);
             const sdfk_f4 t1 = *reinterpret_cast<const sdfk_f4*>(cw + 256 + 4 * lane);
             const sdfk_f4 t2 = *reinterpret_cast<const sdfk_f4*>(cw + 512 + 4 * lane);
             __builtin_amdgcn_wave_barrier();
+#else
+            const sdfk_f4 t0 = {0.0f, 0.0f, 0.0f, 0.0f}, t1 = t0, t2 = t0;   // a .W-only delegate leaves (0,0,0) everywhere (Voxels.cs:88-92)
+#endif
             float* c = A.colors + (MODE == SDFK_FLAT ? (long)ix * plane + f0 : ((long)ix * A.ny + blockIdx.y) * P + z0) * 3;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
@@ -413,6 +424,7 @@ inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t 
     }
     snprintf(buf, sizeof buf, "    W = v%d;\n}\n", out_rgbw[3]);
     src += buf;
+    src += writes_color ? "#define SDFK_WRITES_COLOR 1\n" : "#define SDFK_WRITES_COLOR 0\n";
     src += kSampleKernels;
     return true;
 }

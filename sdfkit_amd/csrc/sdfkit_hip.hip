@@ -2237,9 +2237,11 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
         g.side_lanes = std::max(0, std::min(Context::NSIDE, atoi(e)));
         if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
     } else {
-        // small grids are launch-latency bound (9 dependent launches): a third job in flight fills the gaps
-        // (256^3: 39 instead of 48 us per step); from 512^3 up two lanes are as good or 1 % better
-        g.side_lanes = (int64_t)nx * ny * nz <= (int64_t(1) << 25) ? 3 : 2;
+        // three lanes: small grids are launch-latency bound (9 dependent launches; 256^3: 39 instead of 48 us per step),
+        // and from 512^3 up a third job in flight is worth 4-5 % since the sampler of a .W-only program holds no LDS any
+        // more and the meshing kernels of two other jobs fit next to it (512^3 sphere 0.172 -> 0.164 ms, 384^3 0.092 ->
+        // 0.087, 1024^3 1.23 -> 1.18; colour scenes unchanged)
+        g.side_lanes = 3;
     }
     if (g.side_lanes > 0 && g.cur_lane == 0) {
         lane = 1 + g.next_side;

@@ -659,6 +659,23 @@ def test_extents_beyond_16_bits(gpu, name, dims):
     assert_mesh_equal(MarchingCubes.CreateMesh(Voxels(ov, oc, mn, mx)), O.march(ov, oc, mn, mx))
 
 
+@pytest.mark.parametrize("dims", [(12, 10, 256), (9, 14, 38), (8, 8, 513)])
+def test_w_only_program_zeroes_the_colors_of_a_colored_volume(gpu, dims):
+    """Voxels.cs:88-92,117-119: a delegate that only assigns .W scatters the zero-initialised scratch colours -- a
+    volume that held colours before holds (0,0,0) everywhere afterwards (the sampler of such a program has no colour
+    staging buffer; it stores the zeros directly)."""
+    mn, mx = [-1.5] * 3, [1.5] * 3
+    rng = np.random.default_rng(5)
+    v = Voxels(rng.standard_normal(dims).astype(np.float32), rng.random(dims + (3,), dtype=np.float32) + 0.25, mn, mx)
+    v._sync_to_device()
+    assert v._has_colors
+    scene, sdf = S.sphere_w(1.0)
+    v.SampleSdf(sdf)
+    ov, _ = O.sample(scene, mn, mx, *dims)
+    np.testing.assert_array_equal(v.Values, ov)
+    assert v._has_colors and not v.Colors.any()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_special_values_in_host_volumes(gpu, seed):
     """Garbage in, the reference's garbage out: uploaded volumes with NaN, +-inf, signed zeros, denormals and huge
