@@ -36,6 +36,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.sdfk_abi_version() == 3
 
 
+def test_graft_entry_version_check_follows_the_header():
+    """__graft_entry__.build() compares the built library with include/sdfkit_hip.h, not with a number of its own
+    (an ABI bump must not break the driver's build check)."""
+    import inspect
+    import __graft_entry__ as G
+    src = inspect.getsource(G.build)
+    assert "SDFK_ABI_VERSION" in src and not re.search(r"sdfk_abi_version\(\)\s*==\s*\d", src)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdfkit_hip.h")) as f:
+        declared = int(re.search(r"#define\s+SDFK_ABI_VERSION\s+(\d+)", f.read()).group(1))
+    assert N.lib().sdfk_abi_version() == declared
+
+
 def test_library_contains_gfx950_code_object(tmp_path):
     # (--offloading extracts the bundles next to its input: work on a copy outside the tree)
     import shutil
