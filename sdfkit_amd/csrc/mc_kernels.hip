@@ -747,6 +747,9 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     const int nrows_total = (P.lay_list_end - P.lay_count_begin) * P.ncy;
     const double iso = (double)P.iso;
     const double stp = (double)P.step;
+    // corner colours: 12-byte gathers from the colour volume (1 MiB apart along x) -- unless the program that sampled the
+    // volume re-evaluates them afterwards (M.vdesc)
+    const bool gather_colors = P.colors != nullptr && M.vdesc == nullptr;
     float bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     __shared__ uint64_t s_part[4];
     // vertices numbered below the first emitted layer (slab runs): prefix of record n_ghost_cells
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     fy += (double)mc_corner_dy(k) * wk;
                     fz += (double)mc_corner_dz(k) * wk;
                     ff += wk;
-                    if (P.colors) {
+                    if (gather_colors) {
                         float ck[3];
                         load_corner_color(P, x, y, z, k, ck);
                         const float wf = (float)wk;
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 pos[0] = (float)((double)xs + stp * fx / ff);
                 pos[1] = (float)((double)ys + stp * fy / ff);
                 pos[2] = (float)((double)zs + stp * fz / ff);
-                if (P.colors) {
+                if (gather_colors) {
 #pragma unroll
                     for (int jj = 0; jj < 3; jj++) colr[jj] = (float)((double)fc[jj] / ff);
                 }
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     pos[1] = (float)((double)ys + stp * fy / ff);
                     pos[2] = (float)((double)zs + stp * fz / ff);
                 }
-                if (P.colors) {
+                if (gather_colors) {
                     float ca[3], cb[3];
                     load_corner_color(P, x, y, z, c1, ca);
                     load_corner_color(P, x, y, z, c2, cb);
@@ -1006,7 +1009,9 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             float* on = M.normals + (size_t)out * 3;
             // (one 12-byte store per array: a third of the store instructions of three dword stores)
             *reinterpret_cast<f3u*>(ov) = f3u{px, py, pz};
-            if (M.colors)   // (null: a slab payload without a colour section -- the volume has no colours, they are all zero)
+            if (M.vdesc)    // colours by re-evaluation: sdfk_vertex_colors needs the creator cell and the edge
+                M.vdesc[out] = make_uint2(base + (uint32_t)rr, (uint32_t)e);
+            else if (M.colors)   // (null: a slab payload without a colour section -- the volume has no colours, they are all zero)
                 *reinterpret_cast<f3u*>(M.colors + (size_t)out * 3) = f3u{colr[0], colr[1], colr[2]};
             *reinterpret_cast<f3u*>(on) = f3u{t0 / tl, t1 / tl, t2 / tl};
             if (M.grid_vertices) {

@@ -77,6 +77,8 @@ struct McMeshOut {
     float* host_bounds;    // pinned, device-mapped mirror
     void* slab_header;     // non-null: the mesh arrays are sections of a slab payload; k_triangles writes its 64-byte header here
     int32_t slab_vbytes;   // 36 or 24 (no colour section)
+    uint2* vdesc;          // non-null: k_vertices leaves (creator record, edge) per emitted vertex here instead of gathering corner
+                           // colours from the volume; the program's own sdfk_vertex_colors kernel re-evaluates them (sample_codegen.h)
 };
 
 }  // namespace sdfk

@@ -217,7 +217,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
     }
 }
 // SDFK_KERNELS: bit mask of the entry points this module contains (the host compiles a program's kernels on demand:
-// bit 0 / 1 = the two instantiations without ClipToBounds, 3 / 4 = with it, 6 = sdfk_corners_eval, 7 = sdfk_raymarch)
+// bit 0 / 1 = the two instantiations without ClipToBounds, 3 / 4 = with it, 5 = sdfk_vertex_colors, 6 = sdfk_corners_eval, 7 = sdfk_raymarch)
 #ifndef SDFK_KERNELS
 #define SDFK_KERNELS 0xff
 #endif
@@ -270,6 +270,72 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A
         float4* o = reinterpret_cast<float4*>(rec_corners + (size_t)i * 8);
         o[0] = make_float4(c0, c1, c2, c3);
         o[1] = make_float4(c4, c5, c6, c7);
+    }
+}
+#endif
+
+// Vertex colours, RE-EVALUATED instead of gathered: k_vertices (mc_kernels.hip) left (creator record, edge) for every
+// emitted vertex; the colour of a vertex on edge (c1, c2) of its creator cell is the blend of the two corner colours
+// weighted by 1 / (eps + |value - iso|) (Cell.AddFaceFromEdgeIndex, Cell.cs:314-350), that of a centre vertex the same
+// over all 8 corners (Cell.CalculateCenterVertex, Cell.cs:501-549) -- and for a volume this program has just sampled the
+// corner colours AND values are two (eight) more evaluations of the same float32 expression, bit-identical to what the
+// sampling kernel stored, instead of two 12-byte gathers 1 MiB apart from a 1.6 GB colour volume (k_vertices of the
+// README scene at 512^3: 121 us with the gathers, of which ~60 us are the gathers).  Arithmetic and order exactly as in
+// k_vertices' gather path: float products and sum, then ONE double division.
+#if (SDFK_KERNELS & 0x20) && SDFK_WRITES_COLOR
+struct VColArgs { const unsigned* vdesc; const unsigned* rec_xy; const unsigned* rec_z; const unsigned* counters; float* colors;
+                  unsigned cap_vertices; int xbits; float iso; };
+__device__ __forceinline__ void sdfk_voxel_rgbw(const SampleArgs& A, int ix, int iy, int iz, float& r, float& g, float& b, float& w)
+{
+    const float px = A.mx + (float)ix * A.dx;
+    const float py = A.my + (float)iy * A.dy;
+    const int zg = A.z0 + iz;
+    const float pz = A.mz + (float)zg * A.dz;
+    sdf_eval(px, py, pz, r, g, b, w);
+    if (A.clip && ((ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1) | (zg == 0) | (zg == A.nz_global - 1)))
+        w = A.outside;
+}
+extern "C" __global__ __launch_bounds__(256) void sdfk_vertex_colors(SampleArgs A, VColArgs V)
+{
+    // McCounters (mc_params.h): total_v = word 3, nghost = word 5; published by k_vertices (stream order)
+    unsigned nv = V.counters[3] - V.counters[5];
+    if (nv > V.cap_vertices) nv = V.cap_vertices;
+    const double iso = (double)V.iso;
+    for (unsigned o = blockIdx.x * 256u + threadIdx.x; o < nv; o += gridDim.x * 256u) {
+        const unsigned rec = V.vdesc[2u * o], e = V.vdesc[2u * o + 1u];
+        const unsigned xy = V.rec_xy[rec];
+        const int x = (int)(xy & ((1u << V.xbits) - 1u)), y = (int)(xy >> V.xbits), z = (int)V.rec_z[rec];
+        float out[3];
+        if (e == 12u) {
+            double ff = 0.0;
+            float fc[3] = {0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < 8; k++) {
+                float c[3], w;
+                sdfk_voxel_rgbw(A, x + (((k + 1) >> 1) & 1), y + ((k >> 1) & 1), z + (k >> 2), c[0], c[1], c[2], w);
+                const double wk = 1.0 / (0.0000001 + __builtin_fabs((double)w - iso));
+                ff += wk;
+                const float wf = (float)wk;
+                if (k == 0) { fc[0] = c[0] * wf; fc[1] = c[1] * wf; fc[2] = c[2] * wf; }
+                else { fc[0] = fc[0] + c[0] * wf; fc[1] = fc[1] + c[1] * wf; fc[2] = fc[2] + c[2] * wf; }
+            }
+            for (int j = 0; j < 3; j++) out[j] = (float)((double)fc[j] / ff);
+        } else {
+            // the two end corners of cube edge e (Luts.cs:30-52)
+            const int c1 = e < 8u ? (int)e : (int)e - 8, c2 = e < 8u ? (int)((e & 4u) | ((e + 1u) & 3u)) : (int)e - 4;
+            float ca[3], cb[3], wa, wb;
+            sdfk_voxel_rgbw(A, x + (((c1 + 1) >> 1) & 1), y + ((c1 >> 1) & 1), z + (c1 >> 2), ca[0], ca[1], ca[2], wa);
+            sdfk_voxel_rgbw(A, x + (((c2 + 1) >> 1) & 1), y + ((c2 >> 1) & 1), z + (c2 >> 2), cb[0], cb[1], cb[2], wb);
+            const double w1 = 1.0 / (0.0000001 + __builtin_fabs((double)wa - iso));
+            const double w2 = 1.0 / (0.0000001 + __builtin_fabs((double)wb - iso));
+            const double ff = w1 + w2;
+            const float w1f = (float)w1, w2f = (float)w2;
+            for (int j = 0; j < 3; j++) {
+                const float cj = ca[j] * w1f + cb[j] * w2f;
+                out[j] = (float)((double)cj / ff);
+            }
+        }
+        float* c = V.colors + 3ul * o;
+        c[0] = out[0]; c[1] = out[1]; c[2] = out[2];
     }
 }
 #endif

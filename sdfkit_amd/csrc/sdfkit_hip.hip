@@ -517,7 +517,7 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
 // opaque objects
 // ---------------------------------------------------------------------------
 // Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
-enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_CORNERS = 6, PK_RAYMARCH = 7, PK_COUNT = 8 };
+enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_VCOLORS = 5, PK_CORNERS = 6, PK_RAYMARCH = 7, PK_COUNT = 8 };
 
 struct sdfk_program {
     std::string source;
@@ -609,6 +609,8 @@ struct sdfk_march_job {
     int lane = 0;                  // lane the job's kernels are queued on
     float* bounds_partial = nullptr;   // per-workgroup AABB partials of k_vertices (allocated once per job: launch_emit is allocation-free after)
     int bounds_blocks = 0;
+    uint2* vdesc = nullptr;        // (creator record, edge) per emitted vertex for sdfk_vertex_colors (same rule)
+    size_t vdesc_cap = 0;
     size_t rec_first = 0;          // first entry of `owned` that belongs to the record arrays
 };
 
@@ -926,7 +928,7 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::string src;
     std::vector<char> code;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
-    return compile_source(src, 0xdbu, code, false);   // every kernel, a real compile: this IS the check
+    return compile_source(src, 0xfbu, code, false);   // every kernel, a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -951,9 +953,12 @@ int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
     sdfk_program* p = const_cast<sdfk_program*>(cp);
     if (!p->fn[k]) {
         static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "", "sdfk_sample_bits_clip",
-                                                    "sdfk_sample_bits_clip_flat", "", "sdfk_corners_eval", "sdfk_raymarch"};
+                                                    "sdfk_sample_bits_clip_flat", "sdfk_vertex_colors", "sdfk_corners_eval", "sdfk_raymarch"};
         unsigned mask = 1u << k;
-        if (k <= PK_BITS_CLIP_FLAT && !p->fn[PK_CORNERS]) mask |= 1u << PK_CORNERS;
+        if (k <= PK_BITS_CLIP_FLAT && !p->fn[PK_CORNERS]) {   // (and, for a program that writes colours, sdfk_vertex_colors)
+            mask |= 1u << PK_CORNERS;
+            if (p->writes_color && !p->fn[PK_VCOLORS]) mask |= 1u << PK_VCOLORS;
+        }
         std::vector<char> code;
         bool cached = false;
         if (int r = compile_source(p->source, mask, code, true, &cached)) return r;
@@ -1337,6 +1342,8 @@ int alloc_records(sdfk_march_job* j, size_t c)
     for (size_t k = j->rec_first; k < j->owned.size(); k++) dev_free(j->owned[k]);
     j->owned.resize(j->rec_first);
     j->bounds_partial = nullptr;   // (allocated after the records: freed with them)
+    j->vdesc = nullptr;
+    j->vdesc_cap = 0;
     int rr = 0;
     rr = rr ? rr : job_alloc(j, &P.rec_xy, c);
     rr = rr ? rr : job_alloc(j, &P.rec_z, c);
@@ -1568,12 +1575,35 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     }
     M.bounds_partial = j->bounds_partial;
     M.bounds_blocks = vgrid;
+    // Vertex colours of a volume its own program has just sampled: re-evaluated by the program (sdfk_vertex_colors) from
+    // the (creator record, edge) descriptors k_vertices leaves, instead of gathered from the colour volume
+    static const bool no_vcol = getenv("SDFK_NO_VCOLOR_EVAL") != nullptr;   // (A/B knob: the gather path)
+    const bool vcol = j->eval_prog && j->eval_prog->writes_color && j->P.colors && M.colors && j->P.step == 1 && !no_vcol;
+    if (vcol) {
+        const size_t need = std::max<size_t>(m->cap_v, 1);
+        if (!j->vdesc || j->vdesc_cap < need) {
+            if (int rr = job_alloc(j, &j->vdesc, need)) return rr;
+            j->vdesc_cap = need;
+        }
+        M.vdesc = j->vdesc;
+    }
     M.bounds = m->bounds;
     M.host_bounds = g.slots_dev[j->slot].bounds;
     {
         ProfScope ps("k_vertices");
         hipLaunchKernelGGL(k_vertices, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
         HIPCHK(hipGetLastError());
+    }
+    if (vcol) {
+        struct VColArgs { const uint2* vdesc; const uint32_t* rec_xy; const uint32_t* rec_z; const McCounters* counters; float* colors;
+                          uint32_t cap_vertices; int32_t xbits; float iso; } V;   // (= VColArgs of sample_codegen.h)
+        V.vdesc = j->vdesc; V.rec_xy = j->P.rec_xy; V.rec_z = j->P.rec_z; V.counters = j->P.counters; V.colors = M.colors;
+        V.cap_vertices = M.cap_vertices; V.xbits = j->P.xbits; V.iso = j->P.iso;
+        hipFunction_t fn = nullptr;
+        if (int rr = program_fn(j->eval_prog, PK_VCOLORS, &fn)) return rr;
+        void* params[] = {&j->eval_args, &V};
+        ProfScope ps("sdfk_vertex_colors");
+        HIPCHK(hipModuleLaunchKernel(fn, (unsigned)grid_for(std::max<size_t>(m->cap_v, 1), 256, 256 * 8), 1, 1, 256, 1, 1, 0, g.stream, params, nullptr));
     }
     {
         ProfScope ps("k_triangles");

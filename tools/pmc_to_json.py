@@ -24,7 +24,7 @@ for k, c in res.items():
     d[f"{name}@{scene}@{n}"] = int(round(b))
     # the kernels of a steady-state step of the fused path (k_publish, k_signbits8, k_gather_corners, k_clip* only run on
     # the exact / host-array / explicit-clip routes)
-    if name.startswith(("sdfk_sample_bits", "k_bits_transpose", "k_compact", "sdfk_corners_eval", "k_resolve", "k_vertices", "k_triangles")):
+    if name.startswith(("sdfk_sample_bits", "k_bits_transpose", "k_compact", "sdfk_corners_eval", "sdfk_vertex_colors", "k_resolve", "k_vertices", "k_triangles")):
         step += b
 d[f"pipeline_step@{scene}@{n}"] = int(round(step))
 json.dump(d, open(out, "w"), indent=1, sort_keys=True)
