@@ -32,6 +32,11 @@ def raw(sdf, mn, mx, dims, clip, iso=0.0):
     return m
 
 
+def graphs_expected():
+    """(the suite is also run with SDFK_GRAPHS=0 / SDFK_LANES=0 in the environment: results must hold, graphs need not appear)"""
+    return os.environ.get("SDFK_GRAPHS", "1") != "0" and os.environ.get("SDFK_LANES", "3") not in ("0", "1")
+
+
 def stats():
     a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
     N.check(N.lib().sdfk_graph_stats(C.byref(a), C.byref(b), C.byref(c)))
@@ -46,22 +51,28 @@ def test_repeat_calls_replay_a_graph_and_match_the_oracle(gpu):
     for _ in range(12):     # 1: exact path (sets the hints); then one build per lane; then replays
         assert_mesh_equal(Mesh._from_handle(raw(sdf, MN, MX, dims, True)), om)
     jobs, launches, nbytes = stats()
-    assert jobs >= 1 and launches - launches0 >= 6 and nbytes > 0
+    if graphs_expected():
+        assert jobs >= 1 and launches - launches0 >= 6 and nbytes > 0
 
 
 def test_graphs_off_on_same_bits(gpu):
     scene, sdf = S.CATALOGUE["union8"]()
     dims = (40, 44, 36)
     res = {}
+    before = os.environ.get("SDFK_GRAPHS")
+    lanes_on = os.environ.get("SDFK_LANES", "3") not in ("0", "1")
     try:
         for mode in ("0", "1", "0", "2"):     # (read per call)
             os.environ["SDFK_GRAPHS"] = mode
             _, l0, _ = stats()
             res[mode] = [Mesh._from_handle(raw(sdf, MN, MX, dims, False)) for _ in range(8)]
             _, l1, _ = stats()
-            assert (l1 > l0) == (mode != "0")
+            assert (l1 > l0) == (mode != "0" and lanes_on)
     finally:
-        del os.environ["SDFK_GRAPHS"]
+        if before is None:
+            del os.environ["SDFK_GRAPHS"]
+        else:
+            os.environ["SDFK_GRAPHS"] = before
     om = oracle_mesh(scene, MN, MX, dims, False)
     for ms in res.values():
         for m in ms:
