@@ -26,6 +26,9 @@ import time
 # RCCL / device-memory sharing between the ranks of a node needs dmabuf IPC on this driver stack; the
 # launcher's environment normally carries this already
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# one hardware queue per stream in play (the library's lanes, torch's stream, RCCL's): with the runtime's default of 4 a
+# stream that waits for an event holds up other streams in the same queue (sdfk_init says more); read at HIP initialisation
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -208,6 +211,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = None
+    force_dist = os.environ.get("SDFK_BENCH_FORCE_DIST") == "1"   # exercise the sharded path on one rank
+    # (the process group comes BEFORE the library's sdfk_init: RCCL's stream then takes its hardware queue first and no
+    # lane of the library ends up sharing one with it -- see GPU_MAX_HW_QUEUES in sdfk_init; the other order costs the
+    # pipelined sharded step a factor 3, tools/hwq_probe.py)
+    if world == 1 and force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        backend = "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if one_gpu else "nccl"
@@ -276,21 +288,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    force_dist = os.environ.get("SDFK_BENCH_FORCE_DIST") == "1"   # exercise the sharded path on one rank
-    if world == 1 and force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        backend = "nccl"
     sharded = world > 1 or force_dist
-    depth_env = int(os.environ.get("SDFK_BENCH_DEPTH", "3"))
+    # steps in flight: the GPU then holds ~1 ms of queued work, so that a hiccup of the host (an interrupt, the interpreter)
+    # inside the 3 ms timed region of the driver's 20-step command does not drain the pipeline (3 and 6 in flight give the
+    # same steady state; with 3 one run in five came out 5-10 % slow)
+    depth_env = int(os.environ.get("SDFK_BENCH_DEPTH", "0"))   # 0 = default: 5 single-GPU (the library itself holds at most 6 unread jobs), 3 sharded
     if not sharded:
         # sdfk_sample_march returns its mesh handle while the kernels are still queued (the
         # sizes are a guess from the previous mesh of this shape; the first accessor waits and
         # verifies).  Steps are therefore enqueued `depth` ahead of the one whose counts are read
         # back: every step is still checked, but the host never idles the GPU in between, and
         # consecutive steps overlap on the library's three internal streams.
-        depth = [depth_env]
+        depth = [depth_env or 5]
         inflight, last = [], [0, 0]
 
         def retire(m):
@@ -316,7 +325,7 @@ def main():
     else:
         # three steps in flight, one RCCL all-gather per step, no host wait inside a step
         # (sdfkit_amd/dist.py: SlabSession)
-        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev, depth=depth_env or 1, headroom=1.0 / 32)
+        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev, depth=depth_env or 3, headroom=1.0 / 32)
         totals = torch.zeros(2, dtype=torch.int64, device=dev)
         last = [0, 0]
 
@@ -332,6 +341,10 @@ def main():
             return tuple(last)
 
     n_warm = max(args.warmup, 1) + 4   # (the extra steps fill the allocator's pool: untimed set-up)
+    import gc
+    gc.collect()
+    gc.disable()   # (no collector pause inside the timed region; collected HERE, before the warm-up: a collection takes
+                   # milliseconds during which the GPU idles, and an idle GPU drops its clocks)
     barrier()
     t0 = time.perf_counter()
     for _ in range(n_warm):
@@ -358,6 +371,7 @@ def main():
     nv, ni = drain()   # every queued step has completed and been checked before the clock stops
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     per_rank = None
     if sharded:   # per-rank counts -> totals of the whole mesh (outside the timed region)
         mine = torch.tensor([nv, ni], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
@@ -610,7 +624,7 @@ def main():
                                    f", {n}^3 voxels, iso 0, step 1; Voxels.SampleSdf -> MarchingCubes.CreateMesh, device-resident",
                        "grid": [n, n, n], "vertices": nv, "triangles": ni // 3,
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, RCCL all-gather of slab meshes"},
-            "value_is": ("throughput of the pipelined steady state: three identical jobs in flight on the library's internal streams, "
+            "value_is": ("throughput of the pipelined steady state: five identical jobs in flight on the library's three internal streams, "
                          "buffers sized from the previous mesh of the shape; see latency_ms_single_stream / first_call_ms for one call"),
             "untimed_steps_before_timing": {"warmup": n_warm, "clock_warmup": n_clock,
                                             "why": "W + 4 steps fill the allocator's pools; then the same step runs for ~80 ms so that the GPU is at "

@@ -10,6 +10,11 @@ import sys
 
 from . import build as _build
 
+# Streams that wait for events must not share hardware queues with the library's lanes (sdfk_init, sdfkit_hip.hip, says
+# why): the HIP runtime reads this when it initialises -- with torch in the process that is the first CUDA call, not the
+# import -- so it is set as early as this module is imported, unless the user chose a value.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 _inited_device = None

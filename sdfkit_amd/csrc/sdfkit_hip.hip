@@ -182,9 +182,26 @@ void dev_free(void* p)
 }
 
 // queue on lane `k` for the lifetime of the scope (allocations included)
+// The stream of lane k, created on first use.  Every stream of a process takes one of the runtime's in-order hardware
+// queues (shared once there are more streams than GPU_MAX_HW_QUEUES), and this GPU serves about eight queues well: a
+// sharded rank uses two lanes, a single-GPU caller three -- the others never exist.  (Tried instead, both far worse for
+// the pipelined sharded step: lanes on a stream priority of their own, 200 us per step where plain streams reach 55;
+// lanes with dedicated queues through hipExtStreamCreateWithCUMask, 110-290 us.)
+hipStream_t lane_stream(int k)
+{
+    if (!g.lanes[k].stream && k > 0) {
+        if (hipStreamCreateWithFlags(&g.lanes[k].stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            g.lanes[k].stream = nullptr;
+            return g.lanes[0].stream;   // (no stream to be had: the caller's stream -- correct, just not concurrent)
+        }
+    }
+    return g.lanes[k].stream;
+}
+
 struct LaneScope {
     int saved;
-    explicit LaneScope(int k) : saved(g.cur_lane) { g.cur_lane = k; g.stream = g.lanes[k].stream; }
+    explicit LaneScope(int k) : saved(g.cur_lane) { g.cur_lane = k; g.stream = lane_stream(k); }
     ~LaneScope() { g.cur_lane = saved; g.stream = g.lanes[saved].stream; }
 };
 
@@ -618,6 +635,7 @@ namespace {
 int mesh_resolve(sdfk_mesh* m);
 void graph_job_retire(sdfk_mesh* m, bool too_small);
 void graph_jobs_destroy_all();
+void graph_jobs_forget_volume(const sdfk_volume* v);
 void resolve_dependents(const sdfk_volume* v);
 void free_mesh_buffers(sdfk_mesh* m);
 void drop_source(sdfk_mesh* m);
@@ -640,6 +658,13 @@ extern "C" int sdfk_init(int device)
         if (device != g.device) return fail(SDFK_ERR_INVALID, "already initialised on device %d", g.device);
         return SDFK_OK;
     }
+    // The library's lanes, the caller's stream and a collective library's stream must not share hardware queues: the HIP
+    // runtime maps all streams of a process onto GPU_MAX_HW_QUEUES (default 4) in-order queues, and a stream that waits
+    // for an event (a lane section's end, a collective) then holds up every OTHER stream behind it in the same queue --
+    // the pipelined sharded step ran fully serialised that way (108 -> 55 us per step on a small slab with 8 queues;
+    // 16 queues: 170 us).  Read by the runtime when it initialises, i.e. only effective if this is the process's first
+    // HIP call (hosts that touch HIP earlier export it themselves: sdfkit_amd/_native.py, bench.py do).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(SDFK_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
@@ -652,7 +677,11 @@ extern "C" int sdfk_init(int device)
     HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
     g.user_stream = g.stream = g.own_stream;
     g.lanes[0].stream = g.own_stream;
-    for (int k = 1; k <= Context::NSIDE; k++) HIPCHK(hipStreamCreateWithFlags(&g.lanes[k].stream, hipStreamNonBlocking));
+    // The three lanes sdfk_sample_march rotates over get their streams NOW, right after the library's own stream: streams
+    // created first get hardware queues of their own (1 % per step against creating them on first use, 15 % when the
+    // process runs with the runtime's default of 4 queues); the fourth lane's stream is created when somebody asks for that
+    // lane (lane_stream()) -- a sharded rank then holds eight streams with torch's two and RCCL's, one per queue.
+    for (int k = 1; k <= 3 && k <= Context::NSIDE; k++) (void)lane_stream(k);
     g.cur_lane = 0;
     HIPCHK(hipHostMalloc((void**)&g.slots, sizeof(Context::HostSlot) * Context::NSLOTS, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&g.slots_dev, g.slots, 0));
@@ -727,9 +756,10 @@ extern "C" int sdfk_lane_begin(int32_t lane, void* wait_hip_event)
     if (int r = require_init()) return r;
     if (lane < 1 || lane > Context::NSIDE) return fail(SDFK_ERR_INVALID, "sdfk_lane_begin: lane %d out of range 1..%d", lane, Context::NSIDE);
     if (g.cur_lane != 0) return fail(SDFK_ERR_INVALID, "sdfk_lane_begin: already inside a lane section");
-    if (wait_hip_event) HIPCHK(hipStreamWaitEvent(g.lanes[lane].stream, (hipEvent_t)wait_hip_event, 0));
+    hipStream_t ls = lane_stream(lane);
+    if (wait_hip_event) HIPCHK(hipStreamWaitEvent(ls, (hipEvent_t)wait_hip_event, 0));
     g.cur_lane = lane;
-    g.stream = g.lanes[lane].stream;
+    g.stream = ls;
     return SDFK_OK;
 }
 
@@ -747,7 +777,7 @@ extern "C" int sdfk_lane_end(int32_t caller_stream_waits)
             HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             g.lane_done[lane] = ev;
         }
-        hipError_t e = hipEventRecord(ev, g.lanes[lane].stream);
+        hipError_t e = hipEventRecord(ev, lane_stream(lane));
         if (e == hipSuccess) e = hipStreamWaitEvent(g.lanes[0].stream, ev, 0);
         if (e != hipSuccess) return fail(SDFK_ERR_HIP, "sdfk_lane_end: %s", hipGetErrorString(e));
     }
@@ -1046,6 +1076,7 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     bind_thread();
     if (!v) return;
+    graph_jobs_forget_volume(v);   // (captured slab steps write into it)
     resolve_dependents(v);
     volume_values_changed(v);   // (drops the reference to the program that sampled it)
     // no sync: the pool is stream-ordered (every kernel and copy runs on g.stream, so a block
@@ -1318,9 +1349,9 @@ void job_release(sdfk_march_job* j, bool kernels_may_be_queued)
         if (kernels_may_be_queued) {
             hipError_t e = hipSuccess;
             if (!st.dropped) e = hipEventCreateWithFlags(&st.dropped, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(st.dropped, g.lanes[j->lane].stream);
+            if (e == hipSuccess) e = hipEventRecord(st.dropped, lane_stream(j->lane));
             if (e == hipSuccess) st.drop_pending = true;
-            else (void)hipStreamSynchronize(g.lanes[j->lane].stream);   // no event: wait here instead
+            else (void)hipStreamSynchronize(lane_stream(j->lane));   // no event: wait here instead
         }
         j->slot = -1;
     }
@@ -1872,6 +1903,14 @@ struct GraphJob {
     hipGraphExec_t exec = nullptr;
     uint64_t key = 0;
     sdfk_mesh* borrower = nullptr;  // the live handle whose arrays are proto's (at most one)
+    // slab form (sdfk_slab_enqueue): the caller's slab volume and send buffer, nothing borrowed, never "busy"
+    bool slab = false;
+    sdfk_volume* ext_vol = nullptr;
+    void* dst = nullptr;
+    int64_t capacity = 0;
+    int lb = 0, le = 0;
+    Context::Hint hint{};           // the size hints the capacities were derived from (other hints now: rebuild)
+    SampleArgs args;                // what sample_impl recorded in the volume (restored on every replay)
     hipEvent_t ran = nullptr;       // after the latest run (a handle dropped unread leaves its run in flight)
     bool busy = false, stale = false;
     size_t bytes = 0;
@@ -1881,7 +1920,7 @@ int g_graph_build_failures = 0;
 
 void graph_job_destroy(GraphJob* q)
 {
-    (void)hipStreamSynchronize(g.lanes[q->lane].stream);   // its kernels may still be queued
+    (void)hipStreamSynchronize(lane_stream(q->lane));   // its kernels may still be queued
     if (q->exec) (void)hipGraphExecDestroy(q->exec);
     if (q->graph) (void)hipGraphDestroy(q->graph);
     if (q->ran) (void)hipEventDestroy(q->ran);
@@ -1918,11 +1957,26 @@ void graph_job_retire(sdfk_mesh* m, bool too_small)
     m->graph_job = nullptr;
 }
 
+void graph_jobs_forget_volume(const sdfk_volume* v)
+{
+    for (size_t i = 0; i < g.graph_jobs.size();) {
+        if (g.graph_jobs[i]->slab && g.graph_jobs[i]->ext_vol == v) graph_job_destroy(g.graph_jobs[i]);   // (erases the entry)
+        else i++;
+    }
+}
+
 bool graphs_enabled(int64_t nvox)
 {
     const char* e = getenv("SDFK_GRAPHS");   // (read per call, like SDFK_LANES) 0: never, 1: launch-bound grids, 2: every grid
     const int mode = e ? atoi(e) : 1;
     return mode == 2 || (mode == 1 && nvox <= (int64_t(1) << 24));   // (measured: 64^3 35 -> 23.5 us per job, 128^3 33 -> 26, 256^3 42 -> 39; 320^3 and up 0-3 % slower)
+}
+
+bool graphs_enabled_slab(int64_t nvox)   // (a sharded step also pays for a collective call on the host: graphs pay up to larger slabs)
+{
+    const char* e = getenv("SDFK_GRAPHS");
+    const int mode = e ? atoi(e) : 1;
+    return mode == 2 || (mode == 1 && nvox <= (int64_t(1) << 25));
 }
 
 // Queue the job of (p, grid, clip, iso) on the current lane from a captured graph.  *out stays null when graphs do not
@@ -1937,7 +1991,7 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
     size_t alive = 0;
     for (size_t i = 0; i < g.graph_jobs.size();) {
         GraphJob* c = g.graph_jobs[i];
-        const bool same = c->prog == p && c->nx == nx && c->ny == ny && c->nz == nz && c->clip == clip && c->lane == lane &&
+        const bool same = !c->slab && c->prog == p && c->nx == nx && c->ny == ny && c->nz == nz && c->clip == clip && c->lane == lane &&
                           memcmp(&c->iso, &iso, 4) == 0 && memcmp(c->mn, mn, 12) == 0 && memcmp(c->mx, mx, 12) == 0;
         if (same && !c->busy && c->stale) { graph_job_destroy(c); continue; }   // (erases g.graph_jobs[i])
         if (same) alive++;
@@ -1974,7 +2028,7 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
         if (!r) r = launch_classify(q->job, false);
         if (!r) r = launch_emit(q->job, q->proto, 0);   // (allocates the AABB partials: the captured run below does not allocate)
         if (!r) {
-            hipStream_t st = g.lanes[lane].stream;
+            hipStream_t st = lane_stream(lane);
             hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 int rc = sample_impl(p, q->vol, clip, iso);
@@ -1999,7 +2053,7 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
     } else {
         if (hipEventQuery(q->ran) != hipSuccess) (void)hipEventSynchronize(q->ran);   // the previous run raises `overflow` in the slot itself
         g.slots[q->job->slot].c.overflow = 0;
-        const hipError_t e = hipGraphLaunch(q->exec, g.lanes[lane].stream);
+        const hipError_t e = hipGraphLaunch(q->exec, lane_stream(lane));
         if (e != hipSuccess) { (void)hipGetLastError(); q->stale = true; return SDFK_OK; }
         g.graph_launches++;
     }
@@ -2013,10 +2067,10 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
     m->graph_job = q;
     q->borrower = m;
     hipError_t e = hipEventCreateWithFlags(&m->done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(m->done, g.lanes[lane].stream);
-    if (e == hipSuccess) e = hipEventRecord(q->ran, g.lanes[lane].stream);
+    if (e == hipSuccess) e = hipEventRecord(m->done, lane_stream(lane));
+    if (e == hipSuccess) e = hipEventRecord(q->ran, lane_stream(lane));
     if (e != hipSuccess) {
-        (void)hipStreamSynchronize(g.lanes[lane].stream);
+        (void)hipStreamSynchronize(lane_stream(lane));
         if (m->done) (void)hipEventDestroy(m->done);
         m->borrowed = false; m->vertices = m->colors = m->normals = m->bounds = nullptr; m->triangles = nullptr;
         q->busy = false;
@@ -2031,6 +2085,90 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
     g.pending.push_back(m);
     while (g.pending.size() > Context::MAX_PENDING) (void)mesh_resolve(g.pending.front());
     *out = m;
+    return SDFK_OK;
+}
+
+// The same for a sharded step (sdfk_slab_enqueue on a lane): sample the caller's slab, mesh its layers straight into the
+// caller's send buffer, header written by the last kernel -- eleven launches as ONE hipGraphLaunch per step.  Key: program,
+// slab volume, clip, iso, layer range, destination and capacity, lane; the GraphJob keeps the job's workspace and result
+// slot, the mesh arrays ARE sections of the destination.  A step whose capacities were too small says so in its header
+// (every rank then redoes it exactly, sdfkit_amd/dist.py), which renews the size hints: a GraphJob built from other hints
+// than today's is rebuilt.  *handled stays false when graphs do not apply (the caller then takes the ordinary path).
+int graph_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int clip, float iso, int lb, int le, void* dst, int64_t capacity, bool* handled)
+{
+    *handled = false;
+    const int lane = g.cur_lane;
+    if (lane == 0 || g.prof_on || g.sampler_only || g_graph_build_failures >= 8) return SDFK_OK;
+    const uint64_t key = hint_key(slab, 1, lb, le);
+    auto hit = g.hints.find(key);
+    if (hit == g.hints.end()) return SDFK_OK;
+    const Context::Hint h = hit->second;
+    GraphJob* q = nullptr;
+    for (GraphJob* c : g.graph_jobs)
+        if (c->slab && c->prog == p && c->ext_vol == slab && c->clip == clip && memcmp(&c->iso, &iso, 4) == 0 && c->lb == lb && c->le == le &&
+            c->dst == dst && c->capacity == capacity && c->lane == lane) { q = c; break; }
+    if (q && memcmp(&q->hint, &h, sizeof h) != 0) { graph_job_destroy(q); q = nullptr; }
+    if (q) {
+        resolve_dependents(slab);
+        volume_values_changed(slab);
+        const hipError_t e = hipGraphLaunch(q->exec, lane_stream(lane));
+        if (e != hipSuccess) { (void)hipGetLastError(); graph_job_destroy(q); return SDFK_OK; }
+        // (what sample_impl leaves in the volume: its values, sign bits and colours are this program's output again)
+        sdfk_program* pp = const_cast<sdfk_program*>(p);
+        pp->refs++;
+        slab->sampled_by = pp;
+        slab->sampled_args = q->args;
+        slab->bits_iso = iso;
+        slab->bits_valid = true;
+        g.graph_launches++;
+        q->last_use = ++g.graph_clock;
+        *handled = true;
+        return SDFK_OK;
+    }
+    // build.  Cheap misfits first (nothing queued yet): they are not failures, the ordinary path packs instead.
+    if (slab->nx < 2 || slab->ny < 2 || slab->nz < 2 || lb >= le) return SDFK_OK;
+    sdfk_mesh* proto = nullptr;
+    if (!external_mesh((char*)dst, capacity, slab->colors != nullptr, h.nv, h.ni, &proto)) return SDFK_OK;
+    if (g.graph_jobs.size() >= 24) {
+        GraphJob* lru = nullptr;
+        for (GraphJob* c : g.graph_jobs)
+            if (!c->busy && (!lru || c->last_use < lru->last_use)) lru = c;
+        if (!lru) { sdfk_mesh_free(proto); return SDFK_OK; }
+        graph_job_destroy(lru);
+    }
+    q = new GraphJob();
+    q->slab = true;
+    q->prog = p; const_cast<sdfk_program*>(p)->refs++;
+    q->ext_vol = slab; q->clip = clip; q->iso = iso; q->lb = lb; q->le = le; q->dst = dst; q->capacity = capacity; q->lane = lane;
+    q->nx = slab->nx; q->ny = slab->ny; q->nz = slab->nz;
+    q->key = key; q->hint = h; q->proto = proto;
+    g.graph_jobs.push_back(q);
+    int r = sample_impl(p, slab, clip, iso);   // (outside the capture: loads the kernels, allocates the sign-bit arrays; this call's run)
+    if (!r) r = setup_job(slab, iso, 1, lb, le, (size_t)h.n_active + h.n_active / 4 + 4096, &q->job);
+    if (!r && (q->job->empty || !q->job->have_bits)) r = -1;
+    if (!r) r = launch_classify(q->job, false);
+    if (!r) r = launch_emit(q->job, q->proto, 0);
+    if (!r) {
+        q->args = slab->sampled_args;
+        hipStream_t st = lane_stream(lane);
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            int rc = sample_impl(p, slab, clip, iso);
+            if (!rc) rc = launch_classify(q->job, false);
+            if (!rc) rc = launch_emit(q->job, q->proto, 0);
+            e = hipStreamEndCapture(st, &q->graph);
+            if (e == hipSuccess && rc) e = hipErrorUnknown;
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&q->exec, q->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); r = -1; }
+    }
+    if (r) {   // (whatever was queued is harmless: the ordinary path redoes the step behind it on the same lane)
+        g_graph_build_failures++;
+        graph_job_destroy(q);
+        return SDFK_OK;
+    }
+    q->last_use = ++g.graph_clock;
+    *handled = true;
     return SDFK_OK;
 }
 
@@ -2198,6 +2336,14 @@ extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32
     if (r) return r;
     sdfk_mesh* m = nullptr;
     r = require_init();
+    if (!r && lane > 0 && graphs_enabled_slab((int64_t)slab->nx * slab->ny * slab->nz)) {   // the repeat step as ONE captured graph launch
+        bool handled = false;
+        r = graph_slab_enqueue(p, slab, clip_to_bounds ? 1 : 0, iso_value, layer_begin, layer_end, dst, capacity_bytes, &handled);
+        if (handled || r) {
+            const int r2 = sdfk_lane_end(1);
+            return r ? r : r2;
+        }
+    }
     if (!r) r = sample_impl(p, slab, clip_to_bounds, iso_value);
     // With size hints for this slab shape the mesh is emitted STRAIGHT into the payload at dst (its arrays are the
     // payload's sections, k_triangles writes the header): no pack launch, no second copy of the mesh.
@@ -2509,7 +2655,7 @@ extern "C" void sdfk_mesh_free(sdfk_mesh* m)
         hipEvent_t ev;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
             (void)hipEventRecord(ev, g.lanes[0].stream);
-            (void)hipStreamWaitEvent(g.lanes[m->lane].stream, ev, 0);
+            (void)hipStreamWaitEvent(lane_stream(m->lane), ev, 0);
             (void)hipEventDestroy(ev);
         }
     }

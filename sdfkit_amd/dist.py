@@ -328,7 +328,7 @@ class SlabSession:
         import os
         self.lanes = 2 if (self.mirror_headers and os.environ.get("SDFK_LANES", "2") != "0") else 0
         self.unfinished = None   # slot whose all-gather has been launched but not yet waited for / rebased
-        self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.copy_stream = None   # (created on first use: every stream of the process takes a hardware queue)
         self.queue = []          # slots in submission order
         self.next_slot = 0
         self.gathered = None     # gather buffer of the step collected last
@@ -378,6 +378,8 @@ class SlabSession:
             cur = torch.cuda.current_stream(self.device)
             done = torch.cuda.Event()
             done.record(cur)
+            if self.copy_stream is None:
+                self.copy_stream = torch.cuda.Stream(self.device)
             with torch.cuda.stream(self.copy_stream):
                 self.copy_stream.wait_event(done)
                 self.hdr_host[slot].copy_(self.gathered_slots[slot][:, :SLAB_HEADER_BYTES], non_blocking=True)

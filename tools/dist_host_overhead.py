@@ -32,6 +32,8 @@ for n in (64, 128, 512):
     ses.drain()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
-    print(f"n={n}: {dt*1e6:.1f} us per step (host + GPU, pipelined)")
+    a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+    N.check(N.lib().sdfk_graph_stats(C.byref(a), C.byref(b), C.byref(c)))
+    print(f"n={n}: {dt*1e6:.1f} us per step (host + GPU, pipelined); captured step graphs alive {a.value}, graph launches so far {b.value}, steps redone {ses.redone}")
     ses.close()
 dist.destroy_process_group()
