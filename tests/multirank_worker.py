@@ -27,7 +27,7 @@ om = O.march(ov, oc, mn, mx)
 N.init(0)
 ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, None, torch.device("cuda", 0), depth=3)
 ok = True
-for it in range(8):
+for it in range(16):
     if len(ses.queue) == ses.depth:
         ses.collect()
         m = ses.mesh()
@@ -39,6 +39,12 @@ while ses.queue:
     ses.collect()
     m = ses.mesh()
     ok &= np.array_equal(m.Triangles, om.triangles) and np.array_equal(m.Vertices, om.vertices)
+import ctypes as C
+jobs, launches = C.c_int64(), C.c_int64()
+N.check(N.lib().sdfk_graph_stats(C.byref(jobs), C.byref(launches), None))
+if os.environ.get("SDFK_GRAPHS", "1") != "0" and os.environ.get("SDFK_LANES", "2") not in ("0", "1"):
+    # the repeat steps were captured step graphs (one per slot and lane), replayed from their second use on
+    ok &= jobs.value >= 1 and launches.value >= 1
 ses.close()
 dist.barrier()
 dist.destroy_process_group()
