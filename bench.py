@@ -346,18 +346,27 @@ def main():
     gc.disable()   # (no collector pause inside the timed region; collected HERE, before the warm-up: a collection takes
                    # milliseconds during which the GPU idles, and an idle GPU drops its clocks)
     barrier()
-    t0 = time.perf_counter()
     for _ in range(n_warm):
         nv, ni = step()
     nv, ni = drain()
     barrier()
+    # (what a step costs once the pools are filled: a second, short batch -- the first one contains one-off costs, device
+    # allocations of half a GB each for one, and on a box that had never run the program before they made the estimate
+    # 40 times too large and the clock warm-up below 9 steps long)
+    n_est = 8
+    t0 = time.perf_counter()
+    for _ in range(n_est):
+        nv, ni = step()
+    nv, ni = drain()
+    barrier()
+    t_est = time.perf_counter() - t0
     # Clock warm-up, untimed: after an idle period the GPU needs 10-15 ms of load to reach its sustained clocks
     # (tools/step_transient_probe.py, 512^3 sphere: 0.20 ms per step over the first 20 steps after >= 20 ms of idling,
     # 0.169 ms from the 80th step on) -- the W warm-up steps of a default run are 1 ms.  So the same step keeps running
     # for SDFK_BENCH_CLOCK_WARM_MS (default 80 ms; 0 = off) before the timed region; the count is derived from the
     # slowest rank's warm-up time so that every rank queues the same number of steps (matched collectives).
     warm_ms = float(os.environ.get("SDFK_BENCH_CLOCK_WARM_MS", "80"))
-    per_warm = torch.tensor([(time.perf_counter() - t0) / n_warm], dtype=torch.float64, device=dev if (world > 1 and backend == "nccl") else "cpu")
+    per_warm = torch.tensor([t_est / n_est], dtype=torch.float64, device=dev if (world > 1 and backend == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(per_warm, op=dist.ReduceOp.MAX)
     n_clock = 0 if warm_ms <= 0 else min(4000, int(warm_ms * 1e-3 / max(float(per_warm.item()), 1e-6)) + 1)
@@ -626,7 +635,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, RCCL all-gather of slab meshes"},
             "value_is": ("throughput of the pipelined steady state: five identical jobs in flight on the library's three internal streams, "
                          "buffers sized from the previous mesh of the shape; see latency_ms_single_stream / first_call_ms for one call"),
-            "untimed_steps_before_timing": {"warmup": n_warm, "clock_warmup": n_clock,
+            "untimed_steps_before_timing": {"warmup": n_warm + n_est, "clock_warmup": n_clock,
                                             "why": "W + 4 steps fill the allocator's pools; then the same step runs for ~80 ms so that the GPU is at "
                                                    "its sustained clocks when the K timed steps start (after idling it needs 10-15 ms of load: "
                                                    "0.20 -> 0.169 ms per step at 512^3, tools/step_transient_probe.py); SDFK_BENCH_CLOCK_WARM_MS=0 switches it off"},
