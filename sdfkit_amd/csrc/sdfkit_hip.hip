@@ -91,6 +91,10 @@ struct Context {
     int cur_lane = 0;
     int side_lanes = 2;         // SDFK_LANES=0 disables the side lanes (everything on lane 0)
     int next_side = 0;
+    // phase tokens of the self-contained jobs on the lanes (see phase_token): kind 0 = sampling kernel, 1 = k_vertices
+    struct Token { hipEvent_t ring[8] = {}; int next = 0; hipEvent_t last = nullptr; int last_lane = -1; };
+    Token tokens[2];
+    int token_mask = 0;         // kinds active for the job being queued (set by sdfk_sample_march)
     struct Block { size_t size; int lane; };
     std::map<void*, Block> live_blocks;
     // profiling
@@ -197,6 +201,30 @@ hipStream_t lane_stream(int k)
         }
     }
     return g.lanes[k].stream;
+}
+
+// Phase tokens.  Left alone, the jobs on the three lanes fall into lock-step (a kernel trace shows pairs of sampling kernels
+// starting together, then pairs of k_vertices): two sampling kernels side by side share the HBM write rate and take 182 us
+// where one takes 80, two k_vertices share the CUs and take 135-143 us where one takes 57 -- same-phase overlap is a loss
+// for exactly these two kernels.  A token per phase keeps them apart: the kernel waits for the event recorded after the
+// previous job's kernel of the same kind (on another lane), so that a sampling kernel runs beside the meshing kernels of
+// the other jobs instead of beside another sampling kernel.
+void phase_token_wait(int kind)
+{
+    Context::Token& t = g.tokens[kind];
+    if (!((g.token_mask >> kind) & 1) || !t.last || t.last_lane == g.cur_lane) return;
+    (void)hipStreamWaitEvent(g.stream, t.last, 0);
+}
+void phase_token_pass(int kind)
+{
+    Context::Token& t = g.tokens[kind];
+    if (!((g.token_mask >> kind) & 1)) return;
+    hipEvent_t& e = t.ring[t.next];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; return; }
+    if (hipEventRecord(e, g.stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    t.last = e;
+    t.last_lane = g.cur_lane;
+    t.next = (t.next + 1) % 8;
 }
 
 struct LaneScope {
@@ -1243,6 +1271,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
             if (int r = program_fn(p, (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode, &fn)) return r;
             ProfScope ps(names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
             const size_t plane = (size_t)v->ny * v->pitch();
+            phase_token_wait(0);
             if (mode == 1) {
                 const dim3 fg = flat_grid(plane, v->nx8());
                 HIPCHK(hipModuleLaunchKernel(fn, fg.x, fg.y, fg.z, tpb, 1, 1, 0, g.stream, params, nullptr));
@@ -1251,6 +1280,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
                 HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
                                              (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
         }
+        phase_token_pass(0);
         if (g.sampler_only) {   // measurement mode (sdfk_profile_enable(2)): the sampling kernel alone, back to back
             v->bits_valid = false;
             return SDFK_OK;
@@ -1620,11 +1650,13 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     }
     M.bounds = m->bounds;
     M.host_bounds = g.slots_dev[j->slot].bounds;
+    phase_token_wait(1);
     {
         ProfScope ps("k_vertices");
         hipLaunchKernelGGL(k_vertices, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
         HIPCHK(hipGetLastError());
     }
+    phase_token_pass(1);
     if (vcol) {
         struct VColArgs { const uint2* vdesc; const uint32_t* rec_xy; const uint32_t* rec_z; const McCounters* counters; float* colors;
                           uint32_t cap_vertices; int32_t xbits; float iso; } V;   // (= VColArgs of sample_codegen.h)
@@ -2433,8 +2465,18 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     int r = sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
     if (r) return r;
     r = require_init();
+    {
+        // (read per call) bit 0: sampling kernels apart, bit 1: k_vertices apart.  Default: the sampling kernels of grids from
+        // 2^27 voxels up (512^3 sphere 0.162 -> 0.156 ms per step, 768^3 0.475 -> 0.462, 1024^3 1.12-1.20 -> 1.10, README scene
+        // 0.49 -> 0.478; 384^3 and below lose 2-3 %: there a sampling kernel is too short to be worth a cross-stream wait).
+        // k_vertices apart costs 2-3 % at every size: its workgroups are long-lived, and a second one fills the first one's tail.
+        const char* et = getenv("SDFK_TOKENS");
+        const int dflt = (int64_t)nx * ny * nz >= (int64_t(1) << 27) ? 1 : 0;
+        g.token_mask = (lane > 0 && g.side_lanes > 1) ? (et ? atoi(et) : dflt) : 0;
+    }
     if (!r) r = sample_impl(p, v, clip_to_bounds, step == 1 ? iso_value : 0.0f);
     if (!r) r = sdfk_march(v, iso_value, step, out);
+    g.token_mask = 0;
     if (!r && (*out)->pending && (*out)->src == v) (*out)->owns_src = true;   // freed when the mesh is resolved
     else sdfk_volume_free(v);
     return r;
