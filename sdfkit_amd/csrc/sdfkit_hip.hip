@@ -732,6 +732,10 @@ extern "C" void sdfk_shutdown(void)
     for (auto e : g.prof_event_pool) (void)hipEventDestroy(e);
     g.prof_event_pool.clear();
     sync_all_lanes();
+    for (auto& t : g.tokens) {   // (phase tokens: nothing is queued any more)
+        for (auto& e : t.ring) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        t.last = nullptr; t.last_lane = -1; t.next = 0;
+    }
     for (auto& lane : g.lanes) {
         for (auto& kv : lane.free_blocks) (void)hipFree(kv.second);
         lane.free_blocks.clear();
