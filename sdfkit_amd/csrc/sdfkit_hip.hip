@@ -162,7 +162,13 @@ int dev_alloc(void** p, size_t n)
         g.live_blocks[*p] = Context::Block{c, g.cur_lane};
         return SDFK_OK;
     }
-    hipError_t e = hipMalloc(p, c);
+    // Experiment knob (SDFK_UNCACHED_MIN_MB=n): blocks of at least n MiB -- the volumes -- as uncached device memory
+    // (hipDeviceMallocUncached).  512^3 sphere: the sampling kernel alone 82 -> 75.6 us per back-to-back launch (7.3 TB/s, 0.915
+    // of the 8 TB/s peak: the store path through L2, not the HBM, sets the 6.7-6.9 TB/s of a plain fill), pipelined step
+    // unchanged; 1024^3: kernel unchanged (702 us), step 4 % slower; README scene: kernel alone 9 % slower, step 4 % faster.
+    // Off by default: no setting is better everywhere.
+    static const long unc_mb = getenv("SDFK_UNCACHED_MIN_MB") ? atol(getenv("SDFK_UNCACHED_MIN_MB")) : 0;
+    hipError_t e = (unc_mb > 0 && c >= (size_t)unc_mb << 20) ? hipExtMallocWithFlags(p, c, hipDeviceMallocUncached) : hipMalloc(p, c);
     if (e != hipSuccess) {
         // drop the caches and retry once (hipFree waits for the device: no block is in use after it)
         for (auto& lane : g.lanes) {
