@@ -63,6 +63,33 @@ def test_many_queued_meshes_read_late_and_out_of_order(gpu):
         assert_mesh_equal(m, oracle_mesh(scene, MN, MX, dims, True))
 
 
+def test_phase_tokens_do_not_change_results(gpu):
+    """SDFK_TOKENS (sdfkit_hip.hip, phase_token_wait/pass): the sampling kernels / k_vertices of consecutive jobs on the
+    lanes wait for each other's events.  Forced on for small grids here (the default applies them from 2^27 voxels up),
+    graphs off so that every job takes the ordinary path: many jobs in flight, two scenes, read late."""
+    before = {k: os.environ.get(k) for k in ("SDFK_TOKENS", "SDFK_GRAPHS")}
+    os.environ["SDFK_GRAPHS"] = "0"
+    try:
+        for mask in ("1", "3", "2"):
+            os.environ["SDFK_TOKENS"] = mask
+            jobs = []
+            for rep in range(4):
+                for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("union8", (36, 40, 32))):
+                    scene, sdf = S.CATALOGUE[name]()
+                    jobs.append((scene, dims, raw_sample_march(sdf, MN, MX, dims, True), sdf))
+                    if len(jobs) > 5:
+                        scene0, dims0, h0, _ = jobs.pop(0)
+                        assert_mesh_equal(Mesh._from_handle(h0), oracle_mesh(scene0, MN, MX, dims0, True))
+            for scene0, dims0, h0, _ in jobs:
+                assert_mesh_equal(Mesh._from_handle(h0), oracle_mesh(scene0, MN, MX, dims0, True))
+    finally:
+        for k, v in before.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_unread_meshes_can_be_freed(gpu):
     """Nobody ever reads these: freeing a pending mesh must neither wait nor corrupt later work
     (more jobs than the ring of result slots)."""
