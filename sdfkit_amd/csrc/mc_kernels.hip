@@ -254,6 +254,19 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     int y = 0, xw = 0;
     // the count pass recorded which wavefronts found nothing: those skip the sign words here
     const bool look = !WRITE || P.wavecnt[b * 4 + (int)(threadIdx.x >> 6)] != 0;
+    // write pass: this lane's share of the counts of all earlier blocks, loaded HERE (four independent loads per trip, in
+    // flight together with the sign words below) -- a plain "load; add" loop after the words cost up to eight dependent L2
+    // round trips for the last blocks of a 512^3 grid
+    uint32_t before = 0;
+    if (WRITE) {
+        for (int i = threadIdx.x; i < b; i += 1024) {
+            const uint32_t c0 = (uint32_t)P.blockcnt[i];
+            const uint32_t c1 = i + 256 < b ? (uint32_t)P.blockcnt[i + 256] : 0u;
+            const uint32_t c2 = i + 512 < b ? (uint32_t)P.blockcnt[i + 512] : 0u;
+            const uint32_t c3 = i + 768 < b ? (uint32_t)P.blockcnt[i + 768] : 0u;
+            before += (c0 + c1) + (c2 + c3);
+        }
+    }
     if (i0 < nseg) {
         y = i0 / P.nxw;
         xw = i0 - y * P.nxw;
@@ -294,8 +307,6 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     }
     // exclusive prefix of this block = sum of the counts of all earlier blocks (a few thousand
     // words, read cooperatively: cheaper than a separate scan launch)
-    uint32_t before = 0;
-    for (int i = threadIdx.x; i < b; i += 256) before += (uint32_t)P.blockcnt[i];
     uint32_t total;
     const uint32_t pre = block_excl_scan_u32(cnt, before, &total);   // also reduces `before` over the workgroup
     if (b == (int)gridDim.x - 1) {   // the last block publishes the totals and the layer marks
@@ -350,15 +361,32 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
 // Sum of the per-chunk (vertices << 31 | triangles) totals of chunks [from, to) over the
 // workgroup (a few thousand words at most, L2 resident): every workgroup derives the prefix of
 // its own chunk this way instead of waiting for a separate scan launch.
-__device__ __forceinline__ uint64_t chunk_totals_sum(const uint64_t* chunktot, uint32_t from, uint32_t to, uint64_t* s_part /*[4]*/)
+// (in two halves, so that a caller can issue these loads together with its other loads: the lane's share, four
+// independent loads per trip -- a plain "load; add" loop is not pipelined by the compiler and costs one L2 round trip per
+// 256 chunks, eight in a row for the last workgroups of a 512^3 sphere --, then the workgroup's sum)
+__device__ __forceinline__ uint64_t chunk_totals_lane(const uint64_t* chunktot, uint32_t from, uint32_t to)
 {
     uint64_t v = 0;
-    for (uint32_t i = from + threadIdx.x; i < to; i += 256u) v += chunktot[i];
+    for (uint32_t i = from + threadIdx.x; i < to; i += 1024u) {
+        const uint64_t a = chunktot[i];
+        const uint64_t b = i + 256u < to ? chunktot[i + 256u] : 0ull;
+        const uint64_t c = i + 512u < to ? chunktot[i + 512u] : 0ull;
+        const uint64_t d = i + 768u < to ? chunktot[i + 768u] : 0ull;
+        v += (a + b) + (c + d);
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t chunk_totals_block(uint64_t v, uint64_t* s_part /*[4]*/)
+{
     v = wave_sum_u64(v);
     __syncthreads();   // s_part may still be read from a previous call
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
     __syncthreads();
     return s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+__device__ __forceinline__ uint64_t chunk_totals_sum(const uint64_t* chunktot, uint32_t from, uint32_t to, uint64_t* s_part /*[4]*/)
+{
+    return chunk_totals_block(chunk_totals_lane(chunktot, from, to), s_part);
 }
 
 // Grand totals, the vertex count of the ghost layer, dead cells: published to the device
@@ -791,6 +819,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int w = i >= nrs, k = w ? i - nrs : i;
             s_rs[w][k] = min(P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)], n);   // never past the stored records
         }
+        uint64_t prefix_lane = 0;
         {
             const uint32_t wtot = w1_cnt + w2_cnt;
             uint32_t rxy[3], rin[3];
@@ -806,6 +835,8 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     rhi[k] = *reinterpret_cast<const float4*>(P.rec_corners + (size_t)g * 8 + 4);
                 }
             }
+            // (the totals of the chunks before this one ride in the same batch of loads)
+            prefix_lane = chunk_totals_lane(P.chunktot, prefix_upto, base >> 8);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const uint32_t slot = threadIdx.x + 256u * k;
@@ -820,7 +851,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         }
         // chunk prefix = totals of all earlier chunks (advanced incrementally when a workgroup
         // takes more than one chunk); left in chunkpre[] for k_triangles
-        chunk_prefix += chunk_totals_sum(P.chunktot, prefix_upto, base >> 8, s_part);
+        chunk_prefix += chunk_totals_block(prefix_lane, s_part);
         prefix_upto = base >> 8;
         if (threadIdx.x == 0) P.chunkpre[base >> 8] = chunk_prefix;
         const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs: LDS is complete)
@@ -1126,6 +1157,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_ni = 0;
         __syncthreads();
+        const uint64_t chunk_pre = P.chunkpre[base >> 8];   // left by k_vertices (loaded with the records: not a round trip of its own after the scan)
         if (irec < n) {
             const uint32_t info = P.rec_info[irec];
             my_ni = 3u * ((info >> 14) & 15u);
@@ -1137,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             for (uint32_t k = 0; 3u * k < my_ni; k++) s_cell[t0 + k] = (uint8_t)threadIdx.x;
         }
         __syncthreads();
-        const size_t chunk_ibase = (size_t)(P.chunkpre[base >> 8] & 0x7fffffffull) * 3;   // left by k_vertices
+        const size_t chunk_ibase = (size_t)(chunk_pre & 0x7fffffffull) * 3;
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
             const size_t o = chunk_ibase + j;   // serial position of this triangle index
             if (o >= M.cap_indices) { P.host_counters->overflow = 1u; continue; }
