@@ -302,21 +302,27 @@ def main():
         depth = [depth_env or 5]
         inflight, last = [], [0, 0]
 
+        # (the foreign-call arguments are built once: on launch-bound grids a step is ~25 us, and the interpreter's share counts)
+        mn_c, mx_c, iso_c, clip_c = N.f3(mn), N.f3(mx), C.c_float(0.0), 1 if clip else 0
+        cnt_a, cnt_b = C.c_int64(), C.c_int64()
+        ref_a, ref_b = C.byref(cnt_a), C.byref(cnt_b)
+        f_march, f_counts, f_free, check = L.sdfk_sample_march, L.sdfk_mesh_counts, L.sdfk_mesh_free, N.check
+
         def retire(m):
-            a, b = C.c_int64(), C.c_int64()
-            N.check(L.sdfk_mesh_counts(m, C.byref(a), C.byref(b)))
-            L.sdfk_mesh_free(m)
-            if last[0] and (a.value, b.value) != tuple(last):
-                raise SystemExit(f"mesh changed between steps: {last} -> {(a.value, b.value)}")
-            last[0], last[1] = a.value, b.value
+            check(f_counts(m, ref_a, ref_b))
+            f_free(m)
+            a, b = cnt_a.value, cnt_b.value
+            if last[0] and (a != last[0] or b != last[1]):
+                raise SystemExit(f"mesh changed between steps: {last} -> {(a, b)}")
+            last[0], last[1] = a, b
 
         def step():
             m = C.c_void_p()
-            N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+            check(f_march(prog, mn_c, mx_c, n, n, n, clip_c, iso_c, 1, C.byref(m)))
             inflight.append(m)
             while len(inflight) > depth[0]:
                 retire(inflight.pop(0))
-            return tuple(last)
+            return last
 
         def drain():
             while inflight:
