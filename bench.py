@@ -10,8 +10,10 @@ writes the volume to HBM, the marching-cubes pipeline reads it and leaves the in
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-N > 1: the SAME 512^3 grid is sharded by Z slab over the ranks (strong scaling), with an RCCL
-all-gather of the slab meshes (sdfkit_amd/dist.py).  Rank 0 prints ONE JSON line.
+N > 1: the SAME 512^3 grid is sharded by Z slab over the ranks (strong scaling); the exchange of the slab
+meshes is done by the LIBRARY, which calls RCCL itself on its own stream (sdfk_dist_*: include/sdfkit_hip.h,
+csrc/dist_rccl.h) -- torch.distributed here only hands the RCCL id round and provides the barrier / max-over-ranks
+of the timing contract (a gloo group: no second communicator, no torch streams on the GPU).  Rank 0 prints ONE JSON line.
 Started as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) it launches
 `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself, as a CHILD process,
 before anything in this process has touched the GPU, and relays rank 0's JSON line.
@@ -60,7 +62,8 @@ def launch_ranks(argv, n):
     tries = [({}, "")]
     # a second, conservative attempt if the pipelined form fails on this node: one step in flight,
     # no internal lanes (same protocol, same kernels)
-    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0"}, "retry: one step in flight, no lanes"))
+    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0", "SDFK_DIST_LANES": "0", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1"},
+                  "retry: one step in flight, no lanes, plain ncclAllGather"))
     rc = 1
     for extra, note in tries:
         e = dict(env)
@@ -210,28 +213,32 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    backend = None
-    force_dist = os.environ.get("SDFK_BENCH_FORCE_DIST") == "1"   # exercise the sharded path on one rank
-    # (the process group comes BEFORE the library's sdfk_init: RCCL's stream then takes its hardware queue first and no
-    # lane of the library ends up sharing one with it -- see GPU_MAX_HW_QUEUES in sdfk_init; the other order costs the
-    # pipelined sharded step a factor 3, tools/hwq_probe.py)
-    if world == 1 and force_dist:
+    force_dist = os.environ.get("SDFK_BENCH_FORCE_DIST") == "1"   # exercise the sharded path on one rank (real RCCL, world 1)
+    sharded = world > 1 or force_dist
+    # Control plane: a gloo group (barrier, max-over-ranks of the timings, handing the RCCL id round).  Data plane: the
+    # library's own RCCL communicator and exchange stream (sdfk_dist_init) -- or, with every rank on ONE GPU (testing), the
+    # library's host transport over the same gloo group.  No torch NCCL group: it would be a second communicator and two
+    # more streams competing for the hardware queues (see GPU_MAX_HW_QUEUES above).
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        backend = "nccl"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "gloo" if one_gpu else "nccl"
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # (the container's hostname may not resolve)
         import datetime
         # (a short collective timeout: a rank that died must fail the run -- and let the launcher retry -- instead of hanging it)
-        if one_gpu:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
-        else:
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     N.init(local_rank)
     L = N.lib()
-    stream = N.bind_torch_stream(dev)   # torch (RCCL, events) and the library on one explicit stream
+    # torch events (the roofline pass) and the library's lane 0 on one explicit stream.  NOT for a sharded run: it uses no
+    # torch GPU work at all, and one more stream in the process changes which of them share a hardware queue (a sharded step
+    # on a small slab: 94 us with the extra stream, 39 us without -- tools/slab_step_trace.py)
+    stream = None if sharded else N.bind_torch_stream(dev)
+    if sharded:
+        if one_gpu and world > 1:
+            D.init_host(device=local_rank)
+        else:
+            D.init(device=local_rank)
+    backend = {0: None, 1: "RCCL, called by the library (librccl via dlopen, own exchange stream)", 2: "host transport (gloo all-gather; ranks share one GPU)"}[D.info()[2]]
 
     n = args.n
     sdf, mn, mx, clip = scene_for(args.scene)
@@ -272,15 +279,12 @@ def main():
                          "allocated from the driver")
         if not args.minimal:
             # the same first call when the machine has never seen the program: a fresh Sdf object, cache off
-            os.environ["SDFK_NO_CACHE"] = "1"
-            try:
+            with N.option(N.OPT_CODE_CACHE, 0):
                 cold_sdf = scene_for(args.scene)[0]
                 t0 = time.perf_counter()
                 cold_sdf.ToMesh(mn, mx, 8, 8, n, clipToBounds=clip)     # same sampler instantiation (same row length), tiny grid
                 first["cold_first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
                 del cold_sdf
-            finally:
-                del os.environ["SDFK_NO_CACHE"]
     first_call_ms = round(first["program_ms"] + first.get("first_mesh_ms", 0.0), 2)
 
     def barrier():
@@ -288,7 +292,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded = world > 1 or force_dist
+    def max_over_ranks(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # steps in flight: the GPU then holds ~1 ms of queued work, so that a hiccup of the host (an interrupt, the interpreter)
     # inside the 3 ms timed region of the driver's 20-step command does not drain the pipeline (3 and 6 in flight give the
     # same steady state; with 3 one run in five came out 5-10 % slow)
@@ -329,20 +339,20 @@ def main():
                 retire(inflight.pop(0))
             return tuple(last)
     else:
-        # three steps in flight, one RCCL all-gather per step, no host wait inside a step
-        # (sdfkit_amd/dist.py: SlabSession)
-        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, None, dev, depth=depth_env or 3, headroom=1.0 / 32)
-        totals = torch.zeros(2, dtype=torch.int64, device=dev)
+        # three steps in flight, one exchange per step issued by the library on its own stream, no host wait inside a step
+        # (sdfk_dist_session_*: csrc/slab_protocol.h + csrc/dist_rccl.h)
+        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 3)
         last = [0, 0]
+        tuned = None
 
         def step():
-            if len(worker.queue) == worker.depth:
+            if worker.in_flight == worker.depth:
                 last[0], last[1] = worker.collect()
             worker.submit()
             return tuple(last)
 
         def drain():
-            while worker.queue:
+            while worker.in_flight:
                 last[0], last[1] = worker.collect()
             return tuple(last)
 
@@ -356,6 +366,10 @@ def main():
         nv, ni = step()
     nv, ni = drain()
     barrier()
+    if sharded and world > 1 and D.info()[2] == 1 and os.environ.get("SDFK_BENCH_NO_TUNE") != "1":
+        # which exchange is faster on this node's fabric is measured, untimed: ncclAllGather against direct grouped sends
+        tuned = worker.tune(20)
+        barrier()
     # (what a step costs once the pools are filled: a second, short batch -- the first one contains one-off costs, device
     # allocations of half a GB each for one, and on a box that had never run the program before they made the estimate
     # 40 times too large and the clock warm-up below 9 steps long)
@@ -372,10 +386,8 @@ def main():
     # for SDFK_BENCH_CLOCK_WARM_MS (default 80 ms; 0 = off) before the timed region; the count is derived from the
     # slowest rank's warm-up time so that every rank queues the same number of steps (matched collectives).
     warm_ms = float(os.environ.get("SDFK_BENCH_CLOCK_WARM_MS", "80"))
-    per_warm = torch.tensor([t_est / n_est], dtype=torch.float64, device=dev if (world > 1 and backend == "nccl") else "cpu")
-    if world > 1:
-        dist.all_reduce(per_warm, op=dist.ReduceOp.MAX)
-    n_clock = 0 if warm_ms <= 0 else min(4000, int(warm_ms * 1e-3 / max(float(per_warm.item()), 1e-6)) + 1)
+    per_warm = max_over_ranks(t_est / n_est)
+    n_clock = 0 if warm_ms <= 0 else min(4000, int(warm_ms * 1e-3 / max(per_warm, 1e-6)) + 1)
     for _ in range(n_clock):
         nv, ni = step()
     nv, ni = drain()
@@ -387,46 +399,62 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    # The same K steps with COLD clocks: the GPU idles long enough to drop its clocks, then W warm-up steps and K timed ones
+    # -- what the driver's command measures without the clock warm-up above (the headline `value` has it, and says so).
+    time.sleep(0.25)
+    barrier()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    drain()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    drain()
+    barrier()
+    dt_cold = max_over_ranks(time.perf_counter() - t0)
     per_rank = None
-    if sharded:   # per-rank counts -> totals of the whole mesh (outside the timed region)
-        mine = torch.tensor([nv, ni], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
-        allc = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allc, mine)
-        per_rank = [[int(t[0]), int(t[1])] for t in allc]
+    if sharded:   # per-rank counts -> totals of the whole mesh (from the gathered headers of the last step)
+        per_rank = [list(c) for c in worker.counts()]
         nv, ni = sum(p[0] for p in per_rank), sum(p[1] for p in per_rank)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
     ms_step = dt / args.steps * 1e3
 
     # ---- the sharded step without its exchange: this rank's slab kernels alone, queued back to back
     # (what "kernel-only" means at N > 1); max over ranks
     dist_extra = {}
     if sharded:
-        w0 = worker.workers[0]
+        st = worker.stats()
         for _ in range(3):
-            w0.enqueue(worker.buf[0])
+            worker.enqueue_only()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            w0.enqueue(worker.buf[0])
+            worker.enqueue_only()
         torch.cuda.synchronize()
-        tk = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        tk = max_over_ranks(time.perf_counter() - t0)
         barrier()
-        recv = (world - 1) * worker.stride
-        dist_extra = {"world": world, "backend": ("RCCL (torch.distributed nccl)" if backend == "nccl" else backend),
-                      "backend_world_size": dist.get_world_size(), "per_rank_vertices_indices": per_rank,
-                      "slab_kernels_only_ms": round(float(tk.item()) / args.steps * 1e3, 4),
+        stride = st["stride_bytes"]
+        mode = st["exchange_mode"]
+        recv = (world - 1) * stride
+        dist_extra = {"world": world, "backend": backend,
+                      "exchange": {-1: "host transport", 0: "ncclAllGather (in place)", 1: "grouped ncclSend / ncclRecv to every peer (all xGMI links at once)",
+                                   2: "grouped sends to rank 0 only (headers to everybody)"}[mode],
+                      "exchange_tuned_ns": tuned,
+                      "per_rank_vertices_indices": per_rank,
+                      "slab_kernels_only_ms": round(tk / args.steps * 1e3, 4),
                       "end_to_end_ms": round(ms_step, 4),
-                      "gather_stride_bytes_per_rank": int(worker.stride), "gather_bytes_received_per_rank": int(recv),
+                      "host_us_per_step": {"submit": round(st["host_ns_submit"] / max(st["steps"], 1) / 1e3, 2),
+                                           "collect": round(st["host_ns_collect"] / max(st["steps"], 1) / 1e3, 2),
+                                           "what": "host time inside sdfk_dist_submit (queueing a step: one captured graph launch + the exchange + the "
+                                                   "rebase kernel) and sdfk_dist_collect (waiting for the oldest step), averaged over every step of "
+                                                   "this run; collect includes waiting for the GPU"},
+                      "gather_stride_bytes_per_rank": int(stride), "gather_bytes_received_per_rank": int(recv),
                       "xgmi": {"links_per_gpu": XGMI_LINKS, "gbs_per_link_per_direction": XGMI_LINK_GBS_PER_DIRECTION,
                                "receive_bound_ms": round(recv / (min(world - 1, XGMI_LINKS) * XGMI_LINK_GBS_PER_DIRECTION * 1e9) * 1e3, 4) if world > 1 else 0.0,
                                "what": "every rank must RECEIVE the other ranks' slab meshes each step: bytes received / (links used x per-direction "
                                        "link rate) is a floor for the step time whatever the kernels do"},
-                      "steps_redone_on_the_exact_path": worker.redone}
+                      "steps_redone_on_the_exact_path": st["redone"], "stride_regrowths": st["regrown"]}
         if os.environ.get("SDFK_BENCH_NOTE"):
             dist_extra["note"] = os.environ["SDFK_BENCH_NOTE"]
 
@@ -435,8 +463,8 @@ def main():
     # jobs stay queued ahead (no host bubbles) but on ONE in-order stream: a kernel's roofline is
     # about the kernel having the GPU to itself, not about how it shares the chip with the
     # previous step's kernels on the other internal stream.
-    lanes_env = os.environ.get("SDFK_LANES")
-    os.environ["SDFK_LANES"] = "0"   # (read by the library per call) every job on ONE in-order stream
+    lanes_before = N.get_option(N.OPT_LANES)
+    N.set_option(N.OPT_LANES, 0)      # every job on ONE in-order stream
     N.check(L.sdfk_profile_reset())
     N.check(L.sdfk_profile_enable(1))
     for _ in range(args.steps):
@@ -459,10 +487,7 @@ def main():
         for _ in range(args.steps):
             sample_march_once()
         latency_ms = (time.perf_counter() - t0) / args.steps * 1e3
-    if lanes_env is None:
-        del os.environ["SDFK_LANES"]
-    else:
-        os.environ["SDFK_LANES"] = lanes_env
+    N.set_option(N.OPT_LANES, lanes_before)
 
     # The roofline kernel on its own: K back-to-back launches of the fused sampling kernel into a
     # resident volume (sdfk_sample), HIP event pairs around each launch on the launch stream.  In
@@ -591,15 +616,16 @@ def main():
             for kind in ("pinned", "managed", "numpy"):
                 ts = [one_call(kind) for _ in range(5)]
                 d2h[kind] = {"median_ms": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "all_ms": [round(t, 3) for t in ts]}
-            extra["one_step_incl_mesh_d2h_ms"] = d2h["pinned"]["median_ms"]
+            extra["one_step_incl_mesh_d2h_ms"] = d2h["managed"]["median_ms"]
             extra["one_step_incl_mesh_d2h"] = {
                 "what": "sdfk_sample_march + sdfk_mesh_counts + sdfk_mesh_copy of V/C/N/T to the host + sdfk_mesh_bounds, one call at a time; "
-                        "median of 4 calls after a warm-up call.  pinned = destination arrays from the library's pinned host arena (the Python "
-                        "mirror's Mesh; the headline figure); managed = freshly mapped, never touched 4 KiB-page memory, as a managed runtime's "
-                        "new arrays are (the library pre-faults it on its thread pool); numpy = fresh numpy.empty arrays (huge-page advised)",
+                        "median of 4 calls after a warm-up call.  managed (the headline figure: what a C# caller gets, Mesh.cs:10-13) = freshly "
+                        "mapped, never touched 4 KiB-page memory, as a managed runtime's new arrays are (the library pre-faults it on its thread "
+                        "pool); pinned = destination arrays from the library's pinned host arena (the Python mirror's Mesh, Span<T> accessors of a "
+                        "shim); numpy = fresh numpy.empty arrays (huge-page advised)",
                 **d2h}
     if rank == 0:
-        nvox_rank = n * n * (D.slab_planes(*D.slab_layers(n - 1, world, rank), n)[1] if world > 1 else n)
+        nvox_rank = n * n * (D.slab(n, world, rank)[3] if world > 1 else n)
         colors = bool(sdf.writes_color)
         # algorithmic bytes per launch: sample stores 4 B/voxel (+12 B colour),
         # signbits loads 4 B/voxel; candidates for "dominant kernel"
@@ -621,12 +647,26 @@ def main():
                                "volumes in turn), divided by K" if own else
                                "hipEvent pairs around each launch on the launch stream, K-step pipeline pass on ONE in-order stream")
                               + "; the timed pass overlaps consecutive steps on three streams, which stretches every kernel"}
-        total_alg = n ** 3 * (32 if colors else 8) + 36 * nv + 4 * ni
+        step_s = dt / args.steps
+        mesh_bytes = 36 * nv + 4 * ni
+        contract_bytes = n ** 3 * (32 if colors else 8) + mesh_bytes
+        # what THIS design has to move per step: the volume is stored once (4 B distance, +12 B colour) with 1/8 B of sign
+        # bits per voxel, never re-read; plus the mesh
+        design_bytes = n ** 3 * (16 if colors else 4) + n ** 3 // 8 + mesh_bytes
         measured_hbm = load_pmc_traffic("pipeline_step", args.scene, n)
+        # the headline fraction: the contract's model (8 B/voxel: 4 stored by sampling + 4 loaded by meshing) for a distance-only
+        # volume; for colour volumes that model (32 B/voxel) counts 16 B/voxel of loads the fused path never does -- fractions
+        # above 1 -- so the design model stands there
+        model_bytes = design_bytes if colors else contract_bytes
+
+        def frac(nbytes, seconds):
+            return None if not nbytes or not seconds else round(nbytes / seconds / 1e9 / HBM_PEAK_GBS, 4)
+
+        lat_s = None if latency_ms is None else latency_ms * 1e-3
         out = {
             "metric": "Mvoxels/s, 512^3 sphere SDF sample->mesh" if (n == 512 and args.scene == "sphere")
                       else f"Mvoxels/s, {n}^3 {args.scene} SDF sample->mesh",
-            "value": round(n ** 3 / (dt / args.steps) / 1e6, 1),
+            "value": round(n ** 3 / step_s / 1e6, 1),
             "unit": "Mvoxels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
@@ -638,23 +678,39 @@ def main():
             "config": {"workload": f"{WORKLOADS[args.scene]}"
                                    f", {n}^3 voxels, iso 0, step 1; Voxels.SampleSdf -> MarchingCubes.CreateMesh, device-resident",
                        "grid": [n, n, n], "vertices": nv, "triangles": ni // 3,
-                       "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, RCCL all-gather of slab meshes"},
-            "value_is": ("throughput of the pipelined steady state: five identical jobs in flight on the library's three internal streams, "
-                         "buffers sized from the previous mesh of the shape; see latency_ms_single_stream / first_call_ms for one call"),
+                       "parallelism": "1 GPU" if world == 1 else
+                                      f"z-slab x{world}, slab meshes exchanged by the library over " + ("RCCL" if D.info()[2] == 1 else "its host transport (gloo; ranks share one GPU)")},
+            "value_is": ("throughput of the pipelined steady state with warm clocks: " +
+                         ("five identical jobs in flight on the library's three internal streams" if not sharded else "three sharded steps in flight") +
+                         ", buffers sized from the previous mesh of the shape; value_cold_clocks = the same K steps after the GPU idled (no clock "
+                         "warm-up); latency_ms_single_stream / frac_single_call = one call at a time; first_call_ms = the first call"),
+            "value_cold_clocks": round(n ** 3 / (dt_cold / args.steps) / 1e6, 1),
+            "ms_per_step_cold_clocks": round(dt_cold / args.steps * 1e3, 4),
             "untimed_steps_before_timing": {"warmup": n_warm + n_est, "clock_warmup": n_clock,
                                             "why": "W + 4 steps fill the allocator's pools; then the same step runs for ~80 ms so that the GPU is at "
                                                    "its sustained clocks when the K timed steps start (after idling it needs 10-15 ms of load: "
-                                                   "0.20 -> 0.169 ms per step at 512^3, tools/step_transient_probe.py); SDFK_BENCH_CLOCK_WARM_MS=0 switches it off"},
-            "mtris_per_s": round(ni / 3 / (dt / args.steps) / 1e6, 2),
+                                                   "0.20 -> 0.169 ms per step at 512^3, tools/step_transient_probe.py); SDFK_BENCH_CLOCK_WARM_MS=0 switches it off; "
+                                                   "value_cold_clocks is the figure without it"},
+            "mtris_per_s": round(ni / 3 / step_s / 1e6, 2),
             "latency_ms_single_stream": None if latency_ms is None else round(latency_ms, 4),
             "first_call_ms": first_call_ms,
             "first_call": first,
-            "pipeline_algorithmic_gbs": round(total_alg / (dt / args.steps) / 1e9, 1),
-            "pipeline_frac_of_hbm_peak": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-            "pipeline_frac_is": "contract model: 8 B/voxel (4 stored by sampling + 4 loaded by meshing; 32 with colours) + 36 B/vertex + 4 B/index, "
-                                "divided by the step time and by 8 TB/s -- the fused path never re-reads the volume, so this is NOT achieved bandwidth",
+            "pipeline_algorithmic_gbs": round(model_bytes / step_s / 1e9, 1),
+            "pipeline_frac_of_hbm_peak": frac(model_bytes, step_s),
+            "pipeline_frac_is": ("contract model: 8 B/voxel (4 stored by sampling + 4 loaded by meshing) + 36 B/vertex + 4 B/index, divided by the step "
+                                 "time and by 8 TB/s -- the fused path never re-reads the volume, so this is NOT achieved bandwidth: see "
+                                 "frac_design_bytes / frac_measured_bytes" if not colors else
+                                 "design model (colour volume): 16 B/voxel stored once + 1/8 B/voxel of sign bits + 36 B/vertex + 4 B/index; the "
+                                 "contract's 32 B/voxel would count 16 B/voxel of loads this fused path never does (fractions above 1)"),
+            "frac_design_bytes": frac(design_bytes, step_s),
+            "frac_measured_bytes": frac(measured_hbm, step_s),
+            "frac_single_call": frac(model_bytes, lat_s),
+            "frac_single_call_measured_bytes": frac(measured_hbm, lat_s),
+            "fracs_are": "bytes / time / 8 TB/s -- design = what this fused design must move per step ((4 | 16) + 1/8 B per voxel + the mesh); measured = "
+                         "HBM bytes of one step from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json); single_call = the same byte "
+                         "models over latency_ms_single_stream (one synchronous call, nothing else in flight) instead of the pipelined step",
             "pipeline_measured_hbm_bytes": measured_hbm,
-            "pipeline_measured_hbm_gbs": None if not measured_hbm else round(measured_hbm / (dt / args.steps) / 1e9, 1),
+            "pipeline_measured_hbm_gbs": None if not measured_hbm else round(measured_hbm / step_s / 1e9, 1),
             "kernels_us": kern,
             "roofline": roof,
         }
@@ -667,6 +723,7 @@ def main():
     if sharded:
         worker.close()
         dist.barrier()
+        D.shutdown()
         dist.destroy_process_group()
 
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDFK_ABI_VERSION 3   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats */
+#define SDFK_ABI_VERSION 4   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint */
 
 typedef enum sdfk_status {
     SDFK_OK = 0,
@@ -93,6 +93,35 @@ int sdfk_lane_begin(int32_t lane, void* wait_hip_event);
 int sdfk_lane_end(int32_t caller_stream_waits);
 const char* sdfk_last_error(void);
 
+/* ---- options ---------------------------------------------------------------
+ * Run-time switches of the library (what used to be environment variables read per call).  sdfk_init takes the
+ * DEFAULTS from the environment once (SDFK_LANES, SDFK_TOKENS, SDFK_GRAPHS, SDFK_COPY_MODE, SDFK_NO_CORNER_EVAL,
+ * SDFK_NO_VCOLOR_EVAL, SDFK_DIST_EXCHANGE, SDFK_NO_CACHE); after that only these calls change or read them. */
+typedef enum sdfk_option {
+    SDFK_OPT_LANES = 1,         /* internal streams sdfk_sample_march rotates over: 0 (caller's stream), 2, 3 (default), 4 */
+    SDFK_OPT_TOKENS = 2,        /* phase tokens, bit 0: sampling kernels of consecutive jobs apart, bit 1: k_vertices apart;
+                                   -1 (default) = bit 0 for grids of >= 2^27 voxels */
+    SDFK_OPT_GRAPHS = 3,        /* captured launch graphs: 0 never, 1 (default) launch-bound grids, 2 every grid */
+    SDFK_OPT_COPY_MODE = 4,     /* device -> caller arrays: 1 (default) bounded pinned ring + thread pool, 0 pre-fault + runtime copy, 2 runtime copy */
+    SDFK_OPT_CORNER_EVAL = 5,   /* 1 (default): cell corners of a freshly sampled volume are re-evaluated; 0: gathered */
+    SDFK_OPT_VCOLOR_EVAL = 6,   /* 1 (default): vertex colours of a freshly sampled volume are re-evaluated; 0: gathered */
+    SDFK_OPT_DIST_EXCHANGE = 7, /* sharded step: 0 ncclAllGather, 1 (default) grouped ncclSend/ncclRecv to every peer, 2 gather to rank 0 */
+    SDFK_OPT_DIST_LANES = 8,    /* sharded step: internal streams the steps alternate between: 2 (default) or 0 */
+    SDFK_OPT_HW_QUEUES = 9,     /* read-only: GPU_MAX_HW_QUEUES as the process had it when the library came up (0 = unset).  The
+                                   HIP runtime maps all streams of a process onto that many in-order hardware queues (default 4);
+                                   the library's streams want 8 (sdfk_init in sdfkit_hip.hip says why), and the variable only
+                                   counts if it is set before the process's FIRST HIP call: host bindings export it, the
+                                   library itself never edits the environment */
+    SDFK_OPT_CODE_CACHE = 10,   /* 1 (default): compiled code objects are kept on disk (sdfk_set_cache_dir); 0: off */
+    SDFK_OPT_COUNT_ = 11
+} sdfk_option;
+int sdfk_set_option(int32_t key, int64_t value);
+int sdfk_get_option(int32_t key, int64_t* value);
+/* Directory of the on-disk code-object cache; NULL = default ($SDFK_CACHE_DIR | $XDG_CACHE_HOME/sdfkit_hip |
+ * ~/.cache/sdfkit_hip as the process had them at start-up).  The directory must belong to the calling user and be
+ * writable by nobody else, otherwise the cache stays off. */
+int sdfk_set_cache_dir(const char* path);
+
 /* out_rgbw = value ids of (colour.X, colour.Y, colour.Z, distance W) -- the Vector4 the
  * delegate writes (Sdf.cs:8).  writes_color = 0 for delegates that only assign `.W`
  * (Sdfs.Sphere/Box/Plane, Sdf.cs:134,153,211): colour stays (0,0,0) (Voxels.cs:88-92). */
@@ -157,15 +186,14 @@ int sdfk_march_host(const float* values, const float* colors3, int32_t nx, int32
 /* SdfEx.ToMesh (Sdf.cs:59-63): sample (+clip) and mesh without leaving the device.
  * Self-contained jobs: consecutive calls are queued on three internal streams in turn (not on the
  * sdfk_set_stream stream) and overlap on the GPU; their results are safe to use from any stream
- * once an accessor has returned.  SDFK_LANES=0 in the environment (read per call) keeps them on
- * the caller's stream.
+ * once an accessor has returned.  sdfk_set_option(SDFK_OPT_LANES, 0) keeps them on the caller's stream.
  * Repeat calls on launch-bound grids (<= 2^24 voxels, step 1): the job of a (program, bounds, grid, clip,
  * iso) is built once per internal stream -- volume, workspace and mesh arrays sized from the previous
  * result of that grid shape -- its kernel launches are captured in a hipGraph, and every later call is
  * ONE hipGraphLaunch; the returned handle borrows the job's arrays until it is freed (up to 3 live
  * handles per key and stream, further calls take the ordinary path).  Same results, same deferred
  * completion; a result that outgrows the captured capacities is redone exactly as always.
- * SDFK_GRAPHS=0 switches this off, =2 applies it to every grid size. */
+ * SDFK_OPT_GRAPHS = 0 switches this off, 2 applies it to every grid size. */
 int sdfk_sample_march(const sdfk_program* p, const float min[3], const float max[3],
                       int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds,
                       float iso_value, int32_t step, sdfk_mesh** out);
@@ -227,6 +255,71 @@ int sdfk_slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes);
  * on the stream, without a copy of its own. */
 int sdfk_slabs_rebase_mirror(void* gathered, int32_t world, int64_t stride_bytes, void* headers_mirror);
 
+/* ---- Z-slab sharding over the GPUs of one node (SdfEx.ToMesh, Sdf.cs:59-63, one process per GPU) -------------
+ * The reference has no distributed path; this is the multi-GPU form of the same call.  The grid is cut into Z slabs
+ * of cell layers (rank r owns a contiguous range of the serial z sweep, MarchingCubes.cs:53-82, so the global vertex /
+ * triangle order is the concatenation of the slabs in rank order); every rank samples its planes + a 2-plane context
+ * (sampling is a pure function of the voxel index, Voxels.cs:99-108: no halo is exchanged), meshes its layers with
+ * slab-local vertex ids straight into its section of a gather buffer, and ONE exchange per step moves the slab meshes:
+ * the library calls RCCL itself (librccl.so.1, loaded on first use) on a stream of its own -- ncclAllGather, or the
+ * same bytes as grouped ncclSend / ncclRecv over every xGMI link at once (SDFK_OPT_DIST_EXCHANGE) -- then one kernel
+ * rebases the gathered indices and mirrors the `world` payload headers to the host.
+ *
+ *   rank 0:  sdfk_dist_unique_id(id)  -> the host hands `id` (128 bytes) to every rank (its own launcher / MPI / a file)
+ *   all:     sdfk_init(local_device); sdfk_dist_init(world, rank, id)
+ *   one-off: sdfk_dist_to_mesh(...)   -> the whole mesh on every rank, an ordinary sdfk_mesh handle
+ *   repeat:  sdfk_dist_session_create(...); { sdfk_dist_submit(s) ... sdfk_dist_collect(s, ...) } with up to `depth`
+ *            steps in flight; sdfk_dist_mesh(s, &m) = the mesh of the step collected last
+ *
+ * Every call below except unique_id / info / slab is COLLECTIVE: all ranks make the same calls in the same order.
+ * Decisions that must agree (payload stride, "a rank's speculative buffers were too small: redo this step exactly")
+ * are taken from the gathered headers, which every rank sees (csrc/slab_protocol.h). */
+#define SDFK_DIST_ID_BYTES 128
+int sdfk_dist_unique_id(void* id_out /* SDFK_DIST_ID_BYTES */);
+int sdfk_dist_init(int32_t world, int32_t rank, const void* id /* SDFK_DIST_ID_BYTES */);
+/* The same with the exchange done by the HOST (ranks that share one GPU, hosts with a transport of their own, tests):
+ * `allgather(ctx, send, recv, bytes_per_rank)` gathers `bytes_per_rank` bytes of every rank's HOST buffer `send` into
+ * `recv` (world x bytes_per_rank, rank order) and returns 0; blocking.  The library stages the payloads through
+ * pinned memory around it; everything else is the same code. */
+typedef int (*sdfk_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank);
+int sdfk_dist_init_host(int32_t world, int32_t rank, sdfk_allgather_fn allgather, void* ctx);
+/* backend: 0 = not initialised, 1 = RCCL, 2 = host transport */
+int sdfk_dist_info(int32_t* world, int32_t* rank, int32_t* backend);
+void sdfk_dist_shutdown(void);
+/* The partition (no device needed): cell layers [layer_begin, layer_end) of rank `rank`, and the voxel planes
+ * [z0, z0 + nz_local) its slab volume holds for them (context planes included, widened to a multiple of 4). */
+int sdfk_dist_slab(int32_t nz, int32_t world, int32_t rank, int32_t* layer_begin, int32_t* layer_end, int32_t* z0, int32_t* nz_local);
+
+typedef struct sdfk_dist_session sdfk_dist_session;
+/* depth = steps that may be in flight (slots: own slab volume and gather buffer each), 1..8. */
+int sdfk_dist_session_create(const sdfk_program* p, const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz,
+                             int32_t clip_to_bounds, float iso_value, int32_t depth, sdfk_dist_session** out);
+/* Queue one step (no host wait from the second step on).  SDFK_ERR_INVALID when `depth` steps are in flight. */
+int sdfk_dist_submit(sdfk_dist_session* s);
+/* Wait for the OLDEST queued step: this rank's slab counts; a step some rank could not fit is redone here by all. */
+int sdfk_dist_collect(sdfk_dist_session* s, int64_t* n_vertices_mine, int64_t* n_indices_mine);
+/* Per-rank (vertices, indices) of the step collected last: counts[2 * world]. */
+int sdfk_dist_counts(const sdfk_dist_session* s, int64_t* counts);
+/* The whole mesh of the step collected last (valid call until the next submit reuses that slot): the slab sections of the
+ * gather buffer concatenated into an ordinary device-resident mesh -- identical to the single-GPU sdfk_sample_march. */
+int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out);
+/* The raw gather buffer of the step collected last: world payloads of stride_bytes each (header + sections, indices
+ * rebased), device memory owned by the session. */
+int sdfk_dist_gathered(const sdfk_dist_session* s, void** device_ptr, int64_t* stride_bytes);
+/* stats[8] = { stride_bytes, steps submitted, steps redone on the exact path, stride regrowths, exchange mode used,
+ *              host nanoseconds spent inside sdfk_dist_submit (total), inside sdfk_dist_collect (total), depth } */
+int sdfk_dist_stats(const sdfk_dist_session* s, int64_t stats[8]);
+/* Which exchange is faster on this node's fabric is a measurement: runs steps_per_mode pipelined steps with ncclAllGather and
+ * with the direct grouped sends, takes the slowest rank's time for each (the same numbers on every rank) and keeps the faster
+ * mode for this session.  Collective, nothing in flight; ns_per_mode[2] (may be NULL): the agreed times, index = mode. */
+int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int64_t* ns_per_mode);
+/* This rank's slab step WITHOUT the exchange, queued like a step (measurement: "kernel-only" time of a sharded step). */
+int sdfk_dist_enqueue_only(sdfk_dist_session* s);
+void sdfk_dist_session_free(sdfk_dist_session* s);
+/* SdfEx.ToMesh (Sdf.cs:59-63) over all ranks, one call: every rank gets the full mesh. */
+int sdfk_dist_to_mesh(const sdfk_program* p, const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz,
+                      int32_t clip_to_bounds, float iso_value, sdfk_mesh** out);
+
 /* ---- RayMarcher (RayMarcher.cs:45-211) ---------------------------------------
  * RenderDepth (depth != NULL) and / or Render (rgb != NULL) of the program's SDF by sphere
  * tracing: one ray per pixel, `depth_iterations` steps, 6 more evaluations for the normal,
@@ -250,7 +343,7 @@ int sdfk_raymarch_device(const sdfk_program* p, int32_t width, int32_t height, c
  * DMA transfers at the link rate (512^3 sphere mesh, 33 MB: 0.6 ms).  Into ordinary pageable
  * memory (managed arrays pinned by the shim for the call) the same entry points first touch the
  * destination pages on a small thread pool, which is what a copy into FRESHLY allocated arrays
- * is otherwise dominated by (SDFK_COPY_THREADS, SDFK_COPY_MODE).  The Python mirror allocates
+ * is otherwise dominated by (SDFK_COPY_THREADS in the environment at start-up, SDFK_OPT_COPY_MODE).  The Python mirror allocates
  * Mesh.Vertices/Colors/Normals/Triangles here; a C# shim can do the same for Span<T>/Memory<T>
  * based accessors, while Mesh's public arrays (Mesh.cs:10-13) have to stay managed arrays.
  * sdfk_host_free returns the block to the arena; blocks that are still out at sdfk_shutdown stay valid (they are

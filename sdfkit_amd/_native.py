@@ -12,7 +12,9 @@ from . import build as _build
 
 # Streams that wait for events must not share hardware queues with the library's lanes (sdfk_init, sdfkit_hip.hip, says
 # why): the HIP runtime reads this when it initialises -- with torch in the process that is the first CUDA call, not the
-# import -- so it is set as early as this module is imported, unless the user chose a value.
+# import -- so it is set as early as this module is imported, unless the user chose a value.  The library itself never
+# edits the environment (a host binding's job: this module, shim/SdfKit.Hip/Native.cs, include/SdfKit.hpp);
+# sdfk_get_option(SDFK_OPT_HW_QUEUES) reports what the process had when the library came up.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -84,9 +86,37 @@ SIGNATURES = {
     "sdfk_lane_end": (C.c_int, [_i32]),
     "sdfk_raymarch": (C.c_int, [_vp, _i32, _i32, _fp, _fp, C.c_float, C.c_float, _i32, _vp, _vp]),
     "sdfk_raymarch_device": (C.c_int, [_vp, _i32, _i32, _fp, _fp, C.c_float, C.c_float, _i32, _vp, _vp]),
+    "sdfk_set_option": (C.c_int, [_i32, _i64]),
+    "sdfk_get_option": (C.c_int, [_i32, C.POINTER(_i64)]),
+    "sdfk_set_cache_dir": (C.c_int, [C.c_char_p]),
+    "sdfk_dist_unique_id": (C.c_int, [_vp]),
+    "sdfk_dist_init": (C.c_int, [_i32, _i32, _vp]),
+    "sdfk_dist_init_host": (C.c_int, [_i32, _i32, _vp, _vp]),
+    "sdfk_dist_info": (C.c_int, [C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "sdfk_dist_shutdown": (None, []),
+    "sdfk_dist_slab": (C.c_int, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "sdfk_dist_session_create": (C.c_int, [_vp, _fp, _fp, _i32, _i32, _i32, _i32, _f, _i32, _vpp]),
+    "sdfk_dist_submit": (C.c_int, [_vp]),
+    "sdfk_dist_collect": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sdfk_dist_counts": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "sdfk_dist_mesh": (C.c_int, [_vp, _vpp]),
+    "sdfk_dist_gathered": (C.c_int, [_vp, _vpp, C.POINTER(_i64)]),
+    "sdfk_dist_stats": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "sdfk_dist_enqueue_only": (C.c_int, [_vp]),
+    "sdfk_dist_tune": (C.c_int, [_vp, _i32, C.POINTER(_i64)]),
+    "sdfk_dist_session_free": (None, [_vp]),
+    "sdfk_dist_to_mesh": (C.c_int, [_vp, _fp, _fp, _i32, _i32, _i32, _i32, _f, _vpp]),
     "sdfk_profile_count": (C.c_int, []),
     "sdfk_profile_get": (C.c_int, [_i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),
 }
+
+
+# sdfk_allgather_fn: int (*)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
+# enum sdfk_option
+OPT_LANES, OPT_TOKENS, OPT_GRAPHS, OPT_COPY_MODE, OPT_CORNER_EVAL, OPT_VCOLOR_EVAL = 1, 2, 3, 4, 5, 6
+OPT_DIST_EXCHANGE, OPT_DIST_LANES, OPT_HW_QUEUES, OPT_CODE_CACHE = 7, 8, 9, 10
 
 
 def library_path():
@@ -191,6 +221,32 @@ def pinned_empty(shape, dtype):
     if n == 0 or os.environ.get("SDFK_PINNED_ARRAYS") == "0":
         return np.empty(shape, dt)
     return np.asarray(_PinnedBlock(n)).view(dt).reshape(shape)
+
+
+def set_option(key, value):
+    check(lib().sdfk_set_option(key, int(value)))
+
+
+def get_option(key):
+    v = C.c_int64()
+    check(lib().sdfk_get_option(key, C.byref(v)))
+    return v.value
+
+
+class option:
+    """with N.option(N.OPT_LANES, 0): ...   -- an option changed for a block and restored after it."""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.old = get_option(self.key)
+        set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.key, self.old)
+        return False
 
 
 def shutdown():

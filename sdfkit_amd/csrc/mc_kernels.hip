@@ -1295,12 +1295,14 @@ __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
 
 // slab r of the gathered buffer: indices += sum of the vertex counts of slabs 0..r-1
 // (nothing is touched when a header is marked invalid: that step is redone by the host)
-__global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathered, int world, int64_t stride, SlabHeader* mirror)
+// (mirror_only: a rank that received headers but no foreign payloads -- gather-to-root exchange -- has nothing to rebase)
+__global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathered, int world, int64_t stride, SlabHeader* mirror, int mirror_only)
 {
     const int r = blockIdx.y;
     if (mirror && blockIdx.x == 0 && threadIdx.x < sizeof(SlabHeader) / 4)   // header r -> the host's (mapped) copy
         reinterpret_cast<uint32_t*>(mirror + r)[threadIdx.x] =
             reinterpret_cast<const uint32_t*>(gathered + (size_t)r * stride)[threadIdx.x];
+    if (mirror_only) return;
     int64_t base = 0;
     for (int q = 0; q < world; q++) {
         const int64_t nvq = reinterpret_cast<const SlabHeader*>(gathered + (size_t)q * stride)->nv;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -36,16 +37,35 @@ using namespace sdfk;
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string t_err;
-// x rows per wavefront of sdfk_sample_bits (compiled into the programs; SDFK_SAMPLE_RPW = 1, 2 or 4 is an experiment knob)
-static int sample_rpw()
-{
-    static const int v = [] {
-        const char* er = getenv("SDFK_SAMPLE_RPW");
-        const int r = er ? atoi(er) : 2;
-        return (r == 1 || r == 2 || r == 4) ? r : 2;
-    }();
-    return v;
-}
+// x rows per wavefront of sdfk_sample_bits (compiled into the programs: 1 and 4 were measured slower)
+static constexpr int kSampleRpw = 2;
+
+// Run-time configuration.  The environment supplies DEFAULTS, read ONCE (config_from_env, called by sdfk_init and by the
+// device-less sdfk_program_check); afterwards only sdfk_set_option / sdfk_set_cache_dir change it.  Nothing else in this
+// file calls getenv.
+namespace {
+struct Config {
+    bool loaded = false;
+    int lanes = 3;            // SDFK_OPT_LANES
+    int tokens = -1;          // SDFK_OPT_TOKENS (-1: by grid size)
+    int graphs = 1;           // SDFK_OPT_GRAPHS
+    int copy_mode = 1;        // SDFK_OPT_COPY_MODE
+    int corner_eval = 1;      // SDFK_OPT_CORNER_EVAL
+    int vcolor_eval = 1;      // SDFK_OPT_VCOLOR_EVAL
+    int dist_exchange = 1;    // SDFK_OPT_DIST_EXCHANGE
+    int dist_lanes = 2;       // SDFK_OPT_DIST_LANES
+    int code_cache = 1;       // SDFK_OPT_CODE_CACHE
+    int copy_threads = 0;     // SDFK_COPY_THREADS (0: min(16, cores / 2)); fixed once the pool has started
+    int sample_mode = -1;     // SDFK_SAMPLE_MODE (debugging: force the row-tiled (0) / plane-chunk (1) sampler)
+    int hw_queues = 0;        // GPU_MAX_HW_QUEUES as the process had it when the library initialised (0: unset)
+    std::string cache_dir;    // resolved lazily (cache_dir()); "" = default resolution
+    bool cache_dir_set = false;
+    std::string jit_flags;    // SDFK_JIT_FLAGS: extra hiprtc options (space separated)
+    std::string dump_source;  // SDFK_DUMP_SOURCE: file that receives the generated source of the last program
+    std::string env_cache_dir, env_xdg, env_home, rccl_lib;
+};
+Config g_cfg;
+}  // namespace
 static int fail(int code, const char* fmt, ...)
 {
     char buf[1024];
@@ -138,6 +158,7 @@ struct Context {
     uint64_t graph_clock = 0;
     size_t graph_bytes = 0;
     int64_t graph_launches = 0;
+    std::map<uint64_t, uint32_t> graph_sightings;   // full job key (+ lane) -> times asked for without a captured job
 };
 
 Context g;
@@ -162,13 +183,9 @@ int dev_alloc(void** p, size_t n)
         g.live_blocks[*p] = Context::Block{c, g.cur_lane};
         return SDFK_OK;
     }
-    // Experiment knob (SDFK_UNCACHED_MIN_MB=n): blocks of at least n MiB -- the volumes -- as uncached device memory
-    // (hipDeviceMallocUncached).  512^3 sphere: the sampling kernel alone 82 -> 75.6 us per back-to-back launch (7.3 TB/s, 0.915
-    // of the 8 TB/s peak: the store path through L2, not the HBM, sets the 6.7-6.9 TB/s of a plain fill), pipelined step
-    // unchanged; 1024^3: kernel unchanged (702 us), step 4 % slower; README scene: kernel alone 9 % slower, step 4 % faster.
-    // Off by default: no setting is better everywhere.
-    static const long unc_mb = getenv("SDFK_UNCACHED_MIN_MB") ? atol(getenv("SDFK_UNCACHED_MIN_MB")) : 0;
-    hipError_t e = (unc_mb > 0 && c >= (size_t)unc_mb << 20) ? hipExtMallocWithFlags(p, c, hipDeviceMallocUncached) : hipMalloc(p, c);
+    // (volumes as UNCACHED device memory, hipDeviceMallocUncached, were measured and dropped: the 512^3 sampling kernel alone
+    // 82 -> 75.6 us, the pipelined step unchanged, 1024^3 4 % slower -- DESIGN.md section 5)
+    hipError_t e = hipMalloc(p, c);
     if (e != hipSuccess) {
         // drop the caches and retry once (hipFree waits for the device: no block is in use after it)
         for (auto& lane : g.lanes) {
@@ -327,15 +344,6 @@ void bind_thread()
     if (g.inited && t_bound_device != g.device && hipSetDevice(g.device) == hipSuccess) t_bound_device = g.device;
 }
 
-// experiment knob: SDFK_GRID_<NAME>=n caps the grid of the marching-cubes kernel NAME (RESOLVE, VERT, TRI)
-int grid_cap(const char* name, int dflt)
-{
-    const std::string key = std::string("SDFK_GRID_") + name;
-    const char* e = getenv(key.c_str());
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : dflt;
-}
-
 int grid_for(size_t work_items, int per_block = 256, int max_blocks = 256 * 8)
 {
     size_t b = (work_items + per_block - 1) / per_block;
@@ -389,8 +397,7 @@ public:
     int size()
     {
         static const int n = [] {
-            int v = 0;
-            if (const char* e = getenv("SDFK_COPY_THREADS")) v = atoi(e);
+            int v = g_cfg.copy_threads;
             if (v <= 0) v = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
             return std::min(v, 64);
         }();
@@ -464,16 +471,21 @@ void prefault_start(void* p, size_t n)
     });
 }
 
-int stage_reserve(size_t n)
+// Pinned staging RING for device -> pageable host copies: kStageSlots chunks of kStageChunk bytes, reused as their events
+// complete (32 MiB of pinned memory whatever the size of the transfer -- a 512^3 volume with colours used to pin 2 GiB
+// for good).  Allocated on first use; if hipHostMalloc fails the caller falls back to the runtime's own copy (mode 0).
+constexpr size_t kStageChunk = size_t(4) << 20;
+constexpr int kStageSlots = 8;
+int stage_reserve()
 {
-    if (g.stage_bytes >= n) return SDFK_OK;
-    if (g.stage) (void)hipHostFree(g.stage);
-    g.stage = nullptr;
-    g.stage_bytes = 0;
-    const size_t want = size_class(n);
-    if (hipHostMalloc(&g.stage, want, hipHostMallocDefault) != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipHostMalloc(%zu) for the copy staging buffer failed", want);
-    memset(g.stage, 0, want);   // touch it once, here
-    g.stage_bytes = want;
+    if (g.stage) return SDFK_OK;
+    if (hipHostMalloc(&g.stage, kStageChunk * kStageSlots, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        g.stage = nullptr;
+        return SDFK_ERR_NOMEM;
+    }
+    memset(g.stage, 0, kStageChunk * kStageSlots);   // touch it once, here
+    g.stage_bytes = kStageChunk * kStageSlots;
     return SDFK_OK;
 }
 
@@ -487,8 +499,7 @@ struct CopyPiece { const void* src; void* dst; size_t bytes; };
 // mode 0: pre-fault on the pool, then the runtime's own copy; mode 2: the runtime's copy alone.
 int copy_to_host(const std::vector<CopyPiece>& pieces)
 {
-    const char* em = getenv("SDFK_COPY_MODE");   // (read per call: tests and probes compare the three)
-    const int mode = em ? atoi(em) : 1;
+    int mode = g_cfg.copy_mode;   // SDFK_OPT_COPY_MODE
     size_t total = 0;
     for (auto& p : pieces) total += p.bytes;
     if (total == 0) return SDFK_OK;
@@ -506,38 +517,46 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
         HIPCHK(hipStreamSynchronize(g.stream));
         return SDFK_OK;
     }
+    if (mode == 1 && stage_reserve() != SDFK_OK) mode = 0;   // no pinned memory to be had: the runtime's copy still works
     if (mode == 1) {
-        if (int r = stage_reserve(total)) return r;
-        constexpr size_t kChunk = size_t(4) << 20;
-        struct Chunk { char* stage; char* dst; size_t bytes; hipEvent_t ev; };
+        // chunk k travels through ring slot k % kStageSlots: DMA into the slot, event; the pool copies the slot into the
+        // destination (pre-faulted while the first chunks were on the wire) and only then is the slot's next DMA queued
+        struct Chunk { char* dst; const char* src; size_t bytes; };
         std::vector<Chunk> chunks;
-        size_t off = 0;
-        hipError_t e = hipSuccess;
         for (auto& p : pieces)
-            for (size_t o = 0; o < p.bytes && e == hipSuccess; o += kChunk) {
-                Chunk c{(char*)g.stage + off, (char*)p.dst + o, std::min(kChunk, p.bytes - o), prof_event()};
-                e = hipMemcpyAsync(c.stage, (const char*)p.src + o, c.bytes, hipMemcpyDeviceToHost, g.stream);
-                if (e == hipSuccess) e = hipEventRecord(c.ev, g.stream);
-                off += c.bytes;
-                chunks.push_back(c);
-            }
+            for (size_t o = 0; o < p.bytes; o += kStageChunk)
+                chunks.push_back(Chunk{(char*)p.dst + o, (const char*)p.src + o, std::min(kStageChunk, p.bytes - o)});
+        hipEvent_t ev[kStageSlots];
+        for (auto& e : ev) e = prof_event();
+        hipError_t e = hipSuccess;
+        auto issue = [&](size_t k) {
+            char* slot = (char*)g.stage + (k % kStageSlots) * kStageChunk;
+            hipError_t r = hipMemcpyAsync(slot, chunks[k].src, chunks[k].bytes, hipMemcpyDeviceToHost, g.stream);
+            if (r == hipSuccess) r = hipEventRecord(ev[k % kStageSlots], g.stream);
+            return r;
+        };
+        size_t issued = 0;
+        for (; issued < chunks.size() && issued < (size_t)kStageSlots && e == hipSuccess; issued++) e = issue(issued);
         if (e == hipSuccess) {
             // pre-fault the whole destination while the first chunks travel
             for (auto& p : pieces) { prefault_start(p.dst, p.bytes); g_pool.wait(); }
             const int nt = g_pool.size() + 1;
-            for (auto& c : chunks) {
-                e = hipEventSynchronize(c.ev);
+            for (size_t k = 0; k < chunks.size() && e == hipSuccess; k++) {
+                e = hipEventSynchronize(ev[k % kStageSlots]);
                 if (e != hipSuccess) break;
+                const Chunk c = chunks[k];
+                const char* slot = (const char*)g.stage + (k % kStageSlots) * kStageChunk;
                 const size_t per = (c.bytes + nt - 1) / nt;
                 g_pool.start(nt, [=](int t) {
                     const size_t a = std::min((size_t)t * per, c.bytes), b = std::min(a + per, c.bytes);
-                    if (b > a) memcpy(c.dst + a, c.stage + a, b - a);
+                    if (b > a) memcpy(c.dst + a, slot + a, b - a);
                 });
                 g_pool.wait();
+                if (issued < chunks.size()) e = issue(issued++);   // the slot is free again
             }
         }
         if (e != hipSuccess) (void)hipStreamSynchronize(g.stream);
-        for (auto& c : chunks) g.prof_event_pool.push_back(c.ev);
+        for (auto& x : ev) g.prof_event_pool.push_back(x);
         if (e != hipSuccess) return fail(SDFK_ERR_HIP, "device-to-host copy: %s", hipGetErrorString(e));
         return SDFK_OK;
     }
@@ -579,6 +598,7 @@ struct sdfk_program {
     hipFunction_t fn[PK_COUNT] = {};
     int writes_color = 0;
     int refs = 1;   // the caller's handle + volumes it has sampled + queued jobs that launch from its module
+    bool orphaned = false;   // the caller's handle is gone (sdfk_program_destroy): captured jobs keyed on it can never be asked for again
 };
 
 struct sdfk_volume {
@@ -670,6 +690,9 @@ int mesh_resolve(sdfk_mesh* m);
 void graph_job_retire(sdfk_mesh* m, bool too_small);
 void graph_jobs_destroy_all();
 void graph_jobs_forget_volume(const sdfk_volume* v);
+void graph_jobs_forget_program(const sdfk_program* p);
+void dist_release();   // (dist_rccl.h)
+bool dist_active();
 void resolve_dependents(const sdfk_volume* v);
 void free_mesh_buffers(sdfk_mesh* m);
 void drop_source(sdfk_mesh* m);
@@ -685,6 +708,33 @@ extern "C" int sdfk_abi_version(void) { return SDFK_ABI_VERSION; }
 
 extern "C" const char* sdfk_last_error(void) { return t_err.c_str(); }
 
+// The ONE place the environment is read (see Config): start-up defaults of the options, the cache location, debugging aids.
+static void config_from_env()
+{
+    if (g_cfg.loaded) return;
+    g_cfg.loaded = true;
+    auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    auto gets = [](const char* name) { const char* e = getenv(name); return std::string(e ? e : ""); };
+    g_cfg.lanes = geti("SDFK_LANES", 3);
+    g_cfg.tokens = geti("SDFK_TOKENS", -1);
+    g_cfg.graphs = geti("SDFK_GRAPHS", 1);
+    g_cfg.copy_mode = geti("SDFK_COPY_MODE", 1);
+    g_cfg.copy_threads = geti("SDFK_COPY_THREADS", 0);
+    g_cfg.corner_eval = geti("SDFK_NO_CORNER_EVAL", 0) ? 0 : 1;
+    g_cfg.vcolor_eval = geti("SDFK_NO_VCOLOR_EVAL", 0) ? 0 : 1;
+    g_cfg.dist_exchange = geti("SDFK_DIST_EXCHANGE", 1);
+    g_cfg.dist_lanes = geti("SDFK_DIST_LANES", 2);
+    g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
+    g_cfg.sample_mode = geti("SDFK_SAMPLE_MODE", -1);
+    g_cfg.hw_queues = geti("GPU_MAX_HW_QUEUES", 0);
+    g_cfg.env_cache_dir = gets("SDFK_CACHE_DIR");
+    g_cfg.env_xdg = gets("XDG_CACHE_HOME");
+    g_cfg.env_home = gets("HOME");
+    g_cfg.jit_flags = gets("SDFK_JIT_FLAGS");
+    g_cfg.dump_source = gets("SDFK_DUMP_SOURCE");
+    g_cfg.rccl_lib = gets("SDFK_RCCL_LIB");
+}
+
 extern "C" int sdfk_init(int device)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -692,13 +742,15 @@ extern "C" int sdfk_init(int device)
         if (device != g.device) return fail(SDFK_ERR_INVALID, "already initialised on device %d", g.device);
         return SDFK_OK;
     }
-    // The library's lanes, the caller's stream and a collective library's stream must not share hardware queues: the HIP
-    // runtime maps all streams of a process onto GPU_MAX_HW_QUEUES (default 4) in-order queues, and a stream that waits
-    // for an event (a lane section's end, a collective) then holds up every OTHER stream behind it in the same queue --
-    // the pipelined sharded step ran fully serialised that way (108 -> 55 us per step on a small slab with 8 queues;
-    // 16 queues: 170 us).  Read by the runtime when it initialises, i.e. only effective if this is the process's first
-    // HIP call (hosts that touch HIP earlier export it themselves: sdfkit_amd/_native.py, bench.py do).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    config_from_env();
+    // The library's lanes, the caller's stream and the exchange stream must not share hardware queues: the HIP runtime maps
+    // all streams of a process onto GPU_MAX_HW_QUEUES (default 4) in-order queues, and a stream that waits for an event (a
+    // lane section's end, a collective) then holds up every OTHER stream behind it in the same queue -- the pipelined
+    // sharded step ran fully serialised that way (108 -> 55 us per step on a small slab with 8 queues; 16 queues: 170 us).
+    // The runtime reads the variable when IT initialises, which may be long before this call (torch, the C# host), and a
+    // library must not edit its process's environment under the feet of other threads: the HOST BINDINGS export
+    // GPU_MAX_HW_QUEUES=8 before their first HIP call (sdfkit_amd/_native.py, shim/SdfKit.Hip/Native.cs, include/SdfKit.hpp);
+    // sdfk_get_option(SDFK_OPT_HW_QUEUES) says what the process had when the library came up.
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(SDFK_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
@@ -733,6 +785,7 @@ extern "C" void sdfk_shutdown(void)
     if (!g.inited) return;
     while (!g.pending.empty()) (void)mesh_resolve(g.pending.front());
     graph_jobs_destroy_all();
+    if (dist_active()) dist_release();   // (sessions that are still alive read as freed: sdfk_dist_session_free after a shutdown only deletes them)
     (void)hipStreamSynchronize(g.stream);
     prof_drain();
     for (auto e : g.prof_event_pool) (void)hipEventDestroy(e);
@@ -833,6 +886,62 @@ extern "C" int sdfk_synchronize(void)
 }
 
 // ---------------------------------------------------------------------------
+// options (include/sdfkit_hip.h: sdfk_option)
+// ---------------------------------------------------------------------------
+extern "C" int sdfk_set_option(int32_t key, int64_t value)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    config_from_env();
+    auto in = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
+    switch (key) {
+    case SDFK_OPT_LANES: if (!in(0, Context::NSIDE)) break; g_cfg.lanes = (int)value; return SDFK_OK;
+    case SDFK_OPT_TOKENS: if (!in(-1, 3)) break; g_cfg.tokens = (int)value; return SDFK_OK;
+    case SDFK_OPT_GRAPHS: if (!in(0, 2)) break; g_cfg.graphs = (int)value; return SDFK_OK;
+    case SDFK_OPT_COPY_MODE: if (!in(0, 2)) break; g_cfg.copy_mode = (int)value; return SDFK_OK;
+    case SDFK_OPT_CORNER_EVAL: if (!in(0, 1)) break; g_cfg.corner_eval = (int)value; return SDFK_OK;
+    case SDFK_OPT_VCOLOR_EVAL: if (!in(0, 1)) break; g_cfg.vcolor_eval = (int)value; return SDFK_OK;
+    case SDFK_OPT_DIST_EXCHANGE: if (!in(0, 2)) break; g_cfg.dist_exchange = (int)value; return SDFK_OK;
+    case SDFK_OPT_DIST_LANES: if (value != 0 && value != 2) break; g_cfg.dist_lanes = (int)value; return SDFK_OK;
+    case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
+    case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
+    default: return fail(SDFK_ERR_INVALID, "sdfk_set_option: unknown option %d", key);
+    }
+    return fail(SDFK_ERR_INVALID, "sdfk_set_option(%d): value %lld out of range", key, (long long)value);
+}
+
+extern "C" int sdfk_get_option(int32_t key, int64_t* value)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!value) return fail(SDFK_ERR_INVALID, "sdfk_get_option: null argument");
+    config_from_env();
+    switch (key) {
+    case SDFK_OPT_LANES: *value = g_cfg.lanes; break;
+    case SDFK_OPT_TOKENS: *value = g_cfg.tokens; break;
+    case SDFK_OPT_GRAPHS: *value = g_cfg.graphs; break;
+    case SDFK_OPT_COPY_MODE: *value = g_cfg.copy_mode; break;
+    case SDFK_OPT_CORNER_EVAL: *value = g_cfg.corner_eval; break;
+    case SDFK_OPT_VCOLOR_EVAL: *value = g_cfg.vcolor_eval; break;
+    case SDFK_OPT_DIST_EXCHANGE: *value = g_cfg.dist_exchange; break;
+    case SDFK_OPT_DIST_LANES: *value = g_cfg.dist_lanes; break;
+    case SDFK_OPT_CODE_CACHE: *value = g_cfg.code_cache; break;
+    case SDFK_OPT_HW_QUEUES: *value = g_cfg.hw_queues; break;
+    default: return fail(SDFK_ERR_INVALID, "sdfk_get_option: unknown option %d", key);
+    }
+    return SDFK_OK;
+}
+
+// Where compiled code objects are kept (NULL: back to $SDFK_CACHE_DIR | $XDG_CACHE_HOME/sdfkit_hip | ~/.cache/sdfkit_hip as
+// the process had them at start-up).  SDFK_OPT_CODE_CACHE = 0 switches the cache off.
+extern "C" int sdfk_set_cache_dir(const char* path)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    config_from_env();
+    g_cfg.cache_dir_set = path != nullptr;
+    g_cfg.cache_dir = path ? path : "";
+    return SDFK_OK;
+}
+
+// ---------------------------------------------------------------------------
 // programs (JIT, counterpart of SdfExprCompiler.Compile, SdfExpr.cs:225-273)
 // ---------------------------------------------------------------------------
 // ---- on-disk cache of compiled code objects ------------------------------------------------
@@ -852,20 +961,28 @@ uint64_t fnv1a64(const std::string& s, uint64_t h)
     return h;
 }
 
+// The directory must be OURS: created here with mode 0700, or an existing directory owned by this user that nobody else
+// can write to -- another local user who pre-creates /tmp/sdfkit_hip-<uid> (the fallback when HOME is unset) could plant
+// code objects otherwise.  Anything else: no cache.
 std::string cache_dir()
 {
-    if (const char* e = getenv("SDFK_NO_CACHE")) if (atoi(e)) return std::string();
+    if (!g_cfg.code_cache) return std::string();
     std::string d;
-    if (const char* e = getenv("SDFK_CACHE_DIR")) d = e;
-    else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/sdfkit_hip";
-    else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/sdfkit_hip";
+    if (g_cfg.cache_dir_set) d = g_cfg.cache_dir;
+    else if (!g_cfg.env_cache_dir.empty()) d = g_cfg.env_cache_dir;
+    else if (!g_cfg.env_xdg.empty()) d = g_cfg.env_xdg + "/sdfkit_hip";
+    else if (!g_cfg.env_home.empty()) d = g_cfg.env_home + "/.cache/sdfkit_hip";
     else d = "/tmp/sdfkit_hip-" + std::to_string((long)getuid());
+    if (d.empty()) return d;
     // mkdir -p
     for (size_t i = 1; i <= d.size(); i++)
         if (i == d.size() || d[i] == '/') {
             const std::string sub = d.substr(0, i);
             if (mkdir(sub.c_str(), 0700) != 0 && errno != EEXIST) return std::string();
         }
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & (S_IWGRP | S_IWOTH)))
+        return std::string();
     return d;
 }
 
@@ -873,8 +990,10 @@ constexpr uint64_t kCacheMagic = 0x31304f434b464453ull;   // "SDFKCO01"
 
 bool cache_load(const std::string& path, const std::string& key, std::vector<char>& code)
 {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    FILE* f = fdopen(fd, "rb");
+    if (!f) { close(fd); return false; }
     uint64_t hdr[3] = {0, 0, 0};
     bool ok = fread(hdr, sizeof hdr, 1, f) == 1 && hdr[0] == kCacheMagic && hdr[1] == key.size() && hdr[2] > 0 && hdr[2] < (1ull << 31);
     if (ok) {
@@ -893,8 +1012,10 @@ bool cache_load(const std::string& path, const std::string& key, std::vector<cha
 void cache_store(const std::string& path, const std::string& key, const std::vector<char>& code)
 {
     const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    FILE* f = fdopen(fd, "wb");
+    if (!f) { close(fd); (void)remove(tmp.c_str()); return; }
     const uint64_t hdr[3] = {kCacheMagic, key.size(), code.size()};
     bool ok = fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(key.data(), 1, key.size(), f) == key.size() &&
               fwrite(code.data(), 1, code.size(), f) == code.size();
@@ -908,16 +1029,13 @@ static int compile_source(const std::string& src, unsigned mask, std::vector<cha
                           bool refresh = false)
 {
     if (from_cache) *from_cache = false;
-    // experiment knobs (the defaults are the tuned values)
-    const char* en = getenv("SDFK_SAMPLE_NT");    // 0: plain instead of nontemporal stores of the values
-    const std::string dn = std::string("-DSDFK_SAMPLE_NT=") + (en && !atoi(en) ? "0" : "1");
-    const std::string dr = "-DSDFK_SAMPLE_RPW=" + std::to_string(sample_rpw());
+    const std::string dr = "-DSDFK_SAMPLE_RPW=" + std::to_string(kSampleRpw);
     const std::string dk = "-DSDFK_KERNELS=" + std::to_string(mask);
-    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", dn.c_str(), dr.c_str(), dk.c_str()};
-    std::vector<std::string> extra;   // experiment knob: SDFK_JIT_FLAGS="-fno-slp-vectorize ..." (space separated)
-    if (const char* ex = getenv("SDFK_JIT_FLAGS")) {
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-DSDFK_SAMPLE_NT=1", dr.c_str(), dk.c_str()};
+    std::vector<std::string> extra;   // SDFK_JIT_FLAGS at start-up: extra hiprtc options, space separated (experiments)
+    {
         std::string t;
-        for (const char* q = ex;; q++) {
+        for (const char* q = g_cfg.jit_flags.c_str();; q++) {
             if (*q == ' ' || *q == 0) { if (!t.empty()) extra.push_back(t); t.clear(); if (!*q) break; }
             else t += *q;
         }
@@ -983,8 +1101,8 @@ static int generate_source(const sdfk_op* ops, int32_t n_ops, const int32_t out_
     std::string err;
     if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err))
         return fail(SDFK_ERR_INVALID, "SDF program: %s", err.c_str());
-    if (const char* dump = getenv("SDFK_DUMP_SOURCE")) {   // debugging aid: the generated HIP source of the last program
-        if (FILE* f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
+    if (!g_cfg.dump_source.empty()) {   // debugging aid (SDFK_DUMP_SOURCE at start-up): the generated HIP source of the last program
+        if (FILE* f = fopen(g_cfg.dump_source.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
     }
     return SDFK_OK;
 }
@@ -996,6 +1114,7 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::string src;
     std::vector<char> code;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
+    config_from_env();
     return compile_source(src, 0xfbu, code, false);   // every kernel, a real compile: this IS the check
 }
 
@@ -1056,6 +1175,10 @@ extern "C" void sdfk_program_destroy(sdfk_program* p)
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     bind_thread();
     if (!p) return;
+    // captured jobs of this program can never be asked for again (the key holds the handle): the free ones go now -- and
+    // with them their references, volumes and modules --, a borrowed one when its mesh handle is freed (graph_job_retire)
+    p->orphaned = true;
+    graph_jobs_forget_program(p);
     program_release(p);
 }
 
@@ -1091,6 +1214,8 @@ extern "C" int sdfk_volume_create_slab(int32_t nx, int32_t ny, int32_t nz_global
         return fail(SDFK_ERR_INVALID, "sdfk_volume_create: bad dimensions %dx%dx%d (slab z0=%d nz=%d)", nx, ny, nz_global, z0, nz_local);
     if ((int64_t)nx * ny * nz_global >= (int64_t(1) << 31))
         return fail(SDFK_ERR_INVALID, "grid exceeds the reference's int32 linear index (Voxels.cs:82)");
+    if ((int64_t)nx * ny * ((nz_local + 3) & ~3) >= (int64_t(1) << 31))   // (the kernels index the PITCHED rows with 32-bit plane offsets)
+        return fail(SDFK_ERR_INVALID, "grid with rows padded to %d voxels exceeds 2^31 voxel slots", (nz_local + 3) & ~3);
     if (int r = require_init()) return r;
     sdfk_volume* v = new sdfk_volume();
     v->nx = nx; v->ny = ny; v->nz = nz_local; v->nz_global = nz_global; v->z0 = z0;
@@ -1269,10 +1394,10 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         A.pitch8 = v->pitch8();
         A.iso = iso_hint;
         {
-            const unsigned tpb = 512u / (unsigned)sample_rpw();
+            const unsigned tpb = 512u / (unsigned)kSampleRpw;
             // 0: z tiles of one y row (nz % 256 == 0); 1: 256-voxel chunks of the (y, z) plane of an x row (any nz:
             // rows are padded to a multiple of 4 voxels)
-            static const int force = getenv("SDFK_SAMPLE_MODE") ? atoi(getenv("SDFK_SAMPLE_MODE")) : -1;   // experiment knob
+            const int force = g_cfg.sample_mode;   // (debugging: SDFK_SAMPLE_MODE at start-up)
             int mode = (v->nz % 256) == 0 ? 0 : 1;
             if (force == 0 && (v->nz & 3) == 0) mode = 0;
             if (force == 1 || v->ny > 65535 || v->nx8() > 65535) mode = 1;   // (the row-tiled form has y and x/8 in 16-bit grid dimensions)
@@ -1475,7 +1600,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
     }
     {
         ProfScope ps("k_resolve");
-        static const int cap = grid_cap("RESOLVE", 256 * 12);
+        constexpr int cap = 256 * 12;
         hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, cap)), dim3(256), 0, g.stream, P);
         // totals for the host: workgroup 0 of k_vertices publishes them, unless the caller
         // needs the counts before (or without) emitting
@@ -1568,7 +1693,7 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     if (cap_records == 0) cap_records = std::max<size_t>(ncell / 12, 1u << 16);
     cap_records = std::min(cap_records, ncell);
     int r = 0;
-    if (step == 1 && v->sampled_by && !getenv("SDFK_NO_CORNER_EVAL")) {
+    if (step == 1 && v->sampled_by && g_cfg.corner_eval) {
         j->eval_prog = v->sampled_by;
         j->eval_prog->refs++;
         j->eval_args = v->sampled_args;
@@ -1638,7 +1763,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
         const float inv_det = 1.0f / det;
         M.inv[0] = yz * inv_det; M.inv[1] = xz * inv_det; M.inv[2] = xy * inv_det;
     }
-    static const int vcap = grid_cap("VERT", 256 * 8), tcap = grid_cap("TRI", 256 * 8);
+    constexpr int vcap = 256 * 8, tcap = 256 * 8;   // (persistent-workgroup caps were measured: +-2 us, noise)
     const int vgrid = grid_for(j->P.cap_active, 256, vcap);
     if (!j->bounds_partial || j->bounds_blocks != vgrid) {
         if (int rr = job_alloc(j, &j->bounds_partial, (size_t)vgrid * 6)) return rr;
@@ -1648,7 +1773,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     M.bounds_blocks = vgrid;
     // Vertex colours of a volume its own program has just sampled: re-evaluated by the program (sdfk_vertex_colors) from
     // the (creator record, edge) descriptors k_vertices leaves, instead of gathered from the colour volume
-    static const bool no_vcol = getenv("SDFK_NO_VCOLOR_EVAL") != nullptr;   // (A/B knob: the gather path)
+    const bool no_vcol = !g_cfg.vcolor_eval;   // (SDFK_OPT_VCOLOR_EVAL = 0: the gather path)
     const bool vcol = j->eval_prog && j->eval_prog->writes_color && j->P.colors && M.colors && j->P.step == 1 && !no_vcol;
     if (vcol) {
         const size_t need = std::max<size_t>(m->cap_v, 1);
@@ -1997,6 +2122,19 @@ void graph_job_retire(sdfk_mesh* m, bool too_small)
     q->busy = false;
     q->borrower = nullptr;
     m->graph_job = nullptr;
+    if (q->prog && q->prog->orphaned) {   // its program handle was destroyed while this mesh was out
+        if (m->src == q->vol) m->src = nullptr;
+        if (m->pending == q->job) m->pending = nullptr;
+        graph_job_destroy(q);
+    }
+}
+
+void graph_jobs_forget_program(const sdfk_program* p)
+{
+    for (size_t i = 0; i < g.graph_jobs.size();) {
+        if (g.graph_jobs[i]->prog == p && !g.graph_jobs[i]->busy) graph_job_destroy(g.graph_jobs[i]);   // (erases the entry)
+        else i++;
+    }
 }
 
 void graph_jobs_forget_volume(const sdfk_volume* v)
@@ -2009,15 +2147,13 @@ void graph_jobs_forget_volume(const sdfk_volume* v)
 
 bool graphs_enabled(int64_t nvox)
 {
-    const char* e = getenv("SDFK_GRAPHS");   // (read per call, like SDFK_LANES) 0: never, 1: launch-bound grids, 2: every grid
-    const int mode = e ? atoi(e) : 1;
+    const int mode = g_cfg.graphs;   // SDFK_OPT_GRAPHS -- 0: never, 1: launch-bound grids, 2: every grid
     return mode == 2 || (mode == 1 && nvox <= (int64_t(1) << 24));   // (measured: 64^3 35 -> 23.5 us per job, 128^3 33 -> 26, 256^3 42 -> 39; 320^3 and up 0-3 % slower)
 }
 
 bool graphs_enabled_slab(int64_t nvox)   // (a sharded step also pays for a collective call on the host: graphs pay up to larger slabs)
 {
-    const char* e = getenv("SDFK_GRAPHS");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = g_cfg.graphs;
     return mode == 2 || (mode == 1 && nvox <= (int64_t(1) << 25));
 }
 
@@ -2047,6 +2183,17 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
         const uint64_t key = hint_key(&probe, 1, 0, std::max(nz - 1, 0));
         auto hit = g.hints.find(key);
         if (hit == g.hints.end() || nx < 2 || ny < 2 || nz < 2) return SDFK_OK;
+        {   // A captured job only pays when the IDENTICAL job comes again: it is built on the second sighting of the full key
+            // (program, grid, bounds, clip, iso) on this lane, not as soon as the grid shape has hints -- a caller whose
+            // program or bounds change per call (an animated SDF) would otherwise pay an un-captured run, a capture, an
+            // instantiation and a set of allocations on every call, and an eviction (a stream synchronisation) from the 25th on.
+            uint64_t fk = fnv1a64(std::string((const char*)&p, sizeof p), 0xcbf29ce484222325ull);
+            const int dims[5] = {nx, ny, nz, clip, lane};
+            fk = fnv1a64(std::string((const char*)dims, sizeof dims), fk);
+            fk = fnv1a64(std::string((const char*)mn, 12) + std::string((const char*)mx, 12) + std::string((const char*)&iso, 4), fk);
+            if (g.graph_sightings.size() > 4096) g.graph_sightings.clear();
+            if (g.graph_sightings[fk]++ == 0) return SDFK_OK;
+        }
         if (alive >= 3 || g.graph_jobs.size() >= 24 || g.graph_bytes > (size_t(4) << 30)) {
             GraphJob* lru = nullptr;   // make room: the least recently used free one, if any
             for (GraphJob* c : g.graph_jobs)
@@ -2367,13 +2514,12 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
     return SDFK_OK;
 }
 
-extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
-                                 int32_t layer_begin, int32_t layer_end, void* dst, int64_t capacity_bytes,
-                                 int32_t lane, void* wait_hip_event)
+// One sharded step of a rank: [lane section] sample the slab -> mesh it into the payload at dst.  caller_stream_waits: the
+// caller's stream waits for the section (sdfk_slab_enqueue); the library's own step driver (dist_rccl.h) orders its exchange
+// stream with an event of its own instead.
+static int slab_enqueue_impl(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value, int32_t layer_begin,
+                             int32_t layer_end, void* dst, int64_t capacity_bytes, int32_t lane, void* wait_hip_event, bool caller_stream_waits)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!p || !slab || !dst) return fail(SDFK_ERR_INVALID, "sdfk_slab_enqueue: null argument");
-    if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_slab_enqueue: capacity below the header size");
     int r = lane > 0 ? sdfk_lane_begin(lane, wait_hip_event) : SDFK_OK;
     if (r) return r;
     sdfk_mesh* m = nullptr;
@@ -2382,7 +2528,7 @@ extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32
         bool handled = false;
         r = graph_slab_enqueue(p, slab, clip_to_bounds ? 1 : 0, iso_value, layer_begin, layer_end, dst, capacity_bytes, &handled);
         if (handled || r) {
-            const int r2 = sdfk_lane_end(1);
+            const int r2 = sdfk_lane_end(caller_stream_waits ? 1 : 0);
             return r ? r : r2;
         }
     }
@@ -2396,10 +2542,20 @@ extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32
     }
     if (m) sdfk_mesh_free(m);   // stream-ordered: the kernels above still use it
     if (lane > 0) {
-        const int r2 = sdfk_lane_end(1);
+        const int r2 = sdfk_lane_end(caller_stream_waits ? 1 : 0);
         if (!r) r = r2;
     }
     return r;
+}
+
+extern "C" int sdfk_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value,
+                                 int32_t layer_begin, int32_t layer_end, void* dst, int64_t capacity_bytes,
+                                 int32_t lane, void* wait_hip_event)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || !slab || !dst) return fail(SDFK_ERR_INVALID, "sdfk_slab_enqueue: null argument");
+    if (capacity_bytes < SDFK_SLAB_HEADER_BYTES) return fail(SDFK_ERR_INVALID, "sdfk_slab_enqueue: capacity below the header size");
+    return slab_enqueue_impl(p, slab, clip_to_bounds, iso_value, layer_begin, layer_end, dst, capacity_bytes, lane, wait_hip_event, true);
 }
 
 static int slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes, void* headers_mirror)
@@ -2409,7 +2565,7 @@ static int slabs_rebase(void* gathered, int32_t world, int64_t stride_bytes, voi
     if (int r = require_init()) return r;
     if (world == 1 && !headers_mirror) return SDFK_OK;
     hipLaunchKernelGGL(k_slabs_rebase, dim3(64, world), dim3(256), 0, g.stream, (char*)gathered, (int)world, (int64_t)stride_bytes,
-                       (SlabHeader*)headers_mirror);
+                       (SlabHeader*)headers_mirror, 0);
     HIPCHK(hipGetLastError());
     return SDFK_OK;
 }
@@ -2451,16 +2607,12 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     // self-contained job (no input but the program; the output is only read after a host-side
     // wait): consecutive calls alternate between the side lanes and overlap on the GPU
     int lane = g.cur_lane;   // (inside sdfk_lane_begin/end: the caller's lane)
-    if (const char* e = getenv("SDFK_LANES")) {   // read per call: measurement passes switch the overlap off and on
-        g.side_lanes = std::max(0, std::min(Context::NSIDE, atoi(e)));
-        if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
-    } else {
-        // three lanes: small grids are launch-latency bound (9 dependent launches; 256^3: 39 instead of 48 us per step),
-        // and from 512^3 up a third job in flight is worth 4-5 % since the sampler of a .W-only program holds no LDS any
-        // more and the meshing kernels of two other jobs fit next to it (512^3 sphere 0.172 -> 0.164 ms, 384^3 0.092 ->
-        // 0.087, 1024^3 1.23 -> 1.18; colour scenes unchanged)
-        g.side_lanes = 3;
-    }
+    // SDFK_OPT_LANES, default three: small grids are launch-latency bound (9 dependent launches; 256^3: 39 instead of 48 us
+    // per step), and from 512^3 up a third job in flight is worth 4-5 % since the sampler of a .W-only program holds no LDS
+    // any more and the meshing kernels of two other jobs fit next to it (512^3 sphere 0.172 -> 0.164 ms, 384^3 0.092 ->
+    // 0.087, 1024^3 1.23 -> 1.18; colour scenes unchanged)
+    g.side_lanes = std::max(0, std::min(Context::NSIDE, g_cfg.lanes));
+    if (g.side_lanes == 1) g.side_lanes = 0;   // one side lane overlaps nothing
     if (g.side_lanes > 0 && g.cur_lane == 0) {
         lane = 1 + g.next_side;
         g.next_side = (g.next_side + 1) % g.side_lanes;
@@ -2476,13 +2628,12 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     if (r) return r;
     r = require_init();
     {
-        // (read per call) bit 0: sampling kernels apart, bit 1: k_vertices apart.  Default: the sampling kernels of grids from
+        // SDFK_OPT_TOKENS -- bit 0: sampling kernels apart, bit 1: k_vertices apart.  Default: the sampling kernels of grids from
         // 2^27 voxels up (512^3 sphere 0.162 -> 0.156 ms per step, 768^3 0.475 -> 0.462, 1024^3 1.12-1.20 -> 1.10, README scene
         // 0.49 -> 0.478; 384^3 and below lose 2-3 %: there a sampling kernel is too short to be worth a cross-stream wait).
         // k_vertices apart costs 2-3 % at every size: its workgroups are long-lived, and a second one fills the first one's tail.
-        const char* et = getenv("SDFK_TOKENS");
         const int dflt = (int64_t)nx * ny * nz >= (int64_t(1) << 27) ? 1 : 0;
-        g.token_mask = (lane > 0 && g.side_lanes > 1) ? (et ? atoi(et) : dflt) : 0;
+        g.token_mask = (lane > 0 && g.side_lanes > 1) ? (g_cfg.tokens >= 0 ? g_cfg.tokens : dflt) : 0;
     }
     if (!r) r = sample_impl(p, v, clip_to_bounds, step == 1 ? iso_value : 0.0f);
     if (!r) r = sdfk_march(v, iso_value, step, out);
@@ -2757,3 +2908,8 @@ extern "C" int sdfk_profile_get(int32_t i, const char** name, double* total_ms, 
     if (launches) *launches = g.prof_n[i];
     return SDFK_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Z-slab sharding: sdfk_dist_* (RCCL called by the library itself)
+// ---------------------------------------------------------------------------
+#include "dist_rccl.h"

@@ -1,6 +1,8 @@
-"""Launched by tests/test_gpu_multirank.py under torch.distributed.run (every rank on GPU 0, gloo):
-pipelined SlabSession over `world` ranks; every rank compares the gathered, rebased mesh with the
-oracle's mesh of the whole grid, array by array.  Exit code 0 = identical on this rank."""
+"""Launched by tests/test_gpu_multirank.py under torch.distributed.run (every rank on GPU 0): a pipelined sharded
+session (sdfk_dist_session_*, the library's own step driver) over `world` ranks with the HOST transport (the ranks share
+one GPU, which RCCL refuses; the exchange goes through the gloo group, everything else is the production path); every
+rank compares the whole mesh of every step with the oracle's mesh of the whole grid, array by array.
+Exit code 0 = identical on this rank."""
 import os
 import sys
 
@@ -11,7 +13,6 @@ import torch
 import torch.distributed as dist
 
 os.environ["LOCAL_RANK"] = "0"
-torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 from oracle import oracle as O          # noqa: E402
 from sdfkit_amd import _native as N     # noqa: E402
@@ -24,29 +25,41 @@ mn, mx = [-2.8125] * 3, [2.8125] * 3
 ov, oc = O.sample(scene, mn, mx, *dims)
 O.clip_to_bounds(ov, mn, mx)
 om = O.march(ov, oc, mn, mx)
-N.init(0)
-ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, None, torch.device("cuda", 0), depth=3)
-ok = True
-for it in range(16):
-    if len(ses.queue) == ses.depth:
-        ses.collect()
-        m = ses.mesh()
-        ok &= (np.array_equal(m.Triangles, om.triangles) and np.array_equal(m.Vertices, om.vertices) and
-               np.array_equal(m.Colors, om.colors) and np.array_equal(m.Normals, om.normals, equal_nan=True) and
+D.init_host(device=0)
+graphs_on = N.get_option(N.OPT_GRAPHS) != 0 and N.get_option(N.OPT_DIST_LANES) != 0
+
+
+def same(m, full=True):
+    ok = np.array_equal(m.Triangles, om.triangles) and np.array_equal(m.Vertices, om.vertices)
+    if full:
+        ok &= (np.array_equal(m.Colors, om.colors) and np.array_equal(m.Normals, om.normals, equal_nan=True) and
                np.array_equal(m.Min, om.min) and np.array_equal(m.Max, om.max))
+    return bool(ok)
+
+
+ok = same(D.sharded_to_mesh(sdf, mn, mx, *dims))          # the one-off form first (sdfk_dist_to_mesh)
+ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=3)
+for it in range(16):
+    if ses.in_flight == ses.depth:
+        ses.collect()
+        ok &= same(ses.mesh())
     ses.submit()
-while ses.queue:
+while ses.in_flight:
     ses.collect()
-    m = ses.mesh()
-    ok &= np.array_equal(m.Triangles, om.triangles) and np.array_equal(m.Vertices, om.vertices)
-import ctypes as C
+    ok &= same(ses.mesh(), full=False)
+counts = ses.counts()
+ok &= sum(c[0] for c in counts) == len(om.vertices) and sum(c[1] for c in counts) == len(om.triangles)
+import ctypes as C                      # noqa: E402
 jobs, launches = C.c_int64(), C.c_int64()
 N.check(N.lib().sdfk_graph_stats(C.byref(jobs), C.byref(launches), None))
-if os.environ.get("SDFK_GRAPHS", "1") != "0" and os.environ.get("SDFK_LANES", "2") not in ("0", "1"):
+if graphs_on:
     # the repeat steps were captured step graphs (one per slot and lane), replayed from their second use on
     ok &= jobs.value >= 1 and launches.value >= 1
+st = ses.stats()
+ok &= st["steps"] == 16 and st["exchange_mode"] == -1
 ses.close()
 dist.barrier()
+D.shutdown()
 dist.destroy_process_group()
-print(f"rank {os.environ.get('RANK')}: {'identical' if ok else 'DIFFERENT'} ({len(om.vertices)} vertices)")
+print(f"rank {os.environ.get('RANK')}: {'identical' if ok else 'DIFFERENT'} ({len(om.vertices)} vertices, {st})")
 sys.exit(0 if ok else 1)

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", N.library_path()], text=True)
     exported = set(re.findall(r" T (sdfk_\w+)", out))
     assert exported == set(syms)
-    assert lib.sdfk_abi_version() == 3
+    assert lib.sdfk_abi_version() == 4
 
 
 def test_graft_entry_version_check_follows_the_header():

@@ -1,9 +1,10 @@
-"""World-size-2 (and 3) CPU tests of the Z-slab exchange protocol (sdfkit_amd/dist.py) over
-the gloo backend.  The compute backend is replaced by a worker that serves slices of a mesh
-computed by the CPU oracle (tests may use the oracle; the product worker is GpuSlabWorker and
-is covered by the -m gpu slab tests) -- what is exercised here is everything torch.distributed
-touches: the count all-gather, the exclusive-prefix vertex bases, the packed padded payload,
-the all-gather and the reassembly in rank order."""
+"""World-size-2 (and 3) CPU tests of the Z-slab step protocol over the gloo backend.  The protocol under test is the
+PRODUCT's C++ class (sdfkit_amd/csrc/slab_protocol.h, sdfk::SlabProtocol -- what libsdfkit_hip.so drives with HIP kernels
+and RCCL), built into a g++ shim and driven through callbacks (tests/proto_host.py): the compute backend is a worker
+that serves slices of a mesh computed by the CPU oracle, the transport is torch.distributed's all_gather.  Exercised:
+bootstrap and stride agreement, pipelined slots, "a rank's speculative buffers were too small -> every rank redoes that
+step exactly", a payload that outgrows the stride -> every rank regrows its buffers, matched collectives throughout.  (The
+GPU half -- sdfk_dist_* with the same class -- is covered by tests/test_gpu_multirank.py.)"""
 import os
 import socket
 import sys
@@ -28,12 +29,12 @@ def _free_port():
 
 
 class FixtureSlabWorker:
-    """Serves the part of a reference mesh that belongs to cell layers [lb, le)."""
+    """The part of a reference mesh that belongs to cell layers [lb, le)."""
 
     def __init__(self, mesh, nx, ny, nz, rank, world):
-        from sdfkit_amd import dist as D
+        from tests import proto_host as P
         self.m = mesh
-        self.lb, self.le = D.slab_layers(nz - 1, world, rank)
+        self.lb, self.le = P.slab_layers(nz - 1, world, rank)
         cz = mesh.cells[:, 0] // (nx * ny)           # layer of every active cell, sweep order
         nt = mesh.cells[:, 3]
         tri_start = np.concatenate([[0], np.cumsum(nt * 3)])
@@ -45,84 +46,26 @@ class FixtureSlabWorker:
         self.v0, self.v1 = int(np.count_nonzero(first < self.t0)), int(np.count_nonzero(first < self.t1))
         mine = np.nonzero((first >= self.t0) & (first < self.t1))[0]
         assert len(mine) == self.v1 - self.v0 and (len(mine) == 0 or (mine[0] == self.v0 and mine[-1] == self.v1 - 1))
-        self.base_seen = None
-
-    def begin(self):
-        return self.v1 - self.v0, self.t1 - self.t0
-
-    def finish(self, vertex_base):
-        self.base_seen = vertex_base
-        assert vertex_base == self.v0  # exclusive prefix of the lower slabs' vertex counts
-
-    def pack_into(self, buf, nv, ni):
-        from sdfkit_amd import dist as D
-        m = self.m
-        v = m.vertices[self.v0:self.v1]
-        hdr = np.zeros(8, np.float32)
-        if nv:
-            hdr[0:3] = v.min(axis=0)
-            hdr[3:6] = v.max(axis=0)
-        parts = [hdr.view(np.uint8), np.ascontiguousarray(v).view(np.uint8).ravel(),
-                 np.ascontiguousarray(m.colors[self.v0:self.v1]).view(np.uint8).ravel(),
-                 np.ascontiguousarray(m.normals[self.v0:self.v1]).view(np.uint8).ravel(),
-                 np.ascontiguousarray(m.triangles[self.t0:self.t1]).view(np.uint8).ravel()]
-        raw = np.concatenate(parts)
-        assert len(raw) == D.payload_bytes(nv, ni)
-        buf[:len(raw)] = torch.from_numpy(raw.copy())
-
-
-def _worker(rank, world, port, dims, out_q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from oracle import oracle as O
-        from sdfkit_amd import dist as D
-        from tests import scenes as S
-        scene, _ = S.readme_repeat_xy()
-        mn, mx = [-2.8125] * 3, [2.8125] * 3
-        v, c = O.sample(scene, mn, mx, *dims)
-        O.clip_to_bounds(v, mn, mx)
-        ref = O.march(v, c, mn, mx)
-        w = FixtureSlabWorker(ref, *dims, rank, world)
-        gathered, nvs, nis = D.sharded_step(w, None, "cpu")
-        V, Cc, Nn, T, bmin, bmax = D.unpack(gathered, nvs, nis)
-        ok = (np.array_equal(V, ref.vertices) and np.array_equal(Cc, ref.colors) and
-              np.array_equal(Nn, ref.normals, equal_nan=True) and np.array_equal(T, ref.triangles) and
-              np.array_equal(bmin, ref.min) and np.array_equal(bmax, ref.max) and sum(nvs) == len(ref.vertices))
-        out_q.put((rank, bool(ok), len(V), len(T)))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_exchange_over_gloo(world):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    dims = (20, 18, 23)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert all(ok for _, ok, _, _ in res), res
-    assert len({(nv, nt) for _, _, nv, nt in res}) == 1  # every rank holds the same full mesh
 
 
 class FixtureSessionWorker:
-    """SlabSession backend over fixtures: the self-describing payload (64-byte header, slab-LOCAL
-    indices) of this rank's part of a reference mesh; `fail_at` = enqueue calls that pretend the
-    speculative buffers were too small (header counts -1, no arrays)."""
+    """Protocol backend over fixtures: the self-describing payload (64-byte header, slab-LOCAL indices) of this rank's
+    part of a reference mesh; `fail_at` = enqueue calls that pretend the speculative buffers were too small (header
+    counts -1, no arrays); `grow_at` = enqueue call from which the worker serves `bigger` (a larger mesh) instead."""
 
-    def __init__(self, mesh, nx, ny, nz, rank, world, fail_at=()):
+    vertex_bytes = 36
+
+    def __init__(self, mesh, nx, ny, nz, rank, world, fail_at=(), bigger=None, grow_at=None):
         self.f = FixtureSlabWorker(mesh, nx, ny, nz, rank, world)
-        self.calls, self.fail_at = 0, set(fail_at)
+        self.big = FixtureSlabWorker(bigger[0], *bigger[1], rank, world) if bigger else None
+        self.calls, self.fail_at, self.grow_at = 0, set(fail_at), grow_at
+
+    def _cur(self):
+        return self.big if (self.big is not None and self.grow_at is not None and self.calls >= self.grow_at) else self.f
 
     def _payload(self):
-        f, m = self.f, self.f.m
+        f = self._cur()
+        m = f.m
         nv, ni = f.v1 - f.v0, f.t1 - f.t0
         v = m.vertices[f.v0:f.v1]
         hdr = np.zeros(64, np.uint8)
@@ -143,6 +86,8 @@ class FixtureSessionWorker:
 
     def pack_self_describing(self, buf):
         _, _, raw = self._payload()
+        if len(raw) > buf.numel():     # does not fit: header only (what sdfk_mesh_pack does)
+            raw = raw[:64]
         buf[:len(raw)] = torch.from_numpy(raw.copy())
 
     def enqueue(self, buf):
@@ -152,23 +97,60 @@ class FixtureSessionWorker:
             return
         self.pack_self_describing(buf)
 
-    def close(self):
-        pass
+
+def _same(arrs, ref):
+    V, Cc, Nn, T, mn, mx = arrs
+    return (np.array_equal(V, ref.vertices) and np.array_equal(Cc, ref.colors) and np.array_equal(Nn, ref.normals, equal_nan=True) and
+            np.array_equal(T, ref.triangles) and np.array_equal(mn, ref.min) and np.array_equal(mx, ref.max))
 
 
-def _rebase_host(gathered, world, stride):
-    """numpy twin of sdfk_slabs_rebase (test fixture only)."""
-    g = gathered.numpy()
-    nvs = [int(g[r, :8].view(np.int64)[0]) for r in range(world)]
-    if min(nvs) < 0:
-        return
-    base = 0
-    for r in range(world):
-        ni = int(g[r, 8:16].view(np.int64)[0])
-        o = 64 + int(g[r, 40:44].view(np.int32)[0]) * nvs[r]
-        if o + 4 * ni <= stride and base:
-            g[r, o:o + 4 * ni].view(np.int32)[:] += base
-        base += nvs[r]
+def _reference(scene_fn, dims):
+    from oracle import oracle as O
+    scene, _ = scene_fn()
+    mn, mx = [-2.8125] * 3, [2.8125] * 3
+    v, c = O.sample(scene, mn, mx, *dims)
+    O.clip_to_bounds(v, mn, mx)
+    return O.march(v, c, mn, mx)
+
+
+def _one_off_worker(rank, world, port, dims, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import proto_host as P
+        from tests import scenes as S
+        ref = _reference(S.readme_repeat_xy, dims)
+        ses = P.ProtoSession(lambda slot: FixtureSessionWorker(ref, *dims, rank, world), depth=1)
+        ses.submit()                       # the one-off form (sdfk_dist_to_mesh): bootstrap = exact step + stride agreement
+        nv, ni = ses.collect()
+        arrs = ses.mesh()
+        ok = _same(arrs, ref) and (nv, ni) == ses.workers[0].run_local()
+        out_q.put((rank, bool(ok), len(arrs[0]), len(arrs[3])))
+        ses.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_exchange_over_gloo(world):
+    res = _spawn(_one_off_worker, world, ((20, 18, 23),))
+    assert all(ok for _, ok, _, _ in res), res
+    assert len({(nv, nt) for _, _, nv, nt in res}) == 1  # every rank holds the same full mesh
 
 
 def _session_worker(rank, world, port, dims, out_q):
@@ -176,41 +158,25 @@ def _session_worker(rank, world, port, dims, out_q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from oracle import oracle as O
-        from sdfkit_amd import dist as D
+        from tests import proto_host as P
         from tests import scenes as S
-        scene, _ = S.union8()
-        mn, mx = [-2.8125] * 3, [2.8125] * 3
-        v, c = O.sample(scene, mn, mx, *dims)
-        O.clip_to_bounds(v, mn, mx)
-        ref = O.march(v, c, mn, mx)
+        ref = _reference(S.union8, dims)
         # rank 1 "fails" its 3rd queued step: every rank must redo exactly that step
         fails = (3,) if rank == 1 else ()
-        workers = []
-
-        def make_worker(slot):
-            w = FixtureSessionWorker(ref, *dims, rank, world, fails if slot == 1 else ())
-            workers.append(w)
-            return w
-
-        ses = D.SlabSession(group=None, device="cpu", depth=3, make_worker=make_worker, rebase=_rebase_host)
+        ses = P.ProtoSession(lambda slot: FixtureSessionWorker(ref, *dims, rank, world, fails if slot == 1 else ()), depth=3)
         ok, steps = True, 0
         for it in range(9):            # keep the pipeline full: submit ahead, collect the oldest
-            if len(ses.queue) == ses.depth:
+            if ses.in_flight == ses.depth:
                 nv, ni = ses.collect()
                 steps += 1
-                m = ses.mesh()
-                ok &= (nv, ni) == workers[0].run_local()
-                ok &= (np.array_equal(m.Vertices, ref.vertices) and np.array_equal(m.Triangles, ref.triangles) and
-                       np.array_equal(m.Normals, ref.normals, equal_nan=True) and np.array_equal(m.Colors, ref.colors) and
-                       np.array_equal(m.Min, ref.min) and np.array_equal(m.Max, ref.max))
+                ok &= (nv, ni) == ses.workers[0].run_local()
+                ok &= _same(ses.mesh(), ref)
             ses.submit()
-        while ses.queue:
+        while ses.in_flight:
             ses.collect()
             steps += 1
-            m = ses.mesh()
-            ok &= np.array_equal(m.Vertices, ref.vertices) and np.array_equal(m.Triangles, ref.triangles)
-        out_q.put((rank, bool(ok), steps, ses.redone))
+            ok &= _same(ses.mesh(), ref)
+        out_q.put((rank, bool(ok), steps, ses.redone, ses.grown))
         ses.close()
     finally:
         dist.destroy_process_group()
@@ -218,44 +184,91 @@ def _session_worker(rank, world, port, dims, out_q):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_pipelined_session_over_gloo(world):
-    """SlabSession with three steps in flight: payload headers carry the counts, a step one rank
-    marks as failed is redone by all ranks, collectives stay matched."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    dims = (22, 20, 19)
-    procs = [ctx.Process(target=_session_worker, args=(r, world, port, dims, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert all(ok for _, ok, _, _ in res), res
-    assert all(steps == 9 for _, _, steps, _ in res), res
-    assert all(redone == 1 for _, _, _, redone in res), res
+    """Three steps in flight: payload headers carry the counts, a step one rank marks as failed is redone by all ranks,
+    collectives stay matched."""
+    res = _spawn(_session_worker, world, ((22, 20, 19),))
+    assert all(ok for _, ok, _, _, _ in res), res
+    assert all(steps == 9 for _, _, steps, _, _ in res), res
+    assert all(redone == 1 and grown == 0 for _, _, _, redone, grown in res), res
+
+
+def _growing_worker(rank, world, port, dims, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import proto_host as P
+        from tests import scenes as S
+        small = _reference(lambda: S.sphere_w(0.6), dims)          # one sphere ...
+        big = _reference(S.union8, dims)              # ... then eight primitives: every slab payload outgrows the stride
+        workers = []
+
+        def make_worker(slot):
+            # the scene changes between the 2nd and the 3rd queued step of every slot (the same steps on every rank)
+            w = FixtureSessionWorker(small, *dims, rank, world, bigger=(big, dims), grow_at=2)
+            workers.append(w)
+            return w
+
+        ses = P.ProtoSession(make_worker, depth=2, headroom=1.0 / 32)
+        ok, seen = True, []
+        for it in range(10):
+            if ses.in_flight == ses.depth:
+                ses.collect()
+                arrs = ses.mesh()
+                seen.append("small" if _same(arrs, small) else ("big" if _same(arrs, big) else "?"))
+            ses.submit()
+        while ses.in_flight:
+            ses.collect()
+            arrs = ses.mesh()
+            seen.append("small" if _same(arrs, small) else ("big" if _same(arrs, big) else "?"))
+        ok &= "?" not in seen and seen[0] == "small" and seen[-1] == "big" and seen == sorted(seen, key=lambda s: s != "small")
+        out_q.put((rank, bool(ok), seen, ses.redone, ses.grown, ses.stride))
+        ses.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_payload_outgrowing_the_stride_regrows_on_every_rank(world):
+    """The scene gets bigger mid-session: the payloads no longer fit the agreed stride.  The headers say so, every rank
+    redoes the step exactly, re-agrees the stride and regrows its buffers; steps that were already queued are re-run."""
+    res = _spawn(_growing_worker, world, ((30, 28, 31),))
+    assert all(ok for _, ok, *_ in res), res
+    assert len({tuple(seen) for _, _, seen, *_ in res}) == 1, res       # every rank saw the same sequence of meshes
+    assert all(grown >= 1 and redone >= 1 for _, _, _, redone, grown, _ in res), res
+    assert len({stride for *_, stride in res}) == 1, res                # ... and agreed on the same new stride
 
 
 def test_slab_partition_covers_all_layers():
-    from sdfkit_amd import dist as D
+    from tests import proto_host as P
     for n_layers in (0, 1, 7, 8, 511, 1023):
         for world in (1, 2, 3, 8):
             got, prev = [], 0
             for r in range(world):
-                lb, le = D.slab_layers(n_layers, world, r)
+                lb, le = P.slab_layers(n_layers, world, r)
                 assert lb == prev and le >= lb
                 got.append(le - lb)
                 prev = le
             assert prev == n_layers and max(got) - min(got) <= 1
-    assert D.slab_planes(0, 64, 512) == (0, 68)       # context [0, 66) widened upwards to a multiple of 4 planes
-    assert D.slab_planes(64, 128, 512) == (62, 68)    # two context planes below, two above: already a multiple of 4
-    assert D.slab_planes(448, 511, 512) == (444, 68)  # clipped at the last plane: widened downwards
-    assert D.slab_planes(0, 4, 5) == (0, 5)           # nowhere to widen to: stays as it is
+    assert P.slab_planes(0, 64, 512) == (0, 68)       # context [0, 66) widened upwards to a multiple of 4 planes
+    assert P.slab_planes(64, 128, 512) == (62, 68)    # two context planes below, two above: already a multiple of 4
+    assert P.slab_planes(448, 511, 512) == (444, 68)  # clipped at the last plane: widened downwards
+    assert P.slab_planes(0, 4, 5) == (0, 5)           # nowhere to widen to: stays as it is
     for nz in (5, 64, 511, 512, 1024):
         for world in (1, 2, 3, 8):
             for r in range(world):
-                lb, le = D.slab_layers(nz - 1, world, r)
-                z0, n = D.slab_planes(lb, le, nz)
+                lb, le = P.slab_layers(nz - 1, world, r)
+                z0, n = P.slab_planes(lb, le, nz)
                 assert z0 <= max(lb - 2, 0) and z0 + n >= min(le + 2, nz) and z0 >= 0 and z0 + n <= nz
                 assert n % 4 == 0 or n == nz or nz < 8
-    assert D.exclusive_prefix([3, 0, 5]) == ([0, 3, 3], 8)
+
+
+def test_library_partition_matches_the_protocol_header():
+    """sdfk_dist_slab (the exported form, no device needed) = slab_layers + slab_planes of slab_protocol.h."""
+    from sdfkit_amd import dist as D
+    from tests import proto_host as P
+    for nz in (2, 5, 64, 511, 512, 1024):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lb, le = P.slab_layers(nz - 1, world, r)
+                assert D.slab(nz, world, r) == (lb, le) + P.slab_planes(lb, le, nz)

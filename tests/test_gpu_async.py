@@ -40,11 +40,8 @@ def test_corner_reevaluation_equals_gather(gpu, name):
     dims = (44, 40, 48)
     om = oracle_mesh(scene, MN, MX, dims, True)
     a = sdf.ToMesh(MN, MX, *dims)                       # corners re-evaluated by the program
-    os.environ["SDFK_NO_CORNER_EVAL"] = "1"
-    try:
+    with N.option(N.OPT_CORNER_EVAL, 0):
         b = sdf.ToMesh(MN, MX, *dims)                   # corners gathered from the stored volume
-    finally:
-        del os.environ["SDFK_NO_CORNER_EVAL"]
     assert_mesh_equal(a, om)
     assert_mesh_equal(b, om)
     for f in ("Vertices", "Colors", "Normals", "Triangles"):
@@ -64,30 +61,22 @@ def test_many_queued_meshes_read_late_and_out_of_order(gpu):
 
 
 def test_phase_tokens_do_not_change_results(gpu):
-    """SDFK_TOKENS (sdfkit_hip.hip, phase_token_wait/pass): the sampling kernels / k_vertices of consecutive jobs on the
+    """SDFK_OPT_TOKENS (sdfkit_hip.hip, phase_token_wait/pass): the sampling kernels / k_vertices of consecutive jobs on the
     lanes wait for each other's events.  Forced on for small grids here (the default applies them from 2^27 voxels up),
     graphs off so that every job takes the ordinary path: many jobs in flight, two scenes, read late."""
-    before = {k: os.environ.get(k) for k in ("SDFK_TOKENS", "SDFK_GRAPHS")}
-    os.environ["SDFK_GRAPHS"] = "0"
-    try:
-        for mask in ("1", "3", "2"):
-            os.environ["SDFK_TOKENS"] = mask
-            jobs = []
-            for rep in range(4):
-                for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("union8", (36, 40, 32))):
-                    scene, sdf = S.CATALOGUE[name]()
-                    jobs.append((scene, dims, raw_sample_march(sdf, MN, MX, dims, True), sdf))
-                    if len(jobs) > 5:
-                        scene0, dims0, h0, _ = jobs.pop(0)
-                        assert_mesh_equal(Mesh._from_handle(h0), oracle_mesh(scene0, MN, MX, dims0, True))
-            for scene0, dims0, h0, _ in jobs:
-                assert_mesh_equal(Mesh._from_handle(h0), oracle_mesh(scene0, MN, MX, dims0, True))
-    finally:
-        for k, v in before.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    with N.option(N.OPT_GRAPHS, 0):
+        for mask in (1, 3, 2):
+            with N.option(N.OPT_TOKENS, mask):
+                jobs = []
+                for rep in range(4):
+                    for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("union8", (36, 40, 32))):
+                        scene, sdf = S.CATALOGUE[name]()
+                        jobs.append((scene, dims, raw_sample_march(sdf, MN, MX, dims, True), sdf))
+                        if len(jobs) > 5:
+                            scene0, dims0, h0, _ = jobs.pop(0)
+                            assert_mesh_equal(Mesh._from_handle(h0), oracle_mesh(scene0, MN, MX, dims0, True))
+                for scene0, dims0, h0, _ in jobs:
+                    assert_mesh_equal(Mesh._from_handle(h0), oracle_mesh(scene0, MN, MX, dims0, True))
 
 
 def test_unread_meshes_can_be_freed(gpu):
@@ -147,13 +136,14 @@ def test_queued_slabs_are_packed_by_the_device(gpu, world):
     same with size hints that are far too small: the headers must say so (-1), nothing else."""
     import torch
     from sdfkit_amd import dist as D
+    from tests import slab_worker as W
     scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
     dims = (44, 40, 48)
     whole = sdf.ToMesh(MN, MX, *dims)
     L = N.lib()
     N.bind_torch_stream()
     try:
-        workers = [D.GpuSlabWorker(sdf, MN, MX, *dims, r, world, True, 0.0) for r in range(world)]
+        workers = [W.GpuSlabWorker(sdf, MN, MX, *dims, r, world, True, 0.0) for r in range(world)]
         counts = [w.run_local() for w in workers]                       # exact path: sets the hints
         stride = max(D.SLAB_HEADER_BYTES + 36 * a + 4 * b for a, b in counts) + 512
         for _ in range(3):
@@ -172,13 +162,13 @@ def test_queued_slabs_are_packed_by_the_device(gpu, world):
             w.close()
         # hints from a tiny mesh of the same slab shapes, then the big scene again: under-sized guesses
         tiny = Sdfs.Sphere(0.05)
-        small = [D.GpuSlabWorker(tiny, MN, MX, *dims, r, world, True, 0.0) for r in range(world)]
+        small = [W.GpuSlabWorker(tiny, MN, MX, *dims, r, world, True, 0.0) for r in range(world)]
         for w in small:
             w.run_local()
             w.close()
-        big_dims_workers = [D.GpuSlabWorker(S.CATALOGUE["union8"]()[1], MN, MX, 4 * dims[0], 4 * dims[1], dims[2], r, world, True, 0.0)
+        big_dims_workers = [W.GpuSlabWorker(S.CATALOGUE["union8"]()[1], MN, MX, 4 * dims[0], 4 * dims[1], dims[2], r, world, True, 0.0)
                             for r in range(world)]
-        tiny_same_shape = [D.GpuSlabWorker(tiny, MN, MX, 4 * dims[0], 4 * dims[1], dims[2], r, world, True, 0.0) for r in range(world)]
+        tiny_same_shape = [W.GpuSlabWorker(tiny, MN, MX, 4 * dims[0], 4 * dims[1], dims[2], r, world, True, 0.0) for r in range(world)]
         for w in tiny_same_shape:
             w.run_local()
             w.close()
@@ -204,6 +194,7 @@ def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
     rebased in one launch).  Size-independent properties + slabs == whole, bit for bit."""
     import torch
     from sdfkit_amd import dist as D
+    from tests import slab_worker as W
     scene, sdf = S.CATALOGUE["union8"]()
     n, world = 1024, 8
     MN, MX = [-2.0] * 3, [2.0] * 3        # BASELINE.md section 3, C4: bounds -2..2 (primitives reach +-1.6), clipToBounds
@@ -223,7 +214,7 @@ def test_c4_union8_1024_eight_slabs_equal_whole(gpu):
         key = e[:, 0].astype(np.int64) * nv + e[:, 1]
         _, cnt = np.unique(key, return_counts=True)
         assert np.all(cnt == 2)                                  # closed surface
-        workers = [D.GpuSlabWorker(sdf, MN, MX, n, n, n, r, world, True, 0.0) for r in range(world)]
+        workers = [W.GpuSlabWorker(sdf, MN, MX, n, n, n, r, world, True, 0.0) for r in range(world)]
         counts = [w.run_local() for w in workers]
         assert sum(a for a, _ in counts) == nv and sum(b for _, b in counts) == len(t)
         stride = (max(D.SLAB_HEADER_BYTES + 36 * a + 4 * b for a, b in counts) + 4096 + 255) // 256 * 256

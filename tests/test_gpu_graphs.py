@@ -33,8 +33,9 @@ def raw(sdf, mn, mx, dims, clip, iso=0.0):
 
 
 def graphs_expected():
-    """(the suite is also run with SDFK_GRAPHS=0 / SDFK_LANES=0 in the environment: results must hold, graphs need not appear)"""
-    return os.environ.get("SDFK_GRAPHS", "1") != "0" and os.environ.get("SDFK_LANES", "3") not in ("0", "1")
+    """(the suite is also run with SDFK_GRAPHS=0 / SDFK_LANES=0 in the environment -- the start-up defaults of the options:
+    results must hold, graphs need not appear)"""
+    return N.get_option(N.OPT_GRAPHS) != 0 and N.get_option(N.OPT_LANES) not in (0, 1)
 
 
 def stats():
@@ -48,7 +49,7 @@ def test_repeat_calls_replay_a_graph_and_match_the_oracle(gpu):
     dims = (44, 40, 48)
     om = oracle_mesh(scene, MN, MX, dims, True)
     _, launches0, _ = stats()
-    for _ in range(12):     # 1: exact path (sets the hints); then one build per lane; then replays
+    for _ in range(16):     # 1: exact path (sets the hints); one sighting per lane; one build per lane; then replays
         assert_mesh_equal(Mesh._from_handle(raw(sdf, MN, MX, dims, True)), om)
     jobs, launches, nbytes = stats()
     if graphs_expected():
@@ -59,20 +60,17 @@ def test_graphs_off_on_same_bits(gpu):
     scene, sdf = S.CATALOGUE["union8"]()
     dims = (40, 44, 36)
     res = {}
-    before = os.environ.get("SDFK_GRAPHS")
-    lanes_on = os.environ.get("SDFK_LANES", "3") not in ("0", "1")
+    lanes_on = N.get_option(N.OPT_LANES) not in (0, 1)
+    before = N.get_option(N.OPT_GRAPHS)
     try:
-        for mode in ("0", "1", "0", "2"):     # (read per call)
-            os.environ["SDFK_GRAPHS"] = mode
+        for k, mode in enumerate((0, 1, 0, 2)):
+            N.set_option(N.OPT_GRAPHS, mode)
             _, l0, _ = stats()
-            res[mode] = [Mesh._from_handle(raw(sdf, MN, MX, dims, False)) for _ in range(8)]
+            res[k] = [Mesh._from_handle(raw(sdf, MN, MX, dims, False)) for _ in range(8)]
             _, l1, _ = stats()
-            assert (l1 > l0) == (mode != "0" and lanes_on)
+            assert (l1 > l0) == (mode != 0 and lanes_on)
     finally:
-        if before is None:
-            del os.environ["SDFK_GRAPHS"]
-        else:
-            os.environ["SDFK_GRAPHS"] = before
+        N.set_option(N.OPT_GRAPHS, before)
     om = oracle_mesh(scene, MN, MX, dims, False)
     for ms in res.values():
         for m in ms:

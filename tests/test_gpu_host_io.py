@@ -26,7 +26,7 @@ def _raw(sdf, mn, mx, dims, clip):
 
 @pytest.mark.parametrize("name,clip", [("sphere_w", False), ("readme_repeat_xy", True)])
 def test_mesh_copy_strategies_agree(gpu, name, clip):
-    """SDFK_COPY_MODE 0 (pre-fault on the pool + runtime copy), 1 (pinned staging + pool memcpy) and
+    """SDFK_OPT_COPY_MODE 0 (pre-fault on the pool + runtime copy), 1 (bounded pinned staging ring + pool memcpy) and
     2 (plain copies) deliver the same bytes; a mesh of > 1 MiB so that the helpers are really used."""
     scene, sdf = S.CATALOGUE[name]()
     mn, mx = ([-1.5] * 3, [1.5] * 3) if name == "sphere_w" else ([-2.8125] * 3, [2.8125] * 3)
@@ -37,14 +37,11 @@ def test_mesh_copy_strategies_agree(gpu, name, clip):
     om = O.march(ov, oc, mn, mx)
     assert len(om.vertices) * 36 + len(om.triangles) * 4 > (1 << 20)
     got = []
-    try:
-        for mode in ("0", "1", "2", "1", "0"):
-            os.environ["SDFK_COPY_MODE"] = mode
+    for mode in (0, 1, 2, 1, 0):
+        with N.option(N.OPT_COPY_MODE, mode):
             m = Mesh._from_handle(_raw(sdf, mn, mx, dims, clip))
             assert_mesh_equal(m, om)
             got.append(m)
-    finally:
-        os.environ.pop("SDFK_COPY_MODE", None)
     for m in got[1:]:
         for f in ("Vertices", "Colors", "Normals", "Triangles"):
             assert np.array_equal(getattr(m, f), getattr(got[0], f), equal_nan=True)
@@ -56,9 +53,8 @@ def test_mesh_copy_partial_and_unaligned_destinations(gpu):
     mn, mx, dims = [-1.5] * 3, [1.5] * 3, (128, 128, 128)
     ref = Mesh._from_handle(_raw(sdf, mn, mx, dims, False))
     L = N.lib()
-    for mode in ("0", "1"):
-        os.environ["SDFK_COPY_MODE"] = mode
-        try:
+    for mode in (0, 1):
+        with N.option(N.OPT_COPY_MODE, mode):
             h = _raw(sdf, mn, mx, dims, False)
             nv, ni = C.c_int64(), C.c_int64()
             N.check(L.sdfk_mesh_counts(h, C.byref(nv), C.byref(ni)))
@@ -72,21 +68,16 @@ def test_mesh_copy_partial_and_unaligned_destinations(gpu):
             N.check(L.sdfk_mesh_copy(h, None, c.ctypes.data, None, None))
             assert not c.any()                                # W-only SDF: colours are zero (Voxels.cs:88-92)
             L.sdfk_mesh_free(h)
-        finally:
-            os.environ.pop("SDFK_COPY_MODE", None)
 
 
 def test_volume_download_through_the_pool(gpu):
     scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
     mn, mx, dims = [-2.8125] * 3, [2.8125] * 3, (96, 100, 104)
     ov, oc = O.sample(scene, mn, mx, *dims)
-    for mode in ("0", "1", "2"):
-        os.environ["SDFK_COPY_MODE"] = mode
-        try:
+    for mode in (0, 1, 2):
+        with N.option(N.OPT_COPY_MODE, mode):
             vol = Voxels.SampleSdf(sdf, mn, mx, *dims)
             assert np.array_equal(vol.Values, ov) and np.array_equal(vol.Colors, oc)
-        finally:
-            os.environ.pop("SDFK_COPY_MODE", None)
     w = Voxels.SampleSdf(Sdfs.Sphere(1.0), mn, mx, *dims)    # no colour array on the device: zeros come from the pool
     assert not w.Colors.any() and w.Colors.shape == dims + (3,)
 
@@ -100,8 +91,7 @@ def _stats():
 def test_code_object_cache_on_disk(gpu, tmp_path):
     """First creation of a program compiles with hiprtc and leaves a code object in the cache directory; the next
     creation of the same program (a new process would do the same) loads it; a damaged entry is recompiled."""
-    old = os.environ.get("SDFK_CACHE_DIR")
-    os.environ["SDFK_CACHE_DIR"] = str(tmp_path / "jit")
+    N.check(N.lib().sdfk_set_cache_dir(str(tmp_path / "jit").encode()))
     try:
         mn, mx, dims = [-2.0] * 3, [2.0] * 3, (40, 44, 48)
 
@@ -130,18 +120,20 @@ def test_code_object_cache_on_disk(gpu, tmp_path):
         assert_mesh_equal(build().ToMesh(mn, mx, *dims), om)
         c3, h3, _ = _stats()
         assert c3 == c2 + 1
-        os.environ["SDFK_NO_CACHE"] = "1"
-        try:
+        with N.option(N.OPT_CODE_CACHE, 0):
             assert_mesh_equal(build().ToMesh(mn, mx, *dims), om)
-        finally:
-            del os.environ["SDFK_NO_CACHE"]
         c4, h4, _ = _stats()
         assert (c4, h4) == (c3 + 1, h3)
+        # a directory somebody else could write to is refused (the cache stays off: compiled again, nothing stored)
+        loose = tmp_path / "loose"
+        loose.mkdir()
+        os.chmod(loose, 0o777)
+        N.check(N.lib().sdfk_set_cache_dir(str(loose).encode()))
+        assert_mesh_equal(build().ToMesh(mn, mx, *dims), om)
+        c5, h5, _ = _stats()
+        assert (c5, h5) == (c4 + 1, h4) and not glob.glob(str(loose / "*.co"))
     finally:
-        if old is None:
-            os.environ.pop("SDFK_CACHE_DIR", None)
-        else:
-            os.environ["SDFK_CACHE_DIR"] = old
+        N.check(N.lib().sdfk_set_cache_dir(None))
 
 
 def test_calls_from_other_threads(gpu):

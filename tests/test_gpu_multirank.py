@@ -1,8 +1,8 @@
-"""The multi-rank benchmark path end to end on ONE GPU: `bench.py --gpus N` under
-torch.distributed.run with SDFK_BENCH_ONE_GPU=1 (every rank on GPU 0, exchange over gloo instead
-of RCCL, which refuses two ranks on one device).  Everything else is the production code: Z-slab
-partition, speculative slab jobs on the library's lanes, device-side pack, pipelined SlabSession,
-rebase, header mirror.  The merged mesh must have the single-GPU vertex / triangle counts."""
+"""The multi-rank path end to end on ONE GPU.  `bench.py --gpus N` under torch.distributed.run with
+SDFK_BENCH_ONE_GPU=1: every rank on GPU 0, the exchange through the library's HOST transport (a gloo all-gather;
+RCCL refuses two ranks on one device).  Everything else is the production code behind the C ABI (sdfk_dist_*): Z-slab
+partition, speculative slab steps on the library's lanes emitted straight into the gather buffer, the C++ step
+protocol, rebase, header mirror, mesh extraction.  Real RCCL is exercised at world = 1."""
 import json
 import os
 import socket
@@ -64,7 +64,7 @@ def test_bench_gpus_n_started_as_plain_python(gpu, world):
     assert many["config"]["vertices"] == one["config"]["vertices"] > 10000
     assert many["config"]["triangles"] == one["config"]["triangles"]
     sh = many["sharded"]
-    assert sh["world"] == world == sh["backend_world_size"] and len(sh["per_rank_vertices_indices"]) == world
+    assert sh["world"] == world and len(sh["per_rank_vertices_indices"]) == world
     assert sum(p[0] for p in sh["per_rank_vertices_indices"]) == many["config"]["vertices"]
     assert sh["gather_bytes_received_per_rank"] == (world - 1) * sh["gather_stride_bytes_per_rank"]
     assert 0 < sh["slab_kernels_only_ms"] and sh["xgmi"]["receive_bound_ms"] > 0
@@ -73,38 +73,68 @@ def test_bench_gpus_n_started_as_plain_python(gpu, world):
     assert one["latency_ms_single_stream"] >= one["ms_per_step"] * 0.8
 
 
-def test_sharded_to_mesh_exact_protocol_single_rank(gpu):
-    """The one-off form (two exact collectives: counts, then payloads) on a single-rank group."""
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from oracle import oracle as O
-    from sdfkit_amd import dist as D
-    from sdfkit_amd import _native as N
-    from tests import scenes as S
-    from tests.test_gpu_parity import assert_mesh_equal
-    scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
-    mn, mx, dims = [-2.8125] * 3, [2.8125] * 3, (40, 36, 44)
+def test_rccl_world_one_through_the_c_abi(gpu):
+    """The library's own step driver over REAL RCCL (sdfk_dist_unique_id / sdfk_dist_init / sdfk_dist_to_mesh /
+    sdfk_dist_session_*), world = 1 -- the only world size RCCL accepts on a one-GPU box: communicator creation through
+    dlopen'ed librccl, the exchange stream, all three exchange modes, rebase + header mirror, mesh extraction.  Every mesh
+    is bit-identical to the oracle's, i.e. to sdf.ToMesh on one GPU.  Runs in a child process: the communicator and its
+    stream live until the process ends."""
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import oracle as O
+from sdfkit_amd import _native as N
+from sdfkit_amd import dist as D
+from tests import scenes as S
+from tests.test_gpu_parity import assert_mesh_equal
+N.init(0)
+L = N.lib()
+buf = (C.c_ubyte * 128)()
+N.check(L.sdfk_dist_unique_id(buf))
+N.check(L.sdfk_dist_init(1, 0, buf))
+assert D.info() == (1, 0, 1)
+for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64))):
+    scene, sdf = S.CATALOGUE[name]()
+    mn, mx = [-2.8125] * 3, [2.8125] * 3
     ov, oc = O.sample(scene, mn, mx, *dims)
     O.clip_to_bounds(ov, mn, mx)
     om = O.march(ov, oc, mn, mx)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
-    try:
-        m = D.sharded_to_mesh(sdf, mn, mx, *dims)
-        assert_mesh_equal(m, om)
-        ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, None, torch.device("cuda", 0), depth=2)
-        for _ in range(5):
-            if len(ses.queue) == ses.depth:
-                ses.collect()
+    assert_mesh_equal(D.sharded_to_mesh(sdf, mn, mx, *dims), om)
+    assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), om)
+    for mode in (0, 1, 2):
+        N.set_option(N.OPT_DIST_EXCHANGE, mode)
+        ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=3)
+        for it in range(12):
+            if ses.in_flight == ses.depth:
+                nv, ni = ses.collect()
+                assert (nv, ni) == (len(om.vertices), len(om.triangles))
+                if it %% 4 == 0:
+                    assert_mesh_equal(ses.mesh(), om)
             ses.submit()
         ses.drain()
         assert_mesh_equal(ses.mesh(), om)
+        st = ses.stats()
+        assert st["steps"] == 12 and st["redone"] == 0 and st["exchange_mode"] == mode, st
+        g, stride = C.c_void_p(), C.c_int64()
+        N.check(L.sdfk_dist_gathered(ses.h, C.byref(g), C.byref(stride)))
+        assert g.value and stride.value == st["stride_bytes"] >= 64 + 24 * len(om.vertices) + 4 * len(om.triangles)
         ses.close()
-    finally:
-        dist.destroy_process_group()
-        torch.cuda.synchronize()
-        N.check(N.lib().sdfk_set_stream(None))
-        torch.cuda.set_stream(torch.cuda.default_stream())
+D.shutdown()
+print("rccl world 1 ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl world 1 ok" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
+
+
+def test_sharded_step_host_cost_world_one(gpu):
+    """bench.py's sharded leg on one rank over real RCCL (SDFK_BENCH_FORCE_DIST=1): the line carries the `sharded`
+    object with the host microseconds a step costs inside sdfk_dist_submit / sdfk_dist_collect."""
+    d = _bench([sys.executable, "bench.py", "--steps", "40", "--warmup", "4", "--no-cpu", "--grid", "128", "--minimal"], {"SDFK_BENCH_FORCE_DIST": "1"})
+    sh = d["sharded"]
+    assert sh["world"] == 1 and sh["backend"].startswith("RCCL") and sh["steps_redone_on_the_exact_path"] == 0
+    assert 0 < sh["host_us_per_step"]["submit"] < 200 and sh["host_us_per_step"]["collect"] >= 0
+    assert d["config"]["vertices"] > 10000
 
 
 @pytest.mark.parametrize("world,name,dims", [(2, "readme_repeat_xy", (40, 36, 44)), (3, "union8", (36, 40, 50)), (4, "sphere_w", (64, 64, 64))])

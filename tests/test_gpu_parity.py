@@ -438,6 +438,14 @@ def test_c3_repeat_xy_512_properties(gpu):
     assert m.Colors.min() >= 0.9 - 3.0 / 6 - 1e-6 and m.Colors.max() <= 0.9 + 1e-6
 
 
+def _exclusive_prefix(counts):
+    out, acc = [], 0
+    for c in counts:
+        out.append(acc)
+        acc += int(c)
+    return out, acc
+
+
 # ---------------------------------------------------------------------------
 # Z-slab sharding: slabs meshed one after another on this GPU must concatenate to exactly
 # the single-volume mesh (what the 8-GPU path relies on; sdfkit_amd/dist.py)
@@ -446,13 +454,14 @@ def test_c3_repeat_xy_512_properties(gpu):
 @pytest.mark.parametrize("scene_name,dims", [("readme_repeat_xy", (40, 36, 44)), ("union8", (33, 30, 26))])
 def test_slab_concatenation_equals_whole(gpu, world, scene_name, dims):
     from sdfkit_amd import dist as D
+    from tests import slab_worker as W
     scene, sdf = S.CATALOGUE[scene_name]()
     mn, mx = [-2.8125] * 3, [2.8125] * 3
     whole = sdf.ToMesh(mn, mx, *dims)
-    workers = [D.GpuSlabWorker(sdf, mn, mx, *dims, r, world, True, 0.0) for r in range(world)]
+    workers = [W.GpuSlabWorker(sdf, mn, mx, *dims, r, world, True, 0.0) for r in range(world)]
     try:
         counts = [w.begin() for w in workers]
-        bases, total = D.exclusive_prefix([c[0] for c in counts])
+        bases, total = _exclusive_prefix([c[0] for c in counts])
         assert total == len(whole.Vertices)
         V, Cc, Nn, T, mins, maxs = [], [], [], [], [], []
         for w, (nv, ni), base in zip(workers, counts, bases):
@@ -482,10 +491,11 @@ def test_slab_with_dead_cells_at_the_seam(gpu):
     L = N.lib()
     world = 2
     from sdfkit_amd import dist as D
+    from tests import slab_worker as W
     got_t, got_v, base = [], [], 0
     for r in range(world):
-        lb, le = D.slab_layers(15, world, r)   # seam at layer 8 (rank 0: [0,8), rank 1: [8,15))
-        z0, nzl = D.slab_planes(lb, le, 16)
+        lb, le = W.slab_layers(15, world, r)   # seam at layer 8 (rank 0: [0,8), rank 1: [8,15))
+        z0, nzl = W.slab_planes(lb, le, 16)
         vol = C.c_void_p()
         N.check(L.sdfk_volume_create_slab(10, 9, 16, N.f3(mn), N.f3(mx), z0, nzl, 0, C.byref(vol)))
         sub = np.ascontiguousarray(v[:, :, z0:z0 + nzl])
@@ -509,13 +519,14 @@ def test_slab_one_call_pack_and_rebase(gpu, world):
     would, one rebase launch -> identical to the single-volume mesh."""
     import torch
     from sdfkit_amd import dist as D
+    from tests import slab_worker as W
     scene, sdf = S.readme_repeat_xy()
     mn, mx, dims = [-2.8125] * 3, [2.8125] * 3, (44, 40, 48)
     whole = sdf.ToMesh(mn, mx, *dims)
     N.bind_torch_stream()
     try:
         for _ in range(2):   # second round runs on the speculative (hinted) path
-            workers = [D.GpuSlabWorker(sdf, mn, mx, *dims, r, world, True, 0.0) for r in range(world)]
+            workers = [W.GpuSlabWorker(sdf, mn, mx, *dims, r, world, True, 0.0) for r in range(world)]
             counts = [w.run_local() for w in workers]
             stride = max(D.SLAB_HEADER_BYTES + 36 * a + 4 * b for a, b in counts) + 512
             g = torch.zeros((world, stride), dtype=torch.uint8, device="cuda")
