@@ -8,7 +8,17 @@
 // Corner order v0..v7 (Luts.cs:30-52): v0=(x,y,z) v1=(x+1,y,z) v2=(x+1,y+1,z) v3=(x,y+1,z),
 // v4..v7 the same at z+1.  "Bit order" index = dz*4+dy*2+dx (Cell.cs:318-319).
 #pragma once
+// MC_HOST_BUILD: the decision functions below instantiated with a plain C++ compiler (tests/cpp/dispatch_host.cpp) --
+// the SAME mc_test_face / mc_test_internal / mc_resolve text the kernels compile, so that the CPU suite can check every
+// branch against the manifest extracted from MarchingCubes.cs (tests/golden/dispatch_manifest.json).  Not a second path
+// of the product: nothing in the library defines it.
+#ifdef MC_HOST_BUILD
+#define __device__
+#define __forceinline__ inline
+#define __constant__ static const
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 #include "mc_luts.h"
 
@@ -20,6 +30,7 @@ namespace sdfk {
 constexpr int MCLUT_PADDED = (MCLUT_BLOB_SIZE + 15) & ~15;   // copied in 16-byte pieces
 __constant__ __attribute__((aligned(16))) int8_t c_lut[MCLUT_PADDED] = {MCLUT_BLOB_VALUES};
 
+#ifndef MC_HOST_BUILD
 // 256-thread workgroups only.  All loads are issued before the first LDS store: a plain
 // "load; store" loop is not unrolled by the compiler and costs one L2 round trip per trip.
 __device__ __forceinline__ void mc_load_lut_to_lds(int8_t* s_lut /* MCLUT_PADDED bytes, 16-byte aligned */)
@@ -34,6 +45,7 @@ __device__ __forceinline__ void mc_load_lut_to_lds(int8_t* s_lut /* MCLUT_PADDED
     dst[t] = r0; dst[t + 256] = r1; dst[t + 512] = r2;
     if (t + 768 < N) dst[t + 768] = r3;
 }
+#endif
 
 // every function below takes `lut` = base of the blob (LDS or constant)
 #define MC_L1(name, i) (lut[MCLUT_OFF_##name + (i)])
