@@ -560,6 +560,8 @@ def main():
                     pass
                 return mm, np.frombuffer(mm, dtype=np.uint8, count=nbytes)
 
+            recycled = {}
+
             def one_call(kind):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -575,9 +577,17 @@ def main():
                 if kind == "managed":
                     keep = [fresh_managed(a.value * 12) for _ in range(3)] + [fresh_managed(b.value * 4)]
                     arrs = [x for _, x in keep]
+                elif kind == "managed_recycled":
+                    if recycled.get("shape") != (a.value, b.value):
+                        recycled["keep"] = [fresh_managed(a.value * 12) for _ in range(3)] + [fresh_managed(b.value * 4)]
+                        recycled["shape"] = (a.value, b.value)
+                    arrs = [x for _, x in recycled["keep"]]
                 else:
                     arrs = [np.empty(a.value * 12, np.uint8) for _ in range(3)] + [np.empty(b.value * 4, np.uint8)]
-                N.check(L.sdfk_mesh_copy(m, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data))
+                # (the Colors of a program that only writes .W are all zero -- Voxels.cs:88-92 -- and a managed runtime's new
+                # array IS zero: the shim passes no colour destination then, and the library has nothing to clear)
+                col = arrs[1].ctypes.data if (colors_written or kind == "numpy") else None
+                N.check(L.sdfk_mesh_copy(m, arrs[0].ctypes.data, col, arrs[2].ctypes.data, arrs[3].ctypes.data))
                 lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
                 N.check(L.sdfk_mesh_bounds(m, lo, hi))
                 L.sdfk_mesh_free(m)
@@ -613,16 +623,19 @@ def main():
                                                    f"all four: {[round(t, 3) for t in ts]}")
                 del host_values, host_colors
             d2h = {}
-            for kind in ("pinned", "managed", "numpy"):
+            colors_written = bool(sdf.writes_color)
+            for kind in ("pinned", "managed", "managed_recycled", "numpy"):
                 ts = [one_call(kind) for _ in range(5)]
                 d2h[kind] = {"median_ms": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "all_ms": [round(t, 3) for t in ts]}
             extra["one_step_incl_mesh_d2h_ms"] = d2h["managed"]["median_ms"]
             extra["one_step_incl_mesh_d2h"] = {
                 "what": "sdfk_sample_march + sdfk_mesh_counts + sdfk_mesh_copy of V/C/N/T to the host + sdfk_mesh_bounds, one call at a time; "
-                        "median of 4 calls after a warm-up call.  managed (the headline figure: what a C# caller gets, Mesh.cs:10-13) = freshly "
-                        "mapped, never touched 4 KiB-page memory, as a managed runtime's new arrays are (the library pre-faults it on its thread "
-                        "pool); pinned = destination arrays from the library's pinned host arena (the Python mirror's Mesh, Span<T> accessors of a "
-                        "shim); numpy = fresh numpy.empty arrays (huge-page advised)",
+                        "median of 4 calls after a warm-up call.  managed (the headline figure: what a C# caller gets, Mesh.cs:10-13, worst "
+                        "case) = freshly mapped, never touched 4 KiB-page memory, as the new arrays of a GROWING managed heap are (the library "
+                        "pre-faults it on its thread pool: the page faults are most of the time); managed_recycled = the same kind of memory "
+                        "already touched, as arrays a managed heap hands out again are (resident pages: the library lets the runtime copy "
+                        "straight into them); pinned = destination arrays from the library's pinned host arena (the Python mirror's Mesh, "
+                        "Span<T> accessors of a shim); numpy = fresh numpy.empty arrays (huge-page advised)",
                 **d2h}
     if rank == 0:
         nvox_rank = n * n * (D.slab(n, world, rank)[3] if world > 1 else n)

@@ -113,7 +113,10 @@ typedef enum sdfk_option {
                                    counts if it is set before the process's FIRST HIP call: host bindings export it, the
                                    library itself never edits the environment */
     SDFK_OPT_CODE_CACHE = 10,   /* 1 (default): compiled code objects are kept on disk (sdfk_set_cache_dir); 0: off */
-    SDFK_OPT_COUNT_ = 11
+    SDFK_OPT_PREFAULT_HUGE = 11,/* 1: whole 2 MiB blocks of a pageable destination are advised MADV_HUGEPAGE before they are first
+                                   touched (sdfk_mesh_copy, sdfk_volume_download, sdfk_host_prefault); 0 (default): left as they are
+                                   (measured slower where the kernel compacts memory inside the fault) */
+    SDFK_OPT_COUNT_ = 12
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);
 int sdfk_get_option(int32_t key, int64_t* value);
@@ -350,12 +353,24 @@ int sdfk_raymarch_device(const sdfk_program* p, int32_t width, int32_t height, c
  * not reclaimed: sdfk_host_free after a shutdown ignores them). */
 int sdfk_host_alloc(int64_t n_bytes, void** out);
 void sdfk_host_free(void* p);
+/* Makes [p, p + n_bytes) of the caller's pageable memory (freshly allocated managed arrays, pinned for the call) present and
+ * writable on the library's thread pool -- what sdfk_mesh_copy does to its destinations anyway, offered separately so that
+ * the host can do it WHILE the GPU computes the mesh: sdfk_sample_march (returns at once) -> sdfk_mesh_size_hint ->
+ * allocate Vertices / Colors / Normals / Triangles -> sdfk_host_prefault each -> sdfk_mesh_counts (waits) -> sdfk_mesh_copy. */
+int sdfk_host_prefault(void* p, int64_t n_bytes);
+/* Phases of the last staged device -> pageable-host copy (measurement): stats[5] = { bytes, ns until every chunk was queued,
+ * ns until the destination pages were present, ns until done, ns of that spent waiting for the DMA }. */
+int sdfk_copy_stats(int64_t stats[5]);
 
 /* ---- Mesh (Mesh.cs:8-64) ----------------------------------------------------
  * Vertices/Colors/Normals: 3 floats each per vertex; Triangles: int32 indices
  * (Mesh.cs:10-13).  Vertices/Normals are already transformed to world space
  * (MarchingCubes.cs:85-90, Mesh.cs:47-64). */
 int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices);
+/* The same WITHOUT waiting: for a mesh whose job is still queued, the counts of the previous mesh of the same grid shape
+ * (what its buffers were sized from: exact whenever the scene repeats), *exact = 0; for a finished mesh its counts, *exact = 1.
+ * Lets a host allocate (and sdfk_host_prefault) the managed arrays of Mesh.cs:10-13 while the GPU still works. */
+int sdfk_mesh_size_hint(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices, int32_t* exact);
 int sdfk_mesh_bounds(const sdfk_mesh* m, float min[3], float max[3]);      /* Mesh.Measure */
 int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* colors3, float* normals3,
                    int32_t* triangles);                                      /* any may be NULL */
@@ -365,6 +380,11 @@ int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, 
  * all-gather inputs), asynchronous on the library stream; any pointer may be NULL */
 int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* colors3, void* normals3,
                           void* triangles);
+/* Mesh.Transform(Matrix4x4) (Mesh.cs:47-64), in place on the device-resident mesh: positions by Vector3.Transform with
+ * `matrix`, normals by Vector3.TransformNormal with `normal_matrix` and Vector3.Normalize, then Mesh.Measure.  Both
+ * matrices row-major M11..M44 (row-vector convention of System.Numerics); normal_matrix = Transpose(Invert(matrix with
+ * M41 = M42 = M43 = 0, M44 = 1)) exactly as Mesh.cs:49-55 derives it -- BCL calls the shim makes with the BCL itself. */
+int sdfk_mesh_transform(sdfk_mesh* m, const float matrix[16], const float normal_matrix[16]);
 /* diagnostics: number of active cells, and of case-13 cells with no tiling
  * ("Impossible case 13?", MarchingCubes.cs:365) seen while meshing */
 int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case13_cells);

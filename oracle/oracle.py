@@ -50,6 +50,13 @@ def lib():
         L.orc_march.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, fp, fp,
                                 C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_march.restype = C.c_void_p
+        L.orc_march_window.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float]
+        L.orc_march_window.restype = C.c_void_p
+        L.orc_sample_window.argtypes = [C.POINTER(_Node), C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]
+        L.orc_sample_window.restype = None
+        L.orc_clip_window.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
+        L.orc_clip_window.restype = None
         for name in ("vertex_count", "index_count", "cell_count", "impossible13"):
             f = getattr(L, "orc_mesh_" + name)
             f.argtypes = [C.c_void_p]
@@ -217,6 +224,58 @@ def march(values, colors, mn, mx, iso=0.0, step=1, progress=None):
     h = lib().orc_march(values.ctypes.data, cp, nx, ny, nz, _f3(mn), _f3(mx),
                         C.c_float(iso), step, C.cast(cb, C.c_void_p) if cb else None, None)
     return OracleMesh(h)
+
+
+def sample_window(scene, mn, mx, nx, ny, nz, z0, nzw, threads=0, with_colors=True, clip=False):
+    """Voxels.SampleSdf (+ ClipToBounds) on the planes [z0, z0 + nzw) of the nx*ny*nz grid: ([nx, ny, nzw], colours)."""
+    values = np.zeros((nx, ny, nzw), dtype=np.float32)
+    colors = np.zeros((nx, ny, nzw, 3), dtype=np.float32) if with_colors else None
+    lib().orc_sample_window(scene.carray(), scene.root, _f3(mn), _f3(mx), nx, ny, nz, z0, nzw, threads,
+                            values.ctypes.data, colors.ctypes.data if with_colors else None)
+    if clip:
+        lib().orc_clip_window(values.ctypes.data, nx, ny, nz, z0, nzw, _f3(mn), _f3(mx))
+    return values, colors
+
+
+def march_window(values, colors, z0, nz_global, mn, mx, iso=0.0):
+    """The serial sweep on a window of planes [z0, z0 + values.shape[2]) of a grid of nz_global planes (global z
+    coordinates, the whole grid's transform).  cells[:, 0] holds window-local linear cell indices."""
+    values = np.ascontiguousarray(values, dtype=np.float32)
+    nx, ny, nzw = values.shape
+    cp = None
+    if colors is not None:
+        colors = np.ascontiguousarray(colors, dtype=np.float32)
+        cp = colors.ctypes.data
+    return OracleMesh(lib().orc_march_window(values.ctypes.data, cp, nx, ny, nzw, z0, nz_global, _f3(mn), _f3(mx), C.c_float(iso)))
+
+
+def window_part(wm, nx, ny, z0, lb, le):
+    """The part of a window mesh `wm` (march_window of planes starting at z0 <= lb - 2, or z0 = 0) that belongs to the cell
+    layers [lb, le): (vertices, colors, normals, triangles with ids local to the part -- seam references are negative).
+    This is what sdfk_march_slab(.., lb, le, vertex_base = 0) returns for the same layers."""
+    assert z0 == 0 or z0 <= lb - 2
+    cz = wm.cells[:, 0] // (nx * ny) + z0           # global layer of every active cell, sweep order
+    nt = wm.cells[:, 3]
+    tri_start = np.concatenate([[0], np.cumsum(nt * 3)])
+    i0, i1 = np.searchsorted(cz, lb, "left"), np.searchsorted(cz, le, "left")
+    t0, t1 = int(tri_start[i0]), int(tri_start[i1])
+    first = np.full(len(wm.vertices), len(wm.triangles), np.int64)   # vertices are numbered in order of first reference
+    np.minimum.at(first, wm.triangles, np.arange(len(wm.triangles)))
+    v0, v1 = int(np.count_nonzero(first < t0)), int(np.count_nonzero(first < t1))
+    tri = (wm.triangles[t0:t1].astype(np.int64) - v0).astype(np.int32)
+    return wm.vertices[v0:v1], wm.colors[v0:v1], wm.normals[v0:v1], tri
+
+
+def transform(vertices, normals, matrix):
+    """Mesh.Transform (Mesh.cs:47-64) on copies of [n,3] float32 arrays: (vertices, normals, min, max)."""
+    v = np.array(vertices, dtype=np.float32, order="C")
+    q = np.array(normals, dtype=np.float32, order="C")
+    m = (C.c_float * 16)(*[float(np.float32(x)) for x in np.asarray(matrix, np.float32).ravel()])
+    lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
+    L = lib()
+    L.orc_transform_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_transform_arrays(v.ctypes.data, q.ctypes.data, len(v), m, lo, hi)
+    return v, q, np.array(lo[:], np.float32), np.array(hi[:], np.float32)
 
 
 def resolve_tiling(v8):

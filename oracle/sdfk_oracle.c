@@ -267,6 +267,66 @@ int orc_sample(const osc_node* nodes, int root, const float min[3], const float 
     return j.nbatches;
 }
 
+/* Voxels.SampleSdf restricted to the planes [z0, z0 + nzw) of the nx*ny*nz grid: the value of a voxel is a pure function of
+   its index (Voxels.cs:99-108: p = (min + D/2) + (ix, iy, iz) * D, evaluated once per voxel), so a window is computed
+   voxel by voxel with exactly the arithmetic of the batched sampler above (test infrastructure for 1024^3 grids;
+   tests/test_oracle_window.py pins it against orc_sample).  values / colors: [nx][ny][nzw]. */
+typedef struct { const osc_node* nodes; int root; float m[3], d[3]; int nx, ny, nzw, z0; float* values; float* colors; int next; } window_job;
+static void* window_worker(void* arg)
+{
+    window_job* j = (window_job*)arg;
+    for (;;) {
+        const int ix = __sync_fetch_and_add(&j->next, 1);
+        if (ix >= j->nx) break;
+        for (int iy = 0; iy < j->ny; iy++)
+            for (int k = 0; k < j->nzw; k++) {
+                float p[3], v[4] = {0.0f, 0.0f, 0.0f, 0.0f};   /* zero-initialised scratch, Voxels.cs:88-92 */
+                p[0] = j->m[0] + (float)ix * j->d[0];
+                p[1] = j->m[1] + (float)iy * j->d[1];
+                p[2] = j->m[2] + (float)(j->z0 + k) * j->d[2];
+                orc_eval(j->nodes, j->root, p, v);
+                const size_t o = ((size_t)ix * j->ny + iy) * j->nzw + k;
+                j->values[o] = v[3];
+                if (j->colors) { j->colors[o * 3] = v[0]; j->colors[o * 3 + 1] = v[1]; j->colors[o * 3 + 2] = v[2]; }
+            }
+    }
+    return NULL;
+}
+
+void orc_sample_window(const osc_node* nodes, int root, const float min[3], const float max[3], int nx, int ny, int nz,
+                       int z0, int nzw, int nthreads, float* values, float* colors)
+{
+    window_job j;
+    memset(&j, 0, sizeof j);
+    j.nodes = nodes; j.root = root;
+    orc_cell_size(min, max, nx, ny, nz, j.d);
+    for (int k = 0; k < 3; k++) j.m[k] = min[k] + 0.5f * j.d[k];
+    j.nx = nx; j.ny = ny; j.nzw = nzw; j.z0 = z0; j.values = values; j.colors = colors;
+    if (nthreads <= 0) nthreads = orc_hardware_threads();
+    if (nthreads > nx) nthreads = nx;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, window_worker, &j);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th);
+}
+
+/* Voxels.ClipToBounds (Voxels.cs:133-167) on the planes [z0, z0 + nzw) of the nx*ny*nz grid */
+void orc_clip_window(float* values, int nx, int ny, int nz, int z0, int nzw, const float min[3], const float max[3])
+{
+    float outside = (max[0] - min[0]) / (float)nx;
+#define VOXW(ix, iy, k) values[((size_t)(ix) * ny + (iy)) * nzw + (k)]
+    for (int iy = 0; iy < ny; iy++)
+        for (int k = 0; k < nzw; k++) { VOXW(0, iy, k) = outside; VOXW(nx - 1, iy, k) = outside; }
+    for (int ix = 0; ix < nx; ix++)
+        for (int k = 0; k < nzw; k++) { VOXW(ix, 0, k) = outside; VOXW(ix, ny - 1, k) = outside; }
+    for (int ix = 0; ix < nx; ix++)
+        for (int iy = 0; iy < ny; iy++) {
+            if (z0 == 0) VOXW(ix, iy, 0) = outside;
+            if (z0 + nzw == nz) VOXW(ix, iy, nzw - 1) = outside;
+        }
+#undef VOXW
+}
+
 void orc_clip_to_bounds(float* values, int nx, int ny, int nz, const float min[3], const float max[3])
 {
     /* Voxels.cs:133-167; outsideValue = Size.X / NX for all six faces */
@@ -616,9 +676,15 @@ static void measure(orc_mesh* m)
     memcpy(m->bmin, mn, sizeof mn); memcpy(m->bmax, mx, sizeof mx);
 }
 
-orc_mesh* orc_march(const float* values, const float* colors, int nx, int ny, int nz,
-                    const float min[3], const float max[3], float iso, int step,
-                    orc_progress_fn progress, void* user)
+/* The sweep on the planes [z0, z0 + nz) of a grid of nz_global planes (z0 = 0, nz_global = nz: the whole volume, which is
+   all the reference has).  Test infrastructure for grids whose whole-volume sweep does not fit a test (1024^3): the cells
+   of a window are the cells of the whole sweep, vertex z coordinates are the global ones (the window's first plane is
+   plane z0: Cell.cs:345-347 adds the cell's z) and the final transform is the whole grid's (MarchingCubes.cs:85-90 uses
+   the volume's N - 1).  What differs from the whole sweep is only what the window's first layer sees below it, so a
+   caller compares layers from the window's third one on (tests/test_oracle_window.py pins that against orc_march). */
+static orc_mesh* march_impl(const float* values, const float* colors, int nx, int ny, int nz, int z0, int nz_global,
+                            const float min[3], const float max[3], float iso, int step,
+                            orc_progress_fn progress, void* user)
 {
     orc_mesh* m = (orc_mesh*)calloc(1, sizeof(orc_mesh));
     cell_t c;
@@ -648,7 +714,7 @@ orc_mesh* orc_march(const float* values, const float* colors, int nx, int ny, in
                 const int cx[8] = {x, xs, xs, x, x, xs, xs, x};
                 const int cy[8] = {y, y, ys, ys, y, y, ys, ys};
                 const int cz[8] = {z, z, z, z, zs, zs, zs, zs};
-                c.x = x; c.y = y; c.z = z;
+                c.x = x; c.y = y; c.z = z + z0;
                 for (int k = 0; k < 8; k++) { /* Cell.SetCube, Cell.cs:191-233 */
                     size_t o = ((size_t)cx[k] * ny + cy[k]) * nz + cz[k];
                     c.v[k] = (double)values[o] - isod;
@@ -677,7 +743,7 @@ orc_mesh* orc_march(const float* values, const float* colors, int nx, int ny, in
        Mesh.cs:47-64). */
     float size[3] = {max[0] - min[0], max[1] - min[1], max[2] - min[2]};
     float center[3] = {(min[0] + max[0]) * 0.5f, (min[1] + max[1]) * 0.5f, (min[2] + max[2]) * 0.5f};
-    int nn[3] = {nx, ny, nz};
+    int nn[3] = {nx, ny, nz_global};
     float sc[3], tr[3];
     for (int j = 0; j < 3; j++) {
         float t1 = (float)(-(nn[j] - 1)) / 2.0f;
@@ -701,6 +767,57 @@ orc_mesh* orc_march(const float* values, const float* colors, int nx, int ny, in
     }
     measure(m);
     return m;
+}
+
+/* Mesh.Transform(Matrix4x4), Mesh.cs:47-64, on plain arrays: vertices by Vector3.Transform, normals by
+   Vector3.TransformNormal with transpose(inverse(M with its translation row zeroed)) and Vector3.Normalize; then
+   Mesh.Measure (bmin / bmax; untouched when n == 0).  System.Numerics arithmetic as documented in sdfk_oracle.h:
+   row-vector convention, products summed left to right, one rounding per operation. */
+int orc_transform_arrays(float* verts, float* norms, int64_t n, const float M[16], float bmin[3], float bmax[3])
+{
+    float nm[16], inv[16], nt[16];
+    memcpy(nm, M, sizeof nm);
+    nm[12] = 0.0f; nm[13] = 0.0f; nm[14] = 0.0f; nm[15] = 1.0f;          /* M41 M42 M43 M44 */
+    if (!orc_mat_invert(nm, inv))                                         /* Matrix4x4.Invert failed: NaN matrix (BCL) */
+        for (int k = 0; k < 16; k++) inv[k] = NAN;
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) nt[r * 4 + c] = inv[c * 4 + r];
+    for (int64_t i = 0; i < n; i++) {
+        float* v = verts + i * 3;
+        float* q = norms + i * 3;
+        const float x = v[0], y = v[1], z = v[2];
+        v[0] = ((x * M[0] + y * M[4]) + z * M[8]) + M[12];
+        v[1] = ((x * M[1] + y * M[5]) + z * M[9]) + M[13];
+        v[2] = ((x * M[2] + y * M[6]) + z * M[10]) + M[14];
+        const float a = q[0], b = q[1], c = q[2];
+        const float tx = (a * nt[0] + b * nt[4]) + c * nt[8];
+        const float ty = (a * nt[1] + b * nt[5]) + c * nt[9];
+        const float tz = (a * nt[2] + b * nt[6]) + c * nt[10];
+        const float len = v3_length(tx, ty, tz);
+        q[0] = tx / len; q[1] = ty / len; q[2] = tz / len;
+    }
+    if (n > 0) {
+        memcpy(bmin, verts, 3 * sizeof(float)); memcpy(bmax, verts, 3 * sizeof(float));
+        for (int64_t i = 1; i < n; i++)
+            for (int j = 0; j < 3; j++) {
+                const float w = verts[i * 3 + j];
+                bmin[j] = sel_min(bmin[j], w); bmax[j] = sel_max(bmax[j], w);
+            }
+    }
+    return 1;
+}
+
+orc_mesh* orc_march(const float* values, const float* colors, int nx, int ny, int nz,
+                    const float min[3], const float max[3], float iso, int step,
+                    orc_progress_fn progress, void* user)
+{
+    return march_impl(values, colors, nx, ny, nz, 0, nz, min, max, iso, step, progress, user);
+}
+
+orc_mesh* orc_march_window(const float* values, const float* colors, int nx, int ny, int nz_window, int z0, int nz_global,
+                           const float min[3], const float max[3], float iso)
+{
+    return march_impl(values, colors, nx, ny, nz_window, z0, nz_global, min, max, iso, 1, NULL, NULL);
 }
 
 int64_t orc_mesh_vertex_count(const orc_mesh* m) { return (int64_t)(m->verts.n / 3); }

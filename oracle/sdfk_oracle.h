@@ -93,6 +93,18 @@ typedef void (*orc_progress_fn)(float value, void* user);
 orc_mesh* orc_march(const float* values, const float* colors, int nx, int ny, int nz,
                     const float min[3], const float max[3], float iso, int step,
                     orc_progress_fn progress, void* user);
+/* Mesh.Transform(Matrix4x4) (Mesh.cs:47-64) on arrays, then Mesh.Measure. */
+int orc_transform_arrays(float* verts, float* norms, int64_t n, const float M[16], float bmin[3], float bmax[3]);
+
+/* Window forms (test infrastructure for grids whose whole-volume sweep does not fit a test, e.g. 1024^3): the planes
+   [z0, z0 + nz_window) of an nx*ny*nz grid.  Sampling and clipping are per-voxel functions of the GLOBAL index; the sweep
+   uses global z coordinates and the whole grid's final transform.  Pinned against the whole-volume functions by
+   tests/test_oracle_window.py. */
+void orc_sample_window(const osc_node* nodes, int root, const float min[3], const float max[3], int nx, int ny, int nz,
+                       int z0, int nz_window, int nthreads, float* values, float* colors);
+void orc_clip_window(float* values, int nx, int ny, int nz, int z0, int nz_window, const float min[3], const float max[3]);
+orc_mesh* orc_march_window(const float* values, const float* colors, int nx, int ny, int nz_window, int z0, int nz_global,
+                           const float min[3], const float max[3], float iso);
 int64_t orc_mesh_vertex_count(const orc_mesh*);
 int64_t orc_mesh_index_count(const orc_mesh*);
 const float* orc_mesh_vertices(const orc_mesh*);   /* 3 floats per vertex, transformed */

@@ -73,11 +73,15 @@ SIGNATURES = {
     "sdfk_slabs_rebase_mirror": (C.c_int, [_vp, _i32, _i64, _vp]),
     "sdfk_host_alloc": (C.c_int, [_i64, _vpp]),
     "sdfk_host_free": (None, [_vp]),
+    "sdfk_host_prefault": (C.c_int, [_vp, _i64]),
+    "sdfk_copy_stats": (C.c_int, [C.POINTER(_i64)]),
+    "sdfk_mesh_size_hint": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "sdfk_mesh_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_mesh_bounds": (C.c_int, [_vp, _fp, _fp]),
     "sdfk_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sdfk_mesh_device_ptrs": (C.c_int, [_vp, _vpp, _vpp, _vpp, _vpp]),
     "sdfk_mesh_copy_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sdfk_mesh_transform": (C.c_int, [_vp, _fp, _fp]),
     "sdfk_mesh_stats": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_mesh_free": (None, [_vp]),
     "sdfk_profile_enable": (C.c_int, [_i32]),
@@ -116,7 +120,7 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 
 # enum sdfk_option
 OPT_LANES, OPT_TOKENS, OPT_GRAPHS, OPT_COPY_MODE, OPT_CORNER_EVAL, OPT_VCOLOR_EVAL = 1, 2, 3, 4, 5, 6
-OPT_DIST_EXCHANGE, OPT_DIST_LANES, OPT_HW_QUEUES, OPT_CODE_CACHE = 7, 8, 9, 10
+OPT_DIST_EXCHANGE, OPT_DIST_LANES, OPT_HW_QUEUES, OPT_CODE_CACHE, OPT_PREFAULT_HUGE = 7, 8, 9, 10, 11
 
 
 def library_path():

@@ -519,6 +519,39 @@ class Mesh:
         m.ActiveCells, m.ImpossibleCase13Cells = na.value, n13.value
         return m
 
+    def Transform(self, transform):
+        """Mesh.Transform(Matrix4x4) (Mesh.cs:47-64) on the host arrays: Vector3.Transform for the positions,
+        Vector3.TransformNormal with Transpose(Invert(transform without its translation row)) + Vector3.Normalize for the
+        normals, then Measure.  float32 throughout, products summed left to right (System.Numerics' row-vector form).
+        (The device-resident form is sdfk_mesh_transform, for hosts that keep the handle.)"""
+        from .raymarch import Matrix4x4
+        f32 = np.float32
+        M = np.array(transform, f32).reshape(4, 4)
+        nm = M.copy()
+        nm[3] = [0, 0, 0, 1]
+        _, inv = Matrix4x4.Invert(nm)
+        NT = inv.T.copy()
+        V, Q = self.Vertices, self.Normals
+        x, y, z = V[:, 0].copy(), V[:, 1].copy(), V[:, 2].copy()
+        a, b, c = Q[:, 0].copy(), Q[:, 1].copy(), Q[:, 2].copy()
+        with np.errstate(all="ignore"):
+            for j in range(3):
+                V[:, j] = ((x * M[0, j] + y * M[1, j]) + z * M[2, j]) + M[3, j]
+            t = [(a * NT[0, j] + b * NT[1, j]) + c * NT[2, j] for j in range(3)]
+            ln = np.sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2])
+            for j in range(3):
+                Q[:, j] = t[j] / ln
+        if len(V):     # Measure (Mesh.cs:30-45): Vector3.Min / Max componentwise, in order
+            self.Min, self.Max = V.min(axis=0), V.max(axis=0)
+
+    @staticmethod
+    def normal_matrix(transform):
+        """The matrix Mesh.Transform applies to normals (Mesh.cs:49-55), for sdfk_mesh_transform."""
+        from .raymarch import Matrix4x4
+        nm = np.array(transform, np.float32).reshape(4, 4).copy()
+        nm[3] = [0, 0, 0, 1]
+        return Matrix4x4.Invert(nm)[1].T.copy()
+
     @property
     def Center(self): return (self.Min + self.Max) * np.float32(0.5)
     @property

@@ -1318,6 +1318,89 @@ __global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathere
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) t[i] += (int32_t)base;
 }
 
+// Mesh.Transform(Matrix4x4), Mesh.cs:47-64, on the device arrays: Vector3.Transform for the positions, Vector3.TransformNormal
+// with the normal matrix the HOST derived (Matrix4x4.Invert / Transpose are BCL calls of the reference: the shim makes them
+// with the BCL itself) + Vector3.Normalize for the normals; per-workgroup AABB partials for Mesh.Measure.  Row-vector
+// convention, products summed left to right, no contraction.
+struct XformArgs {
+    float* vertices;
+    float* normals;
+    int64_t n;
+    float m[16], nm[16];
+    float* partial;   // [grid][6]
+};
+
+__global__ __launch_bounds__(256) void k_mesh_transform(XformArgs A)
+{
+    __shared__ float s_red[6][4];
+    float r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * 256) {
+        const f3u v = *reinterpret_cast<const f3u*>(A.vertices + i * 3);
+        const f3u q = *reinterpret_cast<const f3u*>(A.normals + i * 3);
+        const float px = ((v.x * A.m[0] + v.y * A.m[4]) + v.z * A.m[8]) + A.m[12];
+        const float py = ((v.x * A.m[1] + v.y * A.m[5]) + v.z * A.m[9]) + A.m[13];
+        const float pz = ((v.x * A.m[2] + v.y * A.m[6]) + v.z * A.m[10]) + A.m[14];
+        const float tx = (q.x * A.nm[0] + q.y * A.nm[4]) + q.z * A.nm[8];
+        const float ty = (q.x * A.nm[1] + q.y * A.nm[5]) + q.z * A.nm[9];
+        const float tz = (q.x * A.nm[2] + q.y * A.nm[6]) + q.z * A.nm[10];
+        const float len = v3len(tx, ty, tz);
+        *reinterpret_cast<f3u*>(A.vertices + i * 3) = f3u{px, py, pz};
+        *reinterpret_cast<f3u*>(A.normals + i * 3) = f3u{tx / len, ty / len, tz / len};
+        r[0] = fminf(r[0], px); r[1] = fminf(r[1], py); r[2] = fminf(r[2], pz);
+        r[3] = fmaxf(r[3], px); r[4] = fmaxf(r[4], py); r[5] = fmaxf(r[5], pz);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) r[j] = fminf(r[j], __shfl_down(r[j], o));
+#pragma unroll
+        for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], __shfl_down(r[j], o));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) s_red[j][wave] = r[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int j = threadIdx.x;
+        float a = s_red[j][0];
+        for (int w = 1; w < 4; w++) a = (j < 3) ? fminf(a, s_red[j][w]) : fmaxf(a, s_red[j][w]);
+        A.partial[(size_t)blockIdx.x * 6 + j] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bounds_reduce(const float* __restrict__ partial, int blocks, float* __restrict__ bounds)
+{
+    __shared__ float s_red[6][4];
+    float r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int b = threadIdx.x; b < blocks; b += 256) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) r[j] = fminf(r[j], partial[(size_t)b * 6 + j]);
+#pragma unroll
+        for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], partial[(size_t)b * 6 + j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) r[j] = fminf(r[j], __shfl_down(r[j], o));
+#pragma unroll
+        for (int j = 3; j < 6; j++) r[j] = fmaxf(r[j], __shfl_down(r[j], o));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) s_red[j][wave] = r[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int j = threadIdx.x;
+        float a = s_red[j][0];
+        for (int w = 1; w < 4; w++) a = (j < 3) ? fminf(a, s_red[j][w]) : fmaxf(a, s_red[j][w]);
+        bounds[j] = a;
+    }
+}
+
 // step > 1 (MarchingCubes.cs:49-80): the sweep only ever touches voxels whose indices are
 // multiples of `step`; gather them into a dense volume and mesh that with unit cells.  sp / dp = row pitches.
 __global__ __launch_bounds__(256) void k_subsample(const float* __restrict__ src, const float* __restrict__ srcc,

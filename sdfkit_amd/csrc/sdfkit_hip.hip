@@ -55,6 +55,7 @@ struct Config {
     int dist_exchange = 1;    // SDFK_OPT_DIST_EXCHANGE
     int dist_lanes = 2;       // SDFK_OPT_DIST_LANES
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
+    int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
     int copy_threads = 0;     // SDFK_COPY_THREADS (0: min(16, cores / 2)); fixed once the pool has started
     int sample_mode = -1;     // SDFK_SAMPLE_MODE (debugging: force the row-tiled (0) / plane-chunk (1) sampler)
     int hw_queues = 0;        // GPU_MAX_HW_QUEUES as the process had it when the library initialised (0: unset)
@@ -461,6 +462,10 @@ void prefault_start(void* p, size_t n)
         const size_t b = t == 0 ? std::min(first, n) : std::min(a + kSlice, n);
         if (b <= a) return;
         const uintptr_t page = 4096, lo = ((uintptr_t)base + a) & ~(page - 1), hi = ((uintptr_t)base + b + page - 1) & ~(page - 1);
+        // SDFK_OPT_PREFAULT_HUGE (off by default): a slice that is a whole, aligned 2 MiB block of the destination is advised
+        // MADV_HUGEPAGE first -- one fault instead of 512.  Measured on the bench box (THP and defrag both "madvise"): SLOWER,
+        // 3.2 instead of 2.5 ms per 512^3 mesh -- the kernel compacts memory inside the fault to find the huge page.
+        if (g_cfg.prefault_huge && t > 0 && b - a == kSlice) (void)madvise((void*)((uintptr_t)base + a), kSlice, MADV_HUGEPAGE);
         static std::atomic<int> have_populate{1};
         if (have_populate.load(std::memory_order_relaxed)) {
             if (madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
@@ -490,6 +495,7 @@ int stage_reserve()
 }
 
 struct CopyPiece { const void* src; void* dst; size_t bytes; };
+int64_t g_copy_stats[5] = {0, 0, 0, 0, 0};   // last staged copy: bytes, ns until queued / destination present / done, ns waiting for the DMA
 
 // Device -> caller arrays.  Default (mode 1): everything goes to the pinned staging buffer in 4 MiB
 // chunks (plain DMA at the link rate) and the pool copies the chunks that have arrived into the
@@ -511,7 +517,26 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
         --it;
         if ((const char*)p.dst + p.bytes > (const char*)it->first + it->second) { pinned = false; break; }
     }
-    if (total < (size_t(1) << 20) || mode == 2 || pinned) {   // small: nothing to gain from helpers
+    // Destinations whose pages are all resident (arrays a managed heap has recycled, buffers the caller has used before): the
+    // runtime's own copy is the fastest there -- 33 MB in 0.57 ms against 0.8-1.4 ms through the staging ring; it is FRESH
+    // pages that it handles badly (2.3-3.0 ms, and anywhere up to 26 ms depending on page size and history), and those
+    // take the staged path below.  One mincore() per destination decides (microseconds).
+    bool resident = mode == 1 && !pinned && total >= (size_t(1) << 20);
+    if (resident) {
+        std::vector<unsigned char> vec;
+        for (auto& p : pieces) {
+            if (!p.bytes) continue;
+            const uintptr_t pg = 4096, lo = (uintptr_t)p.dst & ~(pg - 1), hi = ((uintptr_t)p.dst + p.bytes + pg - 1) & ~(pg - 1);
+            vec.resize((hi - lo) / pg);
+            if (mincore((void*)lo, hi - lo, vec.data()) != 0) { resident = false; break; }
+            for (unsigned char c : vec)
+                if (!(c & 1)) { resident = false; break; }
+            if (!resident) break;
+        }
+    }
+    g_copy_stats[0] = (int64_t)total;
+    g_copy_stats[1] = g_copy_stats[2] = g_copy_stats[3] = g_copy_stats[4] = resident ? -1 : 0;
+    if (total < (size_t(1) << 20) || mode == 2 || pinned || resident) {   // small: nothing to gain from helpers
         for (auto& p : pieces)
             if (p.bytes) HIPCHK(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -519,6 +544,8 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
     }
     if (mode == 1 && stage_reserve() != SDFK_OK) mode = 0;   // no pinned memory to be had: the runtime's copy still works
     if (mode == 1) {
+        const auto tp0 = std::chrono::steady_clock::now();
+        auto since = [&](std::chrono::steady_clock::time_point t) { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
         // chunk k travels through ring slot k % kStageSlots: DMA into the slot, event; the pool copies the slot into the
         // destination (pre-faulted while the first chunks were on the wire) and only then is the slot's next DMA queued
         struct Chunk { char* dst; const char* src; size_t bytes; };
@@ -538,11 +565,17 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
         size_t issued = 0;
         for (; issued < chunks.size() && issued < (size_t)kStageSlots && e == hipSuccess; issued++) e = issue(issued);
         if (e == hipSuccess) {
+            g_copy_stats[0] = (int64_t)total;
+            g_copy_stats[1] = since(tp0);   // chunks queued
             // pre-fault the whole destination while the first chunks travel
             for (auto& p : pieces) { prefault_start(p.dst, p.bytes); g_pool.wait(); }
+            g_copy_stats[2] = since(tp0);   // destination present
+            g_copy_stats[4] = 0;
             const int nt = g_pool.size() + 1;
             for (size_t k = 0; k < chunks.size() && e == hipSuccess; k++) {
+                const auto tw = std::chrono::steady_clock::now();
                 e = hipEventSynchronize(ev[k % kStageSlots]);
+                g_copy_stats[4] += since(tw);   // waiting for the DMA
                 if (e != hipSuccess) break;
                 const Chunk c = chunks[k];
                 const char* slot = (const char*)g.stage + (k % kStageSlots) * kStageChunk;
@@ -555,6 +588,7 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
                 if (issued < chunks.size()) e = issue(issued++);   // the slot is free again
             }
         }
+        g_copy_stats[3] = since(tp0);       // done
         if (e != hipSuccess) (void)hipStreamSynchronize(g.stream);
         for (auto& x : ev) g.prof_event_pool.push_back(x);
         if (e != hipSuccess) return fail(SDFK_ERR_HIP, "device-to-host copy: %s", hipGetErrorString(e));
@@ -725,6 +759,7 @@ static void config_from_env()
     g_cfg.dist_exchange = geti("SDFK_DIST_EXCHANGE", 1);
     g_cfg.dist_lanes = geti("SDFK_DIST_LANES", 2);
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
+    g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0);
     g_cfg.sample_mode = geti("SDFK_SAMPLE_MODE", -1);
     g_cfg.hw_queues = geti("GPU_MAX_HW_QUEUES", 0);
     g_cfg.env_cache_dir = gets("SDFK_CACHE_DIR");
@@ -903,6 +938,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_DIST_EXCHANGE: if (!in(0, 2)) break; g_cfg.dist_exchange = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_LANES: if (value != 0 && value != 2) break; g_cfg.dist_lanes = (int)value; return SDFK_OK;
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
+    case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;
     case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
     default: return fail(SDFK_ERR_INVALID, "sdfk_set_option: unknown option %d", key);
     }
@@ -924,6 +960,7 @@ extern "C" int sdfk_get_option(int32_t key, int64_t* value)
     case SDFK_OPT_DIST_EXCHANGE: *value = g_cfg.dist_exchange; break;
     case SDFK_OPT_DIST_LANES: *value = g_cfg.dist_lanes; break;
     case SDFK_OPT_CODE_CACHE: *value = g_cfg.code_cache; break;
+    case SDFK_OPT_PREFAULT_HUGE: *value = g_cfg.prefault_huge; break;
     case SDFK_OPT_HW_QUEUES: *value = g_cfg.hw_queues; break;
     default: return fail(SDFK_ERR_INVALID, "sdfk_get_option: unknown option %d", key);
     }
@@ -2738,9 +2775,55 @@ extern "C" void sdfk_host_free(void* p)
     g.host_live.erase(it);
 }
 
+// Makes [p, p + n_bytes) of the caller's (pageable) memory present and writable on the library's thread pool: what
+// sdfk_mesh_copy / sdfk_volume_download do to their destinations anyway, offered separately so that a host can do it WHILE
+// the GPU is still computing the mesh (sdfk_mesh_size_hint tells how large the arrays will be).
+// Phases of the last staged device -> pageable-host copy (SDFK_OPT_COPY_MODE 1): stats[5] = { bytes, ns until every chunk was
+// queued, ns until the destination pages were present, ns until done, ns of that spent waiting for the DMA } (measurement).
+extern "C" int sdfk_copy_stats(int64_t stats[5])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!stats) return fail(SDFK_ERR_INVALID, "sdfk_copy_stats: null argument");
+    memcpy(stats, g_copy_stats, sizeof g_copy_stats);
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_host_prefault(void* p, int64_t n_bytes)
+{
+    if (n_bytes < 0) return fail(SDFK_ERR_INVALID, "sdfk_host_prefault: bad size");
+    if (!p || n_bytes == 0) return SDFK_OK;
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    config_from_env();
+    prefault_start(p, (size_t)n_bytes);
+    g_pool.wait();
+    return SDFK_OK;
+}
+
 // ---------------------------------------------------------------------------
 // meshes
 // ---------------------------------------------------------------------------
+// How large will the mesh be?  Without waiting: for a mesh whose job is still queued, the sizes of the previous mesh of the
+// same grid shape (what its buffers were sized from; exact whenever the scene repeats) -- the host can allocate and
+// pre-fault its arrays while the GPU works and only re-allocates if sdfk_mesh_counts says otherwise; for a finished mesh,
+// its counts.  *exact = 1 in the second case.
+extern "C" int sdfk_mesh_size_hint(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices, int32_t* exact)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
+    int64_t nv = m->nv, ni = m->ni;
+    int ex = 1;
+    if (m->pending && !m->status) {
+        ex = 0;
+        auto it = g.hints.find(m->key);
+        if (it != g.hints.end()) { nv = it->second.nv; ni = it->second.ni; }
+        else { nv = (int64_t)m->cap_v; ni = (int64_t)m->cap_i; }
+    }
+    if (n_vertices) *n_vertices = nv;
+    if (n_indices) *n_indices = ni;
+    if (exact) *exact = ex;
+    return SDFK_OK;
+}
+
 extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -2833,6 +2916,32 @@ extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void*
     if (colors3) *colors3 = m->colors;
     if (normals3) *normals3 = m->normals;
     if (triangles) *triangles = m->triangles;
+    return SDFK_OK;
+}
+
+// Mesh.Transform(Matrix4x4) (Mesh.cs:47-64) on the device-resident mesh, in place.
+extern "C" int sdfk_mesh_transform(sdfk_mesh* m, const float matrix[16], const float normal_matrix[16])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!m || !matrix || !normal_matrix) return fail(SDFK_ERR_INVALID, "sdfk_mesh_transform: null argument");
+    if (int r = require_init()) return r;
+    if (int r = mesh_resolve(m)) return r;
+    if (m->borrowed || m->external) return fail(SDFK_ERR_UNSUPPORTED, "sdfk_mesh_transform: the mesh arrays belong to a captured job or a slab payload");
+    if (m->nv == 0) return SDFK_OK;   // (Mesh.Measure leaves Min / Max alone, Mesh.cs:32)
+    if (m->lane != g.cur_lane) m->used_on_main = true;
+    const int grid = grid_for((size_t)m->nv, 256, 1024);
+    float* partial = nullptr;
+    if (int r = dev_alloc((void**)&partial, (size_t)grid * 6 * sizeof(float))) return r;
+    XformArgs A;
+    A.vertices = m->vertices; A.normals = m->normals; A.n = m->nv; A.partial = partial;
+    memcpy(A.m, matrix, sizeof A.m);
+    memcpy(A.nm, normal_matrix, sizeof A.nm);
+    hipLaunchKernelGGL(k_mesh_transform, dim3(grid), dim3(256), 0, g.stream, A);
+    hipLaunchKernelGGL(k_bounds_reduce, dim3(1), dim3(256), 0, g.stream, (const float*)partial, grid, m->bounds);
+    const hipError_t e = hipGetLastError();
+    dev_free(partial);   // (stream-ordered)
+    if (e != hipSuccess) return fail(SDFK_ERR_HIP, "sdfk_mesh_transform: %s", hipGetErrorString(e));
+    m->bounds_valid = false;   // sdfk_mesh_bounds reads the new AABB from the device
     return SDFK_OK;
 }
 

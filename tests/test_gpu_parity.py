@@ -436,6 +436,63 @@ def test_c3_repeat_xy_512_properties(gpu):
     assert np.array_equal(vol.Colors, oc)
     # colour blend stays inside the palette range of the scene
     assert m.Colors.min() >= 0.9 - 3.0 / 6 - 1e-6 and m.Colors.max() <= 0.9 + 1e-6
+    # ... and the whole mesh against the reference's serial sweep at FULL size (MarchingCubes.cs:39-92 on the README scene,
+    # README.md:24-30): vertices, colours, normals, triangles, AABB -- about 30 s of one CPU core
+    del vals
+    om = O.march(ov, oc, mn, mx)
+    assert len(om.vertices) > 900_000
+    assert_mesh_equal(m, om)
+    assert m.ActiveCells == len(om.cells)
+
+
+def test_c4_union8_1024_windows_equal_oracle(gpu):
+    """BASELINE config C4 at its full size, 1024^3 CSG union of 8 primitives, against the reference's serial sweep on z
+    WINDOWS (the whole sweep of 10^9 cells does not fit a test; the window form of the oracle is pinned against the
+    whole-volume oracle by tests/test_oracle_window.py): the slab the 8-GPU run gives rank 3 right at its seam with rank 2,
+    the layers through the centre plane of the upper primitives, and the two clip faces of the grid.  For each window the
+    product meshes exactly those layers of a slab volume (sdfk_march_slab, slab-local vertex ids) and every array must be
+    the oracle's, bit for bit -- including the negative ids that point across the seam."""
+    from tests import slab_worker as W
+    scene, sdf = S.CATALOGUE["union8"]()
+    n = 1024
+    mn, mx = [-2.0] * 3, [2.0] * 3        # BASELINE.md section 3, C4: bounds -2..2, clipToBounds
+    L = N.lib()
+    seam = W.slab_layers(n - 1, 8, 3)[0]
+    # (the primitives span z indices 102..410 and 614..922: the last two windows cut their lowest tips and hold nothing at all)
+    windows = [(seam, seam + 12), (seam - 6, seam + 6), (762, 774), (100, 112), (914, 926), (0, 10)]
+    prog = sdf.program()
+    total_v = 0
+    for lb, le in windows:
+        z0, nzl = W.slab_planes(lb, le, n)
+        ov, oc = O.sample_window(scene, mn, mx, n, n, n, z0, nzl, clip=True)
+        wm = O.march_window(ov, oc, z0, n, mn, mx)
+        want = O.window_part(wm, n, n, z0, lb, le)
+        vol, mesh = C.c_void_p(), C.c_void_p()
+        N.check(L.sdfk_volume_create_slab(n, n, n, N.f3(mn), N.f3(mx), z0, nzl, 1, C.byref(vol)))
+        try:
+            for rep in range(2):      # exact path first, then the speculative one (hints of this slab shape)
+                N.check(L.sdfk_sample(prog, vol, 1))
+                if rep == 0:          # the slab's voxels are the oracle's
+                    gv, gc = np.empty((n, n, nzl), np.float32), np.empty((n, n, nzl, 3), np.float32)
+                    N.check(L.sdfk_volume_download(vol, gv.ctypes.data, gc.ctypes.data))
+                    assert np.array_equal(gv, ov) and np.array_equal(gc, oc)
+                    del gv, gc
+                N.check(L.sdfk_march_slab(vol, C.c_float(0.0), lb, le, 0, C.byref(mesh)))
+                nv, ni = C.c_int64(), C.c_int64()
+                N.check(L.sdfk_mesh_counts(mesh, C.byref(nv), C.byref(ni)))
+                assert (nv.value, ni.value) == (len(want[0]), len(want[3])), (lb, le, nv.value, ni.value)
+                got = [np.empty((nv.value, 3), np.float32) for _ in range(3)] + [np.empty(ni.value, np.int32)]
+                N.check(L.sdfk_mesh_copy(mesh, *[a.ctypes.data for a in got]))
+                L.sdfk_mesh_free(mesh)
+                for a, b, what in zip(got, want, ("vertices", "colours", "normals", "triangles")):
+                    assert np.array_equal(a, b, equal_nan=True), f"window [{lb}, {le}) pass {rep}: {what} differ"
+                if lb > 0 and len(got[3]) and lb not in (100,):
+                    assert got[3].min() < 0          # triangles of the first layer reach across the seam
+        finally:
+            L.sdfk_volume_free(vol)
+        total_v += len(want[0])
+        del ov, oc, wm
+    assert total_v > 100_000
 
 
 def _exclusive_prefix(counts):
