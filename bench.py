@@ -45,12 +45,29 @@ WORKLOADS = {
 }
 
 
+def _run_ranks(cmd, env, limit_s):
+    """Runs the launcher command in a process group of its own; (exit code, stdout).  On a timeout the whole group is
+    killed (the ranks, not only torch.distributed.run) and the exit code is 124."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=limit_s)
+        return p.returncode, out
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)     # (the exact group this function started)
+        except ProcessLookupError:
+            pass
+        out, _ = p.communicate()
+        return 124, out or ""
+
+
 def launch_ranks(argv, n):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU under
     torch.distributed.run as a child process (never exec: see the module docstring), forward its
     output and return its exit code.  Nothing here imports torch or touches HIP."""
     import socket
-    import subprocess
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -60,10 +77,13 @@ def launch_ranks(argv, n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     tries = [({}, "")]
-    # a second, conservative attempt if the pipelined form fails on this node: one step in flight,
-    # no internal lanes (same protocol, same kernels)
+    # if the pipelined form fails (or hangs) on this node: first RCCL's own all-gather instead of the grouped point-to-point
+    # sends, one step in flight, no exchange tuning; then, on top, no internal lanes at all (same protocol, same kernels)
+    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1"},
+                  "retry: one step in flight, plain ncclAllGather, no exchange tuning"))
     tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0", "SDFK_DIST_LANES": "0", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1"},
                   "retry: one step in flight, no lanes, plain ncclAllGather"))
+    limit = float(os.environ.get("SDFK_BENCH_RANKS_TIMEOUT_S", "420"))   # (a hung collective must not eat the caller's whole budget)
     rc = 1
     for extra, note in tries:
         e = dict(env)
@@ -71,14 +91,15 @@ def launch_ranks(argv, n):
         if note:
             print(f"bench.py: multi-rank run failed (rc {rc}); {note}", file=sys.stderr, flush=True)
             e["SDFK_BENCH_NOTE"] = note
-        p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, text=True)
-        rc = p.returncode
-        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        rc, out = _run_ranks(cmd, e, limit)
+        if rc == 124:
+            print(f"bench.py: the ranks did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
         if rc == 0 and lines:
-            sys.stdout.write(p.stdout)
+            sys.stdout.write(out)
             sys.stdout.flush()
             return 0
-        sys.stderr.write(p.stdout)
+        sys.stderr.write(out)
     return rc or 1
 
 

@@ -395,10 +395,10 @@ __device__ __forceinline__ uint64_t chunk_totals_sum(const uint64_t* chunktot, u
 __device__ __forceinline__ void publish_totals(const McParams& P)
 {
     const uint32_t nrec = min(P.counters->n_active, P.cap_active);
-    const uint32_t nch = (nrec + 255u) >> 8;
+    const uint32_t nch = (nrec + MC_CHUNK - 1u) / MC_CHUNK;
     // vertices numbered before the first emitted cell: chunk prefix + in-chunk prefix
     const uint32_t i0 = min(P.counters->n_ghost_cells, nrec);
-    const uint32_t c0 = i0 >> 8;
+    const uint32_t c0 = i0 / MC_CHUNK;
     uint64_t all = 0, upto = 0, dead = 0;
     for (uint32_t i = threadIdx.x; i < nch; i += 256u) {
         const uint64_t v = P.chunktot[i];
@@ -574,13 +574,14 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
     __syncthreads();
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const bool check_dead = P.counters->n_case13 != 0;
-    const int nchunks = (int)((n + 255u) >> 8);
+    const int nchunks = (int)((n + MC_CHUNK - 1u) / MC_CHUNK);
     float* col = s_v + threadIdx.x;
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint32_t i = (uint32_t)c * 256u + threadIdx.x;
+        const uint32_t i = (uint32_t)c * MC_CHUNK + threadIdx.x;
+        const bool mine_rec = threadIdx.x < MC_CHUNK && i < n;   // (lanes MC_CHUNK..255 idle here: see MC_CHUNK)
         uint32_t nown = 0, nt_emit = 0, info = 0, dead = 0;
         uint64_t own = 0;
-        if (i < n) {
+        if (mine_rec) {
             const uint32_t xy = P.rec_xy[i];
             const int x = (int)(xy & P.xmask), y = (int)(xy >> P.xbits), z = (int)P.rec_z[i];
             corners_to_column(*reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8),
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
         // in-chunk prefix and chunk total of (created vertices, triangles), packed v << 31 | t
         uint64_t total;
         const uint64_t pre = block_excl_scan_u64(((uint64_t)nown << 31) | nt_emit, s_wave, &total);
-        if (i < n) {
+        if (mine_rec) {
             P.rec_info[i] = info;
             P.rec_own[i] = own;
             P.rec_pre[i] = (uint32_t)(pre >> 31) | ((uint32_t)(pre & 0x7fffffffull) << 16);
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
             P.chunktot[c] = total;
             P.chunkdead[c] = (uint32_t)ndead;
             // rows spanned by the chunk: lets K4 fetch its windows without first reading records
-            const uint32_t first = (uint32_t)c * 256u, last = min(first + 255u, n - 1u);
+            const uint32_t first = (uint32_t)c * MC_CHUNK, last = min(first + MC_CHUNK - 1u, n - 1u);
             const uint32_t rf = (P.rec_z[first] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[first] >> P.xbits);
             const uint32_t rl = (P.rec_z[last] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[last] >> P.xbits);
             // ... and the record ranges of its two neighbour windows (see k_vertices)
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
 // ---------------------------------------------------------------------------
 // K4 / K5 helpers
 // ---------------------------------------------------------------------------
-// Workgroup-level re-balancing: a chunk of 256 cells owns a variable number of output items
+// Workgroup-level re-balancing: a chunk of MC_CHUNK cells owns a variable number of output items
 // each (created vertices / triangle indices).  An exclusive prefix in LDS plus a small
 // item -> cell table (filled by the cells' own lanes) turns "one lane per cell" into "one lane
 // per output item".
@@ -711,7 +712,7 @@ __device__ __forceinline__ int mc_edge_corner_b(int e) { return e < 8 ? ((e & 4)
 // ---------------------------------------------------------------------------
 // K4: vertices
 // ---------------------------------------------------------------------------
-// Records are sorted by (z, y, x), so everything a chunk of 256 consecutive records needs
+// Records are sorted by (z, y, x), so everything a chunk of MC_CHUNK consecutive records needs
 // from its neighbours lives in two CONTIGUOUS windows of the record list:
 //   W1 = the chunk itself up to the end of the row after its last row   (+x, +y sharers)
 //   W2 = the same rows (+1) of the next layer                           (+z, +y+z sharers)
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     {
         const uint32_t i0 = min(P.counters->n_ghost_cells, n);
         if (i0 > 0)   // (all records ghost: every chunk counts)
-            nghost = (uint32_t)(chunk_totals_sum(P.chunktot, 0, i0 < n ? i0 >> 8 : (n + 255u) >> 8, s_part) >> 31) +
+            nghost = (uint32_t)(chunk_totals_sum(P.chunktot, 0, i0 < n ? i0 / MC_CHUNK : (n + MC_CHUNK - 1u) / MC_CHUNK, s_part) >> 31) +
                      (i0 < n ? (P.rec_pre[i0] & 0xffffu) : 0u);
     }
     if (blockIdx.x == 0) publish_totals(P);   // k_resolve has completed (stream order)
@@ -794,22 +795,23 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 #if SDFK_K4_ABLATE == 1
     if (n) return;
 #endif
-    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
-        const uint32_t cnt = min(256u, n - base);
+    for (uint32_t base = blockIdx.x * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
+        const uint32_t cnt = min(MC_CHUNK, n - base);
+        const uint32_t ci = base / MC_CHUNK;   // chunk index
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_nown = 0;
         __syncthreads();   // previous chunk is done with all s_* arrays
         // ---- one batch of loads: own chunk fields, rowstart slices of the two windows (rows
         // [r_f, r_l+2] and the same + ncy) and the windows themselves.  Rows and window
         // ranges were left per chunk by k_resolve, so nothing here waits on another load.
-        const uint4 cw = P.chunkwin[base >> 8];
+        const uint4 cw = P.chunkwin[ci];
         const int r_f = (int)cw.x, r_l = (int)cw.y;
         const int nrs = min(r_l - r_f + 3, K4_RMAX);
         const uint32_t w1_start = base;                              // +x / +y sharers come after the chunk start
         // (at least the chunk itself: the row slice may have been cut at K4_RMAX rows)
         const uint32_t w1_cnt = min(max(cw.z, base + cnt) - w1_start, (uint32_t)K4_WMAX);
         const uint32_t w2_start = cw.w;
-        const uint32_t w2_cnt = min(P.chunkwin2[base >> 8] - w2_start, (uint32_t)K4_WMAX - w1_cnt);
+        const uint32_t w2_cnt = min(P.chunkwin2[ci] - w2_start, (uint32_t)K4_WMAX - w1_cnt);
         if (threadIdx.x < cnt) {
             my_nown = (P.rec_info[irec] >> 18) & 15u;
             s_own[threadIdx.x] = P.rec_own[irec];
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 }
             }
             // (the totals of the chunks before this one ride in the same batch of loads)
-            prefix_lane = chunk_totals_lane(P.chunktot, prefix_upto, base >> 8);
+            prefix_lane = chunk_totals_lane(P.chunktot, prefix_upto, ci);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const uint32_t slot = threadIdx.x + 256u * k;
@@ -852,8 +854,8 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         // chunk prefix = totals of all earlier chunks (advanced incrementally when a workgroup
         // takes more than one chunk); left in chunkpre[] for k_triangles
         chunk_prefix += chunk_totals_block(prefix_lane, s_part);
-        prefix_upto = base >> 8;
-        if (threadIdx.x == 0) P.chunkpre[base >> 8] = chunk_prefix;
+        prefix_upto = ci;
+        if (threadIdx.x == 0) P.chunkpre[ci] = chunk_prefix;
         const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs: LDS is complete)
         {   // vertex -> creator table (a cell creates at most 13): one LDS read per vertex instead of a search
             const uint32_t p0 = s_pre[threadIdx.x];
@@ -1153,12 +1155,12 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             *reinterpret_cast<SlabHeader*>(M.slab_header) = h;
         }
     }
-    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+    for (uint32_t base = blockIdx.x * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
         const uint32_t irec = base + threadIdx.x;
         uint32_t my_ni = 0;
         __syncthreads();
-        const uint64_t chunk_pre = P.chunkpre[base >> 8];   // left by k_vertices (loaded with the records: not a round trip of its own after the scan)
-        if (irec < n) {
+        const uint64_t chunk_pre = P.chunkpre[base / MC_CHUNK];   // left by k_vertices (loaded with the records: not a round trip of its own after the scan)
+        if (threadIdx.x < MC_CHUNK && irec < n) {
             const uint32_t info = P.rec_info[irec];
             my_ni = 3u * ((info >> 14) & 15u);
             s_lo[threadIdx.x] = info & 0x3fffu;

@@ -5,6 +5,17 @@
 
 namespace sdfk {
 
+// Records per chunk of k_resolve / k_vertices / k_triangles (one 256-thread workgroup per chunk).  Not 256: a smooth surface
+// creates ~1.00 vertices per active cell, so a 256-record chunk holds 256 +- 15 vertices and every other chunk needed a
+// SECOND, almost empty pass of the per-vertex loop of k_vertices (x1.36 passes per chunk on the 256^3 sphere, x1.45 on the
+// README scene); with 240 records (16 idle lanes in the per-record phases) it is x1.02 / x1.09: a fifth fewer passes of the
+// loop that is 80 % of the kernel.
+#ifndef MC_CHUNK_RECORDS
+#define MC_CHUNK_RECORDS 240   // (A/B builds: tools/variants.sh build c256 "-DMC_CHUNK_RECORDS=256")
+#endif
+constexpr uint32_t MC_CHUNK = MC_CHUNK_RECORDS;
+static_assert(MC_CHUNK >= 64 && MC_CHUNK <= 256, "one 256-thread workgroup per chunk");
+
 struct McCounters {
     uint32_t n_active;     // active cells listed (may exceed the list capacity)
     uint32_t n_case13;     // cells whose sign word is 0xA5/0x5A (candidates for "impossible 13")
@@ -37,7 +48,7 @@ struct McParams {
     int bpl;               // logical blocks of k_compact per layer: ceil(ncy * nxw / 1024)
     uint64_t* blockcnt;    // per logical block of k_compact: active cells | case-13 sign words << 32
     uint32_t* wavecnt;     // active cells per wavefront of the count pass ([block][4])
-    uint64_t* chunktot;    // (vertices << 31 | triangles) per 256-cell chunk (k_resolve)
+    uint64_t* chunktot;    // (vertices << 31 | triangles) per MC_CHUNK-record chunk (k_resolve)
     uint64_t* chunkpre;    // exclusive prefix of chunktot, per chunk (k_vertices, read by k_triangles)
     // Active cells ("records") in serial-sweep order.  Everything the emit kernels read is
     // compact (tens of MB, L2/MALL resident): no per-voxel maps.
@@ -52,7 +63,7 @@ struct McParams {
     float* rec_corners;    // 8 corner voxel values (v0..v7), 32 bytes per record
     uint32_t* rec_vid;     // [edge 0..12][cap_active]: vertex id of the cell's edge e, pushed by the creator (edge-major:
                            // consecutive vertices push into consecutive records of the same few edge planes)
-    uint32_t* chunkdead;   // "impossible case 13" cells per 256-cell chunk
+    uint32_t* chunkdead;   // "impossible case 13" cells per MC_CHUNK-record chunk
     uint4* chunkwin;       // per chunk: (first row, last row, end of window 1, start of window 2) (K4 set-up)
     uint32_t* chunkwin2;   // per chunk: end of window 2
     uint32_t cap_active;

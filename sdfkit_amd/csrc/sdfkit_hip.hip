@@ -1585,11 +1585,11 @@ int alloc_records(sdfk_march_job* j, size_t c)
     rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
     rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
     rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 13);
-    rr = rr ? rr : job_alloc(j, &P.chunktot, c / 256 + 2);
-    rr = rr ? rr : job_alloc(j, &P.chunkpre, c / 256 + 2);
-    rr = rr ? rr : job_alloc(j, &P.chunkdead, c / 256 + 2);
-    rr = rr ? rr : job_alloc(j, &P.chunkwin, c / 256 + 2);
-    rr = rr ? rr : job_alloc(j, &P.chunkwin2, c / 256 + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunktot, c / MC_CHUNK + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunkpre, c / MC_CHUNK + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunkdead, c / MC_CHUNK + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunkwin, c / MC_CHUNK + 2);
+    rr = rr ? rr : job_alloc(j, &P.chunkwin2, c / MC_CHUNK + 2);
     P.cap_active = (uint32_t)c;
     return rr;
 }
@@ -1621,7 +1621,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
         hipLaunchKernelGGL(k_compact<true>, dim3(nlog), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
-    const int nchunks = (int)((P.cap_active + 255u) / 256u);
+    const int nchunks = (int)((P.cap_active + MC_CHUNK - 1u) / MC_CHUNK);
     if (j->eval_prog) {   // the volume still is this program's output: evaluate the corners
         hipFunction_t fn_corners = nullptr;
         if (int r = program_fn(j->eval_prog, PK_CORNERS, &fn_corners)) return r;
@@ -1801,7 +1801,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
         M.inv[0] = yz * inv_det; M.inv[1] = xz * inv_det; M.inv[2] = xy * inv_det;
     }
     constexpr int vcap = 256 * 8, tcap = 256 * 8;   // (persistent-workgroup caps were measured: +-2 us, noise)
-    const int vgrid = grid_for(j->P.cap_active, 256, vcap);
+    const int vgrid = grid_for(j->P.cap_active, (int)MC_CHUNK, vcap);
     if (!j->bounds_partial || j->bounds_blocks != vgrid) {
         if (int rr = job_alloc(j, &j->bounds_partial, (size_t)vgrid * 6)) return rr;
         j->bounds_blocks = vgrid;
@@ -1842,7 +1842,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     }
     {
         ProfScope ps("k_triangles");
-        hipLaunchKernelGGL(k_triangles, dim3(grid_for(j->P.cap_active, 256, tcap)), dim3(256), 0, g.stream, j->P, M);
+        hipLaunchKernelGGL(k_triangles, dim3(grid_for(j->P.cap_active, (int)MC_CHUNK, tcap)), dim3(256), 0, g.stream, j->P, M);
         HIPCHK(hipGetLastError());
     }
     return SDFK_OK;

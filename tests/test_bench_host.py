@@ -29,17 +29,13 @@ def test_launcher_spawns_torchrun_as_a_child(monkeypatch):
     whose JSON line is relayed; a failing first attempt is retried conservatively."""
     calls = []
 
-    class P:
-        def __init__(self, rc, out):
-            self.returncode, self.stdout = rc, out
-
-    def fake_run(cmd, env=None, stdout=None, text=None):
+    def fake_run(cmd, env, limit_s):
         calls.append((cmd, env))
         if len(calls) == 1:
-            return P(1, "boom\n")
-        return P(0, '{"metric": "x", "n_gpus": 4}\n')
+            return 1, "boom\n"
+        return 0, '{"metric": "x", "n_gpus": 4}\n'
 
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "_run_ranks", fake_run)
     rc = bench.launch_ranks(["--gpus", "4", "--steps", "5"], 4)
     assert rc == 0 and len(calls) == 2
     cmd, env = calls[0]
@@ -47,7 +43,7 @@ def test_launcher_spawns_torchrun_as_a_child(monkeypatch):
     assert "--nproc-per-node=4" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
     assert "SDFK_BENCH_DEPTH" not in env or env["SDFK_BENCH_DEPTH"] != "1" or "SDFK_BENCH_DEPTH" in os.environ
-    assert calls[1][1]["SDFK_BENCH_DEPTH"] == "1" and calls[1][1]["SDFK_LANES"] == "0" and "SDFK_BENCH_NOTE" in calls[1][1]
+    assert calls[1][1]["SDFK_BENCH_DEPTH"] == "1" and calls[1][1]["SDFK_DIST_EXCHANGE"] == "0" and "SDFK_BENCH_NOTE" in calls[1][1]
 
 
 def test_plain_python_with_gpus_gt_1_launches_before_touching_torch():

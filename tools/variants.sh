@@ -9,7 +9,7 @@ if [ "$1" = build ]; then
     shift; mkdir -p $D
     while [ $# -ge 2 ]; do
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fno-fast-math \
-            -Wno-unused-function $2 -o $D/$1.so sdfkit_amd/csrc/sdfkit_hip.hip -lhiprtc &
+            -Wno-unused-function $2 -o $D/$1.so sdfkit_amd/csrc/sdfkit_hip.hip -lhiprtc -ldl &
         shift 2
     done
     wait; ls -la $D
