@@ -12,6 +12,7 @@
 #pragma once
 #include <charconv>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -48,7 +49,21 @@ inline void Check(int status)
 inline void EnsureInit()
 {
     static bool done = false;
-    if (!done) { Check(sdfk_init(0)); done = true; }
+    if (!done) {
+        // The library's streams want 8 hardware queues (sdfk_init in sdfkit_hip.hip says why); the HIP runtime reads the
+        // variable when it initialises, and the library never edits the environment itself: a host binding's job.
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        Check(sdfk_init(0));
+        done = true;
+    }
+}
+// sdfk_set_option / sdfk_get_option (enum sdfk_option): run-time switches that used to be environment variables
+inline void SetOption(sdfk_option key, int64_t value) { Check(sdfk_set_option((int32_t)key, value)); }
+inline int64_t GetOption(sdfk_option key)
+{
+    int64_t v = 0;
+    Check(sdfk_get_option((int32_t)key, &v));
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------

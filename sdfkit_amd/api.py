@@ -92,8 +92,18 @@ class Sdf:
 
     def ToMesh(self, min, max, nx, ny, nz, batchSize=DefaultBatchSize, maxDegreeOfParallelism=-1,
                clipToBounds=True, isoValue=0.0, step=1, progress=None):
-        """SdfEx.ToMesh (Sdf.cs:59-63): device-resident sample -> mesh."""
+        """SdfEx.ToMesh (Sdf.cs:59-63): device-resident sample -> mesh.  In a process that has joined a sharding context
+        (sdfkit_amd.dist.init: one process per GPU) the SAME call cuts the grid into Z slabs over the GPUs of the node and
+        every rank gets the whole mesh -- collective: every rank makes the call (sdfk_dist_to_mesh)."""
         h = C.c_void_p()
+        if step == 1:
+            w, r, b = C.c_int32(), C.c_int32(), C.c_int32()
+            N.check(N.lib().sdfk_dist_info(C.byref(w), C.byref(r), C.byref(b)))
+            if b.value and w.value > 1:
+                N.check(N.lib().sdfk_dist_to_mesh(self.program(), N.f3(min), N.f3(max), nx, ny, nz, 1 if clipToBounds else 0,
+                                                  C.c_float(isoValue), C.byref(h)))
+                _report_progress(progress, nz, step)
+                return Mesh._from_handle(h)
         N.check(N.lib().sdfk_sample_march(self.program(), N.f3(min), N.f3(max), nx, ny, nz,
                                           1 if clipToBounds else 0, C.c_float(isoValue), step, C.byref(h)))
         _report_progress(progress, nz, step)

@@ -39,9 +39,16 @@ namespace SdfKit
             var prog = GpuSdf.ProgramOf(sdf);
             if (prog == null)   // opaque delegate: the reference's own path (CPU sampler), meshing still on the GPU via the host arrays
                 return ToVoxels(sdf, min, max, nx, ny, nz, batchSize, maxDegreeOfParallelism, clipToBounds).ToMesh(isoValue, step, progress);
+            // one process per GPU with Dist.Init done: the same call shards the grid by Z slab over the GPUs of the node and
+            // every rank gets the whole mesh (collective: every rank makes the call) -- Dist.cs, sdfk_dist_to_mesh
+            if (Dist.World > 1 && step == 1) {
+                var whole = Dist.ToMesh(prog, min, max, nx, ny, nz, clipToBounds, isoValue);
+                MarchingCubes.ReportProgress(progress, nz, step);
+                return whole;
+            }
             Native.Check(Native.sdfk_sample_march(prog.Handle, (float*)&min, (float*)&max, nx, ny, nz, clipToBounds ? 1 : 0, isoValue, step, out var h));
             MarchingCubes.ReportProgress(progress, nz, step);
-            try { return Mesh.FromNative(h); } finally { Native.sdfk_mesh_free(h); }
+            try { return Mesh.FromNative(h, prog.WritesColor); } finally { Native.sdfk_mesh_free(h); }
         }
     }
 

@@ -1,0 +1,89 @@
+// Dist.cs -- SdfEx.ToMesh (Sdf.cs:59-63) over the GPUs of one node: one process per GPU, the grid cut into Z slabs, the
+// slab meshes exchanged by the LIBRARY (it calls RCCL itself; include/sdfkit_hip.h, "Z-slab sharding").  What is left for
+// the host is what only the host can do: start one process per GPU and hand the 128-byte RCCL id from rank 0 to the others.
+// UNCOMPILED IN THIS REPOSITORY (no .NET toolchain in the build image); the same calls, in the same order, are what
+// sdfkit_amd/dist.py makes through ctypes, and tests/test_gpu_multirank.py runs them on the GPU.
+using System;
+using System.IO;
+using System.Numerics;
+using System.Threading;
+
+namespace SdfKit.Hip
+{
+    public static unsafe class Dist
+    {
+        public static int World { get; private set; } = 1;
+        public static int Rank { get; private set; }
+
+        /// <summary>One process per GPU, started by any launcher that sets WORLD_SIZE / RANK / LOCAL_RANK (mpirun, torchrun,
+        /// a shell loop).  The id travels through a file both sides can see (`rendezvousPath`); a host with MPI or sockets of
+        /// its own passes the bytes that way instead (InitWithId).</summary>
+        public static void Init(string rendezvousPath)
+        {
+            int world = int.Parse(Environment.GetEnvironmentVariable("WORLD_SIZE") ?? "1");
+            int rank = int.Parse(Environment.GetEnvironmentVariable("RANK") ?? "0");
+            Native.EnsureInit();                       // sdfk_init(LOCAL_RANK)
+            var id = new byte[128];
+            if (rank == 0) {
+                fixed (byte* p = id) Native.Check(Native.sdfk_dist_unique_id(p));
+                File.WriteAllBytes(rendezvousPath + ".tmp", id);
+                File.Move(rendezvousPath + ".tmp", rendezvousPath);            // appears atomically
+            } else {
+                while (!File.Exists(rendezvousPath)) Thread.Sleep(5);
+                id = File.ReadAllBytes(rendezvousPath);
+            }
+            InitWithId(world, rank, id);
+        }
+
+        public static void InitWithId(int world, int rank, byte[] id128)
+        {
+            Native.EnsureInit();
+            fixed (byte* p = id128) Native.Check(Native.sdfk_dist_init(world, rank, p));
+            World = world; Rank = rank;
+        }
+
+        /// <summary>SdfEx.ToMesh on all ranks: COLLECTIVE (every rank makes the call), every rank gets the whole mesh --
+        /// bit for bit the mesh of the single-GPU call.</summary>
+        public static Mesh ToMesh(GpuProgram program, Vector3 min, Vector3 max, int nx, int ny, int nz, bool clipToBounds = true, float isoValue = 0)
+        {
+            float* mn = stackalloc float[3] { min.X, min.Y, min.Z };
+            float* mx = stackalloc float[3] { max.X, max.Y, max.Z };
+            Native.Check(Native.sdfk_dist_to_mesh(program.Handle, mn, mx, nx, ny, nz, clipToBounds ? 1 : 0, isoValue, out var mesh));
+            try { return SdfKit.Mesh.FromNative(mesh, program.WritesColor); } finally { Native.sdfk_mesh_free(mesh); }   // (Voxels.Hip.cs)
+        }
+
+        /// <summary>Repeated sharded meshing of one grid (an animation, a parameter sweep): up to `depth` steps in flight,
+        /// no host wait inside a step.  Submit() queues a step, Collect() waits for the oldest one.</summary>
+        public sealed class Session : IDisposable
+        {
+            IntPtr h;
+            readonly bool writesColor;
+            public Session(GpuProgram program, Vector3 min, Vector3 max, int nx, int ny, int nz, bool clipToBounds = true, float isoValue = 0, int depth = 3)
+            {
+                float* mn = stackalloc float[3] { min.X, min.Y, min.Z };
+                float* mx = stackalloc float[3] { max.X, max.Y, max.Z };
+                writesColor = program.WritesColor;
+                Native.Check(Native.sdfk_dist_session_create(program.Handle, mn, mx, nx, ny, nz, clipToBounds ? 1 : 0, isoValue, depth, out h));
+            }
+            public void Submit() => Native.Check(Native.sdfk_dist_submit(h));
+            public (long vertices, long indices) Collect()
+            {
+                Native.Check(Native.sdfk_dist_collect(h, out var nv, out var ni));
+                return (nv, ni);
+            }
+            /// <summary>Measures both exchanges on this node's fabric and keeps the faster one (collective).</summary>
+            public void Tune(int stepsPerMode = 20) => Native.Check(Native.sdfk_dist_tune(h, stepsPerMode, null));
+            /// <summary>The whole mesh of the step collected last.</summary>
+            public Mesh Mesh()
+            {
+                Native.Check(Native.sdfk_dist_mesh(h, out var mesh));
+                try { return SdfKit.Mesh.FromNative(mesh, writesColor); } finally { Native.sdfk_mesh_free(mesh); }
+            }
+            public void Dispose()
+            {
+                if (h != IntPtr.Zero) Native.sdfk_dist_session_free(h);
+                h = IntPtr.Zero;
+            }
+        }
+    }
+}

@@ -53,6 +53,27 @@ namespace SdfKit.Hip
         [DllImport(Lib)] public static extern int sdfk_mesh_bounds(IntPtr mesh, float* min, float* max);
         [DllImport(Lib)] public static extern int sdfk_mesh_copy(IntPtr mesh, float* v, float* c, float* n, int* tri);
         [DllImport(Lib)] public static extern void sdfk_mesh_free(IntPtr mesh);
+        [DllImport(Lib)] public static extern int sdfk_mesh_size_hint(IntPtr mesh, out long nVertices, out long nIndices, out int exact);
+        [DllImport(Lib)] public static extern int sdfk_mesh_transform(IntPtr mesh, float* matrix16, float* normalMatrix16);
+        [DllImport(Lib)] public static extern int sdfk_host_prefault(void* p, long nBytes);
+        // options (what used to be environment variables): enum sdfk_option
+        [DllImport(Lib)] public static extern int sdfk_set_option(int key, long value);
+        [DllImport(Lib)] public static extern int sdfk_get_option(int key, out long value);
+        [DllImport(Lib)] public static extern int sdfk_set_cache_dir([MarshalAs(UnmanagedType.LPStr)] string path);
+        // Z-slab sharding over the GPUs of one node, one process per GPU (SdfEx.ToMesh, Sdf.cs:59-63): Dist.cs
+        [DllImport(Lib)] public static extern int sdfk_dist_unique_id(byte* id128);
+        [DllImport(Lib)] public static extern int sdfk_dist_init(int world, int rank, byte* id128);
+        [DllImport(Lib)] public static extern int sdfk_dist_info(out int world, out int rank, out int backend);
+        [DllImport(Lib)] public static extern void sdfk_dist_shutdown();
+        [DllImport(Lib)] public static extern int sdfk_dist_to_mesh(IntPtr program, float* min, float* max, int nx, int ny, int nz, int clip, float iso, out IntPtr mesh);
+        [DllImport(Lib)] public static extern int sdfk_dist_session_create(IntPtr program, float* min, float* max, int nx, int ny, int nz, int clip, float iso, int depth, out IntPtr session);
+        [DllImport(Lib)] public static extern int sdfk_dist_submit(IntPtr session);
+        [DllImport(Lib)] public static extern int sdfk_dist_collect(IntPtr session, out long nVerticesMine, out long nIndicesMine);
+        [DllImport(Lib)] public static extern int sdfk_dist_counts(IntPtr session, long* counts2PerRank);
+        [DllImport(Lib)] public static extern int sdfk_dist_mesh(IntPtr session, out IntPtr mesh);
+        [DllImport(Lib)] public static extern int sdfk_dist_tune(IntPtr session, int stepsPerMode, long* nsPerMode2);
+        [DllImport(Lib)] public static extern int sdfk_dist_stats(IntPtr session, long* stats8);
+        [DllImport(Lib)] public static extern void sdfk_dist_session_free(IntPtr session);
         // RayMarcher (RayMarcher.cs:45-211)
         [DllImport(Lib)] public static extern int sdfk_raymarch(IntPtr program, int width, int height, float* cameraPosition, float* viewProjectionInverse,
                                                                 float near, float far, int depthIterations, float* depth, float* rgb);
@@ -60,13 +81,28 @@ namespace SdfKit.Hip
         static readonly object initLock = new object();
         static bool inited;
 
+        /// <summary>enum sdfk_option</summary>
+        public const int OptLanes = 1, OptTokens = 2, OptGraphs = 3, OptCopyMode = 4, OptCornerEval = 5, OptVcolorEval = 6,
+                         OptDistExchange = 7, OptDistLanes = 8, OptHwQueues = 9, OptCodeCache = 10, OptPrefaultHuge = 11;
+
+        /// <summary>The HIP runtime maps all streams of a process onto GPU_MAX_HW_QUEUES in-order hardware queues (default 4) and reads
+        /// the variable when IT initialises; the library's streams want 8 (sdfk_init in sdfkit_hip.hip says why).  A library must not
+        /// edit the environment of its process; this binding does, once, before its first native call -- which is this
+        /// process's first HIP call unless the host used HIP before (then the host exports the variable itself).</summary>
+        static Native()
+        {
+            if (Environment.GetEnvironmentVariable("GPU_MAX_HW_QUEUES") == null)
+                Environment.SetEnvironmentVariable("GPU_MAX_HW_QUEUES", "8");
+        }
+
         /// <summary>sdfk_init once per process; device = LOCAL_RANK (one process per GPU) or 0.</summary>
         public static void EnsureInit()
         {
             if (inited) return;
             lock (initLock) {
                 if (inited) return;
-                if (sdfk_abi_version() < 2) throw new InvalidOperationException("libsdfkit_hip.so is older than this shim");
+                // (the entry points this shim binds -- sdfk_set_option, sdfk_dist_*, sdfk_mesh_size_hint -- are ABI 4)
+                if (sdfk_abi_version() != 4) throw new InvalidOperationException("libsdfkit_hip.so does not have the ABI version (4) this shim was written for");
                 int device = int.TryParse(Environment.GetEnvironmentVariable("LOCAL_RANK"), out var r) ? r : 0;
                 Check(sdfk_init(device));
                 inited = true;

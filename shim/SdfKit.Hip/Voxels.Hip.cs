@@ -135,12 +135,14 @@ namespace SdfKit
         /// <summary>sdfk_mesh_counts waits for the (deferred) job and verifies its size guess; the four managed arrays
         /// are exact-length like the reference's (tests assert Vertices.Length); Min/Max come from the device
         /// (Mesh.Measure, Mesh.cs:30-45, is fused into the vertex kernel) through an internal constructor that skips Measure().</summary>
-        internal static unsafe Mesh FromNative(IntPtr h)
+        internal static unsafe Mesh FromNative(IntPtr h, bool colors = true)
         {
             Native.Check(Native.sdfk_mesh_counts(h, out long nv, out long ni));
             var v = new Vector3[nv]; var c = new Vector3[nv]; var n = new Vector3[nv]; var t = new int[ni];
+            // colors == false: the program only writes .W, every colour is (0,0,0) (Voxels.cs:88-92) -- and a new managed array
+            // IS zero: no colour destination is passed, the library has nothing to clear or to fault in (0.7 of 2.4 ms at 512^3)
             fixed (Vector3* pv = v, pc = c, pn = n) fixed (int* pt = t)
-                Native.Check(Native.sdfk_mesh_copy(h, (float*)pv, (float*)pc, (float*)pn, pt));
+                Native.Check(Native.sdfk_mesh_copy(h, (float*)pv, colors ? (float*)pc : null, (float*)pn, pt));
             Vector3 mn, mx;
             Native.Check(Native.sdfk_mesh_bounds(h, (float*)&mn, (float*)&mx));
             return new Mesh(v, c, n, t, mn, mx);
