@@ -20,4 +20,4 @@ for f in sorted(glob.glob("gpurun_out/r03a/bench*.json")):
     if "sharded" in d:
         s=d["sharded"]; print("   ", s["host_us_per_step"]["submit"], s["host_us_per_step"]["collect"], s["slab_kernels_only_ms"], s["exchange"], s["steps_redone_on_the_exact_path"])
 PY
-tail -5 $O/*.err
+for f in $O/*.err; do echo "== $f"; tail -n 3 $f; done

@@ -1,6 +1,6 @@
 #!/bin/bash
-# On the GPU box: everything profiles/ needs for a round.  usage: tools/gpu_round_profiles.sh r02
-tag=${1:-r02}
+# On the GPU box: everything profiles/ needs for a round.  usage: tools/gpu_round_profiles.sh r03
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; export TMPDIR=/tmp
 O=gpurun_out/profiles_$tag; mkdir -p $O
@@ -24,7 +24,11 @@ rm -rf $O/stats_c3 $O/pmc_w3 $O/pmc_f3
 cp $O/stats/s_kernel_stats.csv $O/kernel_stats.csv
 cp $O/stats_serial/s_kernel_stats.csv $O/kernel_stats_serial.csv
 rm -rf $O/stats $O/stats_serial $O/pmc_w $O/pmc_f
-# C4 at its full size on one GPU, and the sharded path as the driver starts it (every rank on this one GPU, gloo)
+# C2 (launch-bound), C4 at its full size on one GPU, the sharded step over real RCCL at world 1 (small slab and 512^3), and the
+# sharded path as the driver starts it (every rank on this one GPU: the library's host transport over gloo)
+python3 bench.py --no-cpu --grid 256 > $O/bench_c2_256.json 2>/dev/null
+SDFK_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu --minimal --grid 128 --steps 200 > $O/bench_rccl_world1_128.json 2>/dev/null
+SDFK_BENCH_FORCE_DIST=1 python3 bench.py --no-cpu --minimal --steps 100 > $O/bench_rccl_world1_512.json 2>/dev/null
 python3 bench.py --no-cpu --scene union8 --grid 1024 --steps 5 --warmup 2 > $O/bench_c4_1024.json 2>/dev/null
 SDFK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --no-cpu > $O/bench_two_ranks_one_gpu.json 2>/dev/null
 grep "^{" $O/bench.json | cut -c1-400
