@@ -79,14 +79,23 @@ int rccl_load()
         if (r_ != ncclSuccess) return fail(SDFK_ERR_HIP, "%s: %s (%s:%d)", #expr, gd.nccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+void dist_release();
+
 int dist_common_init(int world, int rank)
 {
     if (int r = require_init()) return r;
     if (gd.backend) return fail(SDFK_ERR_INVALID, "sdfk_dist_init: already initialised (world %d, rank %d)", gd.world, gd.rank);
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(SDFK_ERR_INVALID, "sdfk_dist_init: bad world %d / rank %d", world, rank);
-    HIPCHK(hipStreamCreateWithFlags(&gd.stream, hipStreamNonBlocking));
-    if (int r = dev_alloc((void**)&gd.agree_dev, sizeof(int64_t) * (1 + world))) return r;
-    HIPCHK(hipHostMalloc((void**)&gd.agree_host, sizeof(int64_t) * (1 + world), hipHostMallocDefault));
+    hipError_t e = hipStreamCreateWithFlags(&gd.stream, hipStreamNonBlocking);
+    int r = e == hipSuccess ? dev_alloc((void**)&gd.agree_dev, sizeof(int64_t) * (1 + world)) : fail(SDFK_ERR_HIP, "exchange stream: %s", hipGetErrorString(e));
+    if (!r && hipHostMalloc((void**)&gd.agree_host, sizeof(int64_t) * (1 + world), hipHostMallocDefault) != hipSuccess)
+        r = fail(SDFK_ERR_NOMEM, "sdfk_dist_init: pinned memory for the stride agreement");
+    if (r) {   // (nothing half-made stays behind: a later sdfk_dist_init starts from scratch)
+        const std::string keep_err = t_err;
+        dist_release();
+        t_err = keep_err;
+        return r;
+    }
     gd.world = world;
     gd.rank = rank;
     return SDFK_OK;
