@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU probe: host<->device transfer rates of the C ABI with pageable caller arrays (what the C# shim
 pins for a call): sdfk_mesh_copy into FRESH (never touched) and into already-touched arrays for each copy
-strategy (SDFK_COPY_MODE 0 / 1 / 2) and pool size, sdfk_volume_download / upload at 512^3."""
+strategy (SDFK_OPT_COPY_MODE 0 / 1 / 2) and pool size, sdfk_volume_download / upload at 512^3."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -35,7 +35,7 @@ def fresh(nbytes):
 
 vb, tb = nv.value * 12, ni.value * 4
 for mode in ("2", "0", "1"):
-    os.environ["SDFK_COPY_MODE"] = mode
+    N.set_option(N.OPT_COPY_MODE, int(mode))
     for touched in (False, True):
         ts = []
         for rep in range(4):
@@ -50,11 +50,11 @@ for mode in ("2", "0", "1"):
             del arrs, keep
         tot = vb * 3 + tb
         print(f"mesh_copy mode {mode} {'touched' if touched else 'fresh  '} {tot/1e6:7.1f} MB  best {min(ts)*1e3:7.2f} ms  ({tot/min(ts)/1e9:5.1f} GB/s)  all {[round(t*1e3, 2) for t in ts]}")
-os.environ.pop("SDFK_COPY_MODE", None)
+N.set_option(N.OPT_COPY_MODE, 1)
 vol = Voxels((-1.5,) * 3, (1.5,) * 3, n, n, n)
 vol._sample(sdf)
 for mode in ("2", "0", "1"):
-    os.environ["SDFK_COPY_MODE"] = mode
+    N.set_option(N.OPT_COPY_MODE, int(mode))
     for touched in (False, True):
         ts = []
         for rep in range(2):
@@ -66,7 +66,7 @@ for mode in ("2", "0", "1"):
             ts.append(time.perf_counter() - t0)
             del host, mm
         print(f"vol download mode {mode} {'touched' if touched else 'fresh  '} {n**3*4/1e6:8.1f} MB  best {min(ts)*1e3:8.2f} ms  {n**3*4/min(ts)/1e9:6.2f} GB/s")
-os.environ.pop("SDFK_COPY_MODE", None)
+N.set_option(N.OPT_COPY_MODE, 1)
 host = np.ones((n, n, n), np.float32)
 for rep in range(3):
     t0 = time.perf_counter()
