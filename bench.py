@@ -79,10 +79,10 @@ def launch_ranks(argv, n):
     tries = [({}, "")]
     # if the pipelined form fails (or hangs) on this node: first RCCL's own all-gather instead of the grouped point-to-point
     # sends, one step in flight, no exchange tuning; then, on top, no internal lanes at all (same protocol, same kernels)
-    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1"},
-                  "retry: one step in flight, plain ncclAllGather, no exchange tuning"))
-    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0", "SDFK_DIST_LANES": "0", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1"},
-                  "retry: one step in flight, no lanes, plain ncclAllGather"))
+    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1", "SDFK_BENCH_INDEX16": "0"},
+                  "retry: one step in flight, plain ncclAllGather of plain payloads, no exchange tuning"))
+    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0", "SDFK_DIST_LANES": "0", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1",
+                   "SDFK_BENCH_INDEX16": "0"}, "retry: one step in flight, no lanes, plain ncclAllGather of plain payloads"))
     limit = float(os.environ.get("SDFK_BENCH_RANKS_TIMEOUT_S", "420"))   # (a hung collective must not eat the caller's whole budget)
     rc = 1
     for extra, note in tries:
@@ -362,6 +362,10 @@ def main():
     else:
         # three steps in flight, one exchange per step issued by the library on its own stream, no host wait inside a step
         # (sdfk_dist_session_*: csrc/slab_protocol.h + csrc/dist_rccl.h)
+        # compact payloads (indices as 16-bit offsets: 48 -> 36 bytes per vertex received from every peer) whenever there IS a
+        # peer; a slab that does not fit sends the session back to int32 indices by itself (SDFK_BENCH_INDEX16=0/1 overrides)
+        idx16_env = os.environ.get("SDFK_BENCH_INDEX16")
+        N.set_option(N.OPT_DIST_INDEX16, int(idx16_env) if idx16_env is not None else (1 if world > 1 else 0))
         worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 3)
         last = [0, 0]
         tuned = None
@@ -462,6 +466,9 @@ def main():
                       "exchange": {-1: "host transport", 0: "ncclAllGather (in place)", 1: "grouped ncclSend / ncclRecv to every peer (all xGMI links at once)",
                                    2: "grouped sends to rank 0 only (headers to everybody)"}[mode],
                       "exchange_tuned_ns": tuned,
+                      "payload": ("compact: indices as 16-bit offsets against one int32 base per 1024 indices, decoded by the step into the whole "
+                                  "mesh's int32 index array" if st["index16"] else "plain: int32 indices, rebased in place by the step") +
+                                 (f" (fell back from the compact form {st['index16_fallbacks']} time(s): a slab did not fit 16 bits)" if st["index16_fallbacks"] else ""),
                       "per_rank_vertices_indices": per_rank,
                       "slab_kernels_only_ms": round(tk / args.steps * 1e3, 4),
                       "end_to_end_ms": round(ms_step, 4),

@@ -116,7 +116,12 @@ typedef enum sdfk_option {
     SDFK_OPT_PREFAULT_HUGE = 11,/* 1: whole 2 MiB blocks of a pageable destination are advised MADV_HUGEPAGE before they are first
                                    touched (sdfk_mesh_copy, sdfk_volume_download, sdfk_host_prefault); 0 (default): left as they are
                                    (measured slower where the kernel compacts memory inside the fault) */
-    SDFK_OPT_COUNT_ = 12
+    SDFK_OPT_DIST_INDEX16 = 12, /* sharded step, sessions created afterwards: 1 = compact payloads -- the slab's indices travel as uint16 offsets
+                                   against one int32 base per 1024 indices (48 -> 36 bytes per vertex of a colourless mesh: what every rank
+                                   has to receive from every other rank per step); sdfk_dist_mesh decodes, sdfk_dist_gathered shows the
+                                   encoded form.  A slab whose ids do not fit sends the session back to int32 indices (every rank
+                                   sees it in the headers).  0 (default): int32 indices, rebased in place by the step */
+    SDFK_OPT_COUNT_ = 13
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);
 int sdfk_get_option(int32_t key, int64_t* value);
@@ -226,7 +231,7 @@ int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, int32_t cli
                            int32_t layer_begin, int32_t layer_end, int64_t vertex_base, sdfk_mesh** out);
 
 /* Self-describing slab payload for a single padded all-gather: 64-byte header
- * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; int32 vertex_bytes; int32 cap_v; pad }
+ * { int64 n_vertices; int64 n_indices; float min[3]; float max[3]; int32 vertex_bytes; int32 cap_v; int32 idx_bits; int32 flags; pad }
  * followed by Vertices | Colors | Normals (3 floats per vertex each) | Triangles (int32).
  * vertex_bytes = 36, or 24 when the volume had no colours: Colors (all zero) is then left out.
  * cap_v = vertex slots each section is laid out for (sections at 64, 64 + 12 cap_v, ...; indices at
@@ -310,7 +315,8 @@ int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out);
  * rebased), device memory owned by the session. */
 int sdfk_dist_gathered(const sdfk_dist_session* s, void** device_ptr, int64_t* stride_bytes);
 /* stats[8] = { stride_bytes, steps submitted, steps redone on the exact path, stride regrowths, exchange mode used,
- *              host nanoseconds spent inside sdfk_dist_submit (total), inside sdfk_dist_collect (total), depth } */
+ *              host nanoseconds spent inside sdfk_dist_submit (total), inside sdfk_dist_collect (total),
+ *              depth | 0x100 if the payloads are in the 16-bit index form | fall-backs to int32 indices << 16 } */
 int sdfk_dist_stats(const sdfk_dist_session* s, int64_t stats[8]);
 /* Which exchange is faster on this node's fabric is a measurement: runs steps_per_mode pipelined steps with ncclAllGather and
  * with the direct grouped sends, takes the slowest rank's time for each (the same numbers on every rank) and keeps the faster

@@ -134,6 +134,7 @@ struct ConcatArgs {
     float* normals;
     int32_t* triangles;
     float* bounds;   // device float[6]
+    const int32_t* decoded;   // compact steps: the whole mesh's indices as the step decoded them (k_slabs_decode16), or null
 };
 
 __global__ __launch_bounds__(256) void k_slabs_concat(ConcatArgs A)
@@ -154,6 +155,10 @@ __global__ __launch_bounds__(256) void k_slabs_concat(ConcatArgs A)
     const uint32_t* sc = reinterpret_cast<const uint32_t*>(sec + 12 * capv);
     const uint32_t* sn = reinterpret_cast<const uint32_t*>(sec + (wc ? 24 : 12) * capv);
     const uint32_t* st = reinterpret_cast<const uint32_t*>(sec + (int64_t)h->vbytes * capv);
+    // compact slab (k_payload_compact): uint16 offsets against one int32 base per 1024 indices, slab-LOCAL ids (not rebased)
+    const bool c16 = h->idx_bits == 16;
+    const uint16_t* t16 = reinterpret_cast<const uint16_t*>(st);
+    const int32_t* bases = reinterpret_cast<const int32_t*>(sec + (int64_t)h->vbytes * capv + ((2 * ni + 3) & ~int64_t(3)));
     uint32_t* dv = reinterpret_cast<uint32_t*>(A.vertices) + 3 * vbase;
     uint32_t* dc = reinterpret_cast<uint32_t*>(A.colors) + 3 * vbase;
     uint32_t* dn = reinterpret_cast<uint32_t*>(A.normals) + 3 * vbase;
@@ -163,7 +168,10 @@ __global__ __launch_bounds__(256) void k_slabs_concat(ConcatArgs A)
         if (i < nf) dv[i] = sv[i];
         else if (i < 2 * nf) dc[i - nf] = wc ? sc[i - nf] : 0u;   // (a volume without colours: all zero, Voxels.cs:88-92)
         else if (i < 3 * nf) dn[i - 2 * nf] = sn[i - 2 * nf];
-        else dt[i - 3 * nf] = st[i - 3 * nf];
+        else {
+            const int64_t k = i - 3 * nf;
+            dt[k] = !c16 ? st[k] : (A.decoded ? (uint32_t)A.decoded[ibase + k] : (uint32_t)(bases[k / sdfk::SLAB_IDX_BLOCK] + (int32_t)t16[k] + (int32_t)vbase));
+        }
     }
     if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0) {   // Mesh.Measure (Mesh.cs:30-45) over the slabs that have vertices
         float b[6] = {0, 0, 0, 0, 0, 0};
@@ -194,6 +202,8 @@ struct sdfk_dist_session final : sdfk::SlabOps {
     int vbytes = 24;
     int exchange_mode = 1;
     int lanes = 2;
+    bool idx16 = false;            // SDFK_OPT_DIST_INDEX16: compact payloads (k_payload_compact); falls back when a slab does not fit
+    int64_t idx16_fallbacks = 0;
     uint64_t nsub = 0;
     int64_t stride = 0;
     int64_t host_ns_submit = 0, host_ns_collect = 0, steps = 0;
@@ -205,6 +215,11 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         hipEvent_t packed = nullptr;      // the step's kernels have written the send buffer
         hipEvent_t ready = nullptr;       // exchange + rebase + header mirror done
         hipEvent_t read = nullptr;        // sdfk_dist_mesh has read the gather buffer
+        char* stage = nullptr;            // idx16: the step emits its plain payload here, k_payload_compact encodes it into the gather buffer
+        int64_t stage_bytes = 0;
+        unsigned long long* ticket = nullptr;   // arrival counter of k_payload_compact (zero between launches)
+        int32_t* decoded = nullptr;       // idx16: the whole mesh's int32 indices, decoded by the step (k_slabs_decode16)
+        int64_t decoded_cap = 0;
         bool ready_valid = false, read_valid = false;
         sdfk_mesh* exact = nullptr;       // mesh of run_exact until pack_exact
     };
@@ -215,6 +230,26 @@ struct sdfk_dist_session final : sdfk::SlabOps {
     sdfk_dist_session(int depth) : slots((size_t)depth), proto(this, depth, 1.0 / 32) {}
 
     char* send_buf(Slot& s) const { return s.gathered + (size_t)gd.rank * stride; }
+    int64_t need_bytes(int64_t nv, int64_t ni) const
+    {
+        if (!idx16) return SDFK_SLAB_HEADER_BYTES + (int64_t)vbytes * nv + 4 * ni;
+        return SDFK_SLAB_HEADER_BYTES + (int64_t)vbytes * nv + ((2 * ni + 3) & ~int64_t(3)) + 4 * ((ni + sdfk::SLAB_IDX_BLOCK - 1) / sdfk::SLAB_IDX_BLOCK);
+    }
+    int64_t payload_bytes(const int64_t* hdr) const override
+    {
+        const int64_t vb = hdr[5] & 0xffffffffll, bits = hdr[6] & 0xffffffffll;
+        if (bits != 16) return SDFK_SLAB_HEADER_BYTES + vb * hdr[0] + 4 * hdr[1];
+        return SDFK_SLAB_HEADER_BYTES + vb * hdr[0] + ((2 * hdr[1] + 3) & ~int64_t(3)) + 4 * ((hdr[1] + sdfk::SLAB_IDX_BLOCK - 1) / sdfk::SLAB_IDX_BLOCK);
+    }
+    // plain payload in the slot's stage buffer -> compact payload in this rank's section of the gather buffer (queued on `st`)
+    int compact(Slot& s, hipStream_t st)
+    {
+        const int64_t words = s.stage_bytes / 4;
+        hipLaunchKernelGGL(sdfk::k_payload_compact, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((words + 4095) / 4096, 1024))), dim3(256), 0, st,
+                           (const char*)s.stage, send_buf(s), stride, s.ticket);
+        if (hipGetLastError() != hipSuccess) return keep(fail(SDFK_ERR_HIP, "k_payload_compact launch failed"));
+        return SDFK_OK;
+    }
     int keep(int r) { if (r) err = t_err; return r; }
 
     int world() const override { return gd.world; }
@@ -227,7 +262,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         if (s.exact) { sdfk_mesh_free(s.exact); s.exact = nullptr; }
         if (int r = sdfk_sample_march_slab(prog, s.vol, clip, iso, lb, le, 0, &s.exact)) return keep(r);
         if (int r = sdfk_mesh_counts(s.exact, nv, ni)) return keep(r);
-        *need = SDFK_SLAB_HEADER_BYTES + (int64_t)vbytes * *nv + 4 * *ni;
+        *need = need_bytes(*nv, *ni);
         return SDFK_OK;
     }
 
@@ -261,6 +296,14 @@ struct sdfk_dist_session final : sdfk::SlabOps {
             if (s.vol) graph_jobs_forget_volume(s.vol);   // (captured steps write into the old send buffer)
             dev_free(s.gathered);
             s.gathered = nullptr;
+            dev_free(s.stage);
+            s.stage = nullptr;
+            s.stage_bytes = 0;
+            dev_free(s.ticket);
+            s.ticket = nullptr;
+            dev_free(s.decoded);
+            s.decoded = nullptr;
+            s.decoded_cap = 0;
             if (s.hdr_host) (void)hipHostFree(s.hdr_host);
             s.hdr_host = nullptr;
             s.hdr_dev = nullptr;
@@ -276,6 +319,15 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         for (Slot& s : slots) {
             if (int r = dev_alloc((void**)&s.gathered, total)) return keep(r);
             hipError_t e = hipMemsetAsync(s.gathered, 0, total, g.stream);
+            if (idx16) {   // (a plain payload is at most twice its compact form: indices 4 instead of 2 bytes)
+                s.stage_bytes = 2 * stride;
+                if (int r = dev_alloc((void**)&s.stage, (size_t)s.stage_bytes)) return keep(r);
+                if (int r = dev_alloc((void**)&s.ticket, sizeof(unsigned long long))) return keep(r);
+                s.decoded_cap = (int64_t)gd.world * (stride / 2);   // (an index takes at least 2 bytes of a payload)
+                if (int r = dev_alloc((void**)&s.decoded, (size_t)s.decoded_cap * sizeof(int32_t))) return keep(r);
+                if (e == hipSuccess) e = hipMemsetAsync(s.ticket, 0, sizeof(unsigned long long), g.stream);
+                if (e == hipSuccess) e = hipMemsetAsync(s.stage, 0, SDFK_SLAB_HEADER_BYTES, g.stream);
+            }
             if (e == hipSuccess) e = hipHostMalloc((void**)&s.hdr_host, (size_t)gd.world * SDFK_SLAB_HEADER_BYTES, hipHostMallocMapped);
             if (e == hipSuccess) { memset(s.hdr_host, 0, (size_t)gd.world * SDFK_SLAB_HEADER_BYTES); e = hipHostGetDevicePointer(&s.hdr_dev, s.hdr_host, 0); }
             if (e != hipSuccess) return keep(fail(SDFK_ERR_HIP, "gather buffers: %s", hipGetErrorString(e)));
@@ -297,9 +349,10 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         Slot& s = slots[k];
         if (!s.exact) return keep(fail(SDFK_ERR_INVALID, "pack_exact without an exact mesh"));
         int64_t need = 0;
-        int r = sdfk_mesh_pack(s.exact, send_buf(s), stride, &need);
+        int r = idx16 ? sdfk_mesh_pack(s.exact, s.stage, s.stage_bytes, &need) : sdfk_mesh_pack(s.exact, send_buf(s), stride, &need);
         sdfk_mesh_free(s.exact);   // (stream-ordered)
         s.exact = nullptr;
+        if (!r && idx16) r = compact(s, g.stream);
         if (r) return keep(r);
         if (hipEventRecord(s.packed, g.stream) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipEventRecord failed"));
         return SDFK_OK;
@@ -316,7 +369,10 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         if (s.read_valid && lane) { if (hipStreamWaitEvent(st, s.read, 0) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipStreamWaitEvent failed")); }
         if (s.ready_valid && !lane) { if (hipStreamWaitEvent(st, s.ready, 0) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipStreamWaitEvent failed")); }
         s.read_valid = false;
-        if (int r = slab_enqueue_impl(prog, s.vol, clip, iso, lb, le, send_buf(s), stride, lane, (lane && s.ready_valid) ? s.ready : nullptr, false)) return keep(r);
+        if (int r = slab_enqueue_impl(prog, s.vol, clip, iso, lb, le, idx16 ? s.stage : send_buf(s), idx16 ? s.stage_bytes : stride, lane,
+                                      (lane && s.ready_valid) ? s.ready : nullptr, false)) return keep(r);
+        if (idx16)
+            if (int r = compact(s, st)) return r;
         if (hipEventRecord(s.packed, st) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipEventRecord failed"));
         return SDFK_OK;
     }
@@ -363,8 +419,12 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         // indices of slab r += vertices of slabs 0..r-1; the headers land in pinned host memory (one event, no copy).
         // (mode 2 on a rank other than 0: there are no foreign payloads to rebase -- the kernel sees header-only slabs)
         const bool headers_only = exchange_mode == 2 && me != 0 && gd.backend == 1 && w > 1;
-        hipLaunchKernelGGL(sdfk::k_slabs_rebase, dim3(headers_only ? 1 : 64, w), dim3(256), 0, cs, s.gathered, w, stride, (sdfk::SlabHeader*)s.hdr_dev,
-                           headers_only ? 1 : 0);
+        if (idx16 && !headers_only)   // compact slabs: decode into the whole mesh's int32 index array (+ the header mirror)
+            hipLaunchKernelGGL(sdfk::k_slabs_decode16, dim3(64, w), dim3(256), 0, cs, (const char*)s.gathered, w, stride, (sdfk::SlabHeader*)s.hdr_dev,
+                               s.decoded, s.decoded_cap);
+        else
+            hipLaunchKernelGGL(sdfk::k_slabs_rebase, dim3(headers_only ? 1 : 64, w), dim3(256), 0, cs, s.gathered, w, stride, (sdfk::SlabHeader*)s.hdr_dev,
+                               headers_only ? 1 : 0);
         if (hipGetLastError() != hipSuccess || hipEventRecord(s.ready, cs) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "rebase launch failed"));
         s.ready_valid = true;
         return SDFK_OK;
@@ -376,6 +436,9 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         if (!s.ready_valid) return keep(fail(SDFK_ERR_INVALID, "headers of a slot that was never exchanged"));
         const hipError_t e = hipEventSynchronize(s.ready);
         if (e != hipSuccess) return keep(fail(SDFK_ERR_HIP, "waiting for the exchange: %s", hipGetErrorString(e)));
+        if (idx16)   // some rank's indices did not fit 16 bits (flags bit 0): every rank sees it here and goes back to int32 indices;
+            for (int q = 0; q < gd.world; q++)   // the step carries -1 / -1 and is redone exactly, which re-agrees (and regrows) the stride
+                if ((s.hdr_host[q * sdfk::kSlabHeaderWords + 6] >> 32) & 1) { idx16 = false; idx16_fallbacks++; break; }
         *hdr = s.hdr_host;
         return SDFK_OK;
     }
@@ -511,6 +574,7 @@ extern "C" int sdfk_dist_session_create(const sdfk_program* p, const float min[3
     s->vbytes = p->writes_color ? 36 : 24;
     s->exchange_mode = g_cfg.dist_exchange;
     s->lanes = g_cfg.dist_lanes;
+    s->idx16 = g_cfg.dist_index16 != 0;
     gd.sessions++;
     int r = SDFK_OK;
     for (auto& sl : s->slots) {
@@ -581,7 +645,8 @@ extern "C" int sdfk_dist_stats(const sdfk_dist_session* s, int64_t stats[8])
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!s || !stats) return fail(SDFK_ERR_INVALID, "sdfk_dist_stats: null argument");
     stats[0] = s->stride; stats[1] = s->steps; stats[2] = s->proto.redone(); stats[3] = s->proto.grown();
-    stats[4] = gd.backend == 2 ? -1 : s->exchange_mode; stats[5] = s->host_ns_submit; stats[6] = s->host_ns_collect; stats[7] = s->proto.depth();
+    stats[4] = gd.backend == 2 ? -1 : s->exchange_mode; stats[5] = s->host_ns_submit; stats[6] = s->host_ns_collect;
+    stats[7] = s->proto.depth() | (s->idx16 ? 0x100 : 0) | (s->idx16_fallbacks << 16);
     return SDFK_OK;
 }
 
@@ -666,7 +731,8 @@ extern "C" int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out)
     sdfk_mesh* m = nullptr;
     if (int r = alloc_mesh(&m, (size_t)nv, (size_t)ni)) return r;
     sdfk_dist_session::Slot& sl = s->slots[k];
-    ConcatArgs A{sl.gathered, gd.world, s->stride, m->vertices, m->colors, m->normals, m->triangles, m->bounds};
+    ConcatArgs A{sl.gathered, gd.world, s->stride, m->vertices, m->colors, m->normals, m->triangles, m->bounds,
+                 (s->idx16 && ni <= sl.decoded_cap) ? sl.decoded : nullptr};
     // (the slot's exchange has completed: collect waited for its `ready` event)
     const int64_t words = 9 * nv + ni;
     hipLaunchKernelGGL(k_slabs_concat, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((words / gd.world + 1023) / 1024, 512)), gd.world), dim3(256), 0,

@@ -31,6 +31,7 @@
 // maps).  Lookup tables are copied from __constant__ to LDS per workgroup.  No MFMA: nothing here
 // is a contraction.  Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 #include "mc_device.h"
 #include "mc_params.h"
@@ -1119,7 +1120,11 @@ __device__ __forceinline__ void reduce_bounds(const McMeshOut& M, float* s_bound
 // cap_v: vertex slots each of the V / (C) / N sections is laid out for -- the sections start at 64, 64 + 12 cap_v, ...,
 // the indices at 64 + vbytes * cap_v.  0 (or nv) = dense.  A step that emits straight into the send buffer lays the
 // sections out for the CAPACITIES it guessed, before it knows the counts.
-struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; int32_t vbytes; int32_t cap_v; float pad[4]; };
+// idx_bits: 0 (or 32) = Triangles as int32; 16 = the compact form k_payload_compact writes (uint16 offsets against one int32
+// base per block of 1024 indices, the bases after the offsets).  flags bit 0: the 16-bit form did not fit (some block of
+// indices spans more than 65535 ids): the step is redone, the session goes back to int32 indices.
+struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; int32_t vbytes; int32_t cap_v; int32_t idx_bits; int32_t flags; float pad[2]; };
+constexpr int SLAB_IDX_BLOCK = 1024;
 static_assert(sizeof(SlabHeader) == 64, "SDFK_SLAB_HEADER_BYTES");
 
 // ---------------------------------------------------------------------------
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             h.vbytes = M.slab_vbytes;
             h.cap_v = (int32_t)M.cap_vertices;
             for (int k = 0; k < 3; k++) { h.bmin[k] = h.nv > 0 ? s_bounds[k] : 0.0f; h.bmax[k] = h.nv > 0 ? s_bounds[3 + k] : 0.0f; }
-            for (int k = 0; k < 4; k++) h.pad[k] = 0.0f;
+            h.idx_bits = 0; h.flags = 0; h.pad[0] = h.pad[1] = 0.0f;
             *reinterpret_cast<SlabHeader*>(M.slab_header) = h;
         }
     }
@@ -1244,7 +1249,7 @@ __global__ void k_slab_header(SlabHeader* dst, int64_t nv, int64_t ni, const flo
         SlabHeader h;
         h.nv = nv; h.ni = ni; h.vbytes = vbytes; h.cap_v = 0;
         for (int k = 0; k < 3; k++) { h.bmin[k] = nv ? bounds[k] : 0.0f; h.bmax[k] = nv ? bounds[3 + k] : 0.0f; }
-        for (int k = 0; k < 4; k++) h.pad[k] = 0.0f;
+        h.idx_bits = 0; h.flags = 0; h.pad[0] = h.pad[1] = 0.0f;
         *dst = h;
     }
 }
@@ -1277,7 +1282,7 @@ __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
         SlabHeader h;
         h.nv = nv; h.ni = ni; h.vbytes = A.vbytes; h.cap_v = 0;
         for (int k = 0; k < 3; k++) { h.bmin[k] = nv > 0 ? A.bounds[k] : 0.0f; h.bmax[k] = nv > 0 ? A.bounds[3 + k] : 0.0f; }
-        for (int k = 0; k < 4; k++) h.pad[k] = 0.0f;
+        h.idx_bits = 0; h.flags = 0; h.pad[0] = h.pad[1] = 0.0f;
         *reinterpret_cast<SlabHeader*>(A.dst) = h;
     }
     if (!ok || (int64_t)sizeof(SlabHeader) + A.vbytes * nv + 4 * ni > A.capacity) return;
@@ -1292,6 +1297,84 @@ __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
         else if (i < t0) w = __float_as_uint(A.normals[i - n0]);
         else w = (uint32_t)A.triangles[i - t0];
         out[i] = w;
+    }
+}
+
+// The slab payload in its compact form: V / (C) / N dense, the indices as uint16 offsets against one int32 base per block of
+// SLAB_IDX_BLOCK indices (a triangle references vertices its own cell, the previous row or the previous layer created:
+// within 1024 consecutive indices the ids span about one layer's worth of vertices), the bases after the offsets:
+//   [ header | V 12 nv | (C 12 nv) | N 12 nv | T16 2 ni (padded to 4) | bases 4 ceil(ni / 1024) ]
+// 48 -> 36 bytes per vertex of a colourless mesh: what every rank has to RECEIVE from every other rank per step.
+// src = a plain payload (header + sections laid out for cap_v, indices int32), dst = the rank's section of the gather buffer.
+// The header goes last, by the block that finishes last (one 64-bit atomic carries both the arrival count and "some block
+// did not fit 16 bits"): counts, idx_bits = 16 -- or nv = ni = -1 with flags bit 0 when a block's ids span more than 65535.
+__device__ __forceinline__ int64_t slab_compact_bytes(int64_t nv, int64_t ni, int vbytes)
+{
+    return (int64_t)sizeof(SlabHeader) + (int64_t)vbytes * nv + ((2 * ni + 3) & ~int64_t(3)) + 4 * ((ni + SLAB_IDX_BLOCK - 1) / SLAB_IDX_BLOCK);
+}
+
+__global__ __launch_bounds__(256) void k_payload_compact(const char* __restrict__ src, char* __restrict__ dst, int64_t dst_capacity,
+                                                         unsigned long long* __restrict__ ticket)
+{
+    __shared__ int s_min[4], s_max[4];
+    __shared__ unsigned long long s_old;
+    const SlabHeader hs = *reinterpret_cast<const SlabHeader*>(src);
+    const int64_t nv = hs.nv, ni = hs.ni;
+    const bool have = nv >= 0 && ni >= 0 && slab_compact_bytes(nv, ni, hs.vbytes) <= dst_capacity;
+    bool overflow = false;
+    if (have) {
+        const int64_t capv = hs.cap_v > 0 ? (int64_t)hs.cap_v : nv;
+        const int nsec = hs.vbytes / 12;                       // V, (C), N
+        const int64_t nf = 3 * nv;
+        const uint32_t* sv = reinterpret_cast<const uint32_t*>(src + sizeof(SlabHeader));
+        uint32_t* dv = reinterpret_cast<uint32_t*>(dst + sizeof(SlabHeader));
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nf * nsec; i += (int64_t)gridDim.x * 256) {
+            const int64_t sec = i / nf, o = i - sec * nf;
+            dv[i] = sv[sec * 3 * capv + o];
+        }
+        const int32_t* st = reinterpret_cast<const int32_t*>(src + sizeof(SlabHeader) + (int64_t)hs.vbytes * capv);
+        uint16_t* t16 = reinterpret_cast<uint16_t*>(dst + sizeof(SlabHeader) + (int64_t)hs.vbytes * nv);
+        int32_t* bases = reinterpret_cast<int32_t*>(dst + sizeof(SlabHeader) + (int64_t)hs.vbytes * nv + ((2 * ni + 3) & ~int64_t(3)));
+        const int64_t nblk = (ni + SLAB_IDX_BLOCK - 1) / SLAB_IDX_BLOCK;
+        for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+            int32_t v[4];
+            int lo = INT_MAX, hi = INT_MIN;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t i = b * SLAB_IDX_BLOCK + threadIdx.x + 256 * q;
+                v[q] = i < ni ? st[i] : 0;
+                if (i < ni) { lo = min(lo, v[q]); hi = max(hi, v[q]); }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+            __syncthreads();   // (s_min / s_max of the previous block are no longer read)
+            if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lo; s_max[threadIdx.x >> 6] = hi; }
+            __syncthreads();
+            lo = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+            hi = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+            if ((int64_t)hi - (int64_t)lo > 65535) overflow = true;
+            if (threadIdx.x == 0) bases[b] = lo;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t i = b * SLAB_IDX_BLOCK + threadIdx.x + 256 * q;
+                if (i < ni) t16[i] = (uint16_t)(uint32_t)(v[q] - lo);
+            }
+        }
+    }
+    // the header, by the block that arrives last
+    if (threadIdx.x == 0) s_old = atomicAdd(ticket, 1ull + (overflow ? (1ull << 32) : 0ull));
+    __syncthreads();
+    if ((uint32_t)s_old != gridDim.x - 1u) return;
+    if (threadIdx.x == 0) {
+        const bool any_overflow = overflow || (s_old >> 32) != 0;
+        SlabHeader h = hs;
+        h.cap_v = 0;
+        h.pad[0] = h.pad[1] = 0.0f;
+        if (nv >= 0 && ni >= 0 && !any_overflow) { h.idx_bits = 16; h.flags = 0; }
+        else if (any_overflow) { h.nv = -1; h.ni = -1; h.idx_bits = 16; h.flags = 1; }
+        else { h.idx_bits = 16; h.flags = 0; }   // (the step's own -1 / -1: passed on)
+        *reinterpret_cast<SlabHeader*>(dst) = h;
+        *ticket = 0ull;                            // ready for the next launch (stream order)
     }
 }
 
@@ -1313,6 +1396,7 @@ __global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathere
     }
     if (r == 0 || base == 0) return;
     const SlabHeader* h = reinterpret_cast<const SlabHeader*>(gathered + (size_t)r * stride);
+    if (h->idx_bits == 16) return;   // (16-bit offsets are decoded -- and rebased -- by whoever extracts the mesh: k_slabs_concat)
     const int64_t capv = h->cap_v > 0 ? (int64_t)h->cap_v : h->nv;
     if ((int64_t)sizeof(SlabHeader) + h->vbytes * capv + 4 * h->ni > stride) return;   // header-only payload
     int32_t* t = reinterpret_cast<int32_t*>(gathered + (size_t)r * stride + sizeof(SlabHeader) + (size_t)capv * h->vbytes);
@@ -1401,6 +1485,34 @@ __global__ __launch_bounds__(256) void k_bounds_reduce(const float* __restrict__
         for (int w = 1; w < 4; w++) a = (j < 3) ? fminf(a, s_red[j][w]) : fmaxf(a, s_red[j][w]);
         bounds[j] = a;
     }
+}
+
+// Gathered COMPACT slabs (idx_bits = 16) -> the whole mesh's int32 index array: out[sum of ni of slabs 0..r-1 + k] = base of k's
+// block + offset + sum of nv of slabs 0..r-1.  The counterpart of k_slabs_rebase for the compact form -- after it every rank
+// holds directly usable global indices (V / N stay where the exchange left them) --, and like it the kernel mirrors the
+// `world` headers into pinned host memory.  Nothing is decoded when a header is marked invalid (that step is redone).
+__global__ __launch_bounds__(256) void k_slabs_decode16(const char* __restrict__ gathered, int world, int64_t stride, SlabHeader* mirror,
+                                                        int32_t* __restrict__ out, int64_t out_capacity)
+{
+    const int r = blockIdx.y;
+    if (mirror && blockIdx.x == 0 && threadIdx.x < sizeof(SlabHeader) / 4)
+        reinterpret_cast<uint32_t*>(mirror + r)[threadIdx.x] =
+            reinterpret_cast<const uint32_t*>(gathered + (size_t)r * stride)[threadIdx.x];
+    int64_t vbase = 0, ibase = 0;
+    for (int q = 0; q < world; q++) {
+        const SlabHeader* hq = reinterpret_cast<const SlabHeader*>(gathered + (size_t)q * stride);
+        if (hq->nv < 0 || hq->ni < 0) return;
+        if (q < r) { vbase += hq->nv; ibase += hq->ni; }
+    }
+    const SlabHeader* h = reinterpret_cast<const SlabHeader*>(gathered + (size_t)r * stride);
+    if (h->idx_bits != 16 || slab_compact_bytes(h->nv, h->ni, h->vbytes) > stride) return;
+    const int64_t ni = h->ni;
+    if (ibase + ni > out_capacity) return;
+    const char* sec = gathered + (size_t)r * stride + sizeof(SlabHeader) + (int64_t)h->vbytes * h->nv;
+    const uint16_t* t16 = reinterpret_cast<const uint16_t*>(sec);
+    const int32_t* bases = reinterpret_cast<const int32_t*>(sec + ((2 * ni + 3) & ~int64_t(3)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ni; i += (int64_t)gridDim.x * 256)
+        out[ibase + i] = bases[i / SLAB_IDX_BLOCK] + (int32_t)t16[i] + (int32_t)vbase;
 }
 
 // step > 1 (MarchingCubes.cs:49-80): the sweep only ever touches voxels whose indices are

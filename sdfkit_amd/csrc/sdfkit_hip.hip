@@ -54,6 +54,7 @@ struct Config {
     int vcolor_eval = 1;      // SDFK_OPT_VCOLOR_EVAL
     int dist_exchange = 1;    // SDFK_OPT_DIST_EXCHANGE
     int dist_lanes = 2;       // SDFK_OPT_DIST_LANES
+    int dist_index16 = 0;     // SDFK_OPT_DIST_INDEX16
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
     int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
     int copy_threads = 0;     // SDFK_COPY_THREADS (0: min(16, cores / 2)); fixed once the pool has started
@@ -758,6 +759,7 @@ static void config_from_env()
     g_cfg.vcolor_eval = geti("SDFK_NO_VCOLOR_EVAL", 0) ? 0 : 1;
     g_cfg.dist_exchange = geti("SDFK_DIST_EXCHANGE", 1);
     g_cfg.dist_lanes = geti("SDFK_DIST_LANES", 2);
+    g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0);
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
     g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0);
     g_cfg.sample_mode = geti("SDFK_SAMPLE_MODE", -1);
@@ -937,6 +939,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_VCOLOR_EVAL: if (!in(0, 1)) break; g_cfg.vcolor_eval = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_EXCHANGE: if (!in(0, 2)) break; g_cfg.dist_exchange = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_LANES: if (value != 0 && value != 2) break; g_cfg.dist_lanes = (int)value; return SDFK_OK;
+    case SDFK_OPT_DIST_INDEX16: if (!in(0, 1)) break; g_cfg.dist_index16 = (int)value; return SDFK_OK;
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
     case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;
     case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
@@ -959,6 +962,7 @@ extern "C" int sdfk_get_option(int32_t key, int64_t* value)
     case SDFK_OPT_VCOLOR_EVAL: *value = g_cfg.vcolor_eval; break;
     case SDFK_OPT_DIST_EXCHANGE: *value = g_cfg.dist_exchange; break;
     case SDFK_OPT_DIST_LANES: *value = g_cfg.dist_lanes; break;
+    case SDFK_OPT_DIST_INDEX16: *value = g_cfg.dist_index16; break;
     case SDFK_OPT_CODE_CACHE: *value = g_cfg.code_cache; break;
     case SDFK_OPT_PREFAULT_HUGE: *value = g_cfg.prefault_huge; break;
     case SDFK_OPT_HW_QUEUES: *value = g_cfg.hw_queues; break;

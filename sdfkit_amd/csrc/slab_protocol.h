@@ -25,7 +25,7 @@
 namespace sdfk {
 
 constexpr int kSlabHeaderBytes = 64;   // SDFK_SLAB_HEADER_BYTES
-constexpr int kSlabHeaderWords = 8;    // int64 words per header: nv, ni, 3 x (bounds), vbytes | cap_v << 32, 2 x pad
+constexpr int kSlabHeaderWords = 8;    // int64 words per header: nv, ni, 3 x (bounds), vbytes | cap_v << 32, idx_bits | flags << 32, pad
 
 struct SlabOps {
     virtual ~SlabOps() {}
@@ -48,6 +48,13 @@ struct SlabOps {
     // Waits for everything this rank has queued.
     virtual int quiesce() = 0;
     virtual const char* last_error() const = 0;
+    // Bytes the payload described by one gathered header needs (the protocol compares it with the stride).  Default: the
+    // plain layout, header + vertex_bytes per vertex + 4 bytes per index; a backend with another encoding overrides it.
+    virtual int64_t payload_bytes(const int64_t* hdr) const
+    {
+        const int64_t vbytes = hdr[5] & 0xffffffffll;
+        return kSlabHeaderBytes + vbytes * hdr[0] + 4 * hdr[1];
+    }
 };
 
 class SlabProtocol {
@@ -96,8 +103,7 @@ public:
             for (int q = 0; q < w && !redo; q++) {
                 const int64_t qv = hdr[q * kSlabHeaderWords], qi = hdr[q * kSlabHeaderWords + 1];
                 if (qv < 0 || qi < 0) { redo = true; break; }   // some rank's guess was too small
-                const int64_t vbytes = hdr[q * kSlabHeaderWords + 5] & 0xffffffffll;
-                if (kSlabHeaderBytes + vbytes * qv + 4 * qi > stride_) redo = true;   // a payload outgrew the stride
+                if (ops_->payload_bytes(hdr + q * kSlabHeaderWords) > stride_) redo = true;   // a payload outgrew the stride
             }
             if (redo) {   // everybody redoes the step exactly (same decision on every rank: same headers)
                 redone_++;
@@ -131,6 +137,23 @@ private:
     // Synchronous, exact form of a step (first step, and the redo of a failed one).  Ends with the stride agreement:
     // every rank is here together, so the max of the bytes needed is known to all, and all grow their buffers -- or none.
     int exact_step(int slot, int64_t* nv, int64_t* ni)
+    {
+        // An exact step can itself come back unresolved when the backend has to change its payload ENCODING (16-bit
+        // indices that do not fit: flagged in the header, seen by every rank, the backend switches to int32 in headers()):
+        // it is then simply done again -- same decision on every rank -- and a second failure is an error.
+        for (int attempt = 0;; attempt++) {
+            if (int r = exact_step_once(slot, nv, ni)) return r;
+            const int64_t* hdr = nullptr;
+            if (int r = ops_->headers(slot, &hdr)) return ops_fail(r);
+            bool unresolved = false;
+            for (int q = 0; q < ops_->world(); q++)
+                if (hdr[q * kSlabHeaderWords] < 0 || hdr[q * kSlabHeaderWords + 1] < 0) unresolved = true;
+            if (!unresolved) return 0;
+            if (attempt == 1) return fail("an exact step came back unresolved twice");
+        }
+    }
+
+    int exact_step_once(int slot, int64_t* nv, int64_t* ni)
     {
         int64_t need = 0, mx = 0;
         if (int r = ops_->run_exact(slot, nv, ni, &need)) return ops_fail(r);

@@ -144,8 +144,10 @@ class SlabSession:
     def stats(self):
         a = (C.c_int64 * 8)()
         N.check(self.L.sdfk_dist_stats(self.h, a))
-        keys = ("stride_bytes", "steps", "redone", "regrown", "exchange_mode", "host_ns_submit", "host_ns_collect", "depth")
-        return dict(zip(keys, (int(x) for x in a)))
+        keys = ("stride_bytes", "steps", "redone", "regrown", "exchange_mode", "host_ns_submit", "host_ns_collect")
+        d = dict(zip(keys, (int(x) for x in a)))
+        d["depth"], d["index16"], d["index16_fallbacks"] = int(a[7]) & 0xff, bool(int(a[7]) & 0x100), int(a[7]) >> 16
+        return d
 
     def tune(self, steps_per_mode=20):
         """sdfk_dist_tune: measure both exchanges on this fabric, keep the faster; {mode: agreed ns}."""
@@ -180,7 +182,8 @@ class SlabSession:
 def unpack_self_describing(g):
     """g: [world, stride] uint8 array of rebased slab payloads (sdfk_dist_gathered copied to the host, or a fixture) ->
     concatenated arrays.  Header (64 bytes): int64 nv, ni; float min[3], max[3]; int32 vertex_bytes (36, or 24: colours,
-    all zero, left out); int32 cap_v = vertex slots the V / (C) / N sections are laid out for (0 = dense: nv)."""
+    all zero, left out); int32 cap_v = vertex slots the V / (C) / N sections are laid out for (0 = dense: nv); int32 idx_bits
+    (16: compact indices, decoded and rebased here; else int32, already rebased by the step)."""
     V, Cc, Nn, T, mins, maxs = [], [], [], [], [], []
     for row in g:
         nv, ni = (int(x) for x in row[:16].view(np.int64))
@@ -197,7 +200,15 @@ def unpack_self_describing(g):
             Cc.append(np.zeros((nv, 3), np.float32))
         Nn.append(row[o:o + vb].view(np.float32).reshape(-1, 3))
         o += sec
-        T.append(row[o:o + 4 * ni].view(np.int32))
+        idx_bits = int(row[48:52].view(np.int32)[0])
+        if idx_bits == 16:     # compact form (k_payload_compact): uint16 offsets + one int32 base per 1024 indices, slab-local ids
+            t16 = row[o:o + 2 * ni].view(np.uint16).astype(np.int64)
+            ob = o + ((2 * ni + 3) & ~3)
+            bases = row[ob:ob + 4 * ((ni + 1023) // 1024)].view(np.int32).astype(np.int64)
+            vbase = sum(len(v) for v in V[:-1])
+            T.append((np.repeat(bases, 1024)[:ni] + t16 + vbase).astype(np.int32))
+        else:
+            T.append(row[o:o + 4 * ni].view(np.int32))
         if nv:
             mins.append(b[0:3]); maxs.append(b[3:6])
     mn = np.min(np.stack(mins), axis=0) if mins else np.zeros(3, np.float32)

@@ -56,7 +56,7 @@ if graphs_on:
     # the repeat steps were captured step graphs (one per slot and lane), replayed from their second use on
     ok &= jobs.value >= 1 and launches.value >= 1
 st = ses.stats()
-ok &= st["steps"] == 16 and st["exchange_mode"] == -1
+ok &= st["steps"] == 16 and st["exchange_mode"] == -1 and st["index16"] == (os.environ.get("SDFK_DIST_INDEX16") == "1")
 ses.close()
 dist.barrier()
 D.shutdown()

@@ -102,8 +102,9 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
     om = O.march(ov, oc, mn, mx)
     assert_mesh_equal(D.sharded_to_mesh(sdf, mn, mx, *dims), om)
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), om)
-    for mode in (0, 1, 2):
+    for mode, idx16 in ((0, 0), (1, 0), (2, 0), (1, 1), (0, 1)):
         N.set_option(N.OPT_DIST_EXCHANGE, mode)
+        N.set_option(N.OPT_DIST_INDEX16, idx16)
         ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=3)
         for it in range(12):
             if ses.in_flight == ses.depth:
@@ -115,16 +116,88 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
         ses.drain()
         assert_mesh_equal(ses.mesh(), om)
         st = ses.stats()
-        assert st["steps"] == 12 and st["redone"] == 0 and st["exchange_mode"] == mode, st
+        assert st["steps"] == 12 and st["redone"] == 0 and st["exchange_mode"] == mode and st["index16"] == bool(idx16), st
         g, stride = C.c_void_p(), C.c_int64()
         N.check(L.sdfk_dist_gathered(ses.h, C.byref(g), C.byref(stride)))
-        assert g.value and stride.value == st["stride_bytes"] >= 64 + 24 * len(om.vertices) + 4 * len(om.triangles)
+        nv_, ni_ = len(om.vertices), len(om.triangles)
+        vb = 36 if sdf.writes_color else 24
+        need = 64 + vb * nv_ + (4 * ni_ if not idx16 else ((2 * ni_ + 3) & ~3) + 4 * ((ni_ + 1023) // 1024))
+        assert g.value and stride.value == st["stride_bytes"] == (need + need // 32 + 4096 + 255) // 256 * 256   # (slab_protocol.h)
         ses.close()
+    N.set_option(N.OPT_DIST_INDEX16, 0)
 D.shutdown()
 print("rccl world 1 ok")
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "rccl world 1 ok" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
+
+
+def test_index16_falls_back_when_a_slab_does_not_fit(gpu):
+    """A tilted plane through a 512 x 512 x 8 grid: it crosses every layer over a third of the x extent, ~100 k active cells per
+    layer, so triangles that reference the layer below reach back far more than 65535 vertex ids.  With SDFK_OPT_DIST_INDEX16 the compact encoder flags it in the payload header, every rank
+    (one here) sees the flag, the session goes back to int32 indices, redoes the step exactly and regrows its buffers; the
+    meshes are the oracle's throughout.  Child process (an RCCL communicator lives until the process ends)."""
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import oracle as O
+from sdfkit_amd import _native as N
+from sdfkit_amd import dist as D
+from tests import scenes as S
+from tests.test_gpu_parity import assert_mesh_equal
+N.init(0)
+L = N.lib()
+buf = (C.c_ubyte * 128)()
+N.check(L.sdfk_dist_unique_id(buf))
+N.check(L.sdfk_dist_init(1, 0, buf))
+scene, sdf = S.plane_w((0.3, 0.0, 1.0), 0.05)
+mn, mx, dims = [-2.0] * 3, [2.0] * 3, (512, 512, 8)
+ov, oc = O.sample(scene, mn, mx, *dims)
+om = O.march(ov, oc, mn, mx)
+assert len(om.vertices) > 200000
+N.set_option(N.OPT_DIST_INDEX16, 1)
+ses = D.SlabSession(sdf, mn, mx, *dims, False, 0.0, depth=2)
+for it in range(7):
+    if ses.in_flight == ses.depth:
+        ses.collect()
+        assert_mesh_equal(ses.mesh(), om)
+    ses.submit()
+ses.drain()
+assert_mesh_equal(ses.mesh(), om)
+st = ses.stats()
+assert not st["index16"] and st["index16_fallbacks"] == 1 and st["regrown"] >= 1, st   # (found by the bootstrap step itself: done again with int32 indices)
+ses.close()
+# a scene that does fit stays compact
+scene, sdf = S.sphere_w(1.0)
+mn, mx, dims = [-1.5] * 3, [1.5] * 3, (96, 96, 96)
+ov, oc = O.sample(scene, mn, mx, *dims)
+om = O.march(ov, oc, mn, mx)
+ses = D.SlabSession(sdf, mn, mx, *dims, False, 0.0, depth=2)
+for it in range(6):
+    if ses.in_flight == ses.depth:
+        ses.collect()
+    ses.submit()
+ses.drain()
+assert_mesh_equal(ses.mesh(), om)
+st = ses.stats()
+assert st["index16"] and st["index16_fallbacks"] == 0 and st["redone"] == 0, st
+g, stride = C.c_void_p(), C.c_int64()
+N.check(L.sdfk_dist_gathered(ses.h, C.byref(g), C.byref(stride)))
+import torch
+raw = np.empty(stride.value, np.uint8)
+torch.cuda.synchronize()
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+assert hip.hipMemcpy(ctypes.c_void_p(raw.ctypes.data), g, ctypes.c_size_t(stride.value), 2) == 0
+V, Cc, Nn, T, bmin, bmax = D.unpack_self_describing(raw.reshape(1, -1))
+assert np.array_equal(T, om.triangles) and np.array_equal(V, om.vertices) and np.array_equal(Nn, om.normals, equal_nan=True)
+ses.close()
+D.shutdown()
+print("index16 fallback ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "index16 fallback ok" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
 
 
 def test_sharded_step_host_cost_world_one(gpu):
@@ -137,12 +210,14 @@ def test_sharded_step_host_cost_world_one(gpu):
     assert d["config"]["vertices"] > 10000
 
 
-@pytest.mark.parametrize("world,name,dims", [(2, "readme_repeat_xy", (40, 36, 44)), (3, "union8", (36, 40, 50)), (4, "sphere_w", (64, 64, 64))])
-def test_pipelined_session_full_parity_multi_rank(gpu, world, name, dims):
-    """2-4 ranks (one GPU, gloo), real kernels: every rank's gathered mesh == the oracle's, bit for bit."""
+@pytest.mark.parametrize("world,name,dims,idx16", [(2, "readme_repeat_xy", (40, 36, 44), 0), (3, "union8", (36, 40, 50), 0), (4, "sphere_w", (64, 64, 64), 0),
+                                                   (3, "readme_repeat_xy", (40, 36, 44), 1), (2, "sphere_w", (64, 64, 64), 1)])
+def test_pipelined_session_full_parity_multi_rank(gpu, world, name, dims, idx16):
+    """2-4 ranks (one GPU, the library's host transport over gloo), real kernels: every rank's whole mesh == the oracle's, bit
+    for bit -- with int32 indices rebased by the step, and with the compact 16-bit index payloads decoded by sdfk_dist_mesh."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join("tests", "multirank_worker.py"), name] + [str(d) for d in dims]
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, SDFK_DIST_INDEX16=str(idx16)))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("identical") == world
 
