@@ -369,10 +369,9 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         if (s.read_valid && lane) { if (hipStreamWaitEvent(st, s.read, 0) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipStreamWaitEvent failed")); }
         if (s.ready_valid && !lane) { if (hipStreamWaitEvent(st, s.ready, 0) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipStreamWaitEvent failed")); }
         s.read_valid = false;
+        const PostCompact pc{send_buf(s), stride, s.ticket};   // (compact payloads: the encoder is the last node of the captured step)
         if (int r = slab_enqueue_impl(prog, s.vol, clip, iso, lb, le, idx16 ? s.stage : send_buf(s), idx16 ? s.stage_bytes : stride, lane,
-                                      (lane && s.ready_valid) ? s.ready : nullptr, false)) return keep(r);
-        if (idx16)
-            if (int r = compact(s, st)) return r;
+                                      (lane && s.ready_valid) ? s.ready : nullptr, false, idx16 ? &pc : nullptr)) return keep(r);
         if (hipEventRecord(s.packed, st) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipEventRecord failed"));
         return SDFK_OK;
     }

@@ -2115,6 +2115,7 @@ struct GraphJob {
     bool slab = false;
     sdfk_volume* ext_vol = nullptr;
     void* dst = nullptr;
+    void* post_out = nullptr;       // compact payloads: where k_payload_compact (the graph's last node) writes
     int64_t capacity = 0;
     int lb = 0, le = 0;
     Context::Hint hint{};           // the size hints the capacities were derived from (other hints now: rebuild)
@@ -2318,13 +2319,28 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
     return SDFK_OK;
 }
 
+// What a sharded step with compact payloads queues right behind its last kernel: the plain payload at the step's dst ->
+// the compact payload at `out` (k_payload_compact, mc_kernels.hip).  Part of the captured step graph.
+struct PostCompact { char* out; int64_t out_capacity; unsigned long long* ticket; };
+int launch_post_compact(const PostCompact* pc, const void* plain, int64_t plain_capacity)
+{
+    if (!pc) return SDFK_OK;
+    const int64_t words = plain_capacity / 4;
+    ProfScope ps("k_payload_compact");
+    hipLaunchKernelGGL(k_payload_compact, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((words + 4095) / 4096, 1024))), dim3(256), 0, g.stream,
+                       (const char*)plain, pc->out, pc->out_capacity, pc->ticket);
+    HIPCHK(hipGetLastError());
+    return SDFK_OK;
+}
+
 // The same for a sharded step (sdfk_slab_enqueue on a lane): sample the caller's slab, mesh its layers straight into the
 // caller's send buffer, header written by the last kernel -- eleven launches as ONE hipGraphLaunch per step.  Key: program,
 // slab volume, clip, iso, layer range, destination and capacity, lane; the GraphJob keeps the job's workspace and result
 // slot, the mesh arrays ARE sections of the destination.  A step whose capacities were too small says so in its header
 // (every rank then redoes it exactly, sdfkit_amd/dist.py), which renews the size hints: a GraphJob built from other hints
 // than today's is rebuilt.  *handled stays false when graphs do not apply (the caller then takes the ordinary path).
-int graph_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int clip, float iso, int lb, int le, void* dst, int64_t capacity, bool* handled)
+int graph_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int clip, float iso, int lb, int le, void* dst, int64_t capacity, bool* handled,
+                       const PostCompact* pc = nullptr)
 {
     *handled = false;
     const int lane = g.cur_lane;
@@ -2336,7 +2352,7 @@ int graph_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int clip, float
     GraphJob* q = nullptr;
     for (GraphJob* c : g.graph_jobs)
         if (c->slab && c->prog == p && c->ext_vol == slab && c->clip == clip && memcmp(&c->iso, &iso, 4) == 0 && c->lb == lb && c->le == le &&
-            c->dst == dst && c->capacity == capacity && c->lane == lane) { q = c; break; }
+            c->dst == dst && c->capacity == capacity && c->lane == lane && c->post_out == (pc ? (void*)pc->out : nullptr)) { q = c; break; }
     if (q && memcmp(&q->hint, &h, sizeof h) != 0) { graph_job_destroy(q); q = nullptr; }
     if (q) {
         resolve_dependents(slab);
@@ -2372,12 +2388,14 @@ int graph_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int clip, float
     q->ext_vol = slab; q->clip = clip; q->iso = iso; q->lb = lb; q->le = le; q->dst = dst; q->capacity = capacity; q->lane = lane;
     q->nx = slab->nx; q->ny = slab->ny; q->nz = slab->nz;
     q->key = key; q->hint = h; q->proto = proto;
+    q->post_out = pc ? (void*)pc->out : nullptr;
     g.graph_jobs.push_back(q);
     int r = sample_impl(p, slab, clip, iso);   // (outside the capture: loads the kernels, allocates the sign-bit arrays; this call's run)
     if (!r) r = setup_job(slab, iso, 1, lb, le, (size_t)h.n_active + h.n_active / 4 + 4096, &q->job);
     if (!r && (q->job->empty || !q->job->have_bits)) r = -1;
     if (!r) r = launch_classify(q->job, false);
     if (!r) r = launch_emit(q->job, q->proto, 0);
+    if (!r) r = launch_post_compact(pc, dst, capacity);
     if (!r) {
         q->args = slab->sampled_args;
         hipStream_t st = lane_stream(lane);
@@ -2386,6 +2404,7 @@ int graph_slab_enqueue(const sdfk_program* p, sdfk_volume* slab, int clip, float
             int rc = sample_impl(p, slab, clip, iso);
             if (!rc) rc = launch_classify(q->job, false);
             if (!rc) rc = launch_emit(q->job, q->proto, 0);
+            if (!rc) rc = launch_post_compact(pc, dst, capacity);
             e = hipStreamEndCapture(st, &q->graph);
             if (e == hipSuccess && rc) e = hipErrorUnknown;
         }
@@ -2559,7 +2578,8 @@ extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_by
 // caller's stream waits for the section (sdfk_slab_enqueue); the library's own step driver (dist_rccl.h) orders its exchange
 // stream with an event of its own instead.
 static int slab_enqueue_impl(const sdfk_program* p, sdfk_volume* slab, int32_t clip_to_bounds, float iso_value, int32_t layer_begin,
-                             int32_t layer_end, void* dst, int64_t capacity_bytes, int32_t lane, void* wait_hip_event, bool caller_stream_waits)
+                             int32_t layer_end, void* dst, int64_t capacity_bytes, int32_t lane, void* wait_hip_event, bool caller_stream_waits,
+                             const PostCompact* pc = nullptr)
 {
     int r = lane > 0 ? sdfk_lane_begin(lane, wait_hip_event) : SDFK_OK;
     if (r) return r;
@@ -2567,7 +2587,7 @@ static int slab_enqueue_impl(const sdfk_program* p, sdfk_volume* slab, int32_t c
     r = require_init();
     if (!r && lane > 0 && graphs_enabled_slab((int64_t)slab->nx * slab->ny * slab->nz)) {   // the repeat step as ONE captured graph launch
         bool handled = false;
-        r = graph_slab_enqueue(p, slab, clip_to_bounds ? 1 : 0, iso_value, layer_begin, layer_end, dst, capacity_bytes, &handled);
+        r = graph_slab_enqueue(p, slab, clip_to_bounds ? 1 : 0, iso_value, layer_begin, layer_end, dst, capacity_bytes, &handled, pc);
         if (handled || r) {
             const int r2 = sdfk_lane_end(caller_stream_waits ? 1 : 0);
             return r ? r : r2;
@@ -2582,6 +2602,7 @@ static int slab_enqueue_impl(const sdfk_program* p, sdfk_volume* slab, int32_t c
         r = sdfk_mesh_pack(m, dst, capacity_bytes, &need);
     }
     if (m) sdfk_mesh_free(m);   // stream-ordered: the kernels above still use it
+    if (!r) r = launch_post_compact(pc, dst, capacity_bytes);
     if (lane > 0) {
         const int r2 = sdfk_lane_end(caller_stream_waits ? 1 : 0);
         if (!r) r = r2;
