@@ -118,14 +118,25 @@ __global__ __launch_bounds__(256) void k_bits_transpose(const uint8_t* __restric
     const int iy = (int)(blockIdx.x / (unsigned)ztiles), z0 = (int)(blockIdx.x % (unsigned)ztiles) * 128;
     const int xw0 = (int)(blockIdx.z + blockIdx.y * 65535u) * 8, row0 = xw0 * 8;
     if (xw0 >= nxw) return;
-    for (int k = threadIdx.x; k < 64 * 32; k += 256) {
+    // (all eight loads of a lane are issued before the first LDS store: as a "load; store" loop the compiler keeps one load
+    // in flight per trip -- eight dependent L2 round trips, 8 us whatever the size of the volume; a slab of 68 planes took as
+    // long as 512 planes)
+    unsigned v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = (int)threadIdx.x + 256 * i;
         const int row = k >> 5, c = (k & 31) * 4;
-        unsigned v = 0;   // (byte rows are pitch8 long, a multiple of 4: a 4-byte group never straddles a row)
+        v[i] = 0;   // (byte rows are pitch8 long, a multiple of 4: a 4-byte group never straddles a row)
         if (row0 + row < nx8 && z0 + c < nz)
-            v = *reinterpret_cast<const unsigned*>(bits8 + ((size_t)iy * nx8 + row0 + row) * pitch8 + z0 + c);
-        *reinterpret_cast<unsigned*>(&t[row][c]) = v;
+            v[i] = *reinterpret_cast<const unsigned*>(bits8 + ((size_t)iy * nx8 + row0 + row) * pitch8 + z0 + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = (int)threadIdx.x + 256 * i;
+        *reinterpret_cast<unsigned*>(&t[k >> 5][(k & 31) * 4]) = v[i];
     }
     __syncthreads();
+#pragma unroll
     for (int k = threadIdx.x; k < 128 * 8; k += 256) {
         const int zz = k >> 3, xw = k & 7;
         if (z0 + zz < nz && xw0 + xw < nxw) {
