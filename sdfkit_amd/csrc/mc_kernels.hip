@@ -255,7 +255,6 @@ __device__ __forceinline__ uint64_t segment_mask(uint64_t a, uint64_t an, uint64
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_compact(McParams P)
 {
-    __shared__ uint64_t s_wave[4];
     const int b = blockIdx.x;
     const int lay = b / P.bpl;
     const int z = P.lay_count_begin + lay;
