@@ -17,6 +17,9 @@ of the timing contract (a gloo group: no second communicator, no torch streams o
 Started as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) it launches
 `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself, as a CHILD process,
 before anything in this process has touched the GPU, and relays rank 0's JSON line.
+Every rank a launcher starts is a SUPERVISOR that never touches HIP: the measuring process is its child, with a time
+limit; the supervisors agree (gloo) whether all workers finished and otherwise ALL start the next, more conservative
+configuration (RANK_TRIES) -- a collective that hangs on first contact with a node costs one time limit, not the run.
 """
 import argparse
 import ctypes as C
@@ -63,10 +66,80 @@ def _run_ranks(cmd, env, limit_s):
         return 124, out or ""
 
 
+# What a multi-rank run falls back to when the pipelined form fails (or hangs) on a node: first RCCL's own all-gather instead of
+# the grouped point-to-point sends, one step in flight, no exchange tuning; then, on top, no internal lanes at all (same
+# protocol, same kernels).  The bench line of a retry says so (`note`).
+RANK_TRIES = [
+    ({}, ""),
+    ({"SDFK_BENCH_DEPTH": "1", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1", "SDFK_BENCH_INDEX16": "0"},
+     "retry: one step in flight, plain ncclAllGather of plain payloads, no exchange tuning"),
+    ({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0", "SDFK_DIST_LANES": "0", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1",
+      "SDFK_BENCH_INDEX16": "0"}, "retry: one step in flight, no lanes, plain ncclAllGather of plain payloads"),
+]
+
+
+def attempt_limit_s():
+    return float(os.environ.get("SDFK_BENCH_RANKS_TIMEOUT_S", "300"))   # (a hung collective must not eat the caller's whole budget)
+
+
+def supervise_rank(argv):
+    """One rank of a multi-rank run as its launcher started it (`torch.distributed.run ... bench.py --gpus N`: RANK /
+    WORLD_SIZE in the environment).  This process is a SUPERVISOR: it never touches HIP.  The measuring process is a child
+    (SDFK_BENCH_WORKER=1) with a time limit; the supervisors agree over a gloo group of their own whether every worker
+    finished, and if one did not -- died, or hung in a collective and was killed -- ALL of them start the next, more
+    conservative configuration of RANK_TRIES.  Rank 0 relays its worker's JSON line."""
+    import datetime
+    import socket
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # (the container's hostname may not resolve)
+    limit = attempt_limit_s()
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=limit + 180))
+    rc = 1
+    for extra, note in RANK_TRIES:
+        port = [0]
+        if rank == 0:   # a rendezvous port of their own for the workers of this attempt (one node: the contract of bench.py)
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+            sk.close()
+        dist.broadcast_object_list(port, src=0)
+        # (without the launcher's TORCHELASTIC_* variables: the workers' rank 0 hosts the store of THEIR rendezvous itself)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(extra)
+        env.update({"SDFK_BENCH_WORKER": "1", "MASTER_PORT": str(port[0])})
+        if note:
+            env["SDFK_BENCH_NOTE"] = note
+            if rank == 0:
+                print(f"bench.py: multi-rank run failed (rc {rc}); {note}", file=sys.stderr, flush=True)
+        # (SDFK_BENCH_WORKER_SCRIPT: tests/test_bench_host.py puts a stub in the worker's place to exercise this ladder on CPU)
+        rc, out = _run_ranks([sys.executable, os.environ.get("SDFK_BENCH_WORKER_SCRIPT", os.path.abspath(__file__))] + argv, env, limit)
+        if rc == 124:
+            print(f"bench.py: rank {rank} did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
+        ok = rc == 0 and (rank != 0 or any(l.startswith("{") for l in out.splitlines()))
+        failed = torch.tensor([0 if ok else 1])
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()) == 0:
+            if rank == 0:
+                sys.stdout.write(out)
+                sys.stdout.flush()
+            dist.destroy_process_group()
+            return 0
+        sys.stderr.write(out)
+        rc = rc or 1
+    dist.destroy_process_group()
+    return rc or 1
+
+
 def launch_ranks(argv, n):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU under
     torch.distributed.run as a child process (never exec: see the module docstring), forward its
-    output and return its exit code.  Nothing here imports torch or touches HIP."""
+    output and return its exit code.  Nothing here imports torch or touches HIP.  (The ranks supervise themselves:
+    supervise_rank.)"""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -76,30 +149,16 @@ def launch_ranks(argv, n):
     env.setdefault("OMP_NUM_THREADS", "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
-    tries = [({}, "")]
-    # if the pipelined form fails (or hangs) on this node: first RCCL's own all-gather instead of the grouped point-to-point
-    # sends, one step in flight, no exchange tuning; then, on top, no internal lanes at all (same protocol, same kernels)
-    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1", "SDFK_BENCH_INDEX16": "0"},
-                  "retry: one step in flight, plain ncclAllGather of plain payloads, no exchange tuning"))
-    tries.append(({"SDFK_BENCH_DEPTH": "1", "SDFK_LANES": "0", "SDFK_DIST_LANES": "0", "SDFK_DIST_EXCHANGE": "0", "SDFK_BENCH_NO_TUNE": "1",
-                   "SDFK_BENCH_INDEX16": "0"}, "retry: one step in flight, no lanes, plain ncclAllGather of plain payloads"))
-    limit = float(os.environ.get("SDFK_BENCH_RANKS_TIMEOUT_S", "420"))   # (a hung collective must not eat the caller's whole budget)
-    rc = 1
-    for extra, note in tries:
-        e = dict(env)
-        e.update(extra)
-        if note:
-            print(f"bench.py: multi-rank run failed (rc {rc}); {note}", file=sys.stderr, flush=True)
-            e["SDFK_BENCH_NOTE"] = note
-        rc, out = _run_ranks(cmd, e, limit)
-        if rc == 124:
-            print(f"bench.py: the ranks did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
-        lines = [l for l in out.splitlines() if l.startswith("{")]
-        if rc == 0 and lines:
-            sys.stdout.write(out)
-            sys.stdout.flush()
-            return 0
-        sys.stderr.write(out)
+    limit = len(RANK_TRIES) * (attempt_limit_s() + 30) + 240
+    rc, out = _run_ranks(cmd, env, limit)
+    if rc == 124:
+        print(f"bench.py: the ranks did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if rc == 0 and lines:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        return 0
+    sys.stderr.write(out)
     return rc or 1
 
 
@@ -213,6 +272,9 @@ def main():
                 "--scene", args.scene, "--cpu-n", str(args.cpu_n), "--cpu-passes", str(args.cpu_passes)] + (["--no-cpu"] if args.no_cpu else []) + \
                (["--minimal"] if args.minimal else [])
         sys.exit(launch_ranks(argv, args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("SDFK_BENCH_WORKER") != "1":
+        # a rank as the launcher (the driver's torch.distributed.run, or launch_ranks above) started it: supervise a worker
+        sys.exit(supervise_rank(sys.argv[1:]))
 
     import numpy as np
     import torch

@@ -26,24 +26,52 @@ def test_cpu_baseline_scenes(scene):
 
 def test_launcher_spawns_torchrun_as_a_child(monkeypatch):
     """WORLD_SIZE unset + --gpus 4: one child `python -m torch.distributed.run --nproc-per-node 4 bench.py ...`
-    whose JSON line is relayed; a failing first attempt is retried conservatively."""
+    whose JSON line is relayed (the retries are the ranks' own business: supervise_rank)."""
     calls = []
 
     def fake_run(cmd, env, limit_s):
-        calls.append((cmd, env))
-        if len(calls) == 1:
-            return 1, "boom\n"
+        calls.append((cmd, env, limit_s))
         return 0, '{"metric": "x", "n_gpus": 4}\n'
 
     monkeypatch.setattr(bench, "_run_ranks", fake_run)
     rc = bench.launch_ranks(["--gpus", "4", "--steps", "5"], 4)
-    assert rc == 0 and len(calls) == 2
-    cmd, env = calls[0]
+    assert rc == 0 and len(calls) == 1
+    cmd, env, limit = calls[0]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nproc-per-node=4" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
-    assert "SDFK_BENCH_DEPTH" not in env or env["SDFK_BENCH_DEPTH"] != "1" or "SDFK_BENCH_DEPTH" in os.environ
-    assert calls[1][1]["SDFK_BENCH_DEPTH"] == "1" and calls[1][1]["SDFK_DIST_EXCHANGE"] == "0" and "SDFK_BENCH_NOTE" in calls[1][1]
+    assert limit >= len(bench.RANK_TRIES) * bench.attempt_limit_s()   # room for every attempt of the ranks' ladder
+
+
+def _launch_with_stub(first_attempt, timeout_s, world=2):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SDFK_BENCH_NOTE", "SDFK_BENCH_WORKER"):
+        env.pop(k, None)
+    env.update({"SDFK_BENCH_WORKER_SCRIPT": os.path.join(ROOT, "tests", "bench_worker_stub.py"), "STUB_FIRST_ATTEMPT": first_attempt,
+                "SDFK_BENCH_RANKS_TIMEOUT_S": str(timeout_s)})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu", "--grid", "32"],
+                          env=env, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("first_attempt", ["ok", "die", "hang"])
+def test_rank_supervisors_agree_on_the_retry_ladder(first_attempt):
+    """bench.py --gpus 2 -> torch.distributed.run -> two SUPERVISOR ranks (no HIP) -> two workers with a rendezvous of their
+    own.  A worker that dies, or hangs and is killed at its time limit, makes BOTH supervisors start the next configuration
+    of RANK_TRIES; rank 0 relays exactly one JSON line, from the attempt that succeeded."""
+    import json
+    p = _launch_with_stub(first_attempt, 25 if first_attempt == "hang" else 120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["argv"][:2] == ["--gpus", "2"]
+    if first_attempt == "ok":
+        assert d["note"] == "" and d["depth"] == ""
+    else:
+        assert d["note"].startswith("retry: one step in flight, plain ncclAllGather") and d["depth"] == "1"
+        assert "multi-rank run failed" in p.stderr
+        if first_attempt == "hang":
+            assert "did not finish within 25 s" in p.stderr
 
 
 def test_plain_python_with_gpus_gt_1_launches_before_touching_torch():
@@ -56,5 +84,5 @@ def test_plain_python_with_gpus_gt_1_launches_before_touching_torch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--grid", "32"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0                      # no GPU here: the ranks refuse to run
-    assert "bench.py needs an MI355X" in p.stderr or "retry" in p.stderr
+    assert "bench.py needs an MI355X" in p.stderr and "retry" in p.stderr   # (every configuration of the ladder was tried)
     assert "launch with torch.distributed.run" not in p.stderr
