@@ -424,10 +424,11 @@ def main():
     else:
         # three steps in flight, one exchange per step issued by the library on its own stream, no host wait inside a step
         # (sdfk_dist_session_*: csrc/slab_protocol.h + csrc/dist_rccl.h)
-        # compact payloads (indices as 16-bit offsets: 48 -> 36 bytes per vertex received from every peer) whenever there IS a
-        # peer; a slab that does not fit sends the session back to int32 indices by itself (SDFK_BENCH_INDEX16=0/1 overrides)
+        # plain or compact payloads (indices as 16-bit offsets: 48 -> 36 bytes per vertex received from every peer, an encode and
+        # a decode pass more): the tuner below measures both on this node's fabric; SDFK_BENCH_INDEX16=0/1 sets the form the
+        # session starts with (and stays with when the tuner is off)
         idx16_env = os.environ.get("SDFK_BENCH_INDEX16")
-        N.set_option(N.OPT_DIST_INDEX16, int(idx16_env) if idx16_env is not None else (1 if world > 1 else 0))
+        N.set_option(N.OPT_DIST_INDEX16, int(idx16_env) if idx16_env is not None else 0)
         worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 3)
         last = [0, 0]
         tuned = None
@@ -454,8 +455,9 @@ def main():
     nv, ni = drain()
     barrier()
     if sharded and world > 1 and D.info()[2] == 1 and os.environ.get("SDFK_BENCH_NO_TUNE") != "1":
-        # which exchange is faster on this node's fabric is measured, untimed: ncclAllGather against direct grouped sends
-        tuned = worker.tune(20)
+        # which exchange and which payload form are faster on this node's fabric is measured, untimed: ncclAllGather against
+        # direct grouped sends, int32 against 16-bit indices
+        tuned = {f"mode{m}_{'compact' if c else 'plain'}": ns for (m, c), ns in worker.tune(20).items()}
         barrier()
     # (what a step costs once the pools are filled: a second, short batch -- the first one contains one-off costs, device
     # allocations of half a GB each for one, and on a box that had never run the program before they made the estimate

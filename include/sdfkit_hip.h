@@ -318,10 +318,13 @@ int sdfk_dist_gathered(const sdfk_dist_session* s, void** device_ptr, int64_t* s
  *              host nanoseconds spent inside sdfk_dist_submit (total), inside sdfk_dist_collect (total),
  *              depth | 0x100 if the payloads are in the 16-bit index form | fall-backs to int32 indices << 16 } */
 int sdfk_dist_stats(const sdfk_dist_session* s, int64_t stats[8]);
-/* Which exchange is faster on this node's fabric is a measurement: runs steps_per_mode pipelined steps with ncclAllGather and
- * with the direct grouped sends, takes the slowest rank's time for each (the same numbers on every rank) and keeps the faster
- * mode for this session.  Collective, nothing in flight; ns_per_mode[2] (may be NULL): the agreed times, index = mode. */
-int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int64_t* ns_per_mode);
+/* Which exchange and which payload form are faster on this node's fabric is a measurement: runs steps_per_mode pipelined steps
+ * with ncclAllGather and with the direct grouped sends, each with plain payloads and with compact ones (16-bit index offsets:
+ * fewer bytes per peer, an encode and a decode pass more), takes the slowest rank's time for each -- the same numbers on every
+ * rank -- and keeps the fastest configuration for this session (a change of the payload form agrees the stride again).
+ * Collective, nothing in flight; ns_per_config[4] (may be NULL): the agreed times, index = mode + 2 * (compact), -1 = the scene
+ * does not fit the compact form; all 0 with the host transport, which has one exchange only. */
+int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int64_t* ns_per_config);
 /* This rank's slab step WITHOUT the exchange, queued like a step (measurement: "kernel-only" time of a sharded step). */
 int sdfk_dist_enqueue_only(sdfk_dist_session* s);
 void sdfk_dist_session_free(sdfk_dist_session* s);

@@ -663,16 +663,14 @@ extern "C" int sdfk_dist_enqueue_only(sdfk_dist_session* s)
 // the xGMI mesh, its own protocol choice per size) against direct grouped sends to every peer.  Runs `steps_per_mode`
 // pipelined steps with each, takes the slowest rank's time per mode (agree_max: the same numbers on every rank), keeps the
 // faster mode for the session.  Collective; nothing may be in flight.  ns_per_mode[2] (may be NULL) = the agreed times.
-extern "C" int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int64_t* ns_per_mode)
+extern "C" int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int64_t* ns_per_config)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!s || steps_per_mode < 1) return fail(SDFK_ERR_INVALID, "sdfk_dist_tune: bad argument");
     if (int r = require_init()) return r;
     if (s->proto.in_flight() != 0) return fail(SDFK_ERR_INVALID, "sdfk_dist_tune: collect every queued step first");
-    if (gd.backend != 1 || gd.world == 1) {   // one exchange only (host transport), or nothing to exchange
-        if (ns_per_mode) ns_per_mode[0] = ns_per_mode[1] = 0;
-        return SDFK_OK;
-    }
+    if (ns_per_config) for (int k = 0; k < 4; k++) ns_per_config[k] = 0;
+    if (gd.backend != 1) return SDFK_OK;   // the host transport has one exchange only
     auto run = [&](int n) {
         for (int i = 0; i < n; i++) {
             if (s->proto.in_flight() == s->proto.depth())
@@ -681,20 +679,38 @@ extern "C" int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int6
         }
         return s->proto.drain();
     };
-    int64_t agreed[2] = {0, 0};
-    for (int mode = 1; mode >= 0; mode--) {
-        s->exchange_mode = mode;
-        int r = run(2 * s->proto.depth() + 2);   // (captured step graphs of every slot and lane exist after this)
-        if (!r) r = s->quiesce();
-        const auto t0 = std::chrono::steady_clock::now();
-        if (!r) r = run(steps_per_mode);
-        if (!r) r = s->quiesce();
-        const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-        if (r) return dist_fail(s, r);
-        if (int r2 = s->agree_max(ns, &agreed[mode])) { t_err = s->err; return r2; }
+    auto set_form = [&](bool idx) -> int {   // the payload form belongs to the buffers: a new bootstrap (every rank alike)
+        if (s->idx16 == idx) return SDFK_OK;
+        if (int r = s->quiesce()) return r;
+        s->idx16 = idx;
+        if (s->proto.reset()) { s->err = s->proto.error(); return SDFK_ERR_INVALID; }
+        return SDFK_OK;
+    };
+    const int64_t kNever = INT64_MAX;
+    int64_t agreed[4] = {kNever, kNever, kNever, kNever};   // index = mode + 2 * (16-bit indices)
+    for (int idx = 0; idx < 2; idx++) {
+        if (int r = set_form(idx != 0)) return dist_fail(s, r);
+        for (int mode = 1; mode >= 0; mode--) {
+            s->exchange_mode = mode;
+            int r = run(2 * s->proto.depth() + 2);   // (captured step graphs of every slot and lane exist after this)
+            if (!r) r = s->quiesce();
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!r) r = run(steps_per_mode);
+            if (!r) r = s->quiesce();
+            const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (r) return dist_fail(s, r);
+            if (int r2 = s->agree_max(ns, &agreed[mode + 2 * idx])) { t_err = s->err; return r2; }
+            // (a slab that does not fit 16-bit offsets sent the session back to int32 indices -- on every rank, seen in the
+            // same step's headers: the compact form is not a candidate for this scene)
+            if (idx && !s->idx16) agreed[mode + 2 * idx] = kNever;
+        }
     }
-    s->exchange_mode = agreed[1] <= agreed[0] ? 1 : 0;
-    if (ns_per_mode) { ns_per_mode[0] = agreed[0]; ns_per_mode[1] = agreed[1]; }
+    int best = 1;
+    for (int k = 0; k < 4; k++)
+        if (agreed[k] < agreed[best]) best = k;
+    if (int r = set_form(best >= 2)) return dist_fail(s, r);
+    s->exchange_mode = best & 1;
+    if (ns_per_config) for (int k = 0; k < 4; k++) ns_per_config[k] = agreed[k] == kNever ? -1 : agreed[k];
     return SDFK_OK;
 }
 

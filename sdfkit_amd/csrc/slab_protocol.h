@@ -128,6 +128,18 @@ public:
         return 0;
     }
 
+    // Forget the agreed stride: the next submit() bootstraps again (exact step, stride agreement, new buffers) -- for a
+    // backend that changes its payload form.  Every rank calls it at the same point, with nothing in flight.
+    int reset()
+    {
+        if (!queue_.empty()) return fail("reset() with steps in flight");
+        stride_ = 0;
+        next_slot_ = 0;
+        last_slot_ = -1;
+        last_hdr_ = nullptr;
+        return 0;
+    }
+
 private:
     struct Entry { int slot; bool exact; int64_t nv, ni; };
 

@@ -150,10 +150,11 @@ class SlabSession:
         return d
 
     def tune(self, steps_per_mode=20):
-        """sdfk_dist_tune: measure both exchanges on this fabric, keep the faster; {mode: agreed ns}."""
-        a = (C.c_int64 * 2)()
+        """sdfk_dist_tune: measure both exchanges, with plain and with compact payloads, on this fabric and keep the fastest;
+        {(mode, compact): agreed ns, -1 = the scene does not fit the compact form}."""
+        a = (C.c_int64 * 4)()
         N.check(self.L.sdfk_dist_tune(self.h, steps_per_mode, a))
-        return {0: int(a[0]), 1: int(a[1])}
+        return {(k & 1, bool(k >> 1)): int(a[k]) for k in range(4)}
 
     def enqueue_only(self):
         """This rank's slab kernels without the exchange (measurement)."""

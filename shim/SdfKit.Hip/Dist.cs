@@ -71,7 +71,7 @@ namespace SdfKit.Hip
                 Native.Check(Native.sdfk_dist_collect(h, out var nv, out var ni));
                 return (nv, ni);
             }
-            /// <summary>Measures both exchanges on this node's fabric and keeps the faster one (collective).</summary>
+            /// <summary>Measures both exchanges, with plain and with compact payloads, on this node's fabric and keeps the fastest configuration (collective, nothing in flight).</summary>
             public void Tune(int stepsPerMode = 20) => Native.Check(Native.sdfk_dist_tune(h, stepsPerMode, null));
             /// <summary>The whole mesh of the step collected last.</summary>
             public Mesh Mesh()

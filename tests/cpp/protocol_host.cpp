@@ -59,6 +59,7 @@ void proto_free(void* h) { delete static_cast<Proto*>(h); }
 int proto_submit(void* h) { return static_cast<Proto*>(h)->p.submit(); }
 int proto_collect(void* h, int64_t* nv, int64_t* ni) { return static_cast<Proto*>(h)->p.collect(nv, ni); }
 int proto_drain(void* h) { return static_cast<Proto*>(h)->p.drain(); }
+int proto_reset(void* h) { return static_cast<Proto*>(h)->p.reset(); }
 int proto_in_flight(void* h) { return static_cast<Proto*>(h)->p.in_flight(); }
 int proto_last_slot(void* h) { return static_cast<Proto*>(h)->p.last_slot(); }
 int64_t proto_stride(void* h) { return static_cast<Proto*>(h)->p.stride(); }

@@ -48,7 +48,7 @@ def lib():
         L.proto_create.argtypes = [C.POINTER(Callbacks), _i32, C.c_double]
         L.proto_free.argtypes = [C.c_void_p]
         L.proto_free.restype = None
-        for name in ("proto_submit", "proto_drain", "proto_in_flight", "proto_last_slot"):
+        for name in ("proto_submit", "proto_drain", "proto_reset", "proto_in_flight", "proto_last_slot"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = C.c_int
         L.proto_collect.argtypes = [C.c_void_p, _p64, _p64]
@@ -178,6 +178,14 @@ class ProtoSession:
         a, b = _i64(), _i64()
         self._check(self.L.proto_collect(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def reset(self):
+        """Forget the agreed stride (nothing in flight): the next submit bootstraps again."""
+        self._check(self.L.proto_reset(self.h))
+
+    @property
+    def agreed_stride(self):
+        return int(self.L.proto_stride(self.h))
 
     @property
     def in_flight(self):

@@ -239,6 +239,50 @@ def test_payload_outgrowing_the_stride_regrows_on_every_rank(world):
     assert len({stride for *_, stride in res}) == 1, res                # ... and agreed on the same new stride
 
 
+def _reset_worker(rank, world, port, dims, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import proto_host as P
+        from tests import scenes as S
+        ref = _reference(S.readme_repeat_xy, dims)
+        ses = P.ProtoSession(lambda slot: FixtureSessionWorker(ref, *dims, rank, world), depth=2)
+        ok, strides = True, []
+        for phase in range(3):
+            for it in range(5):
+                if ses.in_flight == ses.depth:
+                    ses.collect()
+                    ok &= _same(ses.mesh(), ref)
+                ses.submit()
+            while ses.in_flight:
+                ses.collect()
+                ok &= _same(ses.mesh(), ref)
+            strides.append(ses.agreed_stride)
+            try:
+                ses.submit()
+                ses.reset()                 # refused with a step in flight
+                ok = False
+            except RuntimeError:
+                pass
+            ses.collect()
+            ses.reset()                     # (what sdfk_dist_tune does when it changes the payload form)
+            ok &= ses.agreed_stride == 0
+        out_q.put((rank, bool(ok), strides, ses.redone, ses.grown))
+        ses.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_reset_bootstraps_again_on_every_rank(world):
+    """SlabProtocol::reset (nothing in flight, every rank at the same point): the next step is an exact one again and agrees
+    the stride anew; results unchanged, no step counted as redone or regrown."""
+    res = _spawn(_reset_worker, world, ((22, 20, 19),))
+    assert all(ok for _, ok, *_ in res), res
+    assert all(len(set(strides)) == 1 and strides[0] > 0 and redone == 0 and grown == 0 for _, _, strides, redone, grown in res), res
+
+
 def test_slab_partition_covers_all_layers():
     from tests import proto_host as P
     for n_layers in (0, 1, 7, 8, 511, 1023):

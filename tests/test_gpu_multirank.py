@@ -125,6 +125,28 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
         assert g.value and stride.value == st["stride_bytes"] == (need + need // 32 + 4096 + 255) // 256 * 256   # (slab_protocol.h)
         ses.close()
     N.set_option(N.OPT_DIST_INDEX16, 0)
+    # the tuner: both exchanges x both payload forms, measured; whatever it keeps, the steps after it are the same mesh
+    N.set_option(N.OPT_DIST_EXCHANGE, 1)
+    for start16 in (0, 1):
+        N.set_option(N.OPT_DIST_INDEX16, start16)
+        ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=3)
+        for it in range(4):
+            ses.submit()
+            ses.collect()
+        t = ses.tune(6)
+        assert set(t) == {(0, False), (1, False), (0, True), (1, True)} and all(v > 0 for v in t.values()), t
+        st = ses.stats()
+        best = min(t, key=lambda k: (t[k], k != (1, False)))
+        assert (st["exchange_mode"], st["index16"]) == best, (st, t)
+        for it in range(7):
+            if ses.in_flight == ses.depth:
+                assert ses.collect() == (len(om.vertices), len(om.triangles))
+            ses.submit()
+        ses.drain()
+        assert_mesh_equal(ses.mesh(), om)
+        assert ses.stats()["redone"] == 0 and ses.stats()["index16_fallbacks"] == 0
+        ses.close()
+    N.set_option(N.OPT_DIST_INDEX16, 0)
 D.shutdown()
 print("rccl world 1 ok")
 """ % ROOT
