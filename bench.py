@@ -385,7 +385,7 @@ def main():
     # steps in flight: the GPU then holds ~1 ms of queued work, so that a hiccup of the host (an interrupt, the interpreter)
     # inside the 3 ms timed region of the driver's 20-step command does not drain the pipeline (3 and 6 in flight give the
     # same steady state; with 3 one run in five came out 5-10 % slow)
-    depth_env = int(os.environ.get("SDFK_BENCH_DEPTH", "0"))   # 0 = default: 5 single-GPU (the library itself holds at most 6 unread jobs), 3 sharded
+    depth_env = int(os.environ.get("SDFK_BENCH_DEPTH", "0"))   # 0 = default: 5 single-GPU (the library itself holds at most 6 unread jobs), 4 sharded
     if not sharded:
         # sdfk_sample_march returns its mesh handle while the kernels are still queued (the
         # sizes are a guess from the previous mesh of this shape; the first accessor waits and
@@ -422,14 +422,15 @@ def main():
                 retire(inflight.pop(0))
             return tuple(last)
     else:
-        # three steps in flight, one exchange per step issued by the library on its own stream, no host wait inside a step
+        # four steps in flight on three internal streams (measured: 128^3 at world 1 27.7 us per step; 3 in flight on 2 streams 39.7),
+        # one exchange per step issued by the library on its own stream, no host wait inside a step
         # (sdfk_dist_session_*: csrc/slab_protocol.h + csrc/dist_rccl.h)
         # plain or compact payloads (indices as 16-bit offsets: 48 -> 36 bytes per vertex received from every peer, an encode and
         # a decode pass more): the tuner below measures both on this node's fabric; SDFK_BENCH_INDEX16=0/1 sets the form the
         # session starts with (and stays with when the tuner is off)
         idx16_env = os.environ.get("SDFK_BENCH_INDEX16")
         N.set_option(N.OPT_DIST_INDEX16, int(idx16_env) if idx16_env is not None else 0)
-        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 3)
+        worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 4)
         last = [0, 0]
         tuned = None
 

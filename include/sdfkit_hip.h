@@ -106,7 +106,8 @@ typedef enum sdfk_option {
     SDFK_OPT_CORNER_EVAL = 5,   /* 1 (default): cell corners of a freshly sampled volume are re-evaluated; 0: gathered */
     SDFK_OPT_VCOLOR_EVAL = 6,   /* 1 (default): vertex colours of a freshly sampled volume are re-evaluated; 0: gathered */
     SDFK_OPT_DIST_EXCHANGE = 7, /* sharded step: 0 ncclAllGather, 1 (default) grouped ncclSend/ncclRecv to every peer, 2 gather to rank 0 */
-    SDFK_OPT_DIST_LANES = 8,    /* sharded step: internal streams the steps alternate between: 2 (default) or 0 */
+    SDFK_OPT_DIST_LANES = 8,    /* sharded step: internal streams consecutive steps rotate over: 0..3, default 3 (measured: a step on an
+                                   8-rank slab of 512^3 takes 82 / 46 / 35 us with 1 / 2 / 3; a fourth shares a hardware queue: 98 us) */
     SDFK_OPT_HW_QUEUES = 9,     /* read-only: GPU_MAX_HW_QUEUES as the process had it when the library came up (0 = unset).  The
                                    HIP runtime maps all streams of a process onto that many in-order hardware queues (default 4);
                                    the library's streams want 8 (sdfk_init in sdfkit_hip.hip says why), and the variable only

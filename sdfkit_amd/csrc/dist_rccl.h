@@ -2,8 +2,8 @@
 // the protocol in slab_protocol.h.  Included by sdfkit_hip.hip (it uses the library's context, lanes, allocator and the
 // slab form of the captured step graphs).
 //
-// Streams of a sharded rank: the library's own stream (exact steps, mesh extraction), lanes 1 and 2 (the steps' kernel
-// chains, alternating per step, one captured hipGraphLaunch each) and ONE exchange stream that carries, per step,
+// Streams of a sharded rank: the library's own stream (exact steps, mesh extraction), lanes 1..3 (the steps' kernel
+// chains, rotating per step, one captured hipGraphLaunch each) and ONE exchange stream that carries, per step,
 //   wait(step packed) -> ncclAllGather | grouped ncclSend/ncclRecv -> k_slabs_rebase (+ header mirror) -> record(ready)
 // so the exchange of step i travels while the kernels of step i+1 run, and nothing on the host waits inside a step.
 // RCCL is loaded with dlopen on first use (librccl.so.1; SDFK_RCCL_LIB at start-up names another file): a process that never
@@ -201,7 +201,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
     int lb = 0, le = 0, z0 = 0, nzl = 0;
     int vbytes = 24;
     int exchange_mode = 1;
-    int lanes = 2;
+    int lanes = 3;
     bool idx16 = false;            // SDFK_OPT_DIST_INDEX16: compact payloads (k_payload_compact); falls back when a slab does not fit
     int64_t idx16_fallbacks = 0;
     uint64_t nsub = 0;

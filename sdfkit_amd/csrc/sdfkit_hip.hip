@@ -53,7 +53,7 @@ struct Config {
     int corner_eval = 1;      // SDFK_OPT_CORNER_EVAL
     int vcolor_eval = 1;      // SDFK_OPT_VCOLOR_EVAL
     int dist_exchange = 1;    // SDFK_OPT_DIST_EXCHANGE
-    int dist_lanes = 2;       // SDFK_OPT_DIST_LANES
+    int dist_lanes = 3;       // SDFK_OPT_DIST_LANES
     int dist_index16 = 0;     // SDFK_OPT_DIST_INDEX16
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
     int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
@@ -758,7 +758,7 @@ static void config_from_env()
     g_cfg.corner_eval = geti("SDFK_NO_CORNER_EVAL", 0) ? 0 : 1;
     g_cfg.vcolor_eval = geti("SDFK_NO_VCOLOR_EVAL", 0) ? 0 : 1;
     g_cfg.dist_exchange = geti("SDFK_DIST_EXCHANGE", 1);
-    g_cfg.dist_lanes = geti("SDFK_DIST_LANES", 2);
+    g_cfg.dist_lanes = std::max(0, std::min(geti("SDFK_DIST_LANES", 3), 3));
     g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0);
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
     g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0);
@@ -938,7 +938,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_CORNER_EVAL: if (!in(0, 1)) break; g_cfg.corner_eval = (int)value; return SDFK_OK;
     case SDFK_OPT_VCOLOR_EVAL: if (!in(0, 1)) break; g_cfg.vcolor_eval = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_EXCHANGE: if (!in(0, 2)) break; g_cfg.dist_exchange = (int)value; return SDFK_OK;
-    case SDFK_OPT_DIST_LANES: if (value != 0 && value != 2) break; g_cfg.dist_lanes = (int)value; return SDFK_OK;
+    case SDFK_OPT_DIST_LANES: if (!in(0, 3)) break; g_cfg.dist_lanes = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_INDEX16: if (!in(0, 1)) break; g_cfg.dist_index16 = (int)value; return SDFK_OK;
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
     case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;

@@ -13,7 +13,7 @@ would use its own launcher), and wrap the handles.
     from sdfkit_amd import dist as D
     D.init(group=None)                          # RCCL; D.init_host(group) = exchange through the group itself (gloo)
     mesh = D.sharded_to_mesh(sdf, mn, mx, nx, ny, nz)        # one-off: the whole mesh on every rank
-    ses = D.SlabSession(sdf, mn, mx, nx, ny, nz, depth=3)    # repeated: up to `depth` steps in flight
+    ses = D.SlabSession(sdf, mn, mx, nx, ny, nz, depth=4)    # repeated: up to `depth` steps in flight
 """
 import ctypes as C
 

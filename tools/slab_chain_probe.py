@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU probe: one rank's share of an 8-rank (or N-rank) sharded step -- the slab chain of a 512^3 grid cut N ways -- without any
-exchange: sdfk_slab_enqueue in a loop on two lanes (captured step graphs), and per kernel on one stream.  PROBE_WORLD, PROBE_RANK, PROBE_N."""
+exchange: sdfk_slab_enqueue in a loop on 0..4 lanes (captured step graphs), and per kernel on one stream.  PROBE_WORLD, PROBE_RANK, PROBE_N."""
 import ctypes as C
 import os
 import sys
@@ -18,8 +18,9 @@ rank = int(os.environ.get("PROBE_RANK", "3"))
 sdf = Sdfs.Sphere(1.0)
 mn, mx = N.f3([-1.5] * 3), N.f3([1.5] * 3)
 lb, le, z0, nzl = D.slab(n, world, rank)
+NBUF = 6
 vols, bufs = [], []
-for k in range(3):
+for k in range(NBUF):
     v = C.c_void_p()
     N.check(L.sdfk_volume_create_slab(n, n, n, mn, mx, z0, nzl, 0, C.byref(v)))
     vols.append(v)
@@ -29,23 +30,24 @@ iso = C.c_float(0.0)
 
 
 def step(i, lane):
-    k = i % 3
+    k = i % NBUF
     N.check(L.sdfk_slab_enqueue(prog, vols[k], 0, iso, lb, le, C.c_void_p(bufs[k].data_ptr()), bufs[k].numel(), lane, None))
 
 
-for i in range(12):
-    step(i, 1 + i % 2)
-N.check(L.sdfk_synchronize())
-torch.cuda.synchronize()
-for lanes in (2, 0):
+for lanes in (2, 3, 4, 1, 0):
+    for i in range(4 * NBUF):   # (the captured step graph of every (buffer, lane) pair exists after this)
+        step(i, (1 + i % lanes) if lanes else 0)
+    N.check(L.sdfk_synchronize())
+    torch.cuda.synchronize()
     steps = 300
     t0 = time.perf_counter()
     for i in range(steps):
-        step(i, (1 + i % 2) if lanes else 0)
+        step(i, (1 + i % lanes) if lanes else 0)
+    t1 = time.perf_counter()
     N.check(L.sdfk_synchronize())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"slab {n}x{n}x{nzl} (layers [{lb},{le}) of {world} ranks): {dt / steps * 1e6:.1f} us per step, lanes {lanes}")
+    print(f"slab {n}x{n}x{nzl} (layers [{lb},{le}) of {world} ranks): {dt / steps * 1e6:.1f} us per step (host {(t1 - t0) / steps * 1e6:.1f}), lanes {lanes}")
 N.check(L.sdfk_profile_reset())
 N.check(L.sdfk_profile_enable(1))
 for i in range(50):
