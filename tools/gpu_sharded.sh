@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; export TMPDIR=/tmp
-O=gpurun_out/r03d; mkdir -p $O
+O=gpurun_out/sharded; mkdir -p $O
 timeout 1200 python3 -m pytest tests/test_gpu_multirank.py -x -q 2>&1 | tail -4
 for i16 in 0 1; do for g in 128 512; do
   SDFK_BENCH_INDEX16=$i16 SDFK_BENCH_FORCE_DIST=1 timeout 300 python3 bench.py --steps 200 --warmup 5 --no-cpu --minimal --grid $g > $O/dist1_${g}_$i16.json 2> $O/err.txt

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 3, first contact: full -m gpu suite, default bench, the sharded step behind the C ABI (RCCL world 1; two ranks on one GPU)
+# full -m gpu suite, default bench, the sharded step behind the C ABI (RCCL world 1; two ranks on one GPU)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; export TMPDIR=/tmp
-O=gpurun_out/r03a; mkdir -p $O
+O=gpurun_out/suite; mkdir -p $O
 timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 tail -30 $O/pytest.log
 timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-n 128 > $O/bench.json 2> $O/bench.err; echo "bench rc $?"
@@ -12,7 +12,7 @@ done
 SDFK_BENCH_ONE_GPU=1 timeout 600 python3 bench.py --gpus 2 --no-cpu --minimal > $O/bench_two_ranks_one_gpu.json 2> $O/bench_two.err; echo "two ranks rc $?"
 python3 - <<'PY'
 import json,glob
-for f in sorted(glob.glob("gpurun_out/r03a/bench*.json")):
+for f in sorted(glob.glob("gpurun_out/suite/bench*.json")):
     ls=[l for l in open(f) if l.startswith("{")]
     if not ls: print(f,"NO LINE"); continue
     d=json.loads(ls[-1])

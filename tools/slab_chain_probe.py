@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU probe: one rank's share of an 8-rank (or N-rank) sharded step -- the slab chain of a 512^3 grid cut N ways -- without any
-exchange: sdfk_slab_enqueue in a loop on 0..4 lanes (captured step graphs), and per kernel on one stream.  PROBE_WORLD, PROBE_RANK, PROBE_N."""
+exchange: sdfk_slab_enqueue in a loop on 0..4 lanes (captured step graphs), and per kernel on one stream.  PROBE_WORLD, PROBE_RANK, PROBE_N, PROBE_LANES (lane counts to try, in order)."""
 import ctypes as C
 import os
 import sys
@@ -18,7 +18,7 @@ rank = int(os.environ.get("PROBE_RANK", "3"))
 sdf = Sdfs.Sphere(1.0)
 mn, mx = N.f3([-1.5] * 3), N.f3([1.5] * 3)
 lb, le, z0, nzl = D.slab(n, world, rank)
-NBUF = 6
+NBUF = 12   # (a multiple of every lane count tried: a buffer is always reused on the lane that used it last)
 vols, bufs = [], []
 for k in range(NBUF):
     v = C.c_void_p()
@@ -34,7 +34,7 @@ def step(i, lane):
     N.check(L.sdfk_slab_enqueue(prog, vols[k], 0, iso, lb, le, C.c_void_p(bufs[k].data_ptr()), bufs[k].numel(), lane, None))
 
 
-for lanes in (2, 3, 4, 1, 0):
+for lanes in [int(x) for x in os.environ.get("PROBE_LANES", "2,3,4,1,0").split(",")]:
     for i in range(4 * NBUF):   # (the captured step graph of every (buffer, lane) pair exists after this)
         step(i, (1 + i % lanes) if lanes else 0)
     N.check(L.sdfk_synchronize())
