@@ -358,7 +358,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         return SDFK_OK;
     }
 
-    // the step's kernels: lane section (alternating lanes), ONE captured graph launch from the second use of a (slot, lane) on
+    // the step's kernels: lane section (the lanes in rotation), ONE captured graph launch from the second use of a (slot, lane) on
     int enqueue(int k) override
     {
         Slot& s = slots[k];

@@ -213,7 +213,8 @@ void dev_free(void* p)
 // queue on lane `k` for the lifetime of the scope (allocations included)
 // The stream of lane k, created on first use.  Every stream of a process takes one of the runtime's in-order hardware
 // queues (shared once there are more streams than GPU_MAX_HW_QUEUES), and this GPU serves about eight queues well: a
-// sharded rank uses two lanes, a single-GPU caller three -- the others never exist.  (Tried instead, both far worse for
+// sharded rank uses three lanes, a single-GPU caller three -- the fourth never exists (four are slower than three wherever
+// it was measured: tools/slab_chain_probe.py).  (Tried instead, both far worse for
 // the pipelined sharded step: lanes on a stream priority of their own, 200 us per step where plain streams reach 55;
 // lanes with dedicated queues through hipExtStreamCreateWithCUMask, 110-290 us.)
 hipStream_t lane_stream(int k)
