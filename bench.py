@@ -801,6 +801,7 @@ def main():
             "latency_ms_single_stream": None if latency_ms is None else round(latency_ms, 4),
             "first_call_ms": first_call_ms,
             "first_call": first,
+            "stream_placement": N.stream_placement(),   # classes of lanes 0..4 / the exchange stream as measured at sdfk_init
             "pipeline_algorithmic_gbs": round(model_bytes / step_s / 1e9, 1),
             "pipeline_frac_of_hbm_peak": frac(model_bytes, step_s),
             "pipeline_frac_is": ("contract model: 8 B/voxel (4 stored by sampling + 4 loaded by meshing) + 36 B/vertex + 4 B/index, divided by the step "

@@ -122,7 +122,10 @@ typedef enum sdfk_option {
                                    has to receive from every other rank per step); sdfk_dist_mesh decodes, sdfk_dist_gathered shows the
                                    encoded form.  A slab whose ids do not fit sends the session back to int32 indices (every rank
                                    sees it in the headers).  0 (default): int32 indices, rebased in place by the step */
-    SDFK_OPT_COUNT_ = 13
+    SDFK_OPT_STREAM_PLACEMENT = 13, /* at sdfk_init (set it before): 1 (default) = the library measures which of its streams run side by side
+                                   on this process's hardware queues / pipes and puts its lanes and the exchange stream where they do not
+                                   get in each other's -- or the caller's stream's -- way (about 10 ms); 0 = streams as they come */
+    SDFK_OPT_COUNT_ = 14
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);
 int sdfk_get_option(int32_t key, int64_t* value);
@@ -371,6 +374,10 @@ int sdfk_host_prefault(void* p, int64_t n_bytes);
 /* Phases of the last staged device -> pageable-host copy (measurement): stats[5] = { bytes, ns until every chunk was queued,
  * ns until the destination pages were present, ns until done, ns of that spent waiting for the DMA }. */
 int sdfk_copy_stats(int64_t stats[5]);
+/* What the stream placement found (diagnostics): out[0] = 1 if measured, out[1] = classes found (streams of one class must not be
+ * busy together: same hardware queue or same pipe), out[2] = class of lane 0 (the caller's stream), out[3..6] = classes of lanes
+ * 1..4 (-1: no placed stream), out[7] = class of the exchange stream of a sharded rank (-1: none kept). */
+int sdfk_stream_placement(int32_t out[8]);
 
 /* ---- Mesh (Mesh.cs:8-64) ----------------------------------------------------
  * Vertices/Colors/Normals: 3 floats each per vertex; Triangles: int32 indices

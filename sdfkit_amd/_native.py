@@ -75,6 +75,7 @@ SIGNATURES = {
     "sdfk_host_free": (None, [_vp]),
     "sdfk_host_prefault": (C.c_int, [_vp, _i64]),
     "sdfk_copy_stats": (C.c_int, [C.POINTER(_i64)]),
+    "sdfk_stream_placement": (C.c_int, [C.POINTER(_i32)]),
     "sdfk_mesh_size_hint": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "sdfk_mesh_counts": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_mesh_bounds": (C.c_int, [_vp, _fp, _fp]),
@@ -120,7 +121,7 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 
 # enum sdfk_option
 OPT_LANES, OPT_TOKENS, OPT_GRAPHS, OPT_COPY_MODE, OPT_CORNER_EVAL, OPT_VCOLOR_EVAL = 1, 2, 3, 4, 5, 6
-OPT_DIST_EXCHANGE, OPT_DIST_LANES, OPT_HW_QUEUES, OPT_CODE_CACHE, OPT_PREFAULT_HUGE, OPT_DIST_INDEX16 = 7, 8, 9, 10, 11, 12
+OPT_DIST_EXCHANGE, OPT_DIST_LANES, OPT_HW_QUEUES, OPT_CODE_CACHE, OPT_PREFAULT_HUGE, OPT_DIST_INDEX16, OPT_STREAM_PLACEMENT = 7, 8, 9, 10, 11, 12, 13
 
 
 def library_path():
@@ -225,6 +226,13 @@ def pinned_empty(shape, dtype):
     if n == 0 or os.environ.get("SDFK_PINNED_ARRAYS") == "0":
         return np.empty(shape, dt)
     return np.asarray(_PinnedBlock(n)).view(dt).reshape(shape)
+
+
+def stream_placement():
+    """sdfk_stream_placement: {'measured', 'classes', 'lanes': [class of lane 0..4], 'exchange'} (-1: no placed stream)."""
+    a = (C.c_int32 * 8)()
+    check(lib().sdfk_stream_placement(a))
+    return {"measured": bool(a[0]), "classes": int(a[1]), "lanes": [int(a[2 + k]) for k in range(5)], "exchange": int(a[7])}
 
 
 def set_option(key, value):

@@ -37,6 +37,7 @@ struct DistContext {
     RcclApi nccl;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;        // the exchange stream
+    bool stream_owned = false;           // (created here, not one of the placed streams of sdfkit_hip.hip)
     sdfk_allgather_fn host_fn = nullptr;
     void* host_ctx = nullptr;
     int64_t* agree_dev = nullptr;        // [1 + world]
@@ -86,7 +87,11 @@ int dist_common_init(int world, int rank)
     if (int r = require_init()) return r;
     if (gd.backend) return fail(SDFK_ERR_INVALID, "sdfk_dist_init: already initialised (world %d, rank %d)", gd.world, gd.rank);
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(SDFK_ERR_INVALID, "sdfk_dist_init: bad world %d / rank %d", world, rank);
-    hipError_t e = hipStreamCreateWithFlags(&gd.stream, hipStreamNonBlocking);
+    // the exchange stream: the one the stream placement keeps for it (lane 0's class: never busy beside a lane's queue or pipe)
+    hipError_t e = hipSuccess;
+    gd.stream = placed_exchange_stream();
+    gd.stream_owned = gd.stream == nullptr;
+    if (!gd.stream) e = hipStreamCreateWithFlags(&gd.stream, hipStreamNonBlocking);
     int r = e == hipSuccess ? dev_alloc((void**)&gd.agree_dev, sizeof(int64_t) * (1 + world)) : fail(SDFK_ERR_HIP, "exchange stream: %s", hipGetErrorString(e));
     if (!r && hipHostMalloc((void**)&gd.agree_host, sizeof(int64_t) * (1 + world), hipHostMallocDefault) != hipSuccess)
         r = fail(SDFK_ERR_NOMEM, "sdfk_dist_init: pinned memory for the stride agreement");
@@ -107,7 +112,7 @@ void dist_release()
 {
     if (gd.comm && gd.nccl.CommDestroy) (void)gd.nccl.CommDestroy(gd.comm);
     gd.comm = nullptr;
-    if (gd.stream) { (void)hipStreamSynchronize(gd.stream); (void)hipStreamDestroy(gd.stream); }
+    if (gd.stream) { (void)hipStreamSynchronize(gd.stream); if (gd.stream_owned) (void)hipStreamDestroy(gd.stream); }
     gd.stream = nullptr;
     dev_free(gd.agree_dev);
     gd.agree_dev = nullptr;

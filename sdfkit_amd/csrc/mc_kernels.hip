@@ -1090,6 +1090,16 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     }
 }
 
+// A kernel that does nothing for `ticks` of the 100 MHz wall clock: the probe of the stream-placement measurement
+// (sdfkit_hip.hip, "stream placement").
+__global__ __launch_bounds__(64) void k_spin(int ticks, int* sink)
+{
+    const long long t0 = wall_clock64();
+    int n = 0;
+    while (wall_clock64() - t0 < ticks) n++;
+    if (sink && n < 0) *sink = n;
+}
+
 // Mesh.Measure (Mesh.cs:30-45): reduce the per-workgroup AABB partials of K4.  Run by one
 // workgroup of K5 (K4 is complete by then), so it costs no launch of its own.
 __device__ __forceinline__ void reduce_bounds(const McMeshOut& M, float* s_bounds /*[6], LDS*/)

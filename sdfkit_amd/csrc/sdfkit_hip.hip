@@ -57,6 +57,7 @@ struct Config {
     int dist_index16 = 0;     // SDFK_OPT_DIST_INDEX16
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
     int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
+    int place_streams = 1;    // SDFK_OPT_STREAM_PLACEMENT
     int copy_threads = 0;     // SDFK_COPY_THREADS (0: min(16, cores / 2)); fixed once the pool has started
     int sample_mode = -1;     // SDFK_SAMPLE_MODE (debugging: force the row-tiled (0) / plane-chunk (1) sampler)
     int hw_queues = 0;        // GPU_MAX_HW_QUEUES as the process had it when the library initialised (0: unset)
@@ -109,6 +110,14 @@ struct Context {
     static constexpr int NSIDE = 4;
     struct Lane { hipStream_t stream = nullptr; std::multimap<size_t, void*> free_blocks; };
     Lane lanes[1 + NSIDE];
+    // stream placement (place_streams): the streams the library made for its lanes and the exchange, the class -- set of
+    // streams that must not be busy together -- each was measured to be in, and who uses which
+    struct Placed { hipStream_t s; int cls; int user; };   // user: 0 none, 1..NSIDE lane, 100 exchange
+    std::vector<Placed> pool;
+    std::map<hipStream_t, int> foreign_cls;   // classes of caller streams seen by sdfk_set_stream
+    int cls_lane0 = -1, n_classes = 0;
+    bool placed = false;
+    int* spin_sink = nullptr;
     hipEvent_t lane_done[1 + NSIDE] = {};   // reused by sdfk_lane_end
     int cur_lane = 0;
     int side_lanes = 2;         // SDFK_LANES=0 disables the side lanes (everything on lane 0)
@@ -263,6 +272,131 @@ void sync_all_lanes()
 {
     for (auto& lane : g.lanes)
         if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+}
+
+// ---------------------------------------------------------------------------
+// stream placement
+// ---------------------------------------------------------------------------
+// Which streams are busy TOGETHER decides everything about overlap on this part (tools/ubench/ub_lanes2.hip: chains of 9 small
+// dependent kernels, one captured graph launch each, dealt round-robin over a subset of 8 streams created in order, with
+// GPU_MAX_HW_QUEUES = 8): streams 0,1,2,3 -> 16 us per chain (one stream: 61), but streams 0 and 4 ALONE -> 191 us, three
+// times slower than one stream: the runtime gives the i-th stream the i-th hardware queue, the queues are dealt over FOUR
+// pipes, and a pipe that has two queues with work switches between them at ~15 us a switch.  (And with the runtime's default
+// of 4 queues streams 0 and 4 share a QUEUE: in order, the one behind an event wait holds up the other.)  Which queue a stream
+// gets depends on how many streams the process -- torch, the host, RCCL -- created before: one more stream in the process
+// used to double the time of a sharded step.  So the library does not guess: it creates up to 7 streams when it initialises,
+// MEASURES for each whether it runs side by side with the ones it keeps (two interleaved chains of 8-us kernels against the
+// same kernels on one stream: side by side 0.5 x, same queue 1 x, same pipe 3 x) and sorts them into classes.  Lanes 1-3
+// get one stream each from three classes other than lane 0's (the caller's stream may be busy too); the exchange stream of a
+// sharded rank and lane 4 come from lane 0's class (a sharded rank's own stream is idle during steps; four lanes are for
+// callers whose own stream is).  ~10 ms at sdfk_init; SDFK_OPT_STREAM_PLACEMENT = 0: streams as they come (round 2's behaviour).
+double chains_us(hipStream_t a, hipStream_t b)
+{
+    double best = 1e30;
+    for (int rep = 0; rep < 2; rep++) {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 6; i++) {
+            hipLaunchKernelGGL(k_spin, dim3(32), dim3(64), 0, a, 800, g.spin_sink);
+            hipLaunchKernelGGL(k_spin, dim3(32), dim3(64), 0, b, 800, g.spin_sink);
+        }
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    (void)hipGetLastError();
+    return best;
+}
+
+// class of stream `s` among the classes whose representatives are `reps` (-1: side by side with all of them)
+int stream_class(hipStream_t s, const std::vector<hipStream_t>& reps, double serial_us)
+{
+    for (size_t c = 0; c < reps.size(); c++)
+        if (reps[c] == s || chains_us(s, reps[c]) > 0.75 * serial_us) return (int)c;
+    return -1;
+}
+
+void assign_placed_streams()
+{
+    for (auto& q : g.pool) q.user = 0;
+    auto take = [&](int user, auto&& ok) -> hipStream_t {
+        for (auto& q : g.pool)
+            if (!q.user && ok(q)) { q.user = user; return q.s; }
+        return nullptr;
+    };
+    bool used[16] = {};
+    if (g.cls_lane0 >= 0 && g.cls_lane0 < 16) used[g.cls_lane0] = true;
+    for (int k = 1; k <= 3 && k <= Context::NSIDE; k++) {
+        hipStream_t st = take(k, [&](const Context::Placed& q) { return q.cls >= 0 && q.cls < 16 && !used[q.cls]; });
+        if (!st) st = take(k, [&](const Context::Placed& q) { return q.cls != g.cls_lane0; });   // (fewer than four classes)
+        if (!st) st = take(k, [&](const Context::Placed&) { return true; });
+        if (st)
+            for (auto& q : g.pool)
+                if (q.s == st && q.cls >= 0 && q.cls < 16) used[q.cls] = true;
+        g.lanes[k].stream = st;   // (null: lane_stream() creates one on first use)
+    }
+    // lane 0's class: the exchange stream first (a sharded rank), then lane 4
+    (void)take(100, [&](const Context::Placed& q) { return q.cls == g.cls_lane0; });
+    if (Context::NSIDE >= 4) g.lanes[4].stream = take(4, [&](const Context::Placed& q) { return q.cls == g.cls_lane0; });
+}
+
+void place_streams()
+{
+    if (!g_cfg.place_streams || g.placed) return;
+    g.placed = true;
+    if (!g.spin_sink && hipMalloc((void**)&g.spin_sink, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); g.spin_sink = nullptr; }
+    hipStream_t s0 = g.lanes[0].stream;
+    (void)chains_us(s0, s0);   // (first launches of the probe: code object load, queue creation)
+    const double serial = chains_us(s0, s0);
+    std::vector<hipStream_t> reps{s0};
+    g.cls_lane0 = 0;
+    g.pool.clear();
+    int have_other = 0, have_same = 0;
+    for (int n = 0; n < 7 && !(have_other >= 3 && have_same >= 2); n++) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        (void)chains_us(st, st);   // (its queue exists from here on)
+        int c = stream_class(st, reps, serial);
+        if (c < 0) { reps.push_back(st); c = (int)reps.size() - 1; have_other++; }
+        else if (c == 0) have_same++;
+        g.pool.push_back(Context::Placed{st, c, 0});
+    }
+    g.n_classes = (int)reps.size();
+    assign_placed_streams();
+}
+
+// the caller's stream became lane 0: its class among the pool's classes decides anew who runs where
+void replace_lane0(hipStream_t s0)
+{
+    if (!g_cfg.place_streams || !g.placed || g.pool.empty()) return;
+    int c = -2;
+    if (s0 == g.own_stream) c = 0;
+    else {
+        auto it = g.foreign_cls.find(s0);
+        if (it != g.foreign_cls.end()) c = it->second;
+    }
+    if (c == -2) {
+        std::vector<hipStream_t> reps((size_t)g.n_classes, nullptr);
+        reps[0] = g.own_stream;
+        for (const auto& q : g.pool)
+            if (q.cls > 0 && q.cls < g.n_classes && !reps[q.cls]) reps[q.cls] = q.s;
+        for (auto& r : reps) if (!r) r = g.own_stream;
+        const double serial = chains_us(g.own_stream, g.own_stream);
+        c = stream_class(s0, reps, serial);   // (-1: a class of its own -- every pool stream runs beside it)
+        if (g.foreign_cls.size() < 64) g.foreign_cls[s0] = c;
+    }
+    if (c == g.cls_lane0) return;
+    sync_all_lanes();
+    g.cls_lane0 = c;
+    assign_placed_streams();
+}
+
+hipStream_t placed_exchange_stream()
+{
+    for (const auto& q : g.pool)
+        if (q.user == 100) return q.s;
+    return nullptr;
 }
 
 int prof_name_id(const char* name)
@@ -763,6 +897,7 @@ static void config_from_env()
     g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0);
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
     g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0);
+    g_cfg.place_streams = geti("SDFK_STREAM_PLACEMENT", 1) ? 1 : 0;
     g_cfg.sample_mode = geti("SDFK_SAMPLE_MODE", -1);
     g_cfg.hw_queues = geti("GPU_MAX_HW_QUEUES", 0);
     g_cfg.env_cache_dir = gets("SDFK_CACHE_DIR");
@@ -783,8 +918,8 @@ extern "C" int sdfk_init(int device)
     config_from_env();
     // The library's lanes, the caller's stream and the exchange stream must not share hardware queues: the HIP runtime maps
     // all streams of a process onto GPU_MAX_HW_QUEUES (default 4) in-order queues, and a stream that waits for an event (a
-    // lane section's end, a collective) then holds up every OTHER stream behind it in the same queue -- the pipelined
-    // sharded step ran fully serialised that way (108 -> 55 us per step on a small slab with 8 queues; 16 queues: 170 us).
+    // lane section's end, a collective) then holds up every OTHER stream behind it in the same queue.  Nor may two of them
+    // that are busy together sit on queues of the same PIPE ("stream placement" above measures both).
     // The runtime reads the variable when IT initialises, which may be long before this call (torch, the C# host), and a
     // library must not edit its process's environment under the feet of other threads: the HOST BINDINGS export
     // GPU_MAX_HW_QUEUES=8 before their first HIP call (sdfkit_amd/_native.py, shim/SdfKit.Hip/Native.cs, include/SdfKit.hpp);
@@ -801,10 +936,9 @@ extern "C" int sdfk_init(int device)
     HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
     g.user_stream = g.stream = g.own_stream;
     g.lanes[0].stream = g.own_stream;
-    // The three lanes sdfk_sample_march rotates over get their streams NOW, right after the library's own stream: streams
-    // created first get hardware queues of their own (1 % per step against creating them on first use, 15 % when the
-    // process runs with the runtime's default of 4 queues); the fourth lane's stream is created when somebody asks for that
-    // lane (lane_stream()) -- a sharded rank then holds eight streams with torch's two and RCCL's, one per queue.
+    // The lanes sdfk_sample_march rotates over get their streams NOW, placed by measurement (or, with the placement off,
+    // simply created right after the library's own stream; a fourth lane's stream is then created when somebody asks for it).
+    place_streams();   // (measured: "stream placement" above)
     for (int k = 1; k <= 3 && k <= Context::NSIDE; k++) (void)lane_stream(k);
     g.cur_lane = 0;
     HIPCHK(hipHostMalloc((void**)&g.slots, sizeof(Context::HostSlot) * Context::NSLOTS, hipHostMallocMapped));
@@ -842,9 +976,19 @@ extern "C" void sdfk_shutdown(void)
     for (int k = 1; k <= Context::NSIDE; k++) {
         if (g.lane_done[k]) (void)hipEventDestroy(g.lane_done[k]);
         g.lane_done[k] = nullptr;
-        if (g.lanes[k].stream) (void)hipStreamDestroy(g.lanes[k].stream);
+        bool pooled = false;
+        for (const auto& q : g.pool) pooled = pooled || q.s == g.lanes[k].stream;
+        if (g.lanes[k].stream && !pooled) (void)hipStreamDestroy(g.lanes[k].stream);
         g.lanes[k].stream = nullptr;
     }
+    for (auto& q : g.pool) (void)hipStreamDestroy(q.s);
+    g.pool.clear();
+    g.foreign_cls.clear();
+    g.placed = false;
+    g.cls_lane0 = -1;
+    g.n_classes = 0;
+    if (g.spin_sink) (void)hipFree(g.spin_sink);
+    g.spin_sink = nullptr;
     g.cur_lane = 0;
     g.lanes[0].stream = nullptr;
     for (auto& st : g.slot_state) {
@@ -874,6 +1018,7 @@ extern "C" int sdfk_set_stream(void* hip_stream)
     HIPCHK(hipStreamSynchronize(g.stream));
     g.user_stream = hip_stream ? (hipStream_t)hip_stream : g.own_stream;
     g.lanes[0].stream = g.user_stream;
+    replace_lane0(g.user_stream);   // (the lanes keep clear of the queue / pipe the caller's stream sits on)
     g.stream = g.lanes[g.cur_lane].stream;
     return SDFK_OK;
 }
@@ -941,6 +1086,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_DIST_EXCHANGE: if (!in(0, 2)) break; g_cfg.dist_exchange = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_LANES: if (!in(0, 3)) break; g_cfg.dist_lanes = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_INDEX16: if (!in(0, 1)) break; g_cfg.dist_index16 = (int)value; return SDFK_OK;
+    case SDFK_OPT_STREAM_PLACEMENT: if (!in(0, 1)) break; g_cfg.place_streams = (int)value; return SDFK_OK;
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
     case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;
     case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
@@ -964,6 +1110,7 @@ extern "C" int sdfk_get_option(int32_t key, int64_t* value)
     case SDFK_OPT_DIST_EXCHANGE: *value = g_cfg.dist_exchange; break;
     case SDFK_OPT_DIST_LANES: *value = g_cfg.dist_lanes; break;
     case SDFK_OPT_DIST_INDEX16: *value = g_cfg.dist_index16; break;
+    case SDFK_OPT_STREAM_PLACEMENT: *value = g_cfg.place_streams; break;
     case SDFK_OPT_CODE_CACHE: *value = g_cfg.code_cache; break;
     case SDFK_OPT_PREFAULT_HUGE: *value = g_cfg.prefault_huge; break;
     case SDFK_OPT_HW_QUEUES: *value = g_cfg.hw_queues; break;
@@ -2806,6 +2953,25 @@ extern "C" void sdfk_host_free(void* p)
 // the GPU is still computing the mesh (sdfk_mesh_size_hint tells how large the arrays will be).
 // Phases of the last staged device -> pageable-host copy (SDFK_OPT_COPY_MODE 1): stats[5] = { bytes, ns until every chunk was
 // queued, ns until the destination pages were present, ns until done, ns of that spent waiting for the DMA } (measurement).
+extern "C" int sdfk_stream_placement(int32_t out[8])
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!out) return fail(SDFK_ERR_INVALID, "sdfk_stream_placement: null argument");
+    if (int r = require_init()) return r;
+    out[0] = g.placed && !g.pool.empty() ? 1 : 0;
+    out[1] = g.n_classes;
+    out[2] = g.cls_lane0;
+    for (int k = 1; k <= 4; k++) {
+        out[2 + k] = -1;
+        for (const auto& q : g.pool)
+            if (k <= Context::NSIDE && q.s == g.lanes[k].stream) out[2 + k] = q.cls;
+    }
+    out[7] = -1;
+    for (const auto& q : g.pool)
+        if (q.user == 100) out[7] = q.cls;
+    return SDFK_OK;
+}
+
 extern "C" int sdfk_copy_stats(int64_t stats[5])
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);

@@ -282,3 +282,18 @@ def test_held_mesh_survives_many_other_jobs(gpu):
             vol.ClipToBounds()
             assert_mesh_equal(MarchingCubes.CreateMesh(vol), oo)
     assert_mesh_equal(Mesh._from_handle(held), om)
+
+
+def test_stream_placement_keeps_the_lanes_apart(gpu):
+    """sdfk_init measured which of its streams run side by side (csrc/sdfkit_hip.hip, "stream placement"): lanes 1-3 sit in three
+    different classes, none of them lane 0's; the stream kept for a sharded rank's exchange is in lane 0's class."""
+    from sdfkit_amd import _native as N
+    p = N.stream_placement()
+    if not N.get_option(N.OPT_STREAM_PLACEMENT):
+        assert not p["measured"]
+        return
+    assert p["measured"] and 2 <= p["classes"] <= 8, p
+    lanes = p["lanes"]
+    if p["classes"] >= 4:
+        assert len({lanes[0], lanes[1], lanes[2], lanes[3]}) == 4 and -1 not in lanes[1:4], p
+        assert p["exchange"] in (-1, lanes[0]), p
