@@ -336,9 +336,10 @@ void assign_placed_streams()
                 if (q.s == st && q.cls >= 0 && q.cls < 16) used[q.cls] = true;
         g.lanes[k].stream = st;   // (null: lane_stream() creates one on first use)
     }
-    // lane 0's class: the exchange stream first (a sharded rank), then lane 4
-    (void)take(100, [&](const Context::Placed& q) { return q.cls == g.cls_lane0; });
-    if (Context::NSIDE >= 4) g.lanes[4].stream = take(4, [&](const Context::Placed& q) { return q.cls == g.cls_lane0; });
+    // lane 0's class (or, failing that, a class no lane uses): the exchange stream first (a sharded rank), then lane 4
+    auto beside_the_lanes = [&](const Context::Placed& q) { return q.cls == g.cls_lane0 || (q.cls >= 0 && q.cls < 16 && !used[q.cls]); };
+    (void)take(100, beside_the_lanes);
+    if (Context::NSIDE >= 4) g.lanes[4].stream = take(4, beside_the_lanes);
 }
 
 void place_streams()

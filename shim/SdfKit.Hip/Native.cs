@@ -60,6 +60,7 @@ namespace SdfKit.Hip
         [DllImport(Lib)] public static extern int sdfk_set_option(int key, long value);
         [DllImport(Lib)] public static extern int sdfk_get_option(int key, out long value);
         [DllImport(Lib)] public static extern int sdfk_set_cache_dir([MarshalAs(UnmanagedType.LPStr)] string path);
+        [DllImport(Lib)] public static extern int sdfk_stream_placement(int* out8);   // diagnostics: which streams run side by side
         // Z-slab sharding over the GPUs of one node, one process per GPU (SdfEx.ToMesh, Sdf.cs:59-63): Dist.cs
         [DllImport(Lib)] public static extern int sdfk_dist_unique_id(byte* id128);
         [DllImport(Lib)] public static extern int sdfk_dist_init(int world, int rank, byte* id128);
