@@ -66,7 +66,8 @@ def test_graphs_off_on_same_bits(gpu):
         for k, mode in enumerate((0, 1, 0, 2)):
             N.set_option(N.OPT_GRAPHS, mode)
             _, l0, _ = stats()
-            res[k] = [Mesh._from_handle(raw(sdf, MN, MX, dims, False)) for _ in range(8)]
+            # (a job is captured at the second sighting of its key on a lane and replayed from the third: three rounds of the lanes)
+            res[k] = [Mesh._from_handle(raw(sdf, MN, MX, dims, False)) for _ in range(3 * max(N.get_option(N.OPT_LANES), 1) + 2)]
             _, l1, _ = stats()
             assert (l1 > l0) == (mode != 0 and lanes_on)
     finally:

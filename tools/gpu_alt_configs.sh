@@ -1,0 +1,18 @@
+#!/bin/bash
+# the -m gpu suite under alternate start-up configurations (each one a path the default run does not take)
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"; export TMPDIR=/tmp
+O=gpurun_out/alt; mkdir -p $O
+run() {
+  tag=$1; shift
+  env "$@" timeout 1500 python3 -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/$tag.log 2>&1
+  echo "$tag ($*): rc $? -- $(tail -1 $O/$tag.log)"
+}
+run placement_off SDFK_STREAM_PLACEMENT=0
+run lanes4 SDFK_LANES=4
+run lanes0 SDFK_LANES=0
+run hwq4 GPU_MAX_HW_QUEUES=4
+run graphs_off SDFK_GRAPHS=0
+run dist_conservative SDFK_DIST_LANES=0 SDFK_DIST_EXCHANGE=0
+run dist_index16 SDFK_DIST_INDEX16=1 SDFK_DIST_EXCHANGE=2
+run gather_paths SDFK_NO_CORNER_EVAL=1 SDFK_NO_VCOLOR_EVAL=1
