@@ -125,7 +125,10 @@ typedef enum sdfk_option {
     SDFK_OPT_STREAM_PLACEMENT = 13, /* at sdfk_init (set it before): 1 (default) = the library measures which of its streams run side by side
                                    on this process's hardware queues / pipes and puts its lanes and the exchange stream where they do not
                                    get in each other's -- or the caller's stream's -- way (about 10 ms); 0 = streams as they come */
-    SDFK_OPT_COUNT_ = 14
+    SDFK_OPT_IDLE_LANE = 14,    /* 1 (default): sdfk_sample_march jobs on launch-bound grids (the captured-graph ones) rotate over a FOURTH
+                                   internal stream while the caller's stream has nothing queued (hipStreamQuery at the call): that stream
+                                   shares the caller's stream's hardware pipe, so it is only used when the caller is not; 0 = never */
+    SDFK_OPT_COUNT_ = 15
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);
 int sdfk_get_option(int32_t key, int64_t* value);
