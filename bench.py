@@ -48,22 +48,57 @@ WORKLOADS = {
 }
 
 
-def _run_ranks(cmd, env, limit_s):
-    """Runs the launcher command in a process group of its own; (exit code, stdout).  On a timeout the whole group is
-    killed (the ranks, not only torch.distributed.run) and the exit code is 124."""
+def _run_ranks(cmd, env, limit_s, graceful=False):
+    """Runs a child command in a process group of its own; (exit code, stdout).  On a timeout the whole group is killed and the
+    exit code is 124.  graceful: SIGTERM to the child first (torch.distributed.run then stops ITS children, the rank
+    supervisors, which stop their workers), SIGKILL to the group a little later.  Nobody is left behind: the child dies with
+    this process (PR_SET_PDEATHSIG), a SIGTERM to this process is passed down first, and a process whose own parent has
+    disappeared (a supervisor whose launcher was killed) takes its child down and leaves."""
     import signal
     import subprocess
-    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        out, _ = p.communicate(timeout=limit_s)
-        return p.returncode, out
-    except subprocess.TimeoutExpired:
+    import time
+
+    def die_with_parent():   # (in the child, before exec)
+        try:
+            C.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)   # PR_SET_PDEATHSIG
+        except OSError:
+            pass
+
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True, preexec_fn=die_with_parent)
+
+    def kill_group():
+        if graceful and p.poll() is None:
+            p.terminate()
+            t0 = time.time()
+            while p.poll() is None and time.time() - t0 < 10:
+                time.sleep(0.1)
         try:
             os.killpg(p.pid, signal.SIGKILL)     # (the exact group this function started)
         except ProcessLookupError:
             pass
-        out, _ = p.communicate()
-        return 124, out or ""
+
+    def on_term(signum, frame):   # the launcher is taking this process down: the child's whole group goes first
+        kill_group()
+        raise SystemExit(128 + signum)
+
+    old_term = signal.signal(signal.SIGTERM, on_term)
+    parent = os.getppid()
+    t_end = time.time() + limit_s
+    try:
+        while True:
+            try:
+                out, _ = p.communicate(timeout=1.0)
+                return p.returncode, out
+            except subprocess.TimeoutExpired:
+                if os.getppid() != parent:   # orphaned: whoever started this process is gone
+                    kill_group()
+                    raise SystemExit(1)
+                if time.time() >= t_end:
+                    kill_group()
+                    out, _ = p.communicate()
+                    return 124, out or ""
+    finally:
+        signal.signal(signal.SIGTERM, old_term)
 
 
 # What a multi-rank run falls back to when the pipelined form fails (or hangs) on a node: first RCCL's own all-gather instead of
@@ -150,7 +185,7 @@ def launch_ranks(argv, n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     limit = len(RANK_TRIES) * (attempt_limit_s() + 30) + 240
-    rc, out = _run_ranks(cmd, env, limit)
+    rc, out = _run_ranks(cmd, env, limit, graceful=True)
     if rc == 124:
         print(f"bench.py: the ranks did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
     lines = [l for l in out.splitlines() if l.startswith("{")]

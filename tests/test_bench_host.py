@@ -29,7 +29,7 @@ def test_launcher_spawns_torchrun_as_a_child(monkeypatch):
     whose JSON line is relayed (the retries are the ranks' own business: supervise_rank)."""
     calls = []
 
-    def fake_run(cmd, env, limit_s):
+    def fake_run(cmd, env, limit_s, graceful=False):
         calls.append((cmd, env, limit_s))
         return 0, '{"metric": "x", "n_gpus": 4}\n'
 
@@ -86,3 +86,45 @@ def test_plain_python_with_gpus_gt_1_launches_before_touching_torch():
     assert p.returncode != 0                      # no GPU here: the ranks refuse to run
     assert "bench.py needs an MI355X" in p.stderr and "retry" in p.stderr   # (every configuration of the ladder was tried)
     assert "launch with torch.distributed.run" not in p.stderr
+
+
+def test_killing_the_launcher_takes_the_workers_down():
+    """SIGTERM to `python bench.py --gpus 2` while its workers hang: the launcher kills torch.distributed.run's process group,
+    the supervisors die with it, and every worker -- a session of its own -- dies with its supervisor (PR_SET_PDEATHSIG):
+    nothing is left behind on the GPU."""
+    import signal
+    import time
+    import psutil
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SDFK_BENCH_NOTE", "SDFK_BENCH_WORKER"):
+        env.pop(k, None)
+    env.update({"SDFK_BENCH_WORKER_SCRIPT": os.path.join(ROOT, "tests", "bench_worker_stub.py"), "STUB_FIRST_ATTEMPT": "hang",
+                "SDFK_BENCH_RANKS_TIMEOUT_S": "600"})
+    marker = "7919"
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", marker, "--warmup", "0", "--no-cpu", "--grid", "32"],
+                         env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def workers():
+        found = []
+        for q in psutil.process_iter(["cmdline"]):
+            c = q.info["cmdline"] or []
+            if any("bench_worker_stub.py" in a for a in c) and marker in c:
+                found.append(q.pid)
+        return found
+
+    try:
+        t0 = time.time()
+        while len(workers()) < 2 and time.time() - t0 < 180:
+            time.sleep(0.5)
+        assert len(workers()) == 2, "the stub workers never came up"
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=60)
+        t0 = time.time()
+        while workers() and time.time() - t0 < 30:
+            time.sleep(0.5)
+        assert workers() == []
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for pid in workers():
+            os.kill(pid, signal.SIGKILL)     # (exact pids found above)
