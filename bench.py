@@ -342,6 +342,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # (the container's hostname may not resolve)
+            # RCCL's bootstrap (the rendezvous behind ncclCommInitRank) picks a network interface by itself; all ranks of this
+            # bench are on ONE node, where the loopback always works -- whatever else the box has or lacks (the data goes over xGMI)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         import datetime
         # (a short collective timeout: a rank that died must fail the run -- and let the launcher retry -- instead of hanging it)
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
