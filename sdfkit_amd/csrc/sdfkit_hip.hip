@@ -369,6 +369,7 @@ void place_streams()
 }
 
 // the caller's stream became lane 0: its class among the pool's classes decides anew who runs where
+bool dist_active();   // (dist_rccl.h)
 void replace_lane0(hipStream_t s0)
 {
     if (!g_cfg.place_streams || !g.placed || g.pool.empty()) return;
@@ -388,7 +389,7 @@ void replace_lane0(hipStream_t s0)
         c = stream_class(s0, reps, serial);   // (-1: a class of its own -- every pool stream runs beside it)
         if (g.foreign_cls.size() < 64) g.foreign_cls[s0] = c;
     }
-    if (c == g.cls_lane0) return;
+    if (c == g.cls_lane0 || dist_active()) return;   // (a sharded rank keeps its layout: its exchange stream is in use)
     sync_all_lanes();
     g.cls_lane0 = c;
     assign_placed_streams();
