@@ -58,7 +58,7 @@ namespace SdfKit.Hip
         {
             IntPtr h;
             readonly bool writesColor;
-            public Session(GpuProgram program, Vector3 min, Vector3 max, int nx, int ny, int nz, bool clipToBounds = true, float isoValue = 0, int depth = 3)
+            public Session(GpuProgram program, Vector3 min, Vector3 max, int nx, int ny, int nz, bool clipToBounds = true, float isoValue = 0, int depth = 4)
             {
                 float* mn = stackalloc float[3] { min.X, min.Y, min.Z };
                 float* mx = stackalloc float[3] { max.X, max.Y, max.Z };
