@@ -61,7 +61,7 @@ def lib():
             f = getattr(L, "orc_mesh_" + name)
             f.argtypes = [C.c_void_p]
             f.restype = C.c_int64
-        for name in ("vertices", "colors", "normals", "grid_vertices", "triangles", "cells"):
+        for name in ("vertices", "colors", "normals", "grid_vertices", "grid_normals", "triangles", "cells"):
             f = getattr(L, "orc_mesh_" + name)
             f.argtypes = [C.c_void_p]
             f.restype = C.c_void_p
@@ -191,6 +191,7 @@ class OracleMesh:
         self.colors = arr(L.orc_mesh_colors(h), nv * 3, np.float32).reshape(-1, 3)
         self.normals = arr(L.orc_mesh_normals(h), nv * 3, np.float32).reshape(-1, 3)
         self.grid_vertices = arr(L.orc_mesh_grid_vertices(h), nv * 3, np.float32).reshape(-1, 3)
+        self.grid_normals = arr(L.orc_mesh_grid_normals(h), nv * 3, np.float32).reshape(-1, 3)   # NegativeNormals before Transform
         self.triangles = arr(L.orc_mesh_triangles(h), ni, np.int32)
         self.cells = arr(L.orc_mesh_cells(h), nc * 4, np.int32).reshape(-1, 4)
         self.impossible13 = int(L.orc_mesh_impossible13(h))

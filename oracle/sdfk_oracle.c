@@ -358,7 +358,7 @@ static void ipush(ibuf* b, int32_t v)
 }
 
 struct orc_mesh {
-    fbuf grid_verts, verts, cols, norms;
+    fbuf grid_verts, grid_norms, verts, cols, norms;
     ibuf tris, cells;
     float bmin[3], bmax[3];
     int64_t impossible13;
@@ -761,6 +761,7 @@ static orc_mesh* march_impl(const float* values, const float* colors, int nx, in
         float* n = m->norms.p + i * 3;
         float len = v3_length(n[0], n[1], n[2]);
         float q[3] = {-(n[0] / len), -(n[1] / len), -(n[2] / len)};
+        fpush3(&m->grid_norms, q[0], q[1], q[2]);   /* Cell.NegativeNormals as the Mesh constructor receives them */
         float t[3] = {q[0] * in[0], q[1] * in[1], q[2] * in[2]};
         float tl = v3_length(t[0], t[1], t[2]);
         n[0] = t[0] / tl; n[1] = t[1] / tl; n[2] = t[2] / tl;
@@ -826,6 +827,7 @@ const float* orc_mesh_vertices(const orc_mesh* m) { return m->verts.p; }
 const float* orc_mesh_colors(const orc_mesh* m) { return m->cols.p; }
 const float* orc_mesh_normals(const orc_mesh* m) { return m->norms.p; }
 const float* orc_mesh_grid_vertices(const orc_mesh* m) { return m->grid_verts.p; }
+const float* orc_mesh_grid_normals(const orc_mesh* m) { return m->grid_norms.p; }
 const int32_t* orc_mesh_triangles(const orc_mesh* m) { return m->tris.p; }
 int64_t orc_mesh_cell_count(const orc_mesh* m) { return (int64_t)(m->cells.n / 4); }
 const int32_t* orc_mesh_cells(const orc_mesh* m) { return m->cells.p; }
@@ -837,6 +839,6 @@ void orc_mesh_bounds(const orc_mesh* m, float mn[3], float mx[3])
 void orc_mesh_free(orc_mesh* m)
 {
     if (!m) return;
-    free(m->grid_verts.p); free(m->verts.p); free(m->cols.p); free(m->norms.p);
+    free(m->grid_verts.p); free(m->grid_norms.p); free(m->verts.p); free(m->cols.p); free(m->norms.p);
     free(m->tris.p); free(m->cells.p); free(m);
 }

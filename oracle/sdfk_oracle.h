@@ -13,8 +13,14 @@
  * assertions, the colour inequality, the sampling-position and batch-slicing
  * tests of Tests/VolumeTests.cs.  Vertex positions beyond the AABB, triangle
  * index contents, normals, colour values, step>1, iso!=0 and the ambiguous /
- * centre-vertex tilings are NOT pinned by any reference test: for those,
- * PARITY IS UNPINNED (oracle <-> HIP agreement only).
+ * centre-vertex tilings are NOT pinned by any reference TEST; they are pinned
+ * (round 3) by vectors obtained from EXECUTING the reference's source for the
+ * marching-cubes stage -- MarchingCubes.cs and Cell.cs run by an interpreter of
+ * the C# subset they are written in (tools/cs_subset.py,
+ * tools/gen_reference_vectors.py -> tests/golden/reference_meshes.npz,
+ * tests/test_reference_vectors.py: bit-exact).  The interpreter's numeric
+ * semantics (IEEE float32 / float64, C#'s promotions) and the BCL pieces below
+ * are ours: that much of the pin is a restatement, not the .NET runtime.
  *
  * Third-party arithmetic restated here (not under /root/reference): .NET BCL
  * System.Numerics (SDK pin 6.0.101, global.json): Vector3.Length =
@@ -111,6 +117,7 @@ const float* orc_mesh_vertices(const orc_mesh*);   /* 3 floats per vertex, trans
 const float* orc_mesh_colors(const orc_mesh*);
 const float* orc_mesh_normals(const orc_mesh*);    /* transformed + normalised */
 const float* orc_mesh_grid_vertices(const orc_mesh*); /* voxel-index units, before Transform */
+const float* orc_mesh_grid_normals(const orc_mesh*);  /* Cell.NegativeNormals (Cell.cs:97-109), before Transform */
 const int32_t* orc_mesh_triangles(const orc_mesh*);
 void orc_mesh_bounds(const orc_mesh*, float min[3], float max[3]); /* Mesh.Measure */
 /* per-cell debug stream: (case index, lut offset, nt) of every active cell in sweep order */

@@ -1,0 +1,78 @@
+"""The oracle against vectors produced by EXECUTING the reference's own source.
+
+tests/golden/reference_meshes.npz was written by tools/gen_reference_vectors.py in the build container: MarchingCubes.CreateMesh
+(MarchingCubes.cs:39-92 with TheBigSwitch, TestFace, TestInternal) and all of Cell.cs, parsed where they lie under
+/root/reference and run by tools/cs_subset.py (an interpreter of the C# subset the two files are written in) on seeded volumes.
+Recorded: what the Mesh constructor receives at MarchingCubes.cs:84 -- vertices in voxel-index units, colours, negative normals,
+faces -- and the number of "Impossible case 13?" messages.  This pins what the reference's NUnit tests do not:
+positions, colours, normals, index contents, every ambiguous and centre-vertex tiling, step > 1, iso != 0 -- bit for bit.
+(The interpreter's arithmetic is IEEE float32 / float64 with C#'s promotions; Vector3.Normalize is the BCL restatement the
+oracle documents.  Mesh.Transform, BCL matrix arithmetic, is outside the vectors.)"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = np.load(os.path.join(ROOT, "tests", "golden", "reference_meshes.npz"))
+NAMES = [str(n) for n in REF["names"]]
+
+
+def case(name):
+    g = lambda k: REF[f"{name}/{k}"]
+    iso, step = g("iso_step")
+    return g("values"), g("colors"), float(iso), int(step), g("vertices"), g("out_colors"), g("normals"), g("faces"), int(g("console_lines")[0])
+
+
+def identity_bounds(shape):
+    """min / max for which CreateMesh's T(-(n-1)/2) S(size/(n-1)) T(center) is the identity: positions stay in voxel units."""
+    return [0.0, 0.0, 0.0], [float(n - 1) for n in shape]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_equals_the_executed_reference(name):
+    values, colors, iso, step, rv, rc, rn, rf, lines = case(name)
+    mn, mx = identity_bounds(values.shape)
+    m = O.march(values, colors, mn, mx, iso=iso, step=step)
+    assert len(m.grid_vertices) == len(rv) and len(m.triangles) == len(rf)
+    assert np.array_equal(m.triangles, rf)
+    assert np.array_equal(m.grid_vertices, rv)
+    assert np.array_equal(m.colors, rc)
+    assert np.array_equal(m.grid_normals, rn, equal_nan=True)
+    assert m.impossible13 == lines
+    assert np.array_equal(m.vertices, rv)   # (identity transform: x * 1 + 0)
+
+
+def test_the_vectors_reach_the_hard_parts():
+    """How much of the algorithm the vectors exercise, counted on the oracle's own record of the cells it resolved for these
+    inputs: distinct (tiling row, triangle count) pairs over all 33 tiling tables -- the reference's own tests reach none of the
+    ambiguous ones --, dead case-13 cells, vertices."""
+    rows = set()
+    for name in NAMES:
+        values, colors, iso, step = case(name)[:4]
+        mn, mx = identity_bounds(values.shape)
+        for _cell, _index, lutoff, nt in O.march(values, colors, mn, mx, iso=iso, step=step).cells:
+            rows.add((int(lutoff), int(nt)))
+    assert len(rows) >= 570, len(rows)
+    assert sum(case(n)[8] for n in NAMES) == 4
+    assert sum(len(case(n)[4]) for n in NAMES) == 19568
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_path_equals_the_executed_reference(gpu, name):
+    from sdfkit_amd import MarchingCubes, Voxels
+    values, colors, iso, step, rv, rc, rn, rf, lines = case(name)
+    mn, mx = identity_bounds(values.shape)
+    m = MarchingCubes.CreateMesh(Voxels(values, colors, mn, mx), iso, step)
+    assert np.array_equal(m.Triangles, rf)
+    assert np.array_equal(m.Vertices, rv)
+    assert np.array_equal(m.Colors, rc)
+    # Mesh.Transform with the identity still re-normalises (Mesh.cs:61): n / |n| of the reference's negative normal, float32
+    with np.errstate(all="ignore"):
+        ln = np.sqrt((rn[:, 0] * rn[:, 0] + rn[:, 1] * rn[:, 1]) + rn[:, 2] * rn[:, 2]).astype(np.float32)
+        want = (rn / ln[:, None]).astype(np.float32)
+    assert np.array_equal(m.Normals, want, equal_nan=True)
+    assert m.ImpossibleCase13Cells == lines
