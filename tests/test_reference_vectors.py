@@ -76,3 +76,18 @@ def test_hip_path_equals_the_executed_reference(gpu, name):
         want = (rn / ln[:, None]).astype(np.float32)
     assert np.array_equal(m.Normals, want, equal_nan=True)
     assert m.ImpossibleCase13Cells == lines
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/SdfKit/Cell.cs"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("name", ["random0", "random4", "dead13", "sphere12_step3"])
+def test_vectors_regenerate_from_the_reference_source(name):
+    """In the build container: parse MarchingCubes.cs / Cell.cs again, execute CreateMesh on the stored inputs with
+    tools/cs_subset.py and get the stored outputs -- the fixture is what the generator says it is."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_reference_vectors as G
+    classes, luts = G.load()
+    values, colors, iso, step, rv, rc, rn, rf, lines = case(name)
+    v, c, n, f, console = G.create_mesh(classes, luts, values, colors, iso, step)
+    assert np.array_equal(v, rv) and np.array_equal(c, rc) and np.array_equal(n, rn, equal_nan=True) and np.array_equal(f, rf)
+    assert console == lines
