@@ -18,7 +18,9 @@
  * marching-cubes stage -- MarchingCubes.cs and Cell.cs run by an interpreter of
  * the C# subset they are written in (tools/cs_subset.py,
  * tools/gen_reference_vectors.py -> tests/golden/reference_meshes.npz,
- * tests/test_reference_vectors.py: bit-exact).  The interpreter's numeric
+ * tests/test_reference_vectors.py: bit-exact; likewise the per-point SDF catalogue
+ * SdfFuncs / SdfFuncEx of Sdf.cs -> tests/golden/reference_sdf_points.npz against
+ * orc_eval).  The interpreter's numeric
  * semantics (IEEE float32 / float64, C#'s promotions) and the BCL pieces below
  * are ours: that much of the pin is a restatement, not the .NET runtime.
  *

@@ -91,3 +91,87 @@ def test_vectors_regenerate_from_the_reference_source(name):
     v, c, n, f, console = G.create_mesh(classes, luts, values, colors, iso, step)
     assert np.array_equal(v, rv) and np.array_equal(c, rc) and np.array_equal(n, rn, equal_nan=True) and np.array_equal(f, rf)
     assert console == lines
+
+
+# ---- the SDF catalogue, executed (tools/gen_reference_sdf_vectors.py: SdfFuncs / SdfFuncEx of Sdf.cs:217-341) ----------
+SDF = np.load(os.path.join(ROOT, "tests", "golden", "reference_sdf_points.npz"))
+SDF_NAMES = [str(n) for n in SDF["names"]]
+
+
+def oracle_scene(descr):
+    sc = O.Scene()
+
+    def build(d):
+        kind = d[0]
+        if kind == "sphere":
+            return sc.f_sphere(d[1])
+        if kind == "box":
+            return sc.f_box(d[1], d[2], d[3])
+        if kind == "with_color":
+            return sc.f_with_color(build(d[1]), d[2], d[3], d[4])
+        if kind == "translate":
+            return sc.f_translate(build(d[1]), d[2], d[3], d[4])
+        if kind == "union":
+            return sc.f_union(build(d[1]), build(d[2]))
+        if kind == "repeat_xy_idx":
+            return sc.f_repeat_xy_idx(build(d[1]), d[2], d[3])
+        if kind == "repeat_xz_idx":
+            return sc.f_repeat_xz_idx(build(d[1]), d[2], d[3])
+        raise KeyError(kind)
+
+    sc.root = build(descr)
+    return sc
+
+
+@pytest.mark.parametrize("name", SDF_NAMES)
+def test_oracle_sdf_catalogue_equals_the_executed_reference(name):
+    """orc_eval against what the reference's own lambdas return (SdfFuncs.Sphere / Box / Union, SdfFuncEx.Translate / WithColor /
+    RepeatXY / RepeatXZ with the README's colour lambda), at 611 points per scene incl. period boundaries, signed zeros and
+    denormals: colour and distance, bit for bit."""
+    import json
+    descr = json.loads(str(SDF["scenes_json"]))[name]
+    sc = oracle_scene(descr)
+    pts, want = SDF[f"{name}/points"], SDF[f"{name}/rgbw"]
+    got = np.stack([O.eval_point(sc, p) for p in pts])
+    same = got.view(np.uint32) == want.view(np.uint32)
+    assert same.all(), (np.argwhere(~same)[:5], got[~same.all(axis=1)][:3], want[~same.all(axis=1)][:3])
+
+
+def mirror_sdf(descr):
+    """The same scene through the product's host mirror (sdfkit_amd.api: what becomes the sdfk_op list the GPU compiles)."""
+    from sdfkit_amd import SdfFuncs
+    from tests.scenes import _readme_color
+    kind = descr[0]
+    if kind == "sphere":
+        return SdfFuncs.Sphere(descr[1])
+    if kind == "box":
+        return SdfFuncs.Box((descr[1], descr[2], descr[3]))
+    if kind == "with_color":
+        return mirror_sdf(descr[1]).WithColor(descr[2], descr[3], descr[4])
+    if kind == "translate":
+        return mirror_sdf(descr[1]).Translate(descr[2], descr[3], descr[4])
+    if kind == "union":
+        return SdfFuncs.Union(mirror_sdf(descr[1]), mirror_sdf(descr[2]))
+    if kind == "repeat_xy_idx":
+        return mirror_sdf(descr[1]).RepeatXY(descr[2], descr[3], _readme_color)
+    if kind == "repeat_xz_idx":
+        return mirror_sdf(descr[1]).RepeatXZ(descr[2], descr[3], _readme_color)
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("name", SDF_NAMES)
+def test_lowered_programs_equal_the_executed_reference(name):
+    """The op list the host mirror lowers each of these scenes to -- the program hiprtc compiles for the GPU -- evaluated by the
+    numpy interpreter of the IR (oracle/ir_interp.py: the semantics the sampling kernels are held to on the GPU,
+    test_random_programs_match_ir_interpreter) gives the reference's own (r, g, b, w) at every point, bit for bit."""
+    import json
+    from oracle import ir_interp
+    sdf = mirror_sdf(json.loads(str(SDF["scenes_json"]))[name]).ToSdf()
+    arr, n, out = sdf.ir()
+    ops = [(arr[i].opcode, arr[i].a, arr[i].b, arr[i].c, arr[i].d, arr[i].imm) for i in range(n)]
+    pts, want = SDF[f"{name}/points"], SDF[f"{name}/rgbw"]
+    got = ir_interp.run(ops, list(out), pts)
+    for k in range(4):
+        assert got[k] is not None
+        same = np.asarray(got[k], np.float32).view(np.uint32) == np.ascontiguousarray(want[:, k]).view(np.uint32)
+        assert same.all(), (name, k, np.argwhere(~same)[:5])

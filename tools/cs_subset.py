@@ -177,7 +177,12 @@ class Parser:
                     body = ("block", [("expr", e)] if ty[1] == "void" else [("return", e)])
                 else:
                     body = self.parse_block()
-                methods[name] = ("method", name, params, body, mods, ty)
+                ext = bool(params) and params[0][0] == "$ext"
+                if ext:
+                    params = params[1:]
+                    mods = mods | {"$ext"}
+                methods.setdefault("$all:" + name, []).append(("method", name, params, body, mods, ty))
+                methods.setdefault(name, ("method", name, params, body, mods, ty))
             elif self.at("=>"):
                 self.eat("=>")
                 e = self.parse_expr()
@@ -210,6 +215,9 @@ class Parser:
         self.eat("(")
         params = []
         while not self.at(")"):
+            if self.at("this"):   # extension method: the receiver
+                self.eat()
+                params.append(("$ext", None))
             ty = self.try_type()
             name = self.ident()
             if self.at("="):   # default value
@@ -335,12 +343,48 @@ class Parser:
 
     # -- expressions
     def parse_expr(self):
+        lam = self.try_lambda()
+        if lam is not None:
+            return lam
         lhs = self.parse_or()
+        if self.at("?") :
+            self.eat("?")
+            a = self.parse_expr()
+            self.eat(":")
+            b = self.parse_expr()
+            return ("cond", lhs, a, b)
         if self.peek()[1] in ("=", "+=", "-=", "*=", "/="):
             op = self.eat()
             rhs = self.parse_expr()
             return ("assign", op, lhs, rhs)
         return lhs
+
+    def try_lambda(self):
+        """p => body | (p, q) => body, body an expression or a block"""
+        save = self.i
+        names = None
+        if self.peek()[0] == "id" and self.peek(1)[1] == "=>" and self.peek()[1] not in ("new", "return"):
+            names = [self.ident()]
+        elif self.at("("):
+            j, names2 = self.i + 1, []
+            while self.t[j][0] == "id" and self.t[j + 1][1] in (",", ")"):
+                names2.append(self.t[j][1])
+                j += 2
+                if self.t[j - 1][1] == ")":
+                    break
+            if names2 and self.t[j - 1][1] == ")" and self.t[j][1] == "=>":
+                self.i = j
+                names = names2
+            elif self.t[self.i + 1][1] == ")" and self.t[self.i + 2][1] == "=>":
+                self.i += 2
+                names = []
+        if names is None:
+            self.i = save
+            return None
+        self.eat("=>")
+        if self.at("{"):
+            return ("lambda", names, self.parse_block())
+        return ("lambda", names, ("block", [("return", self.parse_expr())]))
 
     def _binary(self, ops, sub):
         e = sub()
@@ -451,6 +495,17 @@ class Parser:
                 self.parse_args()
                 return ("newlist",)
             ty = self.try_type_for_new()
+            if self.at("{"):   # object initialiser
+                self.eat("{")
+                inits = []
+                while not self.at("}"):
+                    name = self.ident()
+                    self.eat("=")
+                    inits.append((name, self.parse_expr()))
+                    if self.at(","):
+                        self.eat(",")
+                self.eat("}")
+                return ("newinit", ty, inits)
             if self.at("["):
                 self.eat("[")
                 n = self.parse_expr()
@@ -495,6 +550,35 @@ class Vec3:
 
     def __repr__(self):
         return f"<{self.X}, {self.Y}, {self.Z}>"
+
+    def Length(self):   # BCL: sqrt(Dot(v, v)), the products summed left to right in float32
+        with np.errstate(all="ignore"):
+            return F32(np.sqrt(F32(F32(F32(self.X * self.X) + F32(self.Y * self.Y)) + F32(self.Z * self.Z))))
+
+
+class Vec4:
+    """System.Numerics.Vector4: four float32, value semantics."""
+    __slots__ = ("X", "Y", "Z", "W")
+
+    def __init__(self, *a):
+        if len(a) == 2:   # (Vector3, w)
+            a = (a[0].X, a[0].Y, a[0].Z, a[1])
+        self.X, self.Y, self.Z, self.W = (F32(q) for q in a)
+
+
+class Closure:
+    def __init__(self, interp, names, body, fr):
+        self.interp, self.names, self.body = interp, names, body
+        self.fr = {"this": fr["this"], "cname": fr["cname"], "vars": list(fr["vars"]), "types": list(fr["types"])}
+
+    def __call__(self, *args):
+        fr = {"this": self.fr["this"], "cname": self.fr["cname"], "vars": self.fr["vars"] + [dict(zip(self.names, args))],
+              "types": self.fr["types"] + [{}]}
+        try:
+            self.interp.exec(self.body, fr)
+        except ReturnEx as r:
+            return r.v
+        return None
 
 
 class CsList(list):
@@ -631,6 +715,7 @@ class Interp:
         self.classes = classes          # name -> parsed class
         self.hosts = hosts              # name -> Python object (static stand-ins: Luts, Math, Console, Vector3, Matrix4x4, Mesh ...)
         self.statics = {}               # class name -> {field: value}
+        self.static_imports = []        # `using static` classes: their methods are callable by bare name
         self.console = []
         for cname, c in classes.items():
             st = {}
@@ -669,8 +754,41 @@ class Interp:
             return coerce(r.v, method[5]) if len(method) > 5 and method[5][1] != "void" else r.v
         return None
 
+    @staticmethod
+    def _matches(ty, v):
+        if ty is None:
+            return True
+        name = ty[1]
+        if name in ("Vector3", "SdfInput", "SdfColor", "SdfIndex"):
+            return isinstance(v, Vec3)
+        if name in ("Vector4", "SdfOutput"):
+            return isinstance(v, Vec4)
+        if name in ("float", "double", "int"):
+            return isinstance(v, (int, float, F32)) and not isinstance(v, bool)
+        return True
+
+    def pick(self, cname, mname, args, ext=False):
+        """the overload of cname.mname for these arguments (arity, then argument kinds); None if the class has none"""
+        c = self.classes.get(cname)
+        if c is None:
+            return None
+        cands = [m for m in c["methods"].get("$all:" + mname, []) if len(m[2]) == len(args) and (("$ext" in m[4]) or not ext)]
+        if len(cands) > 1:
+            cands = [m for m in cands if all(self._matches(ty, v) for (_, ty), v in zip(m[2], args))] or cands
+        return cands[0] if cands else None
+
     def call_static(self, cname, mname, args):
-        return self.invoke(None, cname, self.classes[cname]["methods"][mname], args)
+        m = self.pick(cname, mname, args)
+        if m is None:
+            raise AttributeError(f"{cname}.{mname}/{len(args)}")
+        return self.invoke(None, cname, m, args)
+
+    def call_extension(self, recv, mname, args):
+        for cname in self.classes:
+            m = self.pick(cname, mname, [recv] + args, ext=True)
+            if m is not None and "$ext" in m[4]:
+                return self.invoke(None, cname, m, [recv] + args)
+        raise AttributeError(f"no extension method {mname} for {type(recv).__name__}")
 
     # -- statements
     def exec(self, s, fr):
@@ -858,7 +976,7 @@ class Interp:
                 return len(obj)
             if isinstance(obj, np.ndarray) and name == "Length":
                 return int(obj.size)
-            if isinstance(obj, Vec3):
+            if isinstance(obj, (Vec3, Vec4)) and name in ("X", "Y", "Z", "W"):
                 return getattr(obj, name)
             return ("bound", obj, name) if callable(getattr(obj, name, None)) else getattr(obj, name)
         if k == "index":
@@ -873,9 +991,14 @@ class Interp:
                 name = f[2]
                 args = [self.eval(a, fr) for a in e[2]]
                 if isinstance(obj, Instance):
-                    return self.invoke(obj, obj.cname, obj.cls["methods"][name], args)
+                    m = self.pick(obj.cname, name, args)
+                    if m is not None:
+                        return self.invoke(obj, obj.cname, m, args)
+                    return self.call_extension(obj, name, args)
                 if isinstance(obj, tuple) and obj and obj[0] == "class":
                     return self.call_static(obj[1], name, args)
+                if isinstance(obj, Closure):
+                    return self.call_extension(obj, name, args)
                 if isinstance(obj, CsList):
                     if name == "Add":
                         obj.append(args[0])
@@ -885,10 +1008,11 @@ class Interp:
                 return getattr(obj, name)(*args)
             args = [self.eval(a, fr) for a in e[2]]
             if f[0] == "name":
-                cname = fr["cname"]
-                m = self.classes[cname]["methods"].get(f[1])
-                if m is not None:
-                    return self.invoke(None if "static" in m[4] else fr["this"], cname, m, args)
+                local = any(f[1] in scope for scope in fr["vars"])   # (a delegate held in a variable shadows a method name)
+                for cname in ([] if local else [fr["cname"]] + self.static_imports):
+                    m = self.pick(cname, f[1], args)
+                    if m is not None:
+                        return self.invoke(None if "static" in m[4] else fr["this"], cname, m, args)
                 target = self.lookup(f[1], fr)
             else:
                 target = self.eval(f, fr)
@@ -902,13 +1026,24 @@ class Interp:
             return getattr(obj, e[2])(*[self.eval(a, fr) for a in e[3]])
         if k == "new":
             args = [self.eval(a, fr) for a in e[2]]
-            if e[1] == "Vector3":
+            if e[1] in ("Vector3", "Vector4"):
                 if any(is_f64(a) for a in args):
-                    raise TypeError("new Vector3 with a double argument")
-                return Vec3(*args)
+                    raise TypeError(f"new {e[1]} with a double argument")
+                if e[1] == "Vector4":
+                    return Vec4(*args)
+                return Vec3(*(args * 3 if len(args) == 1 else args))
             if e[1] in self.classes:
                 return self.new(e[1], args)
             return self.hosts[e[1]](*args)
+        if k == "lambda":
+            return Closure(self, e[1], e[2], fr)
+        if k == "cond":
+            return self.eval(e[2], fr) if self.truth(self.eval(e[1], fr)) else self.eval(e[3], fr)
+        if k == "newinit":
+            o = self.new(e[1], [])
+            for name, ex in e[2]:
+                o.f[name] = self.eval(ex, fr)
+            return o
         if k == "newarray":
             n = self.eval(e[2], fr)
             d = {"int": 0, "double": 0.0, "float": F32(0)}
