@@ -175,3 +175,70 @@ def test_lowered_programs_equal_the_executed_reference(name):
         assert got[k] is not None
         same = np.asarray(got[k], np.float32).view(np.uint32) == np.ascontiguousarray(want[:, k]).view(np.uint32)
         assert same.all(), (name, k, np.argwhere(~same)[:5])
+
+
+# ---- the whole path, executed (tools/gen_reference_path_vectors.py: Voxels ctor + SampleSdf + ClipToBounds + CreateMesh) ------
+PATH = np.load(os.path.join(ROOT, "tests", "golden", "reference_path.npz"))
+PATH_META = __import__("json").loads(str(PATH["meta_json"]))
+
+
+@pytest.mark.parametrize("name", sorted(PATH_META))
+def test_oracle_path_equals_the_executed_reference(name):
+    """Sample points, index mapping and scatter of Voxels.SampleSdf (Voxels.cs:72-125), the clip value of ClipToBounds
+    (:133-167) and the mesh CreateMesh builds from that volume: the oracle's volumes and meshes against the ones the reference's
+    own source produced when executed -- bit for bit.  (Two of the cases are scenes of the reference's NUnit tests; the executed
+    source gave their asserted 104 and 1248 vertices, checked by the generator.)"""
+    md = PATH_META[name]
+    sc = oracle_scene(md["scene"])
+    nx, ny, nz = md["grid"]
+    v, c = O.sample(sc, md["min"], md["max"], nx, ny, nz)
+    if md["clip"]:
+        O.clip_to_bounds(v, md["min"], md["max"])
+    assert np.array_equal(v.view(np.uint32), PATH[f"{name}/values"].view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), PATH[f"{name}/colors"].view(np.uint32))
+    m = O.march(v, c, md["min"], md["max"], iso=md["iso"], step=md["step"])
+    assert np.array_equal(m.triangles, PATH[f"{name}/faces"])
+    assert np.array_equal(m.grid_vertices, PATH[f"{name}/vertices"])
+    assert np.array_equal(m.colors, PATH[f"{name}/out_colors"])
+    assert np.array_equal(m.grid_normals, PATH[f"{name}/normals"], equal_nan=True)
+    assert m.impossible13 == md["console_lines"]
+    if name == "colored_spheres_32":
+        assert len(m.vertices) == 104 and m.colors[0][0] > 0.5        # Tests/MarchingCubesTests.cs:11-28
+    if name == "sphere_32_clipped":
+        assert len(m.vertices) == 1248                                 # Tests/SdfTests.cs:29-52
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(PATH_META))
+def test_hip_path_volume_and_mesh_equal_the_executed_reference(gpu, name):
+    from sdfkit_amd import MarchingCubes, Voxels
+    md = PATH_META[name]
+    sdf = mirror_sdf(md["scene"]).ToSdf()
+    nx, ny, nz = md["grid"]
+    vol = Voxels.SampleSdf(sdf, md["min"], md["max"], nx, ny, nz)
+    if md["clip"]:
+        vol.ClipToBounds()
+    assert np.array_equal(np.asarray(vol.Values).view(np.uint32), PATH[f"{name}/values"].view(np.uint32))
+    assert np.array_equal(np.asarray(vol.Colors).view(np.uint32), PATH[f"{name}/colors"].view(np.uint32))
+    m = MarchingCubes.CreateMesh(vol, md["iso"], md["step"])
+    assert np.array_equal(m.Triangles, PATH[f"{name}/faces"])
+    assert np.array_equal(m.Colors, PATH[f"{name}/out_colors"])
+    assert len(m.Vertices) == len(PATH[f"{name}/vertices"])
+    # positions: the reference's voxel-unit vertices through CreateMesh's T S T (MarchingCubes.cs:85-90), float32, as the oracle restates it
+    om = O.march(PATH[f"{name}/values"], PATH[f"{name}/colors"], md["min"], md["max"], iso=md["iso"], step=md["step"])
+    assert np.array_equal(om.grid_vertices, PATH[f"{name}/vertices"])
+    assert np.array_equal(m.Vertices, om.vertices) and np.array_equal(m.Normals, om.normals, equal_nan=True)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/SdfKit/Voxels.cs"), reason="the reference tree only exists in the build container")
+def test_path_vectors_regenerate_from_the_reference_source():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_reference_path_vectors as G
+    it, console = G.load()
+    name = "box_16_clipped_step2"
+    descr, mn, mx, grid, clip, iso, step = G.CASES[name]
+    values, colors, v, c, n, f, lines = G.run_case(it, console, descr, mn, mx, grid, clip, iso, step)
+    assert np.array_equal(values, PATH[f"{name}/values"]) and np.array_equal(colors, PATH[f"{name}/colors"])
+    assert np.array_equal(v, PATH[f"{name}/vertices"]) and np.array_equal(f, PATH[f"{name}/faces"])
+    assert np.array_equal(n, PATH[f"{name}/normals"], equal_nan=True)

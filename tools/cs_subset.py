@@ -3,10 +3,12 @@
 (SdfKit/MarchingCubes.cs, SdfKit/Cell.cs: classes with fields, properties and methods; int / double / float / bool locals;
 arrays, List<T>, System.Numerics.Vector3; if / while / for; tuple assignment; casts).
 
-Why: the image has no .NET, so the reference cannot be RUN here -- but its source can be EXECUTED: tools/gen_reference_vectors.py
-parses the two files where they lie under /root/reference, runs MarchingCubes.CreateMesh on small volumes through this
-interpreter and commits the inputs and outputs as golden vectors (tests/golden/reference_meshes.npz).  Nothing of the
-reference's text is stored; this file contains no reference code.  Build container only (the GPU box has no /root/reference).
+Why: the image has no .NET, so the reference cannot be RUN here -- but its source can be EXECUTED: the generators
+tools/gen_reference_vectors.py (MarchingCubes.CreateMesh on seeded volumes), gen_reference_sdf_vectors.py (the SdfFuncs
+catalogue at seeded points: lambdas, closures, extension methods, overloads) and gen_reference_path_vectors.py (Voxels ->
+SampleSdf -> ClipToBounds -> CreateMesh) parse the files where they lie under /root/reference, run them through this
+interpreter and commit the inputs and outputs as golden vectors (tests/golden/reference_*.npz).  Nothing of the reference's
+text is stored; this file contains no reference code.  Build container only (the GPU box has no /root/reference).
 
 Numeric semantics (ours, as documented for the oracle in oracle/sdfk_oracle.h): int = Python int with C# truncating division;
 double = Python float; float = numpy.float32, one rounding per operation; binary numeric promotion int < float < double;
@@ -161,8 +163,15 @@ class Parser:
             if self.peek()[1] == cname and self.peek(1)[1] == "(":   # constructor
                 self.eat()
                 params = self.parse_params()
+                chain = None
+                if self.at(":"):   # : this(args) -- the other constructor runs first
+                    self.eat(":")
+                    self.eat("this")
+                    self.eat("(")
+                    chain = self.parse_args()
                 body = self.parse_block()
-                methods[".ctor"] = ("method", ".ctor", params, body, mods)
+                methods.setdefault("$all:.ctor", []).append(("method", ".ctor", params, body, mods, ("type", "void", ()), chain))
+                methods.setdefault(".ctor", ("method", ".ctor", params, body, mods))
                 continue
             ty = self.try_type()
             if ty is None:
@@ -188,6 +197,11 @@ class Parser:
                 e = self.parse_expr()
                 self.eat(";")
                 props[name] = ("block", [("return", e)])
+            elif self.at("{") and self.peek(1)[1] == "get" and self.peek(2)[1] == ";":   # auto-property: a field
+                while not self.at("}"):
+                    self.eat()
+                self.eat("}")
+                fields.append((name, ty, None, "static" in mods))
             elif self.at("{"):
                 self.eat("{")
                 self.eat("get")
@@ -329,6 +343,18 @@ class Parser:
             e = None if self.at(";") else self.parse_expr()
             self.eat(";")
             return ("return", e)
+        if self.at("var") and self.peek(1)[1] == "(":
+            self.eat()
+            self.eat("(")
+            names = [self.ident()]
+            while self.at(","):
+                self.eat(",")
+                names.append(self.ident())
+            self.eat(")")
+            self.eat("=")
+            e = self.parse_expr()
+            self.eat(";")
+            return ("decl_tuple", names, e)
         d = self.try_decl()
         if d is not None:
             self.eat(";")
@@ -446,6 +472,22 @@ class Parser:
             if self.at("."):
                 self.eat(".")
                 e = ("member", e, self.ident())
+                if self.at("<"):   # explicit generic arguments, if that is what they are: only type-ish tokens up to '>' '('
+                    j, depth = self.i, 0
+                    while True:
+                        kind, v = self.t[j]
+                        if v == "<":
+                            depth += 1
+                        elif v == ">":
+                            depth -= 1
+                            if depth == 0:
+                                break
+                        elif not (kind == "id" or v in (",", "(", ")", "[", "]", ".", "?")):
+                            j = -1
+                            break
+                        j += 1
+                    if j > 0 and self.t[j + 1][1] == "(":
+                        self.i = j + 1
             elif self.at("?."):
                 self.eat("?.")
                 name = self.ident()
@@ -508,9 +550,8 @@ class Parser:
                 return ("newinit", ty, inits)
             if self.at("["):
                 self.eat("[")
-                n = self.parse_expr()
-                self.eat("]")
-                return ("newarray", ty, n)
+                dims = self.parse_args("]")
+                return ("newarray", ty, dims[0]) if len(dims) == 1 else ("newarray_nd", ty, dims)
             self.eat("(")
             return ("new", ty, self.parse_args())
         if v in ("true", "false"):
@@ -529,6 +570,9 @@ class Parser:
 
     def try_type_for_new(self):
         name = self.ident()
+        while self.at(".") and self.peek(1)[0] == "id":
+            self.eat(".")
+            name = self.ident()   # (the last component names the class)
         if self.at("<"):
             self.eat("<")
             depth = 1
@@ -585,6 +629,37 @@ class CsList(list):
     pass
 
 
+class SpanHost:
+    """Span<T> over a slice of a Python list: element access goes to the underlying storage."""
+    def __init__(self, store, start, n):
+        self.store, self.start, self.Length = store, start, n
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.Length:
+            raise IndexError(i)
+        return self.store[self.start + i]
+
+    def __setitem__(self, i, v):
+        if not 0 <= i < self.Length:
+            raise IndexError(i)
+        self.store[self.start + i] = v
+
+
+class MemoryHost:
+    """Memory<T>: Slice, Length, Span"""
+    def __init__(self, store, start, n):
+        self.store, self.start, self.Length = store, start, n
+
+    def Slice(self, start, n):
+        if start < 0 or n < 0 or start + n > self.Length:
+            raise IndexError((start, n))
+        return MemoryHost(self.store, self.start + start, n)
+
+    @property
+    def Span(self):
+        return SpanHost(self.store, self.start, self.Length)
+
+
 class Opaque:
     """Host stand-in whose every operation yields itself (the matrices after the point where the vectors are taken)."""
     def __getattr__(self, name):
@@ -605,8 +680,18 @@ def is_f64(v):
     return isinstance(v, float) and not isinstance(v, F32)
 
 
+def value_copy(v):
+    """Vector3 / Vector4 are structs: assignment copies."""
+    if isinstance(v, Vec3):
+        return Vec3(v.X, v.Y, v.Z)
+    if isinstance(v, Vec4):
+        return Vec4(v.X, v.Y, v.Z, v.W)
+    return v
+
+
 def coerce(v, ty):
     """Implicit conversion on assignment to a variable of declared type `ty` (None / var: as is)."""
+    v = value_copy(v)
     if ty is None or v is None:
         return v
     name, rank = ty[1], ty[2]
@@ -736,9 +821,22 @@ class Interp:
             o.f[name] = coerce(self.eval(init, frame), ty) if init is not None else default_of(ty)
             if init is not None and init[0] == "newlist":
                 o.f[name] = CsList()
-        if ".ctor" in c["methods"]:
-            self.invoke(o, cname, c["methods"][".ctor"], args)
+        ctors = c["methods"].get("$all:.ctor", [])
+        if ctors:
+            self.construct(o, cname, ctors, args)
         return o
+
+    def construct(self, o, cname, ctors, args):
+        cands = [m for m in ctors if len(m[2]) == len(args)]
+        if len(cands) > 1:
+            cands = [m for m in cands if all(self._matches(ty, v) for (_, ty), v in zip(m[2], args))] or cands
+        if not cands:
+            raise TypeError(f"no constructor of {cname} takes {len(args)} arguments")
+        m = cands[0]
+        if len(m) > 6 and m[6] is not None:   # : this(...) -- evaluated with the parameters in scope
+            frame = {"this": o, "cname": cname, "vars": [{name: coerce(v, ty) for (name, ty), v in zip(m[2], args)}], "types": [{}]}
+            self.construct(o, cname, ctors, [self.eval(a, frame) for a in m[6]])
+        self.invoke(o, cname, m, args)
 
     def invoke(self, this, cname, method, args):
         params, body = method[2], method[3]
@@ -810,6 +908,11 @@ class Interp:
                 v = self.eval(init, fr) if init is not None else (default_of(ty) if ty else None)
                 fr["vars"][-1][name] = coerce(v, ty)
                 fr["types"][-1][name] = ty
+        elif k == "decl_tuple":
+            vals = self.eval(s[2], fr)
+            for name, v in zip(s[1], vals):
+                fr["vars"][-1][name] = v
+                fr["types"][-1][name] = None
         elif k == "tuple_assign":
             vals = [self.eval(e, fr) for e in s[2]]
             for lv, v in zip(s[1], vals):
@@ -893,13 +996,26 @@ class Interp:
             if isinstance(obj, Instance):
                 obj.f[lv[2]] = coerce(v, obj.ftype.get(lv[2]))
                 return
-            raise TypeError(f"cannot assign member {lv[2]}")
+            if isinstance(obj, (Vec3, Vec4)) and lv[2] in ("X", "Y", "Z", "W"):
+                if is_f64(v):
+                    raise TypeError("double into a float component")
+                setattr(obj, lv[2], F32(v))   # (obj is the variable's / the array element's own struct: mutated in place)
+                return
+            setattr(obj, lv[2], v)            # (a host object's property)
+            return
         if k == "index":
             arr = self.eval(lv[1], fr)
             idx = [self.eval(e, fr) for e in lv[2]]
             if len(idx) != 1:
-                raise TypeError("assignment into a multi-dimensional array")
+                if arr.dtype == np.float32:
+                    if is_f64(v):
+                        raise TypeError("double into a float[,,]")
+                    arr[tuple(idx)] = F32(v)
+                else:
+                    arr[tuple(idx)] = value_copy(v)
+                return
             old = arr[idx[0]]
+            v = value_copy(v)
             if is_f64(old) and not isinstance(old, bool):
                 v = float(v)
             elif isinstance(old, int) and not isinstance(old, bool):
@@ -976,9 +1092,11 @@ class Interp:
                 return len(obj)
             if isinstance(obj, np.ndarray) and name == "Length":
                 return int(obj.size)
+            if isinstance(obj, np.ndarray) and name == "GetLength":
+                return lambda k: int(obj.shape[k])
             if isinstance(obj, (Vec3, Vec4)) and name in ("X", "Y", "Z", "W"):
                 return getattr(obj, name)
-            return ("bound", obj, name) if callable(getattr(obj, name, None)) else getattr(obj, name)
+            return getattr(obj, name)
         if k == "index":
             arr = self.eval(e[1], fr)
             idx = [self.eval(q, fr) for q in e[2]]
@@ -999,6 +1117,10 @@ class Interp:
                     return self.call_static(obj[1], name, args)
                 if isinstance(obj, Closure):
                     return self.call_extension(obj, name, args)
+                if isinstance(obj, np.ndarray) and name == "GetLength":
+                    return int(obj.shape[args[0]])
+                if isinstance(obj, list) and not isinstance(obj, CsList) and name == "AsMemory":
+                    return MemoryHost(obj, 0, len(obj))
                 if isinstance(obj, CsList):
                     if name == "Add":
                         obj.append(args[0])
@@ -1040,15 +1162,30 @@ class Interp:
         if k == "cond":
             return self.eval(e[2], fr) if self.truth(self.eval(e[1], fr)) else self.eval(e[3], fr)
         if k == "newinit":
-            o = self.new(e[1], [])
+            if e[1] in self.classes:
+                o = self.new(e[1], [])
+                for name, ex in e[2]:
+                    o.f[name] = self.eval(ex, fr)
+                return o
+            o = self.hosts[e[1]]()
             for name, ex in e[2]:
-                o.f[name] = self.eval(ex, fr)
+                setattr(o, name, self.eval(ex, fr))
             return o
+        if k == "newarray_nd":
+            dims = [self.eval(q, fr) for q in e[2]]
+            if e[1] == "float":
+                return np.zeros(dims, dtype=np.float32)
+            a = np.empty(dims, dtype=object)
+            for ix in np.ndindex(*dims):
+                a[ix] = Vec3() if e[1] == "Vector3" else None
+            return a
         if k == "newarray":
             n = self.eval(e[2], fr)
             d = {"int": 0, "double": 0.0, "float": F32(0)}
             if e[1] == "Vector3":
                 return [Vec3() for _ in range(n)]
+            if e[1] == "Vector4":
+                return [Vec4(0, 0, 0, 0) for _ in range(n)]
             return [d[e[1]]] * n
         if k == "newlist":
             return CsList()

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Golden vectors for the WHOLE path, produced by EXECUTING the reference's own source (build container only).
+
+`new Voxels(min, max, nx, ny, nz)` -> `voxels.SampleSdf(sdf)` (Voxels.cs:23-40, 72-125: cell-centred sample points, the index
+mapping of the batches, the scatter into Values / Colors) -> `voxels.ClipToBounds()` (Voxels.cs:133-167) ->
+`MarchingCubes.CreateMesh(voxels, iso, step)` (MarchingCubes.cs, Cell.cs), with the scene a composition of the per-point
+catalogue `SdfFuncs` / `SdfFuncEx` turned into a batched `Sdf` by `SdfFuncEx.ToSdf` (Sdf.cs:301-313) -- all of it parsed where
+it lies under /root/reference and run by tools/cs_subset.py.  `Parallel.For` runs its batches in order (the reference's result
+does not depend on the order: every voxel is written once); `Memory<T>` / `Span<T>` are views of the arrays.
+
+Output, committed: tests/golden/reference_path.npz -- per case the scene description, bounds, grid, clip / iso / step, the sampled
+Values and Colors, and what `new Mesh(...)` receives (MarchingCubes.cs:84).  Two cases are scenes of the reference's own NUnit
+tests, and the executed source gives their asserted vertex counts (104: ColoredSpheres; 1248: a sphere of radius 0.5 in 32^3).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import cs_subset as CS                      # noqa: E402
+import gen_luts                             # noqa: E402
+import gen_reference_sdf_vectors as GS      # noqa: E402
+import gen_reference_vectors as GM          # noqa: E402
+
+REF = "/root/reference/SdfKit"
+F32 = np.float32
+
+
+class ParallelHost:
+    @staticmethod
+    def For(lo, hi, options, init, body, final):
+        local = init()
+        for i in range(lo, hi):
+            local = body(i, None, local)
+        final(local)
+
+
+class ParallelOptions:
+    MaxDegreeOfParallelism = -1
+
+
+class Namespace:
+    pass
+
+
+class MathHost(GS.MathHost):
+    @staticmethod
+    def Min(a, b):
+        return min(a, b)
+
+
+def load():
+    sdf_cs = open(os.path.join(REF, "Sdf.cs")).read()
+    vec_cs = open(os.path.join(REF, "VectorData.cs")).read()
+    expr_cs = open(os.path.join(REF, "SdfExpr.cs")).read()
+    vox_cs = open(os.path.join(REF, "Voxels.cs")).read()
+    head = vox_cs[vox_cs.index("{", vox_cs.index("public class Voxels")) + 1:vox_cs.index("public Voxels(float[,,] values")]
+    voxels = "\n".join([
+        "public class Voxels {", head,
+        GS.cut_braced(vox_cs, r"public Voxels\(float\[,,\] values"),
+        GS.cut_braced(vox_cs, r"public Voxels\(Vector3 min, Vector3 max, int nx"),
+        GS.cut_braced(vox_cs, r"public void SampleSdf\(Sdf sdf"),
+        GS.cut_braced(vox_cs, r"public void ClipToBounds\(\)"),
+        "}",
+    ])
+    text = "\n".join([
+        GS.cut_braced(sdf_cs, r"public class SdfConfig\b"),
+        GS.cut_braced(sdf_cs, r"public static class SdfFuncs\b"),
+        GS.cut_braced(sdf_cs, r"public static class SdfFuncEx\b"),
+        GS.cut_braced(expr_cs, r"public struct SdfIndexedInput\b"),
+        "public static class VectorOps {",
+        GS.cut_expression_bodied(vec_cs, r"public static float Mod\(float a, float b\)"),
+        GS.cut_expression_bodied(vec_cs, r"public static float VMax\(Vector3 v\)"),
+        "}",
+        voxels,
+        open(os.path.join(REF, "MarchingCubes.cs")).read(),
+        open(os.path.join(REF, "Cell.cs")).read(),
+    ])
+    classes = CS.parse(text)
+    luts = type("LutsHost", (), {})()
+    for name, shape, vals in gen_luts.parse_tables(open(os.path.join(REF, "Luts.cs")).read()):
+        setattr(luts, name, np.array(vals, dtype=np.int8).reshape(shape))
+    system = Namespace()
+    system.Threading = Namespace()
+    system.Threading.Tasks = Namespace()
+    system.Threading.Tasks.Parallel = ParallelHost
+    console = GM.ConsoleHost()
+    hosts = {"Luts": luts, "Math": MathHost, "MathF": GS.MathFHost, "Console": console, "Vector3": Vector3Host, "Matrix4x4": GM.OpaqueCallable(),
+             "Mesh": GM.MeshCapture, "System": system, "ParallelOptions": ParallelOptions}
+    it = CS.Interp(classes, hosts)
+    it.static_imports = ["VectorOps"]
+    return it, console
+
+
+class Vector3Host(GS.Vector3Host):
+    Normalize = staticmethod(GM.Vector3Host.Normalize)
+
+
+def run_case(it, console, descr, mn, mx, grid, clip, iso, step):
+    sdf_fn = build(it, descr)
+    sdf = it.call_extension(sdf_fn, "ToSdf", [])
+    vox = it.new("Voxels", [CS.Vec3(*mn), CS.Vec3(*mx), int(grid[0]), int(grid[1]), int(grid[2])])
+    it.invoke(vox, "Voxels", it.pick("Voxels", "SampleSdf", [sdf, 2048, -1]), [sdf, 2048, -1])
+    if clip:
+        it.invoke(vox, "Voxels", it.pick("Voxels", "ClipToBounds", []), [])
+    values = np.array(vox.f["Values"], dtype=np.float32)
+    colors = np.zeros(values.shape + (3,), dtype=np.float32)
+    for ix in np.ndindex(*values.shape):
+        c = vox.f["Colors"][ix]
+        colors[ix] = (c.X, c.Y, c.Z)
+    console.lines.clear()
+    GM.MeshCapture.last = None
+    it.call_static("MarchingCubes", "CreateMesh", [vox, F32(iso), int(step), None])
+    m = GM.MeshCapture.last
+    v3 = lambda lst: np.array([[q.X, q.Y, q.Z] for q in lst], dtype=np.float32).reshape(-1, 3)
+    return values, colors, v3(m.vertices), v3(m.colors), v3(m.normals), np.array(m.faces, dtype=np.int32), len(console.lines)
+
+
+def build(it, d):
+    f = F32
+    S = lambda *a: it.call_static("SdfFuncs", *a)
+    X = lambda recv, name, *a: it.call_extension(recv, name, list(a))
+    kind = d[0]
+    if kind == "sphere":
+        return S("Sphere", [f(d[1])])
+    if kind == "box":
+        return S("Box", [CS.Vec3(d[1], d[2], d[3])])
+    if kind == "with_color":
+        return X(build(it, d[1]), "WithColor", f(d[2]), f(d[3]), f(d[4]))
+    if kind == "translate":
+        return X(build(it, d[1]), "Translate", f(d[2]), f(d[3]), f(d[4]))
+    if kind == "union":
+        return S("Union", [build(it, d[1]), build(it, d[2])])
+    user = CS.Interp(CS.parse(GS.README_COLOUR), {"Vector3": GS.Vector3Host})
+    colour = lambda i, p, q: user.call_static("UserCode", "Colour", [i, p, q])
+    if kind == "repeat_xy_idx":
+        return X(build(it, d[1]), "RepeatXY", f(d[2]), f(d[3]), colour)
+    if kind == "repeat_xz_idx":
+        return X(build(it, d[1]), "RepeatXZ", f(d[2]), f(d[3]), colour)
+    raise KeyError(kind)
+
+
+CASES = {
+    # Tests/MarchingCubesTests.cs:11-28 (ColoredSpheres): 104 vertices
+    "colored_spheres_32": (["union", ["translate", ["with_color", ["sphere", 0.4], 1, 0.2, 0.3], -1, 0, 0],
+                            ["translate", ["with_color", ["sphere", 0.2], 0.1, 1, 0.3], 1, 0, 0]], [-3, -3, -3], [3, 3, 3], (32, 32, 32), False, 0.0, 1),
+    # a sphere of radius 0.5 in 32^3 with clipToBounds (Tests/SdfTests.cs:29-52): 1248 vertices
+    "sphere_32_clipped": (["sphere", 0.5], [-1, -1, -1], [1, 1, 1], (32, 32, 32), True, 0.0, 1),
+    "readme_24_clipped": (["repeat_xy_idx", ["sphere", 0.5], 1.125, 1.125], [-2.8125] * 3, [2.8125] * 3, (24, 24, 24), True, 0.0, 1),
+    "union_box_sphere_iso": (["union", ["box", 0.5, 0.5, 0.5], ["translate", ["sphere", 0.6], 0.4, 0.3, -0.2]], [-1.5, -1.25, -1.75], [1.5, 1.75, 1.25],
+                             (20, 18, 22), False, 0.1, 1),
+    "box_16_clipped_step2": (["box", 0.6, 0.6, 0.6], [-1, -1, -1], [1, 1, 1], (17, 16, 19), True, 0.0, 2),
+    "repeat_xz_box_clipped": (["repeat_xz_idx", ["box", 0.3, 0.3, 0.3], 1.5, 0.875], [-2.5, -1.0, -2.0], [2.5, 1.0, 2.0], (21, 9, 25), True, 0.0, 1),
+}
+EXPECT_VERTICES = {"colored_spheres_32": 104, "sphere_32_clipped": 1248}
+
+
+def main():
+    it, console = load()
+    blob, meta = {}, {}
+    for name, (descr, mn, mx, grid, clip, iso, step) in CASES.items():
+        values, colors, v, c, n, f, lines = run_case(it, console, descr, mn, mx, grid, clip, iso, step)
+        print(f"{name}: grid {grid} clip {clip} iso {iso} step {step} -> {len(v)} vertices, {len(f) // 3} triangles, {lines} console lines")
+        if name in EXPECT_VERTICES and len(v) != EXPECT_VERTICES[name]:
+            raise SystemExit(f"{name}: the reference's own test asserts {EXPECT_VERTICES[name]} vertices")
+        meta[name] = {"scene": descr, "min": mn, "max": mx, "grid": list(grid), "clip": clip, "iso": iso, "step": step, "console_lines": lines}
+        blob[f"{name}/values"], blob[f"{name}/colors"] = values, colors
+        blob[f"{name}/vertices"], blob[f"{name}/out_colors"], blob[f"{name}/normals"], blob[f"{name}/faces"] = v, c, n, f
+    blob["meta_json"] = np.array(json.dumps(meta))
+    path = os.path.join(ROOT, "tests", "golden", "reference_path.npz")
+    np.savez_compressed(path, **blob)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
