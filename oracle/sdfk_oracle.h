@@ -21,8 +21,8 @@
  * tests/test_reference_vectors.py: bit-exact; likewise the per-point SDF catalogue
  * SdfFuncs / SdfFuncEx of Sdf.cs -> tests/golden/reference_sdf_points.npz against
  * orc_eval, and the whole path Voxels ctor -> SampleSdf -> ClipToBounds -> CreateMesh
- * -> tests/golden/reference_path.npz, where the executed source also yields the 104
- * and 1248 vertices the reference's own tests assert).  The interpreter's numeric
+ * -> tests/golden/reference_path.npz, where the executed source also yields every
+ * vertex count the reference's own tests assert: 104, 54, 312, 0, 384, 384, 1248, 1248).  The interpreter's numeric
  * semantics (IEEE float32 / float64, C#'s promotions) and the BCL pieces below
  * are ours: that much of the pin is a restatement, not the .NET runtime.
  *

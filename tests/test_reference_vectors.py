@@ -103,6 +103,12 @@ def oracle_scene(descr):
 
     def build(d):
         kind = d[0]
+        if kind == "sdfs_sphere":
+            return sc.sphere_w(d[1])
+        if kind == "sdfs_box":
+            return sc.box_w(d[1])
+        if kind == "sdfs_plane":
+            return sc.plane_w(d[1], d[2], d[3], d[4])
         if kind == "sphere":
             return sc.f_sphere(d[1])
         if kind == "box":
@@ -142,6 +148,12 @@ def mirror_sdf(descr):
     from sdfkit_amd import SdfFuncs
     from tests.scenes import _readme_color
     kind = descr[0]
+    if kind.startswith("sdfs_"):   # the batched catalogue: already an Sdf (ToSdf below is then the identity)
+        from sdfkit_amd import Sdfs
+        sdf = {"sdfs_sphere": lambda: Sdfs.Sphere(descr[1]), "sdfs_box": lambda: Sdfs.Box(descr[1]),
+               "sdfs_plane": lambda: Sdfs.Plane((descr[1], descr[2], descr[3]), descr[4])}[kind]()
+        sdf.ToSdf = lambda: sdf
+        return sdf
     if kind == "sphere":
         return SdfFuncs.Sphere(descr[1])
     if kind == "box":
@@ -186,8 +198,8 @@ PATH_META = __import__("json").loads(str(PATH["meta_json"]))
 def test_oracle_path_equals_the_executed_reference(name):
     """Sample points, index mapping and scatter of Voxels.SampleSdf (Voxels.cs:72-125), the clip value of ClipToBounds
     (:133-167) and the mesh CreateMesh builds from that volume: the oracle's volumes and meshes against the ones the reference's
-    own source produced when executed -- bit for bit.  (Two of the cases are scenes of the reference's NUnit tests; the executed
-    source gave their asserted 104 and 1248 vertices, checked by the generator.)"""
+    own source produced when executed -- bit for bit.  (Eight of the cases are scenes of the reference's NUnit tests; the executed
+    source gave every vertex count they assert -- 104, 54, 312, 0, 384, 384, 1248, 1248 -- checked by the generator and again here.)"""
     md = PATH_META[name]
     sc = oracle_scene(md["scene"])
     nx, ny, nz = md["grid"]
@@ -202,10 +214,13 @@ def test_oracle_path_equals_the_executed_reference(name):
     assert np.array_equal(m.colors, PATH[f"{name}/out_colors"])
     assert np.array_equal(m.grid_normals, PATH[f"{name}/normals"], equal_nan=True)
     assert m.impossible13 == md["console_lines"]
+    # the vertex counts the reference's own NUnit tests assert for these scenes (Tests/MarchingCubesTests.cs:11-115, Tests/SdfTests.cs:29-52)
+    nunit = {"colored_spheres_32": 104, "sphere_32_clipped": 1248, "nunit_sphere5": 54, "nunit_sphere10": 312, "nunit_unclipped_sphere10": 0,
+             "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248}
+    if name in nunit:
+        assert len(m.vertices) == len(PATH[f"{name}/vertices"]) == nunit[name]
     if name == "colored_spheres_32":
-        assert len(m.vertices) == 104 and m.colors[0][0] > 0.5        # Tests/MarchingCubesTests.cs:11-28
-    if name == "sphere_32_clipped":
-        assert len(m.vertices) == 1248                                 # Tests/SdfTests.cs:29-52
+        assert m.colors[0][0] > 0.5
 
 
 @pytest.mark.gpu

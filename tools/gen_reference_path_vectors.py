@@ -9,8 +9,9 @@ it lies under /root/reference and run by tools/cs_subset.py.  `Parallel.For` run
 does not depend on the order: every voxel is written once); `Memory<T>` / `Span<T>` are views of the arrays.
 
 Output, committed: tests/golden/reference_path.npz -- per case the scene description, bounds, grid, clip / iso / step, the sampled
-Values and Colors, and what `new Mesh(...)` receives (MarchingCubes.cs:84).  Two cases are scenes of the reference's own NUnit
-tests, and the executed source gives their asserted vertex counts (104: ColoredSpheres; 1248: a sphere of radius 0.5 in 32^3).
+Values and Colors, and what `new Mesh(...)` receives (MarchingCubes.cs:84).  Eight cases are scenes of the reference's own NUnit
+tests (the batched `Sdfs.Sphere` / `Sdfs.Box` of Sdf.cs:118-214 among them), and the executed source gives every vertex count
+those tests assert: 104, 54, 312, 0, 384, 384, 1248, 1248 (the generator refuses to write the file otherwise).
 """
 import json
 import os
@@ -68,6 +69,7 @@ def load():
     ])
     text = "\n".join([
         GS.cut_braced(sdf_cs, r"public class SdfConfig\b"),
+        GS.cut_braced(sdf_cs, r"public static class Sdfs\b"),
         GS.cut_braced(sdf_cs, r"public static class SdfFuncs\b"),
         GS.cut_braced(sdf_cs, r"public static class SdfFuncEx\b"),
         GS.cut_braced(expr_cs, r"public struct SdfIndexedInput\b"),
@@ -98,10 +100,17 @@ def load():
 class Vector3Host(GS.Vector3Host):
     Normalize = staticmethod(GM.Vector3Host.Normalize)
 
+    @staticmethod
+    def Dot(a, b):   # BCL: the three products summed left to right in float32
+        with np.errstate(all="ignore"):
+            return F32(F32(F32(a.X * b.X) + F32(a.Y * b.Y)) + F32(a.Z * b.Z))
+
 
 def run_case(it, console, descr, mn, mx, grid, clip, iso, step):
-    sdf_fn = build(it, descr)
-    sdf = it.call_extension(sdf_fn, "ToSdf", [])
+    if descr[0].startswith("sdfs_"):   # the batched catalogue (Sdf.cs:118-214): already an `Sdf`
+        sdf = build(it, descr)
+    else:
+        sdf = it.call_extension(build(it, descr), "ToSdf", [])
     vox = it.new("Voxels", [CS.Vec3(*mn), CS.Vec3(*mx), int(grid[0]), int(grid[1]), int(grid[2])])
     it.invoke(vox, "Voxels", it.pick("Voxels", "SampleSdf", [sdf, 2048, -1]), [sdf, 2048, -1])
     if clip:
@@ -124,6 +133,12 @@ def build(it, d):
     S = lambda *a: it.call_static("SdfFuncs", *a)
     X = lambda recv, name, *a: it.call_extension(recv, name, list(a))
     kind = d[0]
+    if kind == "sdfs_sphere":
+        return it.call_static("Sdfs", "Sphere", [f(d[1])])
+    if kind == "sdfs_box":
+        return it.call_static("Sdfs", "Box", [f(d[1])])
+    if kind == "sdfs_plane":
+        return it.call_static("Sdfs", "Plane", [CS.Vec3(d[1], d[2], d[3]), f(d[4])])
     if kind == "sphere":
         return S("Sphere", [f(d[1])])
     if kind == "box":
@@ -153,9 +168,18 @@ CASES = {
     "union_box_sphere_iso": (["union", ["box", 0.5, 0.5, 0.5], ["translate", ["sphere", 0.6], 0.4, 0.3, -0.2]], [-1.5, -1.25, -1.75], [1.5, 1.75, 1.25],
                              (20, 18, 22), False, 0.1, 1),
     "box_16_clipped_step2": (["box", 0.6, 0.6, 0.6], [-1, -1, -1], [1, 1, 1], (17, 16, 19), True, 0.0, 2),
+    # the reference's other known answers on the path (Tests/MarchingCubesTests.cs:31-115, Tests/SdfTests.cs:29-39), batched Sdfs.*
+    "nunit_sphere5": (["sdfs_sphere", 1.0], [-1.5] * 3, [1.5] * 3, (5, 5, 5), False, 0.0, 1),
+    "nunit_sphere10": (["sdfs_sphere", 2.0], [-2.5] * 3, [2.5] * 3, (10, 10, 10), False, 0.0, 1),
+    "nunit_unclipped_sphere10": (["sdfs_sphere", 2.0], [-1] * 3, [1] * 3, (10, 10, 10), False, 0.0, 1),
+    "nunit_clipped_sphere10": (["sdfs_sphere", 2.0], [-1] * 3, [1] * 3, (10, 10, 10), True, 0.0, 1),
+    "nunit_box10": (["sdfs_box", 2.0], [-2.5] * 3, [2.5] * 3, (10, 10, 10), False, 0.0, 1),
+    "nunit_create_mesh_sphere": (["sdfs_sphere", 0.5], [-1] * 3, [1] * 3, (32, 32, 32), True, 0.0, 1),
+    "plane_tilted": (["sdfs_plane", 0.3, 0.0, 1.0, 0.05], [-1, -1, -1], [1, 1, 1], (14, 12, 10), False, 0.0, 1),
     "repeat_xz_box_clipped": (["repeat_xz_idx", ["box", 0.3, 0.3, 0.3], 1.5, 0.875], [-2.5, -1.0, -2.0], [2.5, 1.0, 2.0], (21, 9, 25), True, 0.0, 1),
 }
-EXPECT_VERTICES = {"colored_spheres_32": 104, "sphere_32_clipped": 1248}
+EXPECT_VERTICES = {"colored_spheres_32": 104, "sphere_32_clipped": 1248, "nunit_sphere5": 54, "nunit_sphere10": 312, "nunit_unclipped_sphere10": 0,
+                   "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248}
 
 
 def main():
