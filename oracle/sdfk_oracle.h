@@ -22,7 +22,8 @@
  * SdfFuncs / SdfFuncEx of Sdf.cs -> tests/golden/reference_sdf_points.npz against
  * orc_eval, and the whole path Voxels ctor -> SampleSdf -> ClipToBounds -> CreateMesh
  * -> tests/golden/reference_path.npz, where the executed source also yields every
- * vertex count the reference's own tests assert: 104, 54, 312, 0, 384, 384, 1248, 1248).  The interpreter's numeric
+ * vertex count the reference's own tests assert: 104, 54, 312, 0, 384, 384, 7456,
+ * 72240, 1248, 1248).  The interpreter's numeric
  * semantics (IEEE float32 / float64, C#'s promotions) and the BCL pieces below
  * are ours: that much of the pin is a restatement, not the .NET runtime.
  *

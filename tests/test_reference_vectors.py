@@ -103,6 +103,12 @@ def oracle_scene(descr):
 
     def build(d):
         kind = d[0]
+        if kind == "exprs_cylinder":
+            return sc.f_cylinder(d[1], d[2], tuple(d[3]) if len(d) > 3 else (1, 1, 1))
+        if kind == "exprs_sphere":
+            return sc.f_sphere(d[1], tuple(d[2]) if len(d) > 2 else (1, 1, 1))
+        if kind == "exprs_box":
+            return sc.f_box(d[1], d[2], d[3])
         if kind == "sdfs_sphere":
             return sc.sphere_w(d[1])
         if kind == "sdfs_box":
@@ -154,6 +160,13 @@ def mirror_sdf(descr):
                "sdfs_plane": lambda: Sdfs.Plane((descr[1], descr[2], descr[3]), descr[4])}[kind]()
         sdf.ToSdf = lambda: sdf
         return sdf
+    if kind.startswith("exprs_"):
+        from sdfkit_amd import SdfExprs
+        if kind == "exprs_cylinder":
+            return SdfExprs.Cylinder(descr[1], descr[2], *( [tuple(descr[3])] if len(descr) > 3 else []))
+        if kind == "exprs_sphere":
+            return SdfExprs.Sphere(descr[1], *([tuple(descr[2])] if len(descr) > 2 else []))
+        return SdfExprs.Box((descr[1], descr[2], descr[3]))
     if kind == "sphere":
         return SdfFuncs.Sphere(descr[1])
     if kind == "box":
@@ -198,8 +211,8 @@ PATH_META = __import__("json").loads(str(PATH["meta_json"]))
 def test_oracle_path_equals_the_executed_reference(name):
     """Sample points, index mapping and scatter of Voxels.SampleSdf (Voxels.cs:72-125), the clip value of ClipToBounds
     (:133-167) and the mesh CreateMesh builds from that volume: the oracle's volumes and meshes against the ones the reference's
-    own source produced when executed -- bit for bit.  (Eight of the cases are scenes of the reference's NUnit tests; the executed
-    source gave every vertex count they assert -- 104, 54, 312, 0, 384, 384, 1248, 1248 -- checked by the generator and again here.)"""
+    own source produced when executed -- bit for bit.  (Nine of the cases are scenes of the reference's NUnit tests; the executed
+    source gave every vertex count they assert -- 104, 54, 312, 0, 384, 384, 7456, 1248, 1248 -- checked by the generator and again here.)"""
     md = PATH_META[name]
     sc = oracle_scene(md["scene"])
     nx, ny, nz = md["grid"]
@@ -216,7 +229,7 @@ def test_oracle_path_equals_the_executed_reference(name):
     assert m.impossible13 == md["console_lines"]
     # the vertex counts the reference's own NUnit tests assert for these scenes (Tests/MarchingCubesTests.cs:11-115, Tests/SdfTests.cs:29-52)
     nunit = {"colored_spheres_32": 104, "sphere_32_clipped": 1248, "nunit_sphere5": 54, "nunit_sphere10": 312, "nunit_unclipped_sphere10": 0,
-             "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248}
+             "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248, "nunit_cylinder50": 7456}
     if name in nunit:
         assert len(m.vertices) == len(PATH[f"{name}/vertices"]) == nunit[name]
     if name == "colored_spheres_32":
@@ -257,3 +270,29 @@ def test_path_vectors_regenerate_from_the_reference_source():
     assert np.array_equal(values, PATH[f"{name}/values"]) and np.array_equal(colors, PATH[f"{name}/colors"])
     assert np.array_equal(v, PATH[f"{name}/vertices"]) and np.array_equal(f, PATH[f"{name}/faces"])
     assert np.array_equal(n, PATH[f"{name}/normals"], equal_nan=True)
+
+
+def _digest(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+BIG_PATH = os.path.join(ROOT, "tests", "golden", "reference_path_big.json")
+
+
+@pytest.mark.skipif(not os.path.exists(BIG_PATH), reason="tests/golden/reference_path_big.json not generated")
+def test_oracle_equals_the_executed_reference_at_128_cubed():
+    """Tests/MarchingCubesTests.cs:141-171 (Sdfs.Sphere(3) in 128^3): the reference's source, executed, gives the asserted 72 240
+    vertices; its arrays are kept as SHA-256 digests (2.1 M voxels, 72 k vertices), and the oracle's arrays have the same digests."""
+    import json
+    for name, md in json.load(open(BIG_PATH)).items():
+        sc = oracle_scene(md["scene"])
+        nx, ny, nz = md["grid"]
+        v, c = O.sample(sc, md["min"], md["max"], nx, ny, nz)
+        if md["clip"]:
+            O.clip_to_bounds(v, md["min"], md["max"])
+        m = O.march(v, c, md["min"], md["max"], iso=md["iso"], step=md["step"])
+        assert len(m.vertices) == md["vertices"] == 72240 and len(m.triangles) == md["indices"]
+        got = {"values": _digest(v), "colors": _digest(c), "vertices": _digest(m.grid_vertices), "out_colors": _digest(m.colors),
+               "normals": _digest(m.grid_normals), "faces": _digest(m.triangles)}
+        assert got == md["sha256"]

@@ -9,9 +9,10 @@ it lies under /root/reference and run by tools/cs_subset.py.  `Parallel.For` run
 does not depend on the order: every voxel is written once); `Memory<T>` / `Span<T>` are views of the arrays.
 
 Output, committed: tests/golden/reference_path.npz -- per case the scene description, bounds, grid, clip / iso / step, the sampled
-Values and Colors, and what `new Mesh(...)` receives (MarchingCubes.cs:84).  Eight cases are scenes of the reference's own NUnit
-tests (the batched `Sdfs.Sphere` / `Sdfs.Box` of Sdf.cs:118-214 among them), and the executed source gives every vertex count
-those tests assert: 104, 54, 312, 0, 384, 384, 1248, 1248 (the generator refuses to write the file otherwise).
+Values and Colors, and what `new Mesh(...)` receives (MarchingCubes.cs:84).  Nine cases are scenes of the reference's own NUnit
+tests (the batched `Sdfs.Sphere` / `Sdfs.Box` of Sdf.cs:118-214 and `Sdfs.Cylinder` = `SdfExprs.Cylinder(...).ToSdf()` among them), and
+the executed source gives every vertex count those tests assert: 104, 54, 312, 0, 384, 384, 7456, 1248, 1248 (the generator refuses to
+write the file otherwise); `--big` adds the tenth, the 128^3 sphere with 72 240 vertices, as digests.
 """
 import json
 import os
@@ -73,6 +74,16 @@ def load():
         GS.cut_braced(sdf_cs, r"public static class SdfFuncs\b"),
         GS.cut_braced(sdf_cs, r"public static class SdfFuncEx\b"),
         GS.cut_braced(expr_cs, r"public struct SdfIndexedInput\b"),
+        # the primitives of the expression-tree catalogue are plain expression lambdas (SdfExpr.cs:18-51); what is NOT executed is
+        # the LINQ plumbing that batches them (SdfExprCompiler, SdfExpr.cs:229-273): SdfFuncEx.ToSdf's loop stands in for it
+        "public static class SdfExprs {",
+        GS.cut_braced(expr_cs, r"public static SdfExpr Box\(Vector3 bounds\)"),
+        GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Box\(float bounds\)"),
+        GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Cylinder\(float r, float h, Vector3 color\)"),
+        GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Cylinder\(float r, float h\)"),
+        GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Sphere\(float r, Vector3 color\)"),
+        GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Sphere\(float r\)"),
+        "}",
         "public static class VectorOps {",
         GS.cut_expression_bodied(vec_cs, r"public static float Mod\(float a, float b\)"),
         GS.cut_expression_bodied(vec_cs, r"public static float VMax\(Vector3 v\)"),
@@ -133,6 +144,12 @@ def build(it, d):
     S = lambda *a: it.call_static("SdfFuncs", *a)
     X = lambda recv, name, *a: it.call_extension(recv, name, list(a))
     kind = d[0]
+    if kind == "exprs_cylinder":
+        return it.call_static("SdfExprs", "Cylinder", [f(d[1]), f(d[2])] + ([CS.Vec3(*d[3])] if len(d) > 3 else []))
+    if kind == "exprs_sphere":
+        return it.call_static("SdfExprs", "Sphere", [f(d[1])] + ([CS.Vec3(*d[2])] if len(d) > 2 else []))
+    if kind == "exprs_box":
+        return it.call_static("SdfExprs", "Box", [CS.Vec3(d[1], d[2], d[3])])
     if kind == "sdfs_sphere":
         return it.call_static("Sdfs", "Sphere", [f(d[1])])
     if kind == "sdfs_box":
@@ -175,14 +192,47 @@ CASES = {
     "nunit_clipped_sphere10": (["sdfs_sphere", 2.0], [-1] * 3, [1] * 3, (10, 10, 10), True, 0.0, 1),
     "nunit_box10": (["sdfs_box", 2.0], [-2.5] * 3, [2.5] * 3, (10, 10, 10), False, 0.0, 1),
     "nunit_create_mesh_sphere": (["sdfs_sphere", 0.5], [-1] * 3, [1] * 3, (32, 32, 32), True, 0.0, 1),
+    # Tests/MarchingCubesTests.cs:118-138 (Cylinder50): Sdfs.Cylinder(1, 3) = SdfExprs.Cylinder(1, 3).ToSdf(), 7456 vertices
+    "nunit_cylinder50": (["exprs_cylinder", 1.0, 3.0], [-1.5, -3.5, -1.5], [1.5, 3.5, 1.5], (50, 50, 50), False, 0.0, 1),
+    "exprs_union_coloured": (["union", ["translate", ["exprs_sphere", 0.45, [0.2, 0.4, 0.6]], 0.3, 0.0, -0.2], ["exprs_cylinder", 0.3, 0.5, [0.9, 0.1, 0.4]]],
+                             [-1, -1, -1], [1, 1, 1], (18, 20, 16), True, 0.0, 1),
     "plane_tilted": (["sdfs_plane", 0.3, 0.0, 1.0, 0.05], [-1, -1, -1], [1, 1, 1], (14, 12, 10), False, 0.0, 1),
     "repeat_xz_box_clipped": (["repeat_xz_idx", ["box", 0.3, 0.3, 0.3], 1.5, 0.875], [-2.5, -1.0, -2.0], [2.5, 1.0, 2.0], (21, 9, 25), True, 0.0, 1),
 }
 EXPECT_VERTICES = {"colored_spheres_32": 104, "sphere_32_clipped": 1248, "nunit_sphere5": 54, "nunit_sphere10": 312, "nunit_unclipped_sphere10": 0,
-                   "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248}
+                   "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248, "nunit_cylinder50": 7456}
+
+
+def digest(a):
+    """SHA-256 of the bytes of an array"""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# Tests/MarchingCubesTests.cs:141-171 (Sphere128Progress): 72 240 vertices.  2.1 M voxels through a tree-walking interpreter take
+# minutes, and the arrays are too big for a fixture: `--big` runs it and stores the counts and SHA-256 digests of the arrays.
+BIG = {"nunit_sphere128": (["sdfs_sphere", 3.0], [-3.1] * 3, [3.1] * 3, (128, 128, 128), False, 0.0, 1, 72240)}
+
+
+def main_big():
+    it, console = load()
+    path = os.path.join(ROOT, "tests", "golden", "reference_path_big.json")
+    out = {}
+    for name, (descr, mn, mx, grid, clip, iso, step, expect) in BIG.items():
+        values, colors, v, c, n, f, lines = run_case(it, console, descr, mn, mx, grid, clip, iso, step)
+        print(f"{name}: {len(v)} vertices, {len(f) // 3} triangles")
+        if len(v) != expect:
+            raise SystemExit(f"{name}: the reference's own test asserts {expect} vertices")
+        out[name] = {"scene": descr, "min": mn, "max": mx, "grid": list(grid), "clip": clip, "iso": iso, "step": step, "vertices": len(v), "indices": len(f),
+                     "sha256": {"values": digest(values), "colors": digest(colors), "vertices": digest(v), "out_colors": digest(c),
+                                "normals": digest(n), "faces": digest(f)}}
+    json.dump(out, open(path, "w"), indent=1)
+    print(path)
 
 
 def main():
+    if "--big" in sys.argv:
+        return main_big()
     it, console = load()
     blob, meta = {}, {}
     for name, (descr, mn, mx, grid, clip, iso, step) in CASES.items():

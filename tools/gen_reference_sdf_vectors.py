@@ -84,6 +84,19 @@ class MathFHost:
     def Floor(x):
         return F32(np.floor(F32(x)))
 
+    @staticmethod
+    def Sqrt(x):   # correctly rounded float32 root
+        with np.errstate(all="ignore"):
+            return F32(np.sqrt(F32(x)))
+
+    @staticmethod
+    def Abs(x):
+        return F32(abs(F32(x)))
+
+    @staticmethod
+    def Max(a, b):
+        return MathHost.Max(F32(a), F32(b))
+
 
 def load():
     sdf_cs = open(os.path.join(REF, "Sdf.cs")).read()
