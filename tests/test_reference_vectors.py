@@ -296,3 +296,22 @@ def test_oracle_equals_the_executed_reference_at_128_cubed():
         got = {"values": _digest(v), "colors": _digest(c), "vertices": _digest(m.grid_vertices), "out_colors": _digest(m.colors),
                "normals": _digest(m.grid_normals), "faces": _digest(m.triangles)}
         assert got == md["sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(BIG_PATH), reason="tests/golden/reference_path_big.json not generated")
+def test_hip_path_equals_the_executed_reference_at_128_cubed(gpu):
+    import json
+    from sdfkit_amd import MarchingCubes, Voxels
+    for name, md in json.load(open(BIG_PATH)).items():
+        sdf = mirror_sdf(md["scene"]).ToSdf()
+        nx, ny, nz = md["grid"]
+        vol = Voxels.SampleSdf(sdf, md["min"], md["max"], nx, ny, nz)
+        if md["clip"]:
+            vol.ClipToBounds()
+        assert _digest(np.asarray(vol.Values, np.float32)) == md["sha256"]["values"]
+        assert _digest(np.asarray(vol.Colors, np.float32)) == md["sha256"]["colors"]
+        m = MarchingCubes.CreateMesh(vol, md["iso"], md["step"])
+        assert len(m.Vertices) == md["vertices"] == 72240
+        assert _digest(np.asarray(m.Triangles, np.int32)) == md["sha256"]["faces"]
+        assert _digest(np.asarray(m.Colors, np.float32)) == md["sha256"]["out_colors"]
