@@ -227,6 +227,12 @@ def test_oracle_path_equals_the_executed_reference(name):
     assert np.array_equal(m.colors, PATH[f"{name}/out_colors"])
     assert np.array_equal(m.grid_normals, PATH[f"{name}/normals"], equal_nan=True)
     assert m.impossible13 == md["console_lines"]
+    # ... and the mesh CreateMesh RETURNS: Mesh.cs (constructor, Measure, Transform) and the T S T composition of MarchingCubes.cs:85-90
+    # executed too, over a float32 restatement of the BCL's Matrix4x4 / Vector3.Transform (tools/gen_reference_path_vectors.py)
+    assert np.array_equal(m.vertices, PATH[f"{name}/final_vertices"])
+    assert np.array_equal(m.normals, PATH[f"{name}/final_normals"], equal_nan=True)
+    if len(m.vertices):
+        assert np.array_equal(m.min, PATH[f"{name}/final_min"]) and np.array_equal(m.max, PATH[f"{name}/final_max"])
     # the vertex counts the reference's own NUnit tests assert for these scenes (Tests/MarchingCubesTests.cs:11-115, Tests/SdfTests.cs:29-52)
     nunit = {"colored_spheres_32": 104, "sphere_32_clipped": 1248, "nunit_sphere5": 54, "nunit_sphere10": 312, "nunit_unclipped_sphere10": 0,
              "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248, "nunit_cylinder50": 7456}
@@ -252,10 +258,11 @@ def test_hip_path_volume_and_mesh_equal_the_executed_reference(gpu, name):
     assert np.array_equal(m.Triangles, PATH[f"{name}/faces"])
     assert np.array_equal(m.Colors, PATH[f"{name}/out_colors"])
     assert len(m.Vertices) == len(PATH[f"{name}/vertices"])
-    # positions: the reference's voxel-unit vertices through CreateMesh's T S T (MarchingCubes.cs:85-90), float32, as the oracle restates it
-    om = O.march(PATH[f"{name}/values"], PATH[f"{name}/colors"], md["min"], md["max"], iso=md["iso"], step=md["step"])
-    assert np.array_equal(om.grid_vertices, PATH[f"{name}/vertices"])
-    assert np.array_equal(m.Vertices, om.vertices) and np.array_equal(m.Normals, om.normals, equal_nan=True)
+    # the final arrays: what the reference's CreateMesh returns after Mesh.Transform and Measure (executed: Mesh.cs, MarchingCubes.cs:85-90)
+    assert np.array_equal(m.Vertices, PATH[f"{name}/final_vertices"])
+    assert np.array_equal(m.Normals, PATH[f"{name}/final_normals"], equal_nan=True)
+    if len(m.Vertices):
+        assert np.array_equal(np.asarray(m.Min, np.float32), PATH[f"{name}/final_min"]) and np.array_equal(np.asarray(m.Max, np.float32), PATH[f"{name}/final_max"])
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/SdfKit/Voxels.cs"), reason="the reference tree only exists in the build container")
@@ -266,7 +273,8 @@ def test_path_vectors_regenerate_from_the_reference_source():
     it, console = G.load()
     name = "box_16_clipped_step2"
     descr, mn, mx, grid, clip, iso, step = G.CASES[name]
-    values, colors, v, c, n, f, lines = G.run_case(it, console, descr, mn, mx, grid, clip, iso, step)
+    values, colors, v, c, n, f, lines, final = G.run_case(it, console, descr, mn, mx, grid, clip, iso, step)
+    assert np.array_equal(final["vertices"], PATH[f"{name}/final_vertices"]) and np.array_equal(final["max"], PATH[f"{name}/final_max"])
     assert np.array_equal(values, PATH[f"{name}/values"]) and np.array_equal(colors, PATH[f"{name}/colors"])
     assert np.array_equal(v, PATH[f"{name}/vertices"]) and np.array_equal(f, PATH[f"{name}/faces"])
     assert np.array_equal(n, PATH[f"{name}/normals"], equal_nan=True)

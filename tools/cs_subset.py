@@ -460,7 +460,15 @@ class Parser:
     def parse_args(self, close=")"):
         args = []
         while not self.at(close):
-            args.append(self.parse_expr())
+            if self.at("out"):   # out var name | out name: the callee's result lands in that variable
+                self.eat()
+                declare = False
+                if self.at("var") or (self.peek()[0] == "id" and self.peek(1)[0] == "id"):
+                    self.eat()
+                    declare = True
+                args.append(("outarg", self.ident(), declare))
+            else:
+                args.append(self.parse_expr())
             if self.at(","):
                 self.eat(",")
         self.eat(close)
@@ -686,7 +694,15 @@ def value_copy(v):
         return Vec3(v.X, v.Y, v.Z)
     if isinstance(v, Vec4):
         return Vec4(v.X, v.Y, v.Z, v.W)
+    if not isinstance(v, Opaque) and hasattr(v, "cs_copy"):   # a host struct (Matrix4x4)
+        return v.cs_copy()
     return v
+
+
+class OutRef:
+    """an `out` argument: the host callee assigns .value"""
+    def __init__(self):
+        self.value = None
 
 
 def coerce(v, ty):
@@ -718,6 +734,8 @@ def default_of(ty):
 def arith(op, a, b):
     if isinstance(a, Opaque) or isinstance(b, Opaque):
         return a if isinstance(a, Opaque) else b
+    if op == "*" and hasattr(a, "cs_mul"):
+        return a.cs_mul(b)
     if isinstance(a, Vec3) or isinstance(b, Vec3):
         if isinstance(a, Vec3) and isinstance(b, Vec3):
             if op == "+":
@@ -824,6 +842,9 @@ class Interp:
         ctors = c["methods"].get("$all:.ctor", [])
         if ctors:
             self.construct(o, cname, ctors, args)
+        hook = getattr(self, "on_new", {}).get(cname)
+        if hook:
+            hook(o)
         return o
 
     def construct(self, o, cname, ctors, args):
@@ -1024,6 +1045,26 @@ class Interp:
             return
         raise TypeError(f"not assignable: {k}")
 
+    def eval_args(self, arg_exprs, fr):
+        """argument values; `out` arguments become OutRef objects, bound to their variables by finish_outs()"""
+        vals, outs = [], []
+        for a in arg_exprs:
+            if a[0] == "outarg":
+                r = OutRef()
+                outs.append((a, r))
+                vals.append(r)
+            else:
+                vals.append(self.eval(a, fr))
+        return vals, outs
+
+    def finish_outs(self, outs, fr):
+        for (_, name, declare), r in outs:
+            if declare:
+                fr["vars"][-1][name] = value_copy(r.value)
+                fr["types"][-1][name] = None
+            else:
+                self.store(("name", name), r.value, fr)
+
     # -- expressions
     def eval(self, e, fr):
         k = e[0]
@@ -1107,7 +1148,11 @@ class Interp:
             if f[0] == "member":   # obj.Method(args): an interpreted instance, a class (static), a List<T>, a host object
                 obj = self.eval(f[1], fr)
                 name = f[2]
-                args = [self.eval(a, fr) for a in e[2]]
+                args, outs = self.eval_args(e[2], fr)
+                if outs:
+                    r = getattr(obj, name)(*args)
+                    self.finish_outs(outs, fr)
+                    return r
                 if isinstance(obj, Instance):
                     m = self.pick(obj.cname, name, args)
                     if m is not None:

@@ -68,6 +68,10 @@ def load():
         GS.cut_braced(vox_cs, r"public void ClipToBounds\(\)"),
         "}",
     ])
+    mesh_cs = open(os.path.join(REF, "Mesh.cs")).read()
+    mesh_head = mesh_cs[mesh_cs.index("{", mesh_cs.index("public class Mesh")) + 1:mesh_cs.index("public Mesh(Vector3[] vertices")]
+    mesh = "\n".join(["public class Mesh {", mesh_head, GS.cut_braced(mesh_cs, r"public Mesh\(Vector3\[\] vertices"),
+                      GS.cut_braced(mesh_cs, r"void Measure\(\)"), GS.cut_braced(mesh_cs, r"public void Transform\(Matrix4x4 transform\)"), "}"])
     text = "\n".join([
         GS.cut_braced(sdf_cs, r"public class SdfConfig\b"),
         GS.cut_braced(sdf_cs, r"public static class Sdfs\b"),
@@ -89,6 +93,7 @@ def load():
         GS.cut_expression_bodied(vec_cs, r"public static float VMax\(Vector3 v\)"),
         "}",
         voxels,
+        mesh,
         open(os.path.join(REF, "MarchingCubes.cs")).read(),
         open(os.path.join(REF, "Cell.cs")).read(),
     ])
@@ -101,15 +106,110 @@ def load():
     system.Threading.Tasks = Namespace()
     system.Threading.Tasks.Parallel = ParallelHost
     console = GM.ConsoleHost()
-    hosts = {"Luts": luts, "Math": MathHost, "MathF": GS.MathFHost, "Console": console, "Vector3": Vector3Host, "Matrix4x4": GM.OpaqueCallable(),
-             "Mesh": GM.MeshCapture, "System": system, "ParallelOptions": ParallelOptions}
+    hosts = {"Luts": luts, "Math": MathHost, "MathF": GS.MathFHost, "Console": console, "Vector3": Vector3Host, "Matrix4x4": Matrix4x4,
+             "System": system, "ParallelOptions": ParallelOptions}
     it = CS.Interp(classes, hosts)
     it.static_imports = ["VectorOps"]
+    # what `new Mesh(...)` receives at MarchingCubes.cs:84, before Mesh.Transform overwrites the arrays in place
+    it.on_new = {"Mesh": lambda o: PRE.update(vertices=[CS.value_copy(q) for q in o.f["Vertices"]], colors=[CS.value_copy(q) for q in o.f["Colors"]],
+                                              normals=[CS.value_copy(q) for q in o.f["Normals"]], faces=list(o.f["Triangles"]))}
     return it, console
+
+
+PRE = {}
+
+
+class Matrix4x4:
+    """System.Numerics.Matrix4x4 (BCL, not reference code), float32, software path, as oracle/sdfk_oracle.h documents it: row-vector
+    convention, every product summed left to right with one rounding per operation, Invert by cofactor expansion."""
+    NAMES = [f"M{r}{c}" for r in range(1, 5) for c in range(1, 5)]
+
+    def __init__(self, vals=None):
+        vals = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1] if vals is None else vals
+        for n, v in zip(self.NAMES, vals):
+            object.__setattr__(self, n, F32(v))
+
+    def __setattr__(self, n, v):
+        if CS.is_f64(v):
+            raise TypeError("double into a float field")
+        object.__setattr__(self, n, F32(v))
+
+    def vals(self):
+        return [getattr(self, n) for n in self.NAMES]
+
+    def cs_copy(self):
+        return Matrix4x4(self.vals())
+
+    def cs_mul(self, o):
+        a, b = np.array(self.vals(), dtype=np.float32).reshape(4, 4), np.array(o.vals(), dtype=np.float32).reshape(4, 4)
+        out = []
+        for r in range(4):
+            for c in range(4):
+                out.append(F32(F32(F32(F32(a[r, 0] * b[0, c]) + F32(a[r, 1] * b[1, c])) + F32(a[r, 2] * b[2, c])) + F32(a[r, 3] * b[3, c])))
+        return Matrix4x4(out)
+
+    @staticmethod
+    def CreateTranslation(*a):
+        x, y, z = (a[0].X, a[0].Y, a[0].Z) if len(a) == 1 else a
+        if any(CS.is_f64(q) for q in (x, y, z)):
+            raise TypeError("double argument")
+        return Matrix4x4([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, x, y, z, 1])
+
+    @staticmethod
+    def CreateScale(x, y, z):
+        if any(CS.is_f64(q) for q in (x, y, z)):
+            raise TypeError("double argument")
+        return Matrix4x4([x, 0, 0, 0, 0, y, 0, 0, 0, 0, z, 0, 0, 0, 0, 1])
+
+    @staticmethod
+    def Transpose(m):
+        v = np.array(m.vals(), dtype=np.float32).reshape(4, 4).T
+        return Matrix4x4(list(v.ravel()))
+
+    @staticmethod
+    def Invert(mat, out):
+        a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p = mat.vals()
+        with np.errstate(all="ignore"):
+            kp_lo, jp_ln, jo_kn = F32(F32(k * p) - F32(l * o)), F32(F32(j * p) - F32(l * n)), F32(F32(j * o) - F32(k * n))
+            ip_lm, io_km, in_jm = F32(F32(i * p) - F32(l * m)), F32(F32(i * o) - F32(k * m)), F32(F32(i * n) - F32(j * m))
+            a11 = F32(F32(F32(f * kp_lo) - F32(g * jp_ln)) + F32(h * jo_kn))
+            a12 = F32(-F32(F32(F32(e * kp_lo) - F32(g * ip_lm)) + F32(h * io_km)))
+            a13 = F32(F32(F32(e * jp_ln) - F32(f * ip_lm)) + F32(h * in_jm))
+            a14 = F32(-F32(F32(F32(e * jo_kn) - F32(f * io_km)) + F32(g * in_jm)))
+            det = F32(F32(F32(F32(a * a11) + F32(b * a12)) + F32(c * a13)) + F32(d * a14))
+            if abs(det) < np.finfo(np.float32).smallest_subnormal:
+                out.value = Matrix4x4([np.nan] * 16)
+                return False
+            inv = F32(F32(1) / det)
+            gp_ho, fp_hn, fo_gn = F32(F32(g * p) - F32(h * o)), F32(F32(f * p) - F32(h * n)), F32(F32(f * o) - F32(g * n))
+            ep_hm, eo_gm, en_fm = F32(F32(e * p) - F32(h * m)), F32(F32(e * o) - F32(g * m)), F32(F32(e * n) - F32(f * m))
+            gl_hk, fl_hj, fk_gj = F32(F32(g * l) - F32(h * k)), F32(F32(f * l) - F32(h * j)), F32(F32(f * k) - F32(g * j))
+            el_hi, ek_gi, ej_fi = F32(F32(e * l) - F32(h * i)), F32(F32(e * k) - F32(g * i)), F32(F32(e * j) - F32(f * i))
+            t = lambda x, y, z, u, v, w, sign: F32(F32(sign * F32(F32(F32(x * u) - F32(y * v)) + F32(z * w))) * inv)
+            r = [F32(a11 * inv), t(b, c, d, kp_lo, jp_ln, jo_kn, -1), t(b, c, d, gp_ho, fp_hn, fo_gn, 1), t(b, c, d, gl_hk, fl_hj, fk_gj, -1),
+                 F32(a12 * inv), t(a, c, d, kp_lo, ip_lm, io_km, 1), t(a, c, d, gp_ho, ep_hm, eo_gm, -1), t(a, c, d, gl_hk, el_hi, ek_gi, 1),
+                 F32(a13 * inv), t(a, b, d, jp_ln, ip_lm, in_jm, -1), t(a, b, d, fp_hn, ep_hm, en_fm, 1), t(a, b, d, fl_hj, el_hi, ej_fi, -1),
+                 F32(a14 * inv), t(a, b, c, jo_kn, io_km, in_jm, 1), t(a, b, c, fo_gn, eo_gm, en_fm, -1), t(a, b, c, fk_gj, ek_gi, ej_fi, 1)]
+        out.value = Matrix4x4(r)
+        return True
 
 
 class Vector3Host(GS.Vector3Host):
     Normalize = staticmethod(GM.Vector3Host.Normalize)
+
+    @staticmethod
+    def Transform(v, m):   # BCL: position . matrix, row vector, products summed left to right, + the translation row
+        with np.errstate(all="ignore"):
+            return CS.Vec3(F32(F32(F32(F32(v.X * m.M11) + F32(v.Y * m.M21)) + F32(v.Z * m.M31)) + m.M41),
+                           F32(F32(F32(F32(v.X * m.M12) + F32(v.Y * m.M22)) + F32(v.Z * m.M32)) + m.M42),
+                           F32(F32(F32(F32(v.X * m.M13) + F32(v.Y * m.M23)) + F32(v.Z * m.M33)) + m.M43))
+
+    @staticmethod
+    def TransformNormal(v, m):
+        with np.errstate(all="ignore"):
+            return CS.Vec3(F32(F32(F32(v.X * m.M11) + F32(v.Y * m.M21)) + F32(v.Z * m.M31)),
+                           F32(F32(F32(v.X * m.M12) + F32(v.Y * m.M22)) + F32(v.Z * m.M32)),
+                           F32(F32(F32(v.X * m.M13) + F32(v.Y * m.M23)) + F32(v.Z * m.M33)))
 
     @staticmethod
     def Dot(a, b):   # BCL: the three products summed left to right in float32
@@ -132,11 +232,13 @@ def run_case(it, console, descr, mn, mx, grid, clip, iso, step):
         c = vox.f["Colors"][ix]
         colors[ix] = (c.X, c.Y, c.Z)
     console.lines.clear()
-    GM.MeshCapture.last = None
-    it.call_static("MarchingCubes", "CreateMesh", [vox, F32(iso), int(step), None])
-    m = GM.MeshCapture.last
+    PRE.clear()
+    mesh = it.call_static("MarchingCubes", "CreateMesh", [vox, F32(iso), int(step), None])
     v3 = lambda lst: np.array([[q.X, q.Y, q.Z] for q in lst], dtype=np.float32).reshape(-1, 3)
-    return values, colors, v3(m.vertices), v3(m.colors), v3(m.normals), np.array(m.faces, dtype=np.int32), len(console.lines)
+    final = {"vertices": v3(mesh.f["Vertices"]), "normals": v3(mesh.f["Normals"]),
+             "min": np.array([mesh.f["Min"].X, mesh.f["Min"].Y, mesh.f["Min"].Z], dtype=np.float32),
+             "max": np.array([mesh.f["Max"].X, mesh.f["Max"].Y, mesh.f["Max"].Z], dtype=np.float32)}
+    return values, colors, v3(PRE["vertices"]), v3(PRE["colors"]), v3(PRE["normals"]), np.array(PRE["faces"], dtype=np.int32), len(console.lines), final
 
 
 def build(it, d):
@@ -219,13 +321,15 @@ def main_big():
     path = os.path.join(ROOT, "tests", "golden", "reference_path_big.json")
     out = {}
     for name, (descr, mn, mx, grid, clip, iso, step, expect) in BIG.items():
-        values, colors, v, c, n, f, lines = run_case(it, console, descr, mn, mx, grid, clip, iso, step)
+        values, colors, v, c, n, f, lines, final = run_case(it, console, descr, mn, mx, grid, clip, iso, step)
         print(f"{name}: {len(v)} vertices, {len(f) // 3} triangles")
         if len(v) != expect:
             raise SystemExit(f"{name}: the reference's own test asserts {expect} vertices")
         out[name] = {"scene": descr, "min": mn, "max": mx, "grid": list(grid), "clip": clip, "iso": iso, "step": step, "vertices": len(v), "indices": len(f),
                      "sha256": {"values": digest(values), "colors": digest(colors), "vertices": digest(v), "out_colors": digest(c),
-                                "normals": digest(n), "faces": digest(f)}}
+                                "normals": digest(n), "faces": digest(f), "final_vertices": digest(final["vertices"]),
+                                "final_normals": digest(final["normals"])},
+                     "final_min": [float(q) for q in final["min"]], "final_max": [float(q) for q in final["max"]]}
     json.dump(out, open(path, "w"), indent=1)
     print(path)
 
@@ -236,13 +340,16 @@ def main():
     it, console = load()
     blob, meta = {}, {}
     for name, (descr, mn, mx, grid, clip, iso, step) in CASES.items():
-        values, colors, v, c, n, f, lines = run_case(it, console, descr, mn, mx, grid, clip, iso, step)
+        values, colors, v, c, n, f, lines, final = run_case(it, console, descr, mn, mx, grid, clip, iso, step)
         print(f"{name}: grid {grid} clip {clip} iso {iso} step {step} -> {len(v)} vertices, {len(f) // 3} triangles, {lines} console lines")
         if name in EXPECT_VERTICES and len(v) != EXPECT_VERTICES[name]:
             raise SystemExit(f"{name}: the reference's own test asserts {EXPECT_VERTICES[name]} vertices")
         meta[name] = {"scene": descr, "min": mn, "max": mx, "grid": list(grid), "clip": clip, "iso": iso, "step": step, "console_lines": lines}
         blob[f"{name}/values"], blob[f"{name}/colors"] = values, colors
         blob[f"{name}/vertices"], blob[f"{name}/out_colors"], blob[f"{name}/normals"], blob[f"{name}/faces"] = v, c, n, f
+        # ... and the mesh CreateMesh returns: after Mesh.Transform (Mesh.cs:47-64) with T(-(n-1)/2) S(size/(n-1)) T(center), Measure'd
+        blob[f"{name}/final_vertices"], blob[f"{name}/final_normals"] = final["vertices"], final["normals"]
+        blob[f"{name}/final_min"], blob[f"{name}/final_max"] = final["min"], final["max"]
     blob["meta_json"] = np.array(json.dumps(meta))
     path = os.path.join(ROOT, "tests", "golden", "reference_path.npz")
     np.savez_compressed(path, **blob)
