@@ -48,7 +48,6 @@ def lex(text):
     return out
 
 
-PRIMS = {"int", "double", "float", "bool", "sbyte", "void", "var", "string"}
 MODIFIERS = {"public", "private", "internal", "protected", "static", "readonly", "const", "sealed", "partial", "unsafe", "override", "virtual"}
 
 
@@ -801,8 +800,6 @@ def arith(op, a, b):
 
 
 def compare(op, a, b):
-    if isinstance(a, (F32, np.integer)) and not is_f64(b):
-        pass
     if is_f64(a) or is_f64(b):
         a, b = float(a), float(b)
     elif isinstance(a, F32) or isinstance(b, F32):
