@@ -302,8 +302,10 @@ def test_oracle_equals_the_executed_reference_at_128_cubed():
         m = O.march(v, c, md["min"], md["max"], iso=md["iso"], step=md["step"])
         assert len(m.vertices) == md["vertices"] == 72240 and len(m.triangles) == md["indices"]
         got = {"values": _digest(v), "colors": _digest(c), "vertices": _digest(m.grid_vertices), "out_colors": _digest(m.colors),
-               "normals": _digest(m.grid_normals), "faces": _digest(m.triangles)}
+               "normals": _digest(m.grid_normals), "faces": _digest(m.triangles), "final_vertices": _digest(m.vertices),
+               "final_normals": _digest(m.normals)}
         assert got == md["sha256"]
+        assert np.array_equal(m.min, np.array(md["final_min"], np.float32)) and np.array_equal(m.max, np.array(md["final_max"], np.float32))
 
 
 @pytest.mark.gpu
@@ -323,3 +325,5 @@ def test_hip_path_equals_the_executed_reference_at_128_cubed(gpu):
         assert len(m.Vertices) == md["vertices"] == 72240
         assert _digest(np.asarray(m.Triangles, np.int32)) == md["sha256"]["faces"]
         assert _digest(np.asarray(m.Colors, np.float32)) == md["sha256"]["out_colors"]
+        assert _digest(np.asarray(m.Vertices, np.float32)) == md["sha256"]["final_vertices"]
+        assert _digest(np.asarray(m.Normals, np.float32)) == md["sha256"]["final_normals"]
