@@ -1169,6 +1169,8 @@ class Interp:
                         return None
                     if name == "ToArray":
                         return list(obj)
+                if not isinstance(obj, Opaque) and not hasattr(obj, name):   # an extension method on a value / host type
+                    return self.call_extension(obj, name, args)
                 return getattr(obj, name)(*args)
             args = [self.eval(a, fr) for a in e[2]]
             if f[0] == "name":
