@@ -103,6 +103,22 @@ def oracle_scene(descr):
 
     def build(d):
         kind = d[0]
+        if kind == "exprs_union":
+            return sc.f_union(build(d[1]), build(d[2]))
+        if kind == "exprs_color":
+            return sc.f_with_color(build(d[1]), d[2], d[3], d[4])
+        if kind == "exprs_translate":
+            return sc.f_translate(build(d[1]), d[2], d[3], d[4])
+        if kind == "exprs_repeat_x":
+            return sc.f_repeat_x(build(d[1]), d[2])
+        if kind == "exprs_repeat_y":
+            return sc.f_repeat_y(build(d[1]), d[2])
+        if kind == "exprs_repeat_xy":
+            return sc.f_repeat_xy(build(d[1]), d[2], d[3])
+        if kind == "exprs_repeat_xy_idx":
+            return sc.f_repeat_xy_idx(build(d[1]), d[2], d[3])
+        if kind == "exprs_repeat_xz_idx":
+            return sc.f_repeat_xz_idx(build(d[1]), d[2], d[3])
         if kind == "exprs_cylinder":
             return sc.f_cylinder(d[1], d[2], tuple(d[3]) if len(d) > 3 else (1, 1, 1))
         if kind == "exprs_sphere":
@@ -160,6 +176,26 @@ def mirror_sdf(descr):
                "sdfs_plane": lambda: Sdfs.Plane((descr[1], descr[2], descr[3]), descr[4])}[kind]()
         sdf.ToSdf = lambda: sdf
         return sdf
+    if kind in ("exprs_union", "exprs_color", "exprs_translate", "exprs_repeat_x", "exprs_repeat_y", "exprs_repeat_xy", "exprs_repeat_xy_idx", "exprs_repeat_xz_idx"):
+        from sdfkit_amd import SdfExprs, Vec3
+        from tests.scenes import _readme_color
+        if kind == "exprs_union":
+            return SdfExprs.Union(mirror_sdf(descr[1]), mirror_sdf(descr[2]))
+        child = mirror_sdf(descr[1])
+        if kind == "exprs_color":
+            return child.Color(descr[2], descr[3], descr[4])
+        if kind == "exprs_translate":
+            off = (descr[2], descr[3], descr[4])
+            return child.ModifyInput(lambda p: p - Vec3.of(p.x.b, off))
+        if kind == "exprs_repeat_x":
+            return child.RepeatX(descr[2])
+        if kind == "exprs_repeat_y":
+            return child.RepeatY(descr[2])
+        if kind == "exprs_repeat_xy":
+            return child.RepeatXY(descr[2], descr[3])
+        if kind == "exprs_repeat_xy_idx":
+            return child.RepeatXY(descr[2], descr[3], _readme_color)
+        return child.RepeatXZ(descr[2], descr[3], _readme_color)
     if kind.startswith("exprs_"):
         from sdfkit_amd import SdfExprs
         if kind == "exprs_cylinder":

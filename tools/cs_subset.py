@@ -537,6 +537,18 @@ class Parser:
                 return ("tuple", items)
             self.eat(")")
             return ("paren", e)
+        if v == "typeof":
+            self.eat()
+            self.eat("(")
+            ty = self.try_type()
+            self.eat(")")
+            return ("lit", ("typeof", ty[1]))
+        if v == "new" and self.peek(1)[1] == "[" and self.peek(2)[1] == "]":   # new[] { a, b }: an implicitly typed array
+            self.eat()
+            self.eat("[")
+            self.eat("]")
+            self.eat("{")
+            return ("arraylit", self.parse_args("}"))
         if v == "new":
             self.eat()
             if self.at("("):   # target-typed new(capacity): an empty List<T>
@@ -1201,6 +1213,8 @@ class Interp:
             if e[1] in self.classes:
                 return self.new(e[1], args)
             return self.hosts[e[1]](*args)
+        if k == "arraylit":
+            return [self.eval(q, fr) for q in e[1]]
         if k == "lambda":
             return Closure(self, e[1], e[2], fr)
         if k == "cond":

@@ -87,7 +87,11 @@ def load():
         GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Cylinder\(float r, float h\)"),
         GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Sphere\(float r, Vector3 color\)"),
         GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Sphere\(float r\)"),
+        GS.cut_braced(expr_cs, r"public static SdfExpr Union\(SdfExpr a, SdfExpr b\)"),
+        GS.cut_braced(expr_cs, r"public static SdfExpr Solid\(SdfDistExpr sdf, Vector3 color\)"),
         "}",
+        # the combinators: LINQ expression trees (SdfExpr.cs:76-212), built through ExpressionHost and evaluated as built
+        GS.cut_braced(expr_cs, r"public static class SdfExprEx\b"),
         "public static class VectorOps {",
         GS.cut_expression_bodied(vec_cs, r"public static float Mod\(float a, float b\)"),
         GS.cut_expression_bodied(vec_cs, r"public static float VMax\(Vector3 v\)"),
@@ -107,7 +111,9 @@ def load():
     system.Threading.Tasks.Parallel = ParallelHost
     console = GM.ConsoleHost()
     hosts = {"Luts": luts, "Math": MathHost, "MathF": GS.MathFHost, "Console": console, "Vector3": Vector3Host, "Matrix4x4": Matrix4x4,
-             "System": system, "ParallelOptions": ParallelOptions}
+             "System": system, "ParallelOptions": ParallelOptions, "Expression": ExpressionHost,
+             # the reflection handles of SdfExprMembers / SdfExprs (SdfExpr.cs:33, 216-225): what they denote
+             "Vector4Ctor": lambda v, w: CS.Vec4(v, w), "WOfVector4": "W", "PositionOfInstance": "Position", "CellOfInstance": "Index"}
     it = CS.Interp(classes, hosts)
     it.static_imports = ["VectorOps"]
     # what `new Mesh(...)` receives at MarchingCubes.cs:84, before Mesh.Transform overwrites the arrays in place
@@ -117,6 +123,102 @@ def load():
 
 
 PRE = {}
+
+
+class ParamEx:
+    def __init__(self, name):
+        self.name = name
+
+
+class LambdaEx:
+    """System.Linq.Expressions.Expression<TDelegate> built by Expression.Lambda: evaluated directly (Compile() is the identity)."""
+    def __init__(self, body, params):
+        self.body, self.params = body, params
+
+    def __call__(self, *args):
+        return ev(self.body, dict(zip(self.params, args)))
+
+    def Compile(self, *a):
+        return self
+
+
+def ev(n, env):
+    if isinstance(n, ParamEx):
+        return env[n]
+    if not (isinstance(n, tuple) and n and isinstance(n[0], str) and n[0].startswith("ex:")):
+        return n   # a constant that was passed as it is
+    k = n[0]
+    if k == "ex:invoke":
+        return n[1](*[ev(a, env) for a in n[2]])
+    if k == "ex:block":
+        r = None
+        for q in n[2]:
+            r = ev(q, env)
+        return r
+    if k == "ex:assign":
+        env[n[1]] = CS.value_copy(ev(n[2], env))
+        return env[n[1]]
+    if k == "ex:cond":
+        return ev(n[2], env) if ev(n[1], env) else ev(n[3], env)
+    if k == "ex:lt":
+        return CS.compare("<", ev(n[1], env), ev(n[2], env))
+    if k == "ex:field":
+        o = ev(n[1], env)
+        return o.f[n[2]] if isinstance(o, CS.Instance) else getattr(o, n[2])
+    if k == "ex:new":
+        return n[1](*[ev(a, env) for a in n[2]])
+    if k == "ex:const":
+        return n[1]
+    raise NotImplementedError(k)
+
+
+class ExpressionHost:
+    """the handful of System.Linq.Expressions factory methods SdfExpr.cs:16-212 calls (BCL, not reference code)"""
+    @staticmethod
+    def Parameter(ty, name):
+        return ParamEx(name)
+
+    Variable = Parameter
+
+    @staticmethod
+    def Invoke(target, *args):
+        return ("ex:invoke", target, args)
+
+    @staticmethod
+    def Lambda(body, *params):
+        flat = []
+        for q in params:
+            flat += list(q) if isinstance(q, list) else [q]
+        return LambdaEx(body, flat)
+
+    @staticmethod
+    def Block(*a):
+        vars_, exprs = (a[0], a[1:]) if isinstance(a[0], list) else ([], a)
+        return ("ex:block", vars_, exprs)
+
+    @staticmethod
+    def Assign(v, e):
+        return ("ex:assign", v, e)
+
+    @staticmethod
+    def Condition(t, a, b):
+        return ("ex:cond", t, a, b)
+
+    @staticmethod
+    def LessThan(a, b):
+        return ("ex:lt", a, b)
+
+    @staticmethod
+    def Field(e, info):
+        return ("ex:field", e, info)
+
+    @staticmethod
+    def New(ctor, *args):
+        return ("ex:new", ctor, args)
+
+    @staticmethod
+    def Constant(v):
+        return ("ex:const", v)
 
 
 class Matrix4x4:
@@ -246,6 +348,24 @@ def build(it, d):
     S = lambda *a: it.call_static("SdfFuncs", *a)
     X = lambda recv, name, *a: it.call_extension(recv, name, list(a))
     kind = d[0]
+    if kind in ("exprs_union", "exprs_color", "exprs_translate", "exprs_repeat_x", "exprs_repeat_y", "exprs_repeat_xy", "exprs_repeat_xy_idx", "exprs_repeat_xz_idx"):
+        E = lambda recv, name, *a: it.call_extension(recv, name, list(a))
+        if kind == "exprs_union":
+            return it.call_static("SdfExprs", "Union", [build(it, d[1]), build(it, d[2])])
+        if kind == "exprs_color":
+            return E(build(it, d[1]), "Color", f(d[2]), f(d[3]), f(d[4]))
+        if kind == "exprs_translate":   # sdf.ModifyInput(p => p - offset): the caller's lambda (BASELINE config C4), a closure over `offset`
+            off = CS.Vec3(d[2], d[3], d[4])
+            return E(build(it, d[1]), "ModifyInput", lambda p: CS.arith("-", p, off))
+        if kind == "exprs_repeat_x":
+            return E(build(it, d[1]), "RepeatX", f(d[2]))
+        if kind == "exprs_repeat_y":
+            return E(build(it, d[1]), "RepeatY", f(d[2]))
+        if kind == "exprs_repeat_xy":
+            return E(build(it, d[1]), "RepeatXY", f(d[2]), f(d[3]))
+        user = CS.Interp(CS.parse(GS.README_COLOUR), {"Vector3": GS.Vector3Host})
+        colour = lambda i, p, q: user.call_static("UserCode", "Colour", [i, p, q])
+        return E(build(it, d[1]), "RepeatXY" if kind == "exprs_repeat_xy_idx" else "RepeatXZ", f(d[2]), f(d[3]), colour)
     if kind == "exprs_cylinder":
         return it.call_static("SdfExprs", "Cylinder", [f(d[1]), f(d[2])] + ([CS.Vec3(*d[3])] if len(d) > 3 else []))
     if kind == "exprs_sphere":
@@ -298,6 +418,14 @@ CASES = {
     "nunit_cylinder50": (["exprs_cylinder", 1.0, 3.0], [-1.5, -3.5, -1.5], [1.5, 3.5, 1.5], (50, 50, 50), False, 0.0, 1),
     "exprs_union_coloured": (["union", ["translate", ["exprs_sphere", 0.45, [0.2, 0.4, 0.6]], 0.3, 0.0, -0.2], ["exprs_cylinder", 0.3, 0.5, [0.9, 0.1, 0.4]]],
                              [-1, -1, -1], [1, 1, 1], (18, 20, 16), True, 0.0, 1),
+    # the expression-tree catalogue (SdfExpr.cs:53-212), its LINQ trees built and evaluated: the README scene as the README writes it,
+    # nested unions with translated primitives (BASELINE config C4's construction, three of its eight), plain repeats, Color
+    "exprs_readme_24_clipped": (["exprs_repeat_xy_idx", ["exprs_sphere", 0.5], 1.125, 1.125], [-2.8125] * 3, [2.8125] * 3, (24, 24, 24), True, 0.0, 1),
+    "exprs_union3_translated": (["exprs_union", ["exprs_union", ["exprs_translate", ["exprs_sphere", 0.6], -1, -1, -1], ["exprs_translate", ["exprs_box", 0.5, 0.5, 0.5], 1, -1, -1]],
+                                 ["exprs_translate", ["exprs_cylinder", 0.4, 0.6], -1, 1, -1]], [-2, -2, -2], [2, 2, 2], (22, 20, 12), True, 0.0, 1),
+    "exprs_repeat_x_y_colour": (["exprs_repeat_y", ["exprs_repeat_x", ["exprs_color", ["exprs_sphere", 0.3], 0.2, 0.4, 0.6], 0.9], 1.1], [-2, -2, -1], [2, 2, 1],
+                                (21, 19, 9), True, 0.0, 1),
+    "exprs_repeat_xy_plain": (["exprs_repeat_xy", ["exprs_box", 0.25, 0.35, 0.3], 1.0, 1.25], [-2, -2, -1], [2, 2, 1], (20, 22, 10), False, 0.0, 1),
     "plane_tilted": (["sdfs_plane", 0.3, 0.0, 1.0, 0.05], [-1, -1, -1], [1, 1, 1], (14, 12, 10), False, 0.0, 1),
     "repeat_xz_box_clipped": (["repeat_xz_idx", ["box", 0.3, 0.3, 0.3], 1.5, 0.875], [-2.5, -1.0, -2.0], [2.5, 1.0, 2.0], (21, 9, 25), True, 0.0, 1),
 }
