@@ -103,6 +103,8 @@ def oracle_scene(descr):
 
     def build(d):
         kind = d[0]
+        if kind == "exprs_solid_sphere":
+            return sc.f_sphere(d[1])
         if kind == "exprs_union":
             return sc.f_union(build(d[1]), build(d[2]))
         if kind == "exprs_color":
@@ -198,6 +200,9 @@ def mirror_sdf(descr):
         return child.RepeatXZ(descr[2], descr[3], _readme_color)
     if kind.startswith("exprs_"):
         from sdfkit_amd import SdfExprs
+        if kind == "exprs_solid_sphere":
+            r = np.float32(descr[1])
+            return SdfExprs.Solid(lambda p: p.Length() - r)
         if kind == "exprs_cylinder":
             return SdfExprs.Cylinder(descr[1], descr[2], *( [tuple(descr[3])] if len(descr) > 3 else []))
         if kind == "exprs_sphere":
@@ -271,7 +276,7 @@ def test_oracle_path_equals_the_executed_reference(name):
         assert np.array_equal(m.min, PATH[f"{name}/final_min"]) and np.array_equal(m.max, PATH[f"{name}/final_max"])
     # the vertex counts the reference's own NUnit tests assert for these scenes (Tests/MarchingCubesTests.cs:11-115, Tests/SdfTests.cs:29-52)
     nunit = {"colored_spheres_32": 104, "sphere_32_clipped": 1248, "nunit_sphere5": 54, "nunit_sphere10": 312, "nunit_unclipped_sphere10": 0,
-             "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248, "nunit_cylinder50": 7456}
+             "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248, "nunit_cylinder50": 7456, "nunit_solid_sphere": 1248}
     if name in nunit:
         assert len(m.vertices) == len(PATH[f"{name}/vertices"]) == nunit[name]
     if name == "colored_spheres_32":

@@ -89,6 +89,7 @@ def load():
         GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Sphere\(float r\)"),
         GS.cut_braced(expr_cs, r"public static SdfExpr Union\(SdfExpr a, SdfExpr b\)"),
         GS.cut_braced(expr_cs, r"public static SdfExpr Solid\(SdfDistExpr sdf, Vector3 color\)"),
+        GS.cut_expression_bodied(expr_cs, r"public static SdfExpr Solid\(SdfDistExpr sdf\)"),
         "}",
         # the combinators: LINQ expression trees (SdfExpr.cs:76-212), built through ExpressionHost and evaluated as built
         GS.cut_braced(expr_cs, r"public static class SdfExprEx\b"),
@@ -366,6 +367,9 @@ def build(it, d):
         user = CS.Interp(CS.parse(GS.README_COLOUR), {"Vector3": GS.Vector3Host})
         colour = lambda i, p, q: user.call_static("UserCode", "Colour", [i, p, q])
         return E(build(it, d[1]), "RepeatXY" if kind == "exprs_repeat_xy_idx" else "RepeatXZ", f(d[2]), f(d[3]), colour)
+    if kind == "exprs_solid_sphere":   # SdfExprs.Solid(p => p.Length() - r): the caller's distance lambda (Tests/SdfTests.cs:42-52)
+        user = CS.Interp(CS.parse("public static class UserDist { public static float D(Vector3 p, float r) => p.Length() - r; }"), {})
+        return it.call_static("SdfExprs", "Solid", [lambda p: user.call_static("UserDist", "D", [p, f(d[1])])])
     if kind == "exprs_cylinder":
         return it.call_static("SdfExprs", "Cylinder", [f(d[1]), f(d[2])] + ([CS.Vec3(*d[3])] if len(d) > 3 else []))
     if kind == "exprs_sphere":
@@ -420,6 +424,8 @@ CASES = {
                              [-1, -1, -1], [1, 1, 1], (18, 20, 16), True, 0.0, 1),
     # the expression-tree catalogue (SdfExpr.cs:53-212), its LINQ trees built and evaluated: the README scene as the README writes it,
     # nested unions with translated primitives (BASELINE config C4's construction, three of its eight), plain repeats, Color
+    # Tests/SdfTests.cs:42-52 (SolidSphere): SdfExprs.Solid(p => p.Length() - 0.5f) in 32^3, clipped: 1248 vertices
+    "nunit_solid_sphere": (["exprs_solid_sphere", 0.5], [-1] * 3, [1] * 3, (32, 32, 32), True, 0.0, 1),
     "exprs_readme_24_clipped": (["exprs_repeat_xy_idx", ["exprs_sphere", 0.5], 1.125, 1.125], [-2.8125] * 3, [2.8125] * 3, (24, 24, 24), True, 0.0, 1),
     "exprs_union3_translated": (["exprs_union", ["exprs_union", ["exprs_translate", ["exprs_sphere", 0.6], -1, -1, -1], ["exprs_translate", ["exprs_box", 0.5, 0.5, 0.5], 1, -1, -1]],
                                  ["exprs_translate", ["exprs_cylinder", 0.4, 0.6], -1, 1, -1]], [-2, -2, -2], [2, 2, 2], (22, 20, 12), True, 0.0, 1),
@@ -430,7 +436,8 @@ CASES = {
     "repeat_xz_box_clipped": (["repeat_xz_idx", ["box", 0.3, 0.3, 0.3], 1.5, 0.875], [-2.5, -1.0, -2.0], [2.5, 1.0, 2.0], (21, 9, 25), True, 0.0, 1),
 }
 EXPECT_VERTICES = {"colored_spheres_32": 104, "sphere_32_clipped": 1248, "nunit_sphere5": 54, "nunit_sphere10": 312, "nunit_unclipped_sphere10": 0,
-                   "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248, "nunit_cylinder50": 7456}
+                   "nunit_clipped_sphere10": 384, "nunit_box10": 384, "nunit_create_mesh_sphere": 1248, "nunit_cylinder50": 7456,
+                   "nunit_solid_sphere": 1248}
 
 
 def digest(a):
