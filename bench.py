@@ -197,12 +197,14 @@ def launch_ranks(argv, n):
     return rc or 1
 
 
-def scene_for(name):
+def scene_for(name, other_constants=False):
+    """other_constants: the same scene STRUCTURE with another radius (the next frame of an animation): no hiprtc compile"""
     from sdfkit_amd import SdfExprs, Sdfs, Vec3
+    dr = -0.03125 if other_constants else 0.0
     if name == "sphere":
-        return Sdfs.Sphere(1.0), [-1.5] * 3, [1.5] * 3, False
+        return Sdfs.Sphere(1.0 + dr), [-1.5] * 3, [1.5] * 3, False
     if name == "repeatxy":  # BASELINE C3 (README scene), clipToBounds = true
-        sdf = SdfExprs.Sphere(0.5).RepeatXY(1.125, 1.125,
+        sdf = SdfExprs.Sphere(0.5 + dr).RepeatXY(1.125, 1.125,
                                             lambda i, p, d: 0.9 * Vec3.of(p.x.b, 1.0) - Vec3.Abs(i) / 6.0).ToSdf()
         return sdf, [-2.8125] * 3, [2.8125] * 3, True
     if name == "union8":    # BASELINE C4: nested Union of 8 primitives at the octant centres of [-2,2]^3
@@ -210,7 +212,7 @@ def scene_for(name):
         for sx in (-1, 1):
             for sy in (-1, 1):
                 for sz in (-1, 1):
-                    q = (SdfExprs.Sphere(0.6), SdfExprs.Box(0.5), SdfExprs.Cylinder(0.4, 0.6))[k % 3]
+                    q = (SdfExprs.Sphere(0.6 + dr), SdfExprs.Box(0.5), SdfExprs.Cylinder(0.4, 0.6))[k % 3]
                     prims.append(q.Translate(sx, sy, sz))
                     k += 1
         prod = prims[0]
@@ -382,12 +384,23 @@ def main():
         L.sdfk_jit_stats(C.byref(a), C.byref(b), C.byref(c))
         return a.value, b.value, c.value
 
+    # the first call when the machine has never seen the program: code-object cache off, and the structure's modules unloaded
+    # with the program afterwards (SDFK_OPT_IDLE_PROGRAMS = 0) so that the legs below start where a fresh process starts
+    cold_first_call_ms = None
+    if world == 1 and not args.minimal:
+        with N.option(N.OPT_CODE_CACHE, 0), N.option(N.OPT_IDLE_PROGRAMS, 0):
+            cold_sdf = scene_for(args.scene)[0]
+            t0 = time.perf_counter()
+            cold_sdf.ToMesh(mn, mx, 8, 8, n, clipToBounds=clip)     # same sampler instantiation (same row length), tiny grid
+            cold_first_call_ms = round((time.perf_counter() - t0) * 1e3, 1)
+            del cold_sdf
     j0 = jit_stats()
     t0 = time.perf_counter()
     prog = sdf.program()
     t_prog = time.perf_counter() - t0
     first = {"program_ms": round(t_prog * 1e3, 2)}
     nv = ni = 0
+    first_call_new_constants_ms = None
     if world == 1:
         t0 = time.perf_counter()
         nv, ni = sample_march_once()
@@ -398,14 +411,26 @@ def main():
         first["what"] = ("sdfk_program_create, then the first sdfk_sample_march + sdfk_mesh_counts of this shape: the sampler instantiation "
                          "the grid needs + sdfk_corners_eval are compiled / loaded here, then the exact two-phase path runs with buffers "
                          "allocated from the driver")
-        if not args.minimal:
-            # the same first call when the machine has never seen the program: a fresh Sdf object, cache off
-            with N.option(N.OPT_CODE_CACHE, 0):
-                cold_sdf = scene_for(args.scene)[0]
-                t0 = time.perf_counter()
-                cold_sdf.ToMesh(mn, mx, 8, 8, n, clipToBounds=clip)     # same sampler instantiation (same row length), tiny grid
-                first["cold_first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
-                del cold_sdf
+        if cold_first_call_ms is not None:
+            first["cold_first_call_ms"] = cold_first_call_ms
+        # The same scene with OTHER constants (a new radius: the next frame of an animation, a parameter sweep).  The constants of
+        # a program are kernel arguments and the compiled kernels belong to the program's STRUCTURE, so this is program creation
+        # (tracing in the Python mirror + sdfk_program_create) + one sample -> mesh + the counts: no hiprtc, no cache file.
+        # In the reference Sdfs.Sphere(radius) is a closure (Sdf.cs:202-214).
+        sdf2 = scene_for(args.scene, other_constants=True)[0]
+        t0 = time.perf_counter()
+        m2 = C.c_void_p()
+        N.check(L.sdfk_sample_march(sdf2.program(), N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m2)))
+        a2, b2 = C.c_int64(), C.c_int64()
+        N.check(L.sdfk_mesh_counts(m2, C.byref(a2), C.byref(b2)))
+        first_call_new_constants_ms = round((time.perf_counter() - t0) * 1e3, 3)
+        L.sdfk_mesh_free(m2)
+        j2 = jit_stats()
+        first["new_constants"] = {"ms": first_call_new_constants_ms, "modules_compiled": j2[0] - j1[0], "loaded_from_cache": j2[1] - j1[1],
+                                  "vertices": a2.value,
+                                  "what": "a fresh Sdf of the same structure with another radius: tracing + sdfk_program_create + sdfk_sample_march + sdfk_mesh_counts"}
+        assert j2[0] == j1[0] and j2[1] == j1[1], "a program with other constants must not compile or load anything"
+        del sdf2
     first_call_ms = round(first["program_ms"] + first.get("first_mesh_ms", 0.0), 2)
 
     def barrier():
@@ -838,6 +863,7 @@ def main():
             "mtris_per_s": round(ni / 3 / step_s / 1e6, 2),
             "latency_ms_single_stream": None if latency_ms is None else round(latency_ms, 4),
             "first_call_ms": first_call_ms,
+            "first_call_new_constants_ms": first_call_new_constants_ms,   # the same structure, another radius: no compile (first_call.new_constants)
             "first_call": first,
             "stream_placement": N.stream_placement(),   # classes of lanes 0..4 / the exchange stream as measured at sdfk_init
             "pipeline_algorithmic_gbs": round(model_bytes / step_s / 1e9, 1),

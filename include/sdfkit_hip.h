@@ -19,6 +19,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported
+ * (tests/test_abi.py compares `nm -D --defined-only` with the declarations). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define SDFK_ABI_VERSION 4   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint */
 
@@ -41,9 +46,19 @@ typedef enum sdfk_status {
  * JIT-compiled with hiprtc -- or loaded from the on-disk code-object cache -- the first time a call
  * needs it (SDFK_ERR_COMPILE is then reported by that call).  The counterpart of
  * SdfExprCompiler.Compile (SdfExpr.cs:225-273).  All arithmetic is IEEE binary32, one rounding
- * per op, no FMA contraction. */
+ * per op, no FMA contraction.
+ * CONSTANTS ARE ARGUMENTS.  The generated source -- hence the compiled module and its entry in the on-disk cache --
+ * depends on the program's STRUCTURE only (opcodes, operand ids, outputs): the `imm` of an SDFK_OP_CONST travels with
+ * every launch in the kernel-argument block.  A program with a known structure and other constants (another radius,
+ * another period, the next frame of an animation) is created in microseconds and launches the kernels that are already
+ * loaded -- in the reference Sdfs.Sphere(radius) is a closure and a new radius costs nothing (Sdf.cs:202-214).  The
+ * exceptions are constants one of whose uses the compiler can fold EXACTLY when it sees the value (x * +-1, x / +-1,
+ * x / 2^k, x + -0, x - +0, -0 - x): those stay literals and belong to the structure, so that they cost what they always
+ * cost; results are bit-identical either way (IEEE-exact foldings only: -ffp-contract=off, no fast-math).  Programs with
+ * more than 256 constants keep all of them as literals.  SDFK_OPT_IDLE_PROGRAMS structures stay loaded after their last
+ * program has been destroyed. */
 typedef enum sdfk_opcode {
-    SDFK_OP_CONST = 0,   /* imm */
+    SDFK_OP_CONST = 0,   /* imm (a kernel argument: see above) */
     SDFK_OP_X = 1, SDFK_OP_Y = 2, SDFK_OP_Z = 3,   /* sample point (Voxels.cs:104-106) */
     SDFK_OP_ADD = 4, SDFK_OP_SUB = 5, SDFK_OP_MUL = 6, SDFK_OP_DIV = 7,  /* a ? b */
     SDFK_OP_NEG = 8, SDFK_OP_ABS = 9, SDFK_OP_SQRT = 10, SDFK_OP_FLOOR = 11, /* f(a) */
@@ -105,7 +120,9 @@ typedef enum sdfk_option {
     SDFK_OPT_COPY_MODE = 4,     /* device -> caller arrays: 1 (default) bounded pinned ring + thread pool, 0 pre-fault + runtime copy, 2 runtime copy */
     SDFK_OPT_CORNER_EVAL = 5,   /* 1 (default): cell corners of a freshly sampled volume are re-evaluated; 0: gathered */
     SDFK_OPT_VCOLOR_EVAL = 6,   /* 1 (default): vertex colours of a freshly sampled volume are re-evaluated; 0: gathered */
-    SDFK_OPT_DIST_EXCHANGE = 7, /* sharded step: 0 ncclAllGather, 1 (default) grouped ncclSend/ncclRecv to every peer, 2 gather to rank 0 */
+    SDFK_OPT_DIST_EXCHANGE = 7, /* sharded step: 0 (default) ncclAllGather, in place -- the plainest collective; opt-ins: 1 grouped
+                                   ncclSend/ncclRecv to every peer (all xGMI links at once), 2 payloads to rank 0 only (headers to all).
+                                   sdfk_dist_tune measures 0 against 1 on the node it runs on */
     SDFK_OPT_DIST_LANES = 8,    /* sharded step: internal streams consecutive steps rotate over: 0..3, default 3 (measured: a step on an
                                    8-rank slab of 512^3 takes 82 / 46 / 35 us with 1 / 2 / 3; a fourth shares a hardware queue: 98 us) */
     SDFK_OPT_HW_QUEUES = 9,     /* read-only: GPU_MAX_HW_QUEUES as the process had it when the library came up (0 = unset).  The
@@ -128,7 +145,10 @@ typedef enum sdfk_option {
     SDFK_OPT_IDLE_LANE = 14,    /* 1 (default): sdfk_sample_march jobs on launch-bound grids (the captured-graph ones) rotate over a FOURTH
                                    internal stream while the caller's stream has nothing queued (hipStreamQuery at the call): that stream
                                    shares the caller's stream's hardware pipe, so it is only used when the caller is not; 0 = never */
-    SDFK_OPT_COUNT_ = 15
+    SDFK_OPT_IDLE_PROGRAMS = 15,/* compiled kernel sets are shared by every program of one STRUCTURE (the constants of a program are kernel
+                                   arguments, sdfk_program_create); this many structures stay loaded after their last program has been
+                                   destroyed (default 32; 0: unloaded at once) -- the next frame of an animation asks for the same one */
+    SDFK_OPT_COUNT_ = 16
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);
 int sdfk_get_option(int32_t key, int64_t* value);
@@ -145,6 +165,7 @@ int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgb
 /* Generate + hiprtc-compile EVERY kernel of the program for gfx950 without loading (needs no
  * device, never uses the cache): a lowering check the shim can run at build time. */
 int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color);
+/* the generated HIP source of the program's STRUCTURE (constants appear as K.k[i]) */
 const char* sdfk_program_source(const sdfk_program* p);
 /* JIT bookkeeping of this process.  Compiled code objects are kept on disk (see sdfkit_hip.hip,
  * "on-disk cache": $SDFK_CACHE_DIR | $XDG_CACHE_HOME/sdfkit_hip | ~/.cache/sdfkit_hip; SDFK_NO_CACHE=1
@@ -305,7 +326,13 @@ void sdfk_dist_shutdown(void);
  * [z0, z0 + nz_local) its slab volume holds for them (context planes included, widened to a multiple of 4). */
 int sdfk_dist_slab(int32_t nz, int32_t world, int32_t rank, int32_t* layer_begin, int32_t* layer_end, int32_t* z0, int32_t* nz_local);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop    /* (an opaque handle: the type itself -- in the library a class with members -- is not exported) */
+#endif
 typedef struct sdfk_dist_session sdfk_dist_session;
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 /* depth = steps that may be in flight (slots: own slab volume and gather buffer each), 1..8. */
 int sdfk_dist_session_create(const sdfk_program* p, const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz,
                              int32_t clip_to_bounds, float iso_value, int32_t depth, sdfk_dist_session** out);
@@ -421,6 +448,9 @@ int sdfk_profile_reset(void);
 int sdfk_profile_count(void);
 int sdfk_profile_get(int32_t i, const char** name, double* total_ms, int64_t* launches);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -7,10 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdfkit_hip.so")
 SOURCES = ["sdfkit_hip.hip"]
-DEPS = ["sdfkit_hip.hip", "mc_kernels.hip", "mc_device.h", "mc_params.h", "mc_luts.h", "sample_codegen.h", "dist_rccl.h", "slab_protocol.h",
+DEPS = ["exports.map", "sdfkit_hip.hip", "mc_kernels.hip", "mc_device.h", "mc_params.h", "mc_luts.h", "sample_codegen.h", "dist_rccl.h", "slab_protocol.h",
         os.path.join("..", "..", "include", "sdfkit_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def needs_build():
@@ -32,7 +32,8 @@ def build(force=False, verbose=False):
             return LIB
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         tmp = f"{LIB}.tmp.{os.getpid()}"
-        cmd = [hipcc] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lhiprtc", "-ldl"]
+        cmd = ([hipcc] + FLAGS + ["-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", tmp] +
+               [os.path.join(CSRC, s) for s in SOURCES] + ["-lhiprtc", "-ldl"])
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         try:

@@ -7,9 +7,12 @@
 //   wait(step packed) -> ncclAllGather | grouped ncclSend/ncclRecv -> k_slabs_rebase (+ header mirror) -> record(ready)
 // so the exchange of step i travels while the kernels of step i+1 run, and nothing on the host waits inside a step.
 // RCCL is loaded with dlopen on first use (librccl.so.1; SDFK_RCCL_LIB at start-up names another file): a process that never
-// shards never loads it.  xGMI is point-to-point -- 7 links x 76.8 GB/s per direction per GPU -- so the default exchange
-// sends every peer its copy directly over the link between the two (one grouped launch); a ring all-gather would pass
-// each slab over ONE link seven times.  SDFK_OPT_DIST_EXCHANGE selects (0 = ncclAllGather, 1 = direct, 2 = to rank 0 only).
+// shards never loads it.  The DEFAULT exchange is the plainest collective there is: ncclAllGather of int32-index payloads,
+// in place (SDFK_OPT_DIST_EXCHANGE = 0) -- the one configuration whose every part has the library's own tests behind it on
+// real RCCL.  xGMI is point-to-point -- 7 links x 76.8 GB/s per direction per GPU --, so sending every peer its copy directly
+// over the link between the two (mode 1: one grouped ncclSend / ncclRecv launch) or to rank 0 only (mode 2), 16-bit-index
+// payloads (SDFK_OPT_DIST_INDEX16) and the tuner that measures them against each other (sdfk_dist_tune) exist -- as explicit
+// opt-ins: none of them has run between two GPUs yet (one GPU per development box).
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -205,7 +208,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
     int nx = 0, ny = 0, nz = 0, clip = 0;
     int lb = 0, le = 0, z0 = 0, nzl = 0;
     int vbytes = 24;
-    int exchange_mode = 1;
+    int exchange_mode = 0;
     int lanes = 3;
     bool idx16 = false;            // SDFK_OPT_DIST_INDEX16: compact payloads (k_payload_compact); falls back when a slab does not fit
     int64_t idx16_fallbacks = 0;
@@ -283,7 +286,8 @@ struct sdfk_dist_session final : sdfk::SlabOps {
             hipError_t e = hipMemcpyAsync(gd.agree_dev, gd.agree_host, sizeof(int64_t), hipMemcpyHostToDevice, gd.stream);
             if (e == hipSuccess) {
                 const ncclResult_t nr = gd.nccl.AllGather(gd.agree_dev, gd.agree_dev + 1, sizeof(int64_t), ncclChar, gd.comm, gd.stream);
-                if (nr != ncclSuccess) return keep(fail(SDFK_ERR_HIP, "ncclAllGather (stride agreement): %s", gd.nccl.GetErrorString(nr)));
+                if (nr != ncclSuccess)
+                    return keep(fail(SDFK_ERR_HIP, "ncclAllGather (stride agreement): %s (rank %d of %d, device %d)", gd.nccl.GetErrorString(nr), gd.rank, w, g.device));
                 e = hipMemcpyAsync(gd.agree_host + 1, gd.agree_dev + 1, sizeof(int64_t) * w, hipMemcpyDeviceToHost, gd.stream);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(gd.stream);
@@ -316,19 +320,29 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         }
     }
 
+    // All-or-nothing: `stride` is committed only when every slot has every buffer; a failure leaves the session without
+    // buffers and with stride 0 (the protocol then bootstraps again instead of enqueueing into a null send buffer).
     int resize(int64_t new_stride) override
     {
         free_buffers();
+        stride = 0;
+        const int r = resize_alloc(new_stride);
+        if (r) { const std::string keep_err = err; free_buffers(); err = keep_err; return r; }
         stride = new_stride;
-        const size_t total = (size_t)gd.world * (size_t)stride;
+        return SDFK_OK;
+    }
+
+    int resize_alloc(int64_t ns)
+    {
+        const size_t total = (size_t)gd.world * (size_t)ns;
         for (Slot& s : slots) {
             if (int r = dev_alloc((void**)&s.gathered, total)) return keep(r);
             hipError_t e = hipMemsetAsync(s.gathered, 0, total, g.stream);
             if (idx16) {   // (a plain payload is at most twice its compact form: indices 4 instead of 2 bytes)
-                s.stage_bytes = 2 * stride;
+                s.stage_bytes = 2 * ns;
                 if (int r = dev_alloc((void**)&s.stage, (size_t)s.stage_bytes)) return keep(r);
                 if (int r = dev_alloc((void**)&s.ticket, sizeof(unsigned long long))) return keep(r);
-                s.decoded_cap = (int64_t)gd.world * (stride / 2);   // (an index takes at least 2 bytes of a payload)
+                s.decoded_cap = (int64_t)gd.world * (ns / 2);   // (an index takes at least 2 bytes of a payload)
                 if (int r = dev_alloc((void**)&s.decoded, (size_t)s.decoded_cap * sizeof(int32_t))) return keep(r);
                 if (e == hipSuccess) e = hipMemsetAsync(s.ticket, 0, sizeof(unsigned long long), g.stream);
                 if (e == hipSuccess) e = hipMemsetAsync(s.stage, 0, SDFK_SLAB_HEADER_BYTES, g.stream);
@@ -337,22 +351,30 @@ struct sdfk_dist_session final : sdfk::SlabOps {
             if (e == hipSuccess) { memset(s.hdr_host, 0, (size_t)gd.world * SDFK_SLAB_HEADER_BYTES); e = hipHostGetDevicePointer(&s.hdr_dev, s.hdr_host, 0); }
             if (e != hipSuccess) return keep(fail(SDFK_ERR_HIP, "gather buffers: %s", hipGetErrorString(e)));
         }
-        if (gd.backend == 2 && gd.stage_stride < stride) {
+        if (gd.backend == 2 && gd.stage_stride < ns) {
             if (gd.stage) (void)hipHostFree(gd.stage);
             gd.stage = nullptr;
             gd.stage_stride = 0;
-            if (hipHostMalloc((void**)&gd.stage, (size_t)(1 + gd.world) * (size_t)stride, hipHostMallocDefault) != hipSuccess)
-                return keep(fail(SDFK_ERR_NOMEM, "pinned staging for the host transport (%lld bytes)", (long long)((1 + gd.world) * stride)));
-            gd.stage_stride = stride;
+            if (hipHostMalloc((void**)&gd.stage, (size_t)(1 + gd.world) * (size_t)ns, hipHostMallocDefault) != hipSuccess)
+                return keep(fail(SDFK_ERR_NOMEM, "pinned staging for the host transport (%lld bytes)", (long long)((1 + gd.world) * ns)));
+            gd.stage_stride = ns;
         }
         if (hipStreamSynchronize(g.stream) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "gather buffers: memset failed"));
         return SDFK_OK;
+    }
+
+    // a slot whose buffers are gone (a failed regrowth) is never written through
+    int have_buffers(const Slot& s, const char* what)
+    {
+        if (stride > 0 && s.gathered && s.hdr_host && (!idx16 || (s.stage && s.ticket && s.decoded))) return SDFK_OK;
+        return keep(fail(SDFK_ERR_INVALID, "%s: the session has no gather buffers (an earlier regrowth failed): submit() bootstraps again", what));
     }
 
     int pack_exact(int k) override
     {
         Slot& s = slots[k];
         if (!s.exact) return keep(fail(SDFK_ERR_INVALID, "pack_exact without an exact mesh"));
+        if (int r = have_buffers(s, "pack_exact")) return r;
         int64_t need = 0;
         int r = idx16 ? sdfk_mesh_pack(s.exact, s.stage, s.stage_bytes, &need) : sdfk_mesh_pack(s.exact, send_buf(s), stride, &need);
         sdfk_mesh_free(s.exact);   // (stream-ordered)
@@ -367,6 +389,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
     int enqueue(int k) override
     {
         Slot& s = slots[k];
+        if (int r = have_buffers(s, "enqueue")) return r;
         const int lane = lanes ? 1 + (int)(++nsub % (uint64_t)lanes) : 0;
         hipStream_t st = lane ? lane_stream(lane) : g.stream;
         // the send buffer is a section of the gather buffer: its last exchange must have finished, and so must a mesh
@@ -384,6 +407,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
     int exchange(int k) override
     {
         Slot& s = slots[k];
+        if (int r = have_buffers(s, "exchange")) return r;
         const int w = gd.world, me = gd.rank;
         hipStream_t cs = gd.stream;
         if (gd.backend == 2) {
@@ -418,7 +442,9 @@ struct sdfk_dist_session final : sdfk::SlabOps {
                 const ncclResult_t ne = N.GroupEnd();
                 if (nr == ncclSuccess) nr = ne;
             }
-            if (nr != ncclSuccess) return keep(fail(SDFK_ERR_HIP, "RCCL exchange: %s", N.GetErrorString(nr)));
+            if (nr != ncclSuccess)
+                return keep(fail(SDFK_ERR_HIP, "RCCL exchange: %s (rank %d of %d, device %d, exchange mode %d, %s payloads, stride %lld bytes, slot %d)",
+                                 N.GetErrorString(nr), me, w, g.device, exchange_mode, idx16 ? "16-bit-index" : "plain", (long long)stride, k));
         }
         // indices of slab r += vertices of slabs 0..r-1; the headers land in pinned host memory (one event, no copy).
         // (mode 2 on a rank other than 0: there are no foreign payloads to rebase -- the kernel sees header-only slabs)

@@ -598,22 +598,14 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
             corners_to_column(*reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8),
                               *reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8 + 4), col);
             const CornersLds v{col, 256, (double)P.iso};
-#if SDFK_K3_ABLATE == 1
-            Tiling t; t.nt = (int)(col[0] > 1e30f); t.lut_off = 0; t.row = 0; t.index = 1;
-#else
             const Tiling t = mc_resolve(s_lut, v);
-#endif
             const bool counted = z < P.lay_emit_end;     // the layer above is context only
             const bool emit = counted && z >= P.lay_emit_begin;
             if (t.nt > 0) {
                 if (counted) {
                     const unsigned pmask = positional_own_mask(x > 0, y > 0, P.z0 + z > 0) | (1u << 12);
                     const uint64_t ord = s_ord[t.row];   // the row's vertex ids in the order of their first reference = creation order
-#if SDFK_K3_ABLATE == 2
-                    const int nd = (int)(col[0] > 1e30f);
-#else
                     const int nd = (int)(ord >> 60);
-#endif
                     for (int k = 0; k < nd; k++) {
                         const int e = (int)((ord >> (4 * k)) & 15ull);
                         bool mine = (pmask >> e) & 1u;
@@ -803,9 +795,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     if (blockIdx.x == 0) publish_totals(P);   // k_resolve has completed (stream order)
     uint64_t chunk_prefix = 0;
     uint32_t prefix_upto = 0;
-#if SDFK_K4_ABLATE == 1
-    if (n) return;
-#endif
     for (uint32_t base = blockIdx.x * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
         const uint32_t cnt = min(MC_CHUNK, n - base);
         const uint32_t ci = base / MC_CHUNK;   // chunk index
@@ -874,9 +863,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         }
         __syncthreads();
         const uint32_t chunk_vbase = (uint32_t)(chunk_prefix >> 31);
-#if SDFK_K4_ABLATE == 2
-        if (n) continue;
-#endif
         // ---- per created vertex
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {
             const int rr = (int)s_creator[j];          // = window slot of the creator (W1 starts at the chunk)
@@ -931,9 +917,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             } else {
                 sl[3] = rr;
             }
-#if SDFK_K4_ABLATE == 3
-            if (n) { if (sl[0] + sl[1] + sl[2] + sl[3] == 123456789) P.rec_vid[0] = vi; continue; }
-#endif
             // push this vertex's id into every live cell around the edge (K5 reads only its own record)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
@@ -943,9 +926,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 P.rec_vid[(size_t)(e == 12 ? 12 : mc_share_edge(dir, s)) * P.cap_active + g] = vi;
             }
             if (!emit) continue;
-#if SDFK_K4_ABLATE == 4
-            if (n) continue;
-#endif
             const int own_row = (int)(info >> 22);
             float pos[3], colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
@@ -1038,9 +1018,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     }
                 }
             }
-#if SDFK_K4_ABLATE == 5
-            if (n) { if (nrm[0] + nrm[1] + nrm[2] + pos[0] + pos[1] + pos[2] + colr[0] == 1.2345e30f) M.vertices[0] = 1.0f; continue; }
-#endif
             // Cell.NegativeNormals (Cell.cs:97-109), then Mesh.Transform (Mesh.cs:47-64)
             const float len = v3len(nrm[0], nrm[1], nrm[2]);
             const float q0 = -(nrm[0] / len), q1 = -(nrm[1] / len), q2 = -(nrm[2] / len);

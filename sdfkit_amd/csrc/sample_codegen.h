@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/sdfkit_hip.h"
 
@@ -100,7 +101,7 @@ __device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float
 #define SDFK_ROWS 0
 #define SDFK_FLAT 1
 template <bool CLIP, int MODE>
-__device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
+__device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const SdfkK& K)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
     __shared__ unsigned char nib[8][64];
@@ -155,7 +156,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
             float w[4], cr[4], cg[4], cb[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                sdf_eval(px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
+                sdf_eval(K, px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
                 if (CLIP && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
             const long o = MODE == SDFK_FLAT ? (long)ix * plane + (f0 + 4 * lane) : ((long)ix * A.ny + iy) * P + z;
@@ -222,16 +223,16 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A)
 #define SDFK_KERNELS 0xff
 #endif
 #if SDFK_KERNELS & 0x01
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_ROWS>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_ROWS>(A, K); }
 #endif
 #if SDFK_KERNELS & 0x02
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_flat(SampleArgs A) { sdfk_sample_bits_body<false, SDFK_FLAT>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_flat(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_FLAT>(A, K); }
 #endif
 #if SDFK_KERNELS & 0x08
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_ROWS>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<true, SDFK_ROWS>(A, K); }
 #endif
 #if SDFK_KERNELS & 0x10
-extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A) { sdfk_sample_bits_body<true, SDFK_FLAT>(A); }
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<true, SDFK_FLAT>(A, K); }
 #endif
 
 // Corner values of the active cells, RE-EVALUATED instead of gathered: for a volume this very
@@ -240,14 +241,14 @@ extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_
 // sampling kernel stored -- and 8 evaluations per ACTIVE cell (a surface, not a volume) are
 // far cheaper than 4 scattered 8-byte loads per cell from a [x][y][z] grid.
 // Corner order v0..v7 = (0,0,0) (1,0,0) (1,1,0) (0,1,0) (0,0,1) (1,0,1) (1,1,1) (0,1,1) (Cell.cs:24-31).
-__device__ __forceinline__ float sdfk_voxel(const SampleArgs& A, int ix, int iy, int iz)
+__device__ __forceinline__ float sdfk_voxel(const SampleArgs& A, const SdfkK& K, int ix, int iy, int iz)
 {
     const float px = A.mx + (float)ix * A.dx;
     const float py = A.my + (float)iy * A.dy;
     const int zg = A.z0 + iz;
     const float pz = A.mz + (float)zg * A.dz;
     float r, g, b, w;
-    sdf_eval(px, py, pz, r, g, b, w);
+    sdf_eval(K, px, py, pz, r, g, b, w);
     if (A.clip && ((ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1) | (zg == 0) | (zg == A.nz_global - 1)))
         w = A.outside;
     return w;
@@ -257,16 +258,16 @@ __device__ __forceinline__ float sdfk_voxel(const SampleArgs& A, int ix, int iy,
 extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A, const unsigned* __restrict__ rec_xy,
                                                                      const unsigned* __restrict__ rec_z,
                                                                      float* __restrict__ rec_corners,
-                                                                     const unsigned* __restrict__ n_active, unsigned cap, int xbits)
+                                                                     const unsigned* __restrict__ n_active, unsigned cap, int xbits, SdfkK K)
 {
     const unsigned n = *n_active < cap ? *n_active : cap;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const unsigned xy = rec_xy[i];
         const int x = (int)(xy & ((1u << xbits) - 1u)), y = (int)(xy >> xbits), z = (int)rec_z[i];
-        const float c0 = sdfk_voxel(A, x, y, z), c1 = sdfk_voxel(A, x + 1, y, z);
-        const float c2 = sdfk_voxel(A, x + 1, y + 1, z), c3 = sdfk_voxel(A, x, y + 1, z);
-        const float c4 = sdfk_voxel(A, x, y, z + 1), c5 = sdfk_voxel(A, x + 1, y, z + 1);
-        const float c6 = sdfk_voxel(A, x + 1, y + 1, z + 1), c7 = sdfk_voxel(A, x, y + 1, z + 1);
+        const float c0 = sdfk_voxel(A, K, x, y, z), c1 = sdfk_voxel(A, K, x + 1, y, z);
+        const float c2 = sdfk_voxel(A, K, x + 1, y + 1, z), c3 = sdfk_voxel(A, K, x, y + 1, z);
+        const float c4 = sdfk_voxel(A, K, x, y, z + 1), c5 = sdfk_voxel(A, K, x + 1, y, z + 1);
+        const float c6 = sdfk_voxel(A, K, x + 1, y + 1, z + 1), c7 = sdfk_voxel(A, K, x, y + 1, z + 1);
         float4* o = reinterpret_cast<float4*>(rec_corners + (size_t)i * 8);
         o[0] = make_float4(c0, c1, c2, c3);
         o[1] = make_float4(c4, c5, c6, c7);
@@ -285,17 +286,17 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_corners_eval(SampleArgs A
 #if (SDFK_KERNELS & 0x20) && SDFK_WRITES_COLOR
 struct VColArgs { const unsigned* vdesc; const unsigned* rec_xy; const unsigned* rec_z; const unsigned* counters; float* colors;
                   unsigned cap_vertices; int xbits; float iso; };
-__device__ __forceinline__ void sdfk_voxel_rgbw(const SampleArgs& A, int ix, int iy, int iz, float& r, float& g, float& b, float& w)
+__device__ __forceinline__ void sdfk_voxel_rgbw(const SampleArgs& A, const SdfkK& K, int ix, int iy, int iz, float& r, float& g, float& b, float& w)
 {
     const float px = A.mx + (float)ix * A.dx;
     const float py = A.my + (float)iy * A.dy;
     const int zg = A.z0 + iz;
     const float pz = A.mz + (float)zg * A.dz;
-    sdf_eval(px, py, pz, r, g, b, w);
+    sdf_eval(K, px, py, pz, r, g, b, w);
     if (A.clip && ((ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1) | (zg == 0) | (zg == A.nz_global - 1)))
         w = A.outside;
 }
-extern "C" __global__ __launch_bounds__(256) void sdfk_vertex_colors(SampleArgs A, VColArgs V)
+extern "C" __global__ __launch_bounds__(256) void sdfk_vertex_colors(SampleArgs A, VColArgs V, SdfkK K)
 {
     // McCounters (mc_params.h): total_v = word 3, nghost = word 5; published by k_vertices (stream order)
     unsigned nv = V.counters[3] - V.counters[5];
@@ -311,7 +312,7 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_vertex_colors(SampleArgs 
             float fc[3] = {0.0f, 0.0f, 0.0f};
             for (int k = 0; k < 8; k++) {
                 float c[3], w;
-                sdfk_voxel_rgbw(A, x + (((k + 1) >> 1) & 1), y + ((k >> 1) & 1), z + (k >> 2), c[0], c[1], c[2], w);
+                sdfk_voxel_rgbw(A, K, x + (((k + 1) >> 1) & 1), y + ((k >> 1) & 1), z + (k >> 2), c[0], c[1], c[2], w);
                 const double wk = 1.0 / (0.0000001 + __builtin_fabs((double)w - iso));
                 ff += wk;
                 const float wf = (float)wk;
@@ -323,8 +324,8 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_vertex_colors(SampleArgs 
             // the two end corners of cube edge e (Luts.cs:30-52)
             const int c1 = e < 8u ? (int)e : (int)e - 8, c2 = e < 8u ? (int)((e & 4u) | ((e + 1u) & 3u)) : (int)e - 4;
             float ca[3], cb[3], wa, wb;
-            sdfk_voxel_rgbw(A, x + (((c1 + 1) >> 1) & 1), y + ((c1 >> 1) & 1), z + (c1 >> 2), ca[0], ca[1], ca[2], wa);
-            sdfk_voxel_rgbw(A, x + (((c2 + 1) >> 1) & 1), y + ((c2 >> 1) & 1), z + (c2 >> 2), cb[0], cb[1], cb[2], wb);
+            sdfk_voxel_rgbw(A, K, x + (((c1 + 1) >> 1) & 1), y + ((c1 >> 1) & 1), z + (c1 >> 2), ca[0], ca[1], ca[2], wa);
+            sdfk_voxel_rgbw(A, K, x + (((c2 + 1) >> 1) & 1), y + ((c2 >> 1) & 1), z + (c2 >> 2), cb[0], cb[1], cb[2], wb);
             const double w1 = 1.0 / (0.0000001 + __builtin_fabs((double)wa - iso));
             const double w2 = 1.0 / (0.0000001 + __builtin_fabs((double)wb - iso));
             const double ff = w1 + w2;
@@ -348,10 +349,10 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_vertex_colors(SampleArgs 
 // caller from ViewTransform (GetCameraRays, RayMarcher.cs:97-112).
 struct RayArgs { float* depth; float* rgb; float cam[3]; float m[16]; int width, height; float nearp, farp; int iters; };
 
-__device__ __forceinline__ float sdfk_scene_w(float x, float y, float z, float& r, float& g, float& b)
+__device__ __forceinline__ float sdfk_scene_w(const SdfkK& K, float x, float y, float z, float& r, float& g, float& b)
 {
     float w;
-    sdf_eval(x, y, z, r, g, b, w);
+    sdf_eval(K, x, y, z, r, g, b, w);
     return w;
 }
 
@@ -365,7 +366,7 @@ __device__ __forceinline__ void sdfk_normalize_inplace(float& x, float& y, float
 }
 
 #if SDFK_KERNELS & 0x80
-extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
+extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A, SdfkK K)
 {
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
     if (k >= (long)A.width * A.height) return;
@@ -382,7 +383,7 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
     float depth = A.nearp - 0.1f;
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     for (int it = 0; it < A.iters; it++) {
-        const float w = sdfk_scene_w(rx * depth + A.cam[0], ry * depth + A.cam[1], rz * depth + A.cam[2], cr, cg, cb);
+        const float w = sdfk_scene_w(K, rx * depth + A.cam[0], ry * depth + A.cam[1], rz * depth + A.cam[2], cr, cg, cb);
         depth = depth + w;
     }
     if (A.depth) A.depth[k] = depth;
@@ -392,12 +393,12 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
     const float sx = A.cam[0] + rx * depth, sy = A.cam[1] + ry * depth, sz = A.cam[2] + rz * depth;
     const float go = 1e-5f;
     float t0, t1, t2;
-    const float wpx = sdfk_scene_w(sx + go * 1.0f, sy + go * 0.0f, sz + go * 0.0f, t0, t1, t2);
-    const float wpy = sdfk_scene_w(sx + go * 0.0f, sy + go * 1.0f, sz + go * 0.0f, t0, t1, t2);
-    const float wpz = sdfk_scene_w(sx + go * 0.0f, sy + go * 0.0f, sz + go * 1.0f, t0, t1, t2);
-    const float wnx = sdfk_scene_w(sx + -go * 1.0f, sy + -go * 0.0f, sz + -go * 0.0f, t0, t1, t2);
-    const float wny = sdfk_scene_w(sx + -go * 0.0f, sy + -go * 1.0f, sz + -go * 0.0f, t0, t1, t2);
-    const float wnz = sdfk_scene_w(sx + -go * 0.0f, sy + -go * 0.0f, sz + -go * 1.0f, t0, t1, t2);
+    const float wpx = sdfk_scene_w(K, sx + go * 1.0f, sy + go * 0.0f, sz + go * 0.0f, t0, t1, t2);
+    const float wpy = sdfk_scene_w(K, sx + go * 0.0f, sy + go * 1.0f, sz + go * 0.0f, t0, t1, t2);
+    const float wpz = sdfk_scene_w(K, sx + go * 0.0f, sy + go * 0.0f, sz + go * 1.0f, t0, t1, t2);
+    const float wnx = sdfk_scene_w(K, sx + -go * 1.0f, sy + -go * 0.0f, sz + -go * 0.0f, t0, t1, t2);
+    const float wny = sdfk_scene_w(K, sx + -go * 0.0f, sy + -go * 1.0f, sz + -go * 0.0f, t0, t1, t2);
+    const float wnz = sdfk_scene_w(K, sx + -go * 0.0f, sy + -go * 0.0f, sz + -go * 1.0f, t0, t1, t2);
     float nx = wpx - wnx, ny = wpy - wny, nz = wpz - wnz;
     sdfk_normalize_inplace(nx, ny, nz);
     float lx = 5.0f - sx, ly = 5.0f - sy, lz = 10.0f - sz;
@@ -414,13 +415,53 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A)
 
 )SRC";
 
+// Constants of a program are kernel ARGUMENTS, not literals: the generated source -- hence the hiprtc module and the
+// on-disk cache entry -- depends on the program's STRUCTURE (opcodes, operand ids, outputs) only, and a program with the same
+// structure and other constants (another radius, another period: Sdf.cs:202-214 is a closure, a new radius costs the
+// reference nothing) reuses the loaded module.  `params` receives the constants in the order of their K.k[] slots.
+// Baked as literals (part of the structure): a constant one of whose uses lets the compiler simplify EXACTLY -- x * +-1,
+// x / +-1, x / 2^k (an exact reciprocal), x + -0, x - +0, -0 - x -- so that the common cases cost what they cost as
+// literals; with -ffp-contract=off and no fast-math every such folding is IEEE-exact, results are bit-identical either way.
+// More than kMaxParams constants: all literals (the kernel-argument segment is 4 KB).
+constexpr int kMaxParams = 256;
+
+inline bool sdfk_const_is_baked(const sdfk_op* ops, int n_ops, int i)
+{
+    uint32_t bits;
+    memcpy(&bits, &ops[i].imm, 4);
+    const uint32_t mag = bits & 0x7fffffffu;
+    const bool one = mag == 0x3f800000u, pzero = bits == 0u, nzero = bits == 0x80000000u;
+    const uint32_t ex = mag >> 23;
+    const bool pow2 = (mag & 0x007fffffu) == 0u && ex >= 2u && ex <= 252u;   // +-2^k whose reciprocal is a normal float too
+    if (!(one || pzero || nzero || pow2)) return false;
+    for (int u = i + 1; u < n_ops; u++) {
+        const sdfk_op& q = ops[u];
+        switch (q.opcode) {
+        case SDFK_OP_MUL: if (one && (q.a == i || q.b == i)) return true; break;
+        case SDFK_OP_DIV: if ((one || pow2) && q.b == i) return true; break;
+        case SDFK_OP_ADD: if (nzero && (q.a == i || q.b == i)) return true; break;
+        case SDFK_OP_SUB: if ((pzero && q.b == i) || (nzero && q.a == i)) return true; break;
+        default: break;
+        }
+    }
+    return false;
+}
+
 inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t out_rgbw[4], int writes_color,
-                                   std::string& src, std::string& err)
+                                   std::string& src, std::string& err, std::vector<float>* params = nullptr)
 {
     char buf[256];
     if (n_ops > (1 << 20)) { err = "program too long"; return false; }
     std::string body;
     body.reserve((size_t)n_ops * 48);
+    int n_params = 0;
+    bool parameterise = true;
+    {
+        int n_const = 0;
+        for (int i = 0; i < n_ops; i++) n_const += ops[i].opcode == SDFK_OP_CONST ? 1 : 0;
+        if (n_const > kMaxParams) parameterise = false;
+    }
+    if (params) params->clear();
     for (int i = 0; i < n_ops; i++) {
         const sdfk_op& o = ops[i];
         auto arg = [&](int32_t id, const char* which) -> bool {
@@ -437,7 +478,11 @@ inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t 
         case SDFK_OP_CONST: {
             uint32_t bits;
             memcpy(&bits, &o.imm, 4);
-            snprintf(buf, sizeof buf, "    const float v%d = __uint_as_float(0x%08xu);\n", i, bits);
+            if (parameterise && !sdfk_const_is_baked(ops, n_ops, i)) {
+                snprintf(buf, sizeof buf, "    const float v%d = K.k[%d];\n", i, n_params++);
+                if (params) params->push_back(o.imm);
+            } else
+                snprintf(buf, sizeof buf, "    const float v%d = __uint_as_float(0x%08xu);\n", i, bits);
             body += buf;
             continue;
         }
@@ -479,7 +524,10 @@ inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t 
     }
     src.clear();
     src += kSamplePrelude;
-    src += "__device__ __forceinline__ void sdf_eval(float X, float Y, float Z, float& R, float& G, float& B, float& W)\n{\n";
+    snprintf(buf, sizeof buf, "struct SdfkK { float k[%d]; };\n", n_params > 0 ? n_params : 1);
+    src += buf;
+    if (params && params->empty()) params->push_back(0.0f);   // (the argument always exists: one unused slot)
+    src += "__device__ __forceinline__ void sdf_eval(const SdfkK& K, float X, float Y, float Z, float& R, float& G, float& B, float& W)\n{\n";
     src += body;
     if (writes_color) {
         snprintf(buf, sizeof buf, "    R = v%d; G = v%d; B = v%d;\n", out_rgbw[0], out_rgbw[1], out_rgbw[2]);

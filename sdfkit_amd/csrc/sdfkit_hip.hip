@@ -25,6 +25,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/sdfkit_hip.h"
@@ -52,10 +53,11 @@ struct Config {
     int copy_mode = 1;        // SDFK_OPT_COPY_MODE
     int corner_eval = 1;      // SDFK_OPT_CORNER_EVAL
     int vcolor_eval = 1;      // SDFK_OPT_VCOLOR_EVAL
-    int dist_exchange = 1;    // SDFK_OPT_DIST_EXCHANGE
+    int dist_exchange = 0;    // SDFK_OPT_DIST_EXCHANGE (0: ncclAllGather; the direct / gather-to-root exchanges are opt-ins)
     int dist_lanes = 3;       // SDFK_OPT_DIST_LANES
     int dist_index16 = 0;     // SDFK_OPT_DIST_INDEX16
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
+    int idle_programs = 32;   // SDFK_OPT_IDLE_PROGRAMS
     int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
     int place_streams = 1;    // SDFK_OPT_STREAM_PLACEMENT
     int idle_lane = 1;        // SDFK_OPT_IDLE_LANE
@@ -762,16 +764,28 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
 // Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
 enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_VCOLORS = 5, PK_CORNERS = 6, PK_RAYMARCH = 7, PK_COUNT = 8 };
 
-struct sdfk_program {
+// The compiled kernels of one program STRUCTURE (opcodes, operand ids, outputs -- the generated source; a program's
+// constants are kernel arguments, csrc/sample_codegen.h): shared by every program of that structure, so that a scene whose
+// constants change per call (an animated radius, a parameter sweep) compiles ONCE -- in the reference Sdfs.Sphere(radius) is a
+// closure and a new radius costs nothing (Sdf.cs:202-214).
+struct ProgCode {
     std::string source;
     // The entry points are compiled ON DEMAND, one hiprtc module per kernel set: what a caller pays on the first call
     // is the sampler instantiation its grid needs + sdfk_corners_eval (they share a module), not all eight kernels
     // (512^3 sphere on the bench box: 150 instead of 310 ms; an 8-primitive union: a third).
     std::vector<hipModule_t> modules;
     hipFunction_t fn[PK_COUNT] = {};
+    int refs = 0;            // programs of this structure that are alive
+    uint64_t last_use = 0;   // (structures without a program are kept for a while: the next frame of an animation asks again)
+};
+
+struct sdfk_program {
+    ProgCode* code = nullptr;
+    std::vector<float> params;   // the constants, in the order of the K.k[] slots of the generated source (never empty)
     int writes_color = 0;
     int refs = 1;   // the caller's handle + volumes it has sampled + queued jobs that launch from its module
     bool orphaned = false;   // the caller's handle is gone (sdfk_program_destroy): captured jobs keyed on it can never be asked for again
+    void* kargs() const { return const_cast<float*>(params.data()); }   // the by-value SdfkK argument of every generated kernel
 };
 
 struct sdfk_volume {
@@ -888,18 +902,21 @@ static void config_from_env()
     g_cfg.loaded = true;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
     auto gets = [](const char* name) { const char* e = getenv(name); return std::string(e ? e : ""); };
-    g_cfg.lanes = geti("SDFK_LANES", 3);
-    g_cfg.tokens = geti("SDFK_TOKENS", -1);
-    g_cfg.graphs = geti("SDFK_GRAPHS", 1);
-    g_cfg.copy_mode = geti("SDFK_COPY_MODE", 1);
-    g_cfg.copy_threads = geti("SDFK_COPY_THREADS", 0);
+    // (a start-up default outside the range sdfk_set_option accepts for that option is ignored: the built-in default stands)
+    auto ranged = [&](const char* name, int dflt, int lo, int hi) { const int v = geti(name, dflt); return v >= lo && v <= hi ? v : dflt; };
+    g_cfg.lanes = ranged("SDFK_LANES", 3, 0, Context::NSIDE);
+    g_cfg.tokens = ranged("SDFK_TOKENS", -1, -1, 3);
+    g_cfg.graphs = ranged("SDFK_GRAPHS", 1, 0, 2);
+    g_cfg.copy_mode = ranged("SDFK_COPY_MODE", 1, 0, 2);
+    g_cfg.copy_threads = ranged("SDFK_COPY_THREADS", 0, 0, 256);
     g_cfg.corner_eval = geti("SDFK_NO_CORNER_EVAL", 0) ? 0 : 1;
     g_cfg.vcolor_eval = geti("SDFK_NO_VCOLOR_EVAL", 0) ? 0 : 1;
-    g_cfg.dist_exchange = geti("SDFK_DIST_EXCHANGE", 1);
-    g_cfg.dist_lanes = std::max(0, std::min(geti("SDFK_DIST_LANES", 3), 3));
-    g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0);
+    g_cfg.dist_exchange = ranged("SDFK_DIST_EXCHANGE", 0, 0, 2);
+    g_cfg.dist_lanes = ranged("SDFK_DIST_LANES", 3, 0, 3);
+    g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0) ? 1 : 0;
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
-    g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0);
+    g_cfg.idle_programs = ranged("SDFK_IDLE_PROGRAMS", 32, 0, 1024);
+    g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0) ? 1 : 0;
     g_cfg.place_streams = geti("SDFK_STREAM_PLACEMENT", 1) ? 1 : 0;
     g_cfg.idle_lane = geti("SDFK_IDLE_LANE", 1) ? 1 : 0;
     g_cfg.sample_mode = geti("SDFK_SAMPLE_MODE", -1);
@@ -1075,6 +1092,7 @@ extern "C" int sdfk_synchronize(void)
 // ---------------------------------------------------------------------------
 // options (include/sdfkit_hip.h: sdfk_option)
 // ---------------------------------------------------------------------------
+namespace { void codes_trim(); }
 extern "C" int sdfk_set_option(int32_t key, int64_t value)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
@@ -1093,6 +1111,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_STREAM_PLACEMENT: if (!in(0, 1)) break; g_cfg.place_streams = (int)value; return SDFK_OK;
     case SDFK_OPT_IDLE_LANE: if (!in(0, 1)) break; g_cfg.idle_lane = (int)value; return SDFK_OK;
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
+    case SDFK_OPT_IDLE_PROGRAMS: if (!in(0, 1024)) break; g_cfg.idle_programs = (int)value; codes_trim(); return SDFK_OK;
     case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;
     case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
     default: return fail(SDFK_ERR_INVALID, "sdfk_set_option: unknown option %d", key);
@@ -1118,6 +1137,7 @@ extern "C" int sdfk_get_option(int32_t key, int64_t* value)
     case SDFK_OPT_STREAM_PLACEMENT: *value = g_cfg.place_streams; break;
     case SDFK_OPT_IDLE_LANE: *value = g_cfg.idle_lane; break;
     case SDFK_OPT_CODE_CACHE: *value = g_cfg.code_cache; break;
+    case SDFK_OPT_IDLE_PROGRAMS: *value = g_cfg.idle_programs; break;
     case SDFK_OPT_PREFAULT_HUGE: *value = g_cfg.prefault_huge; break;
     case SDFK_OPT_HW_QUEUES: *value = g_cfg.hw_queues; break;
     default: return fail(SDFK_ERR_INVALID, "sdfk_get_option: unknown option %d", key);
@@ -1291,10 +1311,60 @@ extern "C" int sdfk_jit_stats(int64_t* n_compiled, int64_t* n_cache_hits, double
     return SDFK_OK;
 }
 
-static int generate_source(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color, std::string& src)
+namespace {
+// structures with loaded modules, keyed by the generated source (the whole text is the key: no collisions)
+std::unordered_map<std::string, ProgCode*> g_codes;
+uint64_t g_code_clock = 0;
+
+void code_unload(ProgCode* c)
+{
+    if (!c->modules.empty() && g.inited) sync_all_lanes();   // kernels of these modules may still be queued
+    for (hipModule_t m : c->modules) (void)hipModuleUnload(m);
+    delete c;
+}
+
+ProgCode* code_acquire(std::string&& src)
+{
+    ProgCode*& slot = g_codes[src];
+    if (!slot) {
+        slot = new ProgCode();
+        slot->source = std::move(src);
+    }
+    slot->refs++;
+    slot->last_use = ++g_code_clock;
+    return slot;
+}
+
+// structures no program uses at the moment stay loaded, up to SDFK_OPT_IDLE_PROGRAMS of them: the one used longest ago goes first
+void codes_trim()
+{
+    for (;;) {
+        size_t idle = 0;
+        ProgCode* oldest = nullptr;
+        for (auto& kv : g_codes)
+            if (kv.second->refs == 0) {
+                idle++;
+                if (!oldest || kv.second->last_use < oldest->last_use) oldest = kv.second;
+            }
+        if (idle <= (size_t)g_cfg.idle_programs || !oldest) return;
+        g_codes.erase(oldest->source);
+        code_unload(oldest);
+    }
+}
+
+void code_release(ProgCode* c)
+{
+    if (!c || --c->refs > 0) return;
+    c->last_use = ++g_code_clock;
+    codes_trim();
+}
+}  // namespace
+
+static int generate_source(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color, std::string& src,
+                           std::vector<float>* params = nullptr)
 {
     std::string err;
-    if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err))
+    if (!generate_sample_source(ops, n_ops, out_rgbw, writes_color, src, err, params))
         return fail(SDFK_ERR_INVALID, "SDF program: %s", err.c_str());
     if (!g_cfg.dump_source.empty()) {   // debugging aid (SDFK_DUMP_SOURCE at start-up): the generated HIP source of the last program
         if (FILE* f = fopen(g_cfg.dump_source.c_str(), "w")) { fputs(src.c_str(), f); fclose(f); }
@@ -1321,8 +1391,10 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     *out = nullptr;
     if (int r = require_init()) return r;
     sdfk_program* p = new sdfk_program();
-    if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, p->source)) { delete p; return r; }   // validates the op list
+    std::string src;
+    if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src, &p->params)) { delete p; return r; }   // validates the op list
     p->writes_color = writes_color;
+    p->code = code_acquire(std::move(src));
     *out = p;
     return SDFK_OK;
 }
@@ -1332,14 +1404,15 @@ namespace {
 // sdfk_corners_eval along (same module): marching cubes on the volume it sampled re-evaluates cell corners with it.
 int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
 {
-    sdfk_program* p = const_cast<sdfk_program*>(cp);
+    ProgCode* p = cp->code;
+    p->last_use = ++g_code_clock;
     if (!p->fn[k]) {
         static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "", "sdfk_sample_bits_clip",
                                                     "sdfk_sample_bits_clip_flat", "sdfk_vertex_colors", "sdfk_corners_eval", "sdfk_raymarch"};
         unsigned mask = 1u << k;
         if (k <= PK_BITS_CLIP_FLAT && !p->fn[PK_CORNERS]) {   // (and, for a program that writes colours, sdfk_vertex_colors)
             mask |= 1u << PK_CORNERS;
-            if (p->writes_color && !p->fn[PK_VCOLORS]) mask |= 1u << PK_VCOLORS;
+            if (cp->writes_color && !p->fn[PK_VCOLORS]) mask |= 1u << PK_VCOLORS;
         }
         std::vector<char> code;
         bool cached = false;
@@ -1363,7 +1436,7 @@ int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
 }
 }  // namespace
 
-extern "C" const char* sdfk_program_source(const sdfk_program* p) { return p ? p->source.c_str() : ""; }
+extern "C" const char* sdfk_program_source(const sdfk_program* p) { return p && p->code ? p->code->source.c_str() : ""; }
 
 extern "C" void sdfk_program_destroy(sdfk_program* p)
 {
@@ -1381,8 +1454,7 @@ namespace {
 void program_release(sdfk_program* p)
 {
     if (!p || --p->refs > 0) return;
-    if (g.inited) sync_all_lanes();   // kernels of these modules may still be queued
-    for (hipModule_t m : p->modules) (void)hipModuleUnload(m);
+    code_release(p->code);   // (the modules stay loaded for the next program of this structure)
     delete p;
 }
 
@@ -1574,7 +1646,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         v->sampled_by = q;
         v->sampled_args = A;
     };
-    void* params[] = {&A};
+    void* params[] = {&A, p->kargs()};
     {
         // fused sampling + sign bits (iso known or guessed 0): marching cubes then skips its
         // dense pass over the volume
@@ -1785,7 +1857,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
         if (int r = program_fn(j->eval_prog, PK_CORNERS, &fn_corners)) return r;
         ProfScope ps("sdfk_corners_eval");
         const unsigned* n_active = &P.counters->n_active;
-        void* params[] = {&j->eval_args, &P.rec_xy, &P.rec_z, &P.rec_corners, &n_active, &P.cap_active, &P.xbits};
+        void* params[] = {&j->eval_args, &P.rec_xy, &P.rec_z, &P.rec_corners, &n_active, &P.cap_active, &P.xbits, j->eval_prog->kargs()};
         HIPCHK(hipModuleLaunchKernel(fn_corners, (unsigned)std::min(nchunks, 256 * 8), 1, 1, 256, 1, 1, 0,
                                      g.stream, params, nullptr));
     } else {
@@ -1994,7 +2066,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
         V.cap_vertices = M.cap_vertices; V.xbits = j->P.xbits; V.iso = j->P.iso;
         hipFunction_t fn = nullptr;
         if (int rr = program_fn(j->eval_prog, PK_VCOLORS, &fn)) return rr;
-        void* params[] = {&j->eval_args, &V};
+        void* params[] = {&j->eval_args, &V, j->eval_prog->kargs()};
         ProfScope ps("sdfk_vertex_colors");
         HIPCHK(hipModuleLaunchKernel(fn, (unsigned)grid_for(std::max<size_t>(m->cap_v, 1), 256, 256 * 8), 1, 1, 256, 1, 1, 0, g.stream, params, nullptr));
     }
@@ -2884,7 +2956,7 @@ static int raymarch_launch(const sdfk_program* p, int32_t width, int32_t height,
     memcpy(A.cam, cam, sizeof A.cam);
     memcpy(A.m, vpi, sizeof A.m);
     A.width = width; A.height = height; A.nearp = nearp; A.farp = farp; A.iters = iters;
-    void* params[] = {&A};
+    void* params[] = {&A, p->kargs()};
     const size_t n = (size_t)width * height;
     ProfScope ps("sdfk_raymarch");
     hipFunction_t fn_raymarch = nullptr;

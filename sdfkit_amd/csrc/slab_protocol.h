@@ -182,7 +182,16 @@ private:
                 last_slot_ = -1;
                 last_hdr_ = nullptr;
             }
-            if (int r = ops_->resize(want)) return ops_fail(r);
+            if (int r = ops_->resize(want)) {
+                // no buffers any more (the backend has released what it had): nothing queued can complete into them, and the
+                // next submit() must bootstrap -- never enqueue into buffers that do not exist
+                stride_ = 0;
+                queue_.clear();
+                next_slot_ = 0;
+                last_slot_ = -1;
+                last_hdr_ = nullptr;
+                return ops_fail(r);
+            }
             stride_ = want;
             // ... and they are queued again -- enqueue + exchange, in submission order -- into the new buffers, here, where
             // every rank does the same (the agreed maximum is what brought them all to this branch)

@@ -26,7 +26,6 @@ class Builder:
 
     def __init__(self):
         self.ops = []           # (opcode, a, b, c, d, imm)
-        self._consts = {}
         self._inputs = {}
 
     def emit(self, opcode, a=-1, b=-1, c=-1, d=-1, imm=0.0):
@@ -34,11 +33,10 @@ class Builder:
         return Val(self, len(self.ops) - 1)
 
     def const(self, x):
-        x32 = np.float32(x)
-        key = x32.tobytes()
-        if key not in self._consts:
-            self._consts[key] = self.emit(OP_CONST, imm=float(x32))
-        return self._consts[key]
+        # One CONST per mention, never merged by VALUE: the constants of a program are kernel arguments and the compiled
+        # kernels are shared by every program of the same structure (sdfk_program_create) -- a structure must not change
+        # because two of a scene's parameters happen to be equal in one frame of an animation.
+        return self.emit(OP_CONST, imm=float(np.float32(x)))
 
     def input(self, axis):
         if axis not in self._inputs:

@@ -84,7 +84,7 @@ namespace SdfKit.Hip
 
         /// <summary>enum sdfk_option</summary>
         public const int OptLanes = 1, OptTokens = 2, OptGraphs = 3, OptCopyMode = 4, OptCornerEval = 5, OptVcolorEval = 6,
-                         OptDistExchange = 7, OptDistLanes = 8, OptHwQueues = 9, OptCodeCache = 10, OptPrefaultHuge = 11, OptDistIndex16 = 12, OptStreamPlacement = 13, OptIdleLane = 14;
+                         OptDistExchange = 7, OptDistLanes = 8, OptHwQueues = 9, OptCodeCache = 10, OptPrefaultHuge = 11, OptDistIndex16 = 12, OptStreamPlacement = 13, OptIdleLane = 14, OptIdlePrograms = 15;
 
         /// <summary>The HIP runtime maps all streams of a process onto GPU_MAX_HW_QUEUES in-order hardware queues (default 4) and reads
         /// the variable when IT initialises; the library's streams want 8 (sdfk_init in sdfkit_hip.hip says why).  A library must not

@@ -1,8 +1,11 @@
-"""Launched by tests/test_gpu_multirank.py under torch.distributed.run (every rank on GPU 0): a pipelined sharded
-session (sdfk_dist_session_*, the library's own step driver) over `world` ranks with the HOST transport (the ranks share
-one GPU, which RCCL refuses; the exchange goes through the gloo group, everything else is the production path); every
-rank compares the whole mesh of every step with the oracle's mesh of the whole grid, array by array.
-Exit code 0 = identical on this rank."""
+"""Launched by tests/test_gpu_multirank.py under torch.distributed.run: a pipelined sharded session (sdfk_dist_session_*, the
+library's own step driver) over `world` ranks; every rank compares the whole mesh of every step with the oracle's mesh of the
+whole grid, array by array.  Exit code 0 = identical on this rank.
+  default               every rank on GPU 0, the HOST transport (RCCL refuses two ranks on one device; the exchange goes through
+                        the gloo group, everything else is the production path)
+  SDFK_TEST_REAL_RCCL=1 one GPU per rank (LOCAL_RANK), the library's own RCCL communicator: ncclAllGather, the grouped
+                        ncclSend / ncclRecv exchange, gather-to-root and the 16-bit-index payloads BETWEEN GPUs
+                        (SDFK_DIST_EXCHANGE / SDFK_DIST_INDEX16 of the environment select; needs >= world GPUs)"""
 import os
 import sys
 
@@ -12,7 +15,10 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-os.environ["LOCAL_RANK"] = "0"
+REAL = os.environ.get("SDFK_TEST_REAL_RCCL") == "1"
+if not REAL:
+    os.environ["LOCAL_RANK"] = "0"
+DEVICE = int(os.environ.get("LOCAL_RANK", "0"))
 dist.init_process_group("gloo")
 from oracle import oracle as O          # noqa: E402
 from sdfkit_amd import _native as N     # noqa: E402
@@ -25,7 +31,12 @@ mn, mx = [-2.8125] * 3, [2.8125] * 3
 ov, oc = O.sample(scene, mn, mx, *dims)
 O.clip_to_bounds(ov, mn, mx)
 om = O.march(ov, oc, mn, mx)
-D.init_host(device=0)
+if REAL:
+    D.init(device=DEVICE)
+else:
+    D.init_host(device=0)
+MODE = N.get_option(N.OPT_DIST_EXCHANGE) if REAL else -1
+HOLDS_MESH = not (REAL and MODE == 2 and dist.get_rank() != 0)   # gather-to-root: only rank 0 holds the whole mesh
 graphs_on = N.get_option(N.OPT_GRAPHS) != 0 and N.get_option(N.OPT_DIST_LANES) != 0
 
 
@@ -37,16 +48,26 @@ def same(m, full=True):
     return bool(ok)
 
 
-ok = same(D.sharded_to_mesh(sdf, mn, mx, *dims))          # the one-off form first (sdfk_dist_to_mesh)
+ok = True
+if HOLDS_MESH:
+    ok = same(D.sharded_to_mesh(sdf, mn, mx, *dims))      # the one-off form first (sdfk_dist_to_mesh)
+elif REAL:   # (collective: every rank makes the call; the ranks that hold no mesh get SDFK_ERR_UNSUPPORTED from the extraction)
+    try:
+        D.sharded_to_mesh(sdf, mn, mx, *dims)
+        ok = False
+    except N.SdfKitNativeError as e:
+        ok = "only rank 0 holds the mesh" in str(e)
 ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=3)
 for it in range(16):
     if ses.in_flight == ses.depth:
         ses.collect()
-        ok &= same(ses.mesh())
+        if HOLDS_MESH:
+            ok &= same(ses.mesh())
     ses.submit()
 while ses.in_flight:
     ses.collect()
-    ok &= same(ses.mesh(), full=False)
+    if HOLDS_MESH:
+        ok &= same(ses.mesh(), full=False)
 counts = ses.counts()
 ok &= sum(c[0] for c in counts) == len(om.vertices) and sum(c[1] for c in counts) == len(om.triangles)
 import ctypes as C                      # noqa: E402
@@ -56,7 +77,7 @@ if graphs_on:
     # the repeat steps were captured step graphs (one per slot and lane), replayed from their second use on
     ok &= jobs.value >= 1 and launches.value >= 1
 st = ses.stats()
-ok &= st["steps"] == 16 and st["exchange_mode"] == -1 and st["index16"] == (os.environ.get("SDFK_DIST_INDEX16") == "1")
+ok &= st["steps"] == 16 and st["exchange_mode"] == MODE and st["index16"] == (os.environ.get("SDFK_DIST_INDEX16") == "1")
 ses.close()
 dist.barrier()
 D.shutdown()

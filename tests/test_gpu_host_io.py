@@ -92,6 +92,8 @@ def test_code_object_cache_on_disk(gpu, tmp_path):
     """First creation of a program compiles with hiprtc and leaves a code object in the cache directory; the next
     creation of the same program (a new process would do the same) loads it; a damaged entry is recompiled."""
     N.check(N.lib().sdfk_set_cache_dir(str(tmp_path / "jit").encode()))
+    idle = N.get_option(N.OPT_IDLE_PROGRAMS)
+    N.set_option(N.OPT_IDLE_PROGRAMS, 0)   # (a structure's modules are unloaded with its last program: every build() below starts cold)
     try:
         mn, mx, dims = [-2.0] * 3, [2.0] * 3, (40, 44, 48)
 
@@ -134,6 +136,7 @@ def test_code_object_cache_on_disk(gpu, tmp_path):
         assert (c5, h5) == (c4 + 1, h4) and not glob.glob(str(loose / "*.co"))
     finally:
         N.check(N.lib().sdfk_set_cache_dir(None))
+        N.set_option(N.OPT_IDLE_PROGRAMS, idle)
 
 
 def test_calls_from_other_threads(gpu):

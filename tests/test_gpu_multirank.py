@@ -73,6 +73,28 @@ def test_bench_gpus_n_started_as_plain_python(gpu, world):
     assert one["latency_ms_single_stream"] >= one["ms_per_step"] * 0.8
 
 
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()   # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.parametrize("exchange,index16", [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1)])
+def test_two_gpus_real_rccl_parity(gpu, exchange, index16):
+    """FIRST CONTACT between two GPUs, as a test: one rank per GPU, the library's own RCCL communicator, every exchange
+    (ncclAllGather, grouped ncclSend / ncclRecv, gather-to-root) and both payload forms; every step's whole mesh must be the
+    oracle's.  Skipped on a one-GPU box (the development boxes): there real RCCL runs at world 1 only
+    (test_rccl_world_one_through_the_c_abi) and 2-4 ranks go through the host transport."""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ)
+    env.update({"SDFK_TEST_REAL_RCCL": "1", "SDFK_DIST_EXCHANGE": str(exchange), "SDFK_DIST_INDEX16": str(index16),
+                "HSA_ENABLE_IPC_MODE_LEGACY": "0", "GPU_MAX_HW_QUEUES": "8", "NCCL_SOCKET_IFNAME": "lo", "GLOO_SOCKET_IFNAME": "lo"})
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multirank_worker.py"), "readme_repeat_xy", "72", "64", "80"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.count("identical") == 2, out.stdout[-3000:] + out.stderr[-4000:]
+
+
 def test_rccl_world_one_through_the_c_abi(gpu):
     """The library's own step driver over REAL RCCL (sdfk_dist_unique_id / sdfk_dist_init / sdfk_dist_to_mesh /
     sdfk_dist_session_*), world = 1 -- the only world size RCCL accepts on a one-GPU box: communicator creation through
@@ -102,10 +124,14 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
     om = O.march(ov, oc, mn, mx)
     assert_mesh_equal(D.sharded_to_mesh(sdf, mn, mx, *dims), om)
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), om)
-    for mode, idx16 in ((0, 0), (1, 0), (2, 0), (1, 1), (0, 1)):
+    assert N.get_option(N.OPT_DIST_EXCHANGE) == 0 and N.get_option(N.OPT_DIST_INDEX16) == 0    # the defaults: the plainest collective
+    # (exchange, payload form, internal streams, steps in flight): the default, the opt-ins, the CONSERVATIVE retry grades of
+    # bench.py (one step in flight; no lanes at all) and the compact gather-to-root form (tools/gpu_alt_configs.sh)
+    for mode, idx16, lanes, depth in ((0, 0, 3, 3), (1, 0, 3, 3), (2, 0, 3, 3), (1, 1, 3, 3), (0, 1, 3, 3), (0, 0, 3, 1), (0, 0, 0, 1), (2, 1, 3, 3), (2, 1, 0, 1)):
         N.set_option(N.OPT_DIST_EXCHANGE, mode)
         N.set_option(N.OPT_DIST_INDEX16, idx16)
-        ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=3)
+        N.set_option(N.OPT_DIST_LANES, lanes)
+        ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=depth)
         for it in range(12):
             if ses.in_flight == ses.depth:
                 nv, ni = ses.collect()
@@ -125,6 +151,7 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
         assert g.value and stride.value == st["stride_bytes"] == (need + need // 32 + 4096 + 255) // 256 * 256   # (slab_protocol.h)
         ses.close()
     N.set_option(N.OPT_DIST_INDEX16, 0)
+    N.set_option(N.OPT_DIST_LANES, 3)
     # the tuner: both exchanges x both payload forms, measured; whatever it keeps, the steps after it are the same mesh
     N.set_option(N.OPT_DIST_EXCHANGE, 1)
     for start16 in (0, 1):
