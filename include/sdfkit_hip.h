@@ -430,7 +430,10 @@ int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* colors3, vo
 /* Mesh.Transform(Matrix4x4) (Mesh.cs:47-64), in place on the device-resident mesh: positions by Vector3.Transform with
  * `matrix`, normals by Vector3.TransformNormal with `normal_matrix` and Vector3.Normalize, then Mesh.Measure.  Both
  * matrices row-major M11..M44 (row-vector convention of System.Numerics); normal_matrix = Transpose(Invert(matrix with
- * M41 = M42 = M43 = 0, M44 = 1)) exactly as Mesh.cs:49-55 derives it -- BCL calls the shim makes with the BCL itself. */
+ * M41 = M42 = M43 = 0, M44 = 1)) exactly as Mesh.cs:49-55 derives it -- BCL calls the shim makes with the BCL itself.
+ * Works on every mesh sdfk_march / sdfk_sample_march / sdfk_dist_mesh return, whatever the call history (a handle that borrows a
+ * captured job's arrays is transformed in place: the job is busy until the handle is freed); SDFK_ERR_UNSUPPORTED only for the
+ * per-rank slab meshes of sdfk_sample_march_slab whose arrays are sections of a gather buffer. */
 int sdfk_mesh_transform(sdfk_mesh* m, const float matrix[16], const float normal_matrix[16]);
 /* diagnostics: number of active cells, and of case-13 cells with no tiling
  * ("Impossible case 13?", MarchingCubes.cs:365) seen while meshing */

@@ -3209,7 +3209,9 @@ extern "C" int sdfk_mesh_transform(sdfk_mesh* m, const float matrix[16], const f
     if (!m || !matrix || !normal_matrix) return fail(SDFK_ERR_INVALID, "sdfk_mesh_transform: null argument");
     if (int r = require_init()) return r;
     if (int r = mesh_resolve(m)) return r;
-    if (m->borrowed || m->external) return fail(SDFK_ERR_UNSUPPORTED, "sdfk_mesh_transform: the mesh arrays belong to a captured job or a slab payload");
+    // (a mesh whose arrays are a captured job's -- every repeat sdfk_sample_march of a launch-bound grid -- is transformed in
+    // place like any other: the job stays busy, its buffers untouched by later launches, until this handle is freed)
+    if (m->external) return fail(SDFK_ERR_UNSUPPORTED, "sdfk_mesh_transform: the mesh arrays are sections of a slab payload (extract the mesh with sdfk_dist_mesh first)");
     if (m->nv == 0) return SDFK_OK;   // (Mesh.Measure leaves Min / Max alone, Mesh.cs:32)
     if (m->lane != g.cur_lane) m->used_on_main = true;
     const int grid = grid_for((size_t)m->nv, 256, 1024);

@@ -86,14 +86,20 @@ namespace SdfKit.Hip
         public const int OptLanes = 1, OptTokens = 2, OptGraphs = 3, OptCopyMode = 4, OptCornerEval = 5, OptVcolorEval = 6,
                          OptDistExchange = 7, OptDistLanes = 8, OptHwQueues = 9, OptCodeCache = 10, OptPrefaultHuge = 11, OptDistIndex16 = 12, OptStreamPlacement = 13, OptIdleLane = 14, OptIdlePrograms = 15;
 
+        // libc's own setenv: on Unix Environment.SetEnvironmentVariable only edits the runtime's managed copy of the environment,
+        // which the getenv of native code -- the HIP runtime's -- never sees
+        [DllImport("libc", EntryPoint = "setenv")] static extern int libc_setenv(string name, string value, int overwrite);
+
         /// <summary>The HIP runtime maps all streams of a process onto GPU_MAX_HW_QUEUES in-order hardware queues (default 4) and reads
         /// the variable when IT initialises; the library's streams want 8 (sdfk_init in sdfkit_hip.hip says why).  A library must not
         /// edit the environment of its process; this binding does, once, before its first native call -- which is this
-        /// process's first HIP call unless the host used HIP before (then the host exports the variable itself).</summary>
+        /// process's first HIP call unless the host used HIP before (then the host's launcher exports the variable itself).  It has to
+        /// be the NATIVE environment: setenv(3) through P/Invoke (overwrite = 0: a value the launcher exported stands).</summary>
         static Native()
         {
-            if (Environment.GetEnvironmentVariable("GPU_MAX_HW_QUEUES") == null)
-                Environment.SetEnvironmentVariable("GPU_MAX_HW_QUEUES", "8");
+            try { libc_setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+            catch (Exception) { /* no libc under that name: EnsureInit's check below says what the process ended up with */ }
+            Environment.SetEnvironmentVariable("GPU_MAX_HW_QUEUES", Environment.GetEnvironmentVariable("GPU_MAX_HW_QUEUES") ?? "8");
         }
 
         /// <summary>sdfk_init once per process; device = LOCAL_RANK (one process per GPU) or 0.</summary>
@@ -106,6 +112,11 @@ namespace SdfKit.Hip
                 if (sdfk_abi_version() != 4) throw new InvalidOperationException("libsdfkit_hip.so does not have the ABI version (4) this shim was written for");
                 int device = int.TryParse(Environment.GetEnvironmentVariable("LOCAL_RANK"), out var r) ? r : 0;
                 Check(sdfk_init(device));
+                // what the library saw when it came up (0 = unset): with fewer than 8 hardware queues its lanes share queues --
+                // correct, slower (a sharded step on a small slab takes twice as long): say so once
+                if (sdfk_get_option(OptHwQueues, out long hwq) == 0 && hwq < 8)
+                    Console.Error.WriteLine($"SdfKit.Hip: GPU_MAX_HW_QUEUES is {(hwq == 0 ? "unset" : hwq.ToString())} in the native environment " +
+                                            "(the HIP runtime was initialised before this binding could export it): export GPU_MAX_HW_QUEUES=8 in the launcher");
                 inited = true;
             }
         }

@@ -130,22 +130,90 @@ namespace SdfKit
         }
     }
 
+    /// <summary>Exact-length arrays of meshes that were handed back with <see cref="Mesh.Recycle"/>, keyed by element type and
+    /// length.  Mesh.cs:10-13 makes a mesh four managed arrays of exactly Vertices.Length / Triangles.Length elements, and on a
+    /// growing heap a new array is memory nobody has touched: 26 MB of page faults, 1.0 of the 1.6 ms one ToMesh call costs at
+    /// 512^3, against 0.75 ms into resident pages.  A host that meshes the same grid again and again gets the same counts again
+    /// and again: the arrays of the mesh it is done with serve the next one (bench.py: one_step_incl_mesh_d2h.pooled; the Python
+    /// mirror has the same class, sdfkit_amd/api.py).  A miss allocates with GC.AllocateUninitializedArray (no zeroing pass).
+    /// Like System.Buffers.ArrayPool: whoever recycles a mesh must not touch its arrays afterwards.</summary>
+    public static class MeshArrayPool
+    {
+        public static int PerLength = 4;              // arrays kept per (type, length)
+        public static long MaxBytes = 1L << 30;
+        static readonly object gate = new object();
+        static readonly System.Collections.Generic.Dictionary<(Type, int), System.Collections.Generic.Stack<Array>> free = new();
+        static readonly System.Collections.Generic.LinkedList<(Type, int)> order = new();   // least recently returned first
+        static long bytes;
+        public static long Hits, Misses;
+
+        public static T[] Rent<T>(long n, out bool recycled) where T : unmanaged
+        {
+            lock (gate) {
+                if (free.TryGetValue((typeof(T), (int)n), out var st) && st.Count > 0) {
+                    var a = (T[])st.Pop();
+                    bytes -= n * System.Runtime.CompilerServices.Unsafe.SizeOf<T>();
+                    Hits++; recycled = true;
+                    return a;
+                }
+                Misses++;
+            }
+            recycled = false;
+            return GC.AllocateUninitializedArray<T>((int)n);
+        }
+
+        public static void Return<T>(T[]? a) where T : unmanaged
+        {
+            if (a == null || a.Length == 0) return;
+            long sz = (long)a.Length * System.Runtime.CompilerServices.Unsafe.SizeOf<T>();
+            lock (gate) {
+                var key = (typeof(T), a.Length);
+                if (!free.TryGetValue(key, out var st)) free[key] = st = new System.Collections.Generic.Stack<Array>();
+                if (st.Count >= PerLength) return;
+                st.Push(a); bytes += sz;
+                order.Remove(key); order.AddLast(key);
+                while (bytes > MaxBytes && order.First != null) {     // the length nobody has returned to for longest goes first
+                    var old = order.First.Value; order.RemoveFirst();
+                    if (free.Remove(old, out var dead))
+                        foreach (var d in dead) bytes -= Buffer.ByteLength(d);
+                }
+            }
+        }
+    }
+
     public partial class Mesh
     {
         /// <summary>sdfk_mesh_counts waits for the (deferred) job and verifies its size guess; the four managed arrays
-        /// are exact-length like the reference's (tests assert Vertices.Length); Min/Max come from the device
-        /// (Mesh.Measure, Mesh.cs:30-45, is fused into the vertex kernel) through an internal constructor that skips Measure().</summary>
+        /// are exact-length like the reference's (tests assert Vertices.Length) and come from <see cref="MeshArrayPool"/> (a miss:
+        /// fresh, uninitialised); Min/Max come from the device (Mesh.Measure, Mesh.cs:30-45, is fused into the vertex kernel)
+        /// through an internal constructor that skips Measure().</summary>
         internal static unsafe Mesh FromNative(IntPtr h, bool colors = true)
         {
             Native.Check(Native.sdfk_mesh_counts(h, out long nv, out long ni));
-            var v = new Vector3[nv]; var c = new Vector3[nv]; var n = new Vector3[nv]; var t = new int[ni];
-            // colors == false: the program only writes .W, every colour is (0,0,0) (Voxels.cs:88-92) -- and a new managed array
-            // IS zero: no colour destination is passed, the library has nothing to clear or to fault in (0.7 of 2.4 ms at 512^3)
+            var v = MeshArrayPool.Rent<Vector3>(nv, out _); var n = MeshArrayPool.Rent<Vector3>(nv, out _); var t = MeshArrayPool.Rent<int>(ni, out _);
+            // colors == false: the program only writes .W, every colour is (0,0,0) (Voxels.cs:88-92).  A NEW array is zero already:
+            // no colour destination is passed, the library has nothing to clear or to fault in (0.7 of 2.4 ms at 512^3); a recycled
+            // one holds an old mesh's colours: it is passed, and the library clears it (resident pages: a memset on its pool)
+            Vector3[] c;
+            bool clear;
+            if (colors) { c = MeshArrayPool.Rent<Vector3>(nv, out _); clear = true; }
+            else {
+                c = MeshArrayPool.Rent<Vector3>(nv, out clear);
+                if (!clear) c = new Vector3[nv];     // (a miss gave an UNINITIALISED array: take a zeroed one instead)
+            }
             fixed (Vector3* pv = v, pc = c, pn = n) fixed (int* pt = t)
-                Native.Check(Native.sdfk_mesh_copy(h, (float*)pv, colors ? (float*)pc : null, (float*)pn, pt));
+                Native.Check(Native.sdfk_mesh_copy(h, (float*)pv, clear ? (float*)pc : null, (float*)pn, pt));
             Vector3 mn, mx;
             Native.Check(Native.sdfk_mesh_bounds(h, (float*)&mn, (float*)&mx));
             return new Mesh(v, c, n, t, mn, mx);
+        }
+
+        /// <summary>Hands the four arrays to <see cref="MeshArrayPool"/>: the next mesh of the same size gets them instead of new,
+        /// untouched memory.  Not in the reference (a Mesh is simply collected); opt-in for hosts that mesh repeatedly.  The mesh
+        /// and its arrays must not be used afterwards.</summary>
+        public void Recycle()
+        {
+            MeshArrayPool.Return(Vertices); MeshArrayPool.Return(Colors); MeshArrayPool.Return(Normals); MeshArrayPool.Return(Triangles);
         }
     }
 }

@@ -23,7 +23,21 @@ dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.ti
 t = torch.tensor([rank + 1])
 dist.all_reduce(t)
 assert int(t.item()) == world * (world + 1) // 2
+line = {"metric": "stub", "n_gpus": world, "note": os.environ.get("SDFK_BENCH_NOTE", ""), "argv": sys.argv[1:],
+        "depth": os.environ.get("SDFK_BENCH_DEPTH", "")}
+# like the real worker: the finished headline goes to the supervisor's file, every rank leaves its marker, THEN the tuned pass
+base = os.environ["SDFK_BENCH_RESULT_BASE"]
 if rank == 0:
-    print(json.dumps({"metric": "stub", "n_gpus": world, "note": os.environ.get("SDFK_BENCH_NOTE", ""), "argv": sys.argv[1:],
-                      "depth": os.environ.get("SDFK_BENCH_DEPTH", "")}), flush=True)
+    with open(base + ".json", "w") as f:
+        f.write(json.dumps(dict(line, tuned_pass="did not finish")) + "\n")
+open(f"{base}.rank{rank}.done", "w").close()
+dist.barrier()
+if first and mode == "tune_die" and rank == world - 1:
+    os._exit(3)
+if first and mode == "tune_hang":      # (one rank hangs in the tuner's collective, the other waits for it: both are killed at the limit)
+    time.sleep(3600)
+if first and mode == "tune_die":       # (rank 0 waits for the dead rank in the next collective and fails)
+    dist.barrier()
+if rank == 0:
+    print(json.dumps(dict(line, tuned_pass="done")), flush=True)
 dist.destroy_process_group()

@@ -66,12 +66,29 @@ def test_rank_supervisors_agree_on_the_retry_ladder(first_attempt):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["argv"][:2] == ["--gpus", "2"]
     if first_attempt == "ok":
-        assert d["note"] == "" and d["depth"] == ""
+        assert d["note"] == "" and d["depth"] == "" and d["tuned_pass"] == "done"
     else:
         assert d["note"].startswith("retry: one step in flight, plain ncclAllGather") and d["depth"] == "1"
         assert "multi-rank run failed" in p.stderr
         if first_attempt == "hang":
             assert "did not finish within 25 s" in p.stderr
+
+
+@pytest.mark.parametrize("first_attempt", ["tune_die", "tune_hang"])
+def test_a_failed_tuned_pass_does_not_cost_the_headline(first_attempt):
+    """The headline pass of a multi-rank run uses the plainest exchange; the tuner -- which tries the exchanges that have never
+    run between two GPUs -- comes AFTER rank 0 has left the finished line with its supervisor and every rank its marker.  A
+    worker that dies or hangs in the tuned pass therefore still counts as a finished attempt: no retry, exactly one line, the
+    headline's, saying that the tuned pass did not finish."""
+    import json
+    p = _launch_with_stub(first_attempt, 20 if first_attempt == "tune_hang" else 120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["note"] == "" and d["depth"] == ""          # the FIRST attempt's line: nobody retried
+    assert d["tuned_pass"] == "did not finish"
+    assert "reporting the headline pass" in p.stderr and "multi-rank run failed" not in p.stderr
 
 
 def test_plain_python_with_gpus_gt_1_launches_before_touching_torch():

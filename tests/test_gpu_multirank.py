@@ -116,6 +116,7 @@ buf = (C.c_ubyte * 128)()
 N.check(L.sdfk_dist_unique_id(buf))
 N.check(L.sdfk_dist_init(1, 0, buf))
 assert D.info() == (1, 0, 1)
+assert N.get_option(N.OPT_DIST_EXCHANGE) == 0 and N.get_option(N.OPT_DIST_INDEX16) == 0    # the defaults: the plainest collective
 for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64))):
     scene, sdf = S.CATALOGUE[name]()
     mn, mx = [-2.8125] * 3, [2.8125] * 3
@@ -124,7 +125,6 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
     om = O.march(ov, oc, mn, mx)
     assert_mesh_equal(D.sharded_to_mesh(sdf, mn, mx, *dims), om)
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), om)
-    assert N.get_option(N.OPT_DIST_EXCHANGE) == 0 and N.get_option(N.OPT_DIST_INDEX16) == 0    # the defaults: the plainest collective
     # (exchange, payload form, internal streams, steps in flight): the default, the opt-ins, the CONSERVATIVE retry grades of
     # bench.py (one step in flight; no lanes at all) and the compact gather-to-root form (tools/gpu_alt_configs.sh)
     for mode, idx16, lanes, depth in ((0, 0, 3, 3), (1, 0, 3, 3), (2, 0, 3, 3), (1, 1, 3, 3), (0, 1, 3, 3), (0, 0, 3, 1), (0, 0, 0, 1), (2, 1, 3, 3), (2, 1, 0, 1)):
@@ -174,6 +174,7 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
         assert ses.stats()["redone"] == 0 and ses.stats()["index16_fallbacks"] == 0
         ses.close()
     N.set_option(N.OPT_DIST_INDEX16, 0)
+    N.set_option(N.OPT_DIST_EXCHANGE, 0)
 D.shutdown()
 print("rccl world 1 ok")
 """ % ROOT
