@@ -372,6 +372,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     N.init(local_rank)
     L = N.lib()
+    N.set_option(N.OPT_ELIDE_VOLUME, 0)   # the contract's step STORES the volume, whatever the environment's default; the elided form has a leg of its own
     # torch events (the roofline pass) and the library's lane 0 on one explicit stream.  NOT for a sharded run: it uses no
     # torch GPU work at all, and one more stream in the process changes which of them share a hardware queue (a sharded step
     # on a small slab: 94 us with the extra stream, 39 us without -- tools/slab_step_trace.py)
@@ -736,6 +737,32 @@ def main():
         for vol in vols:
             vol._free()
 
+    # ---- SDFK_OPT_ELIDE_VOLUME (opt-in, never `value`): the same pipelined steps without STORING the volume -- sdfk_sample_march
+    # never hands its Voxels out (SdfEx.ToMesh, Sdf.cs:59-63: a temporary), and with the sign bits, re-evaluated corners and
+    # re-evaluated vertex colours the meshing chain does not read it.  Meshes are bit-identical (tests/test_gpu_elide_volume.py).
+    # The contract's step includes the stores, so the headline keeps them.
+    def timed_elided(step_fn, drain_fn, k):
+        with N.option(N.OPT_ELIDE_VOLUME, 1):
+            for _ in range(8):
+                step_fn()
+            drain_fn()
+            t_w = time.perf_counter()
+            while (time.perf_counter() - t_w) * 1e3 < warm_ms * 0.5:
+                for _ in range(8):
+                    step_fn()
+                drain_fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step_fn()
+            drain_fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / k
+
+    elided_ms = None
+    if not sharded and not args.minimal and n ** 3 > (1 << 24):
+        elided_ms = timed_elided(step, drain, args.steps) * 1e3
+
     # ---- BASELINE config C3 ("HBM roofline run": the README's RepeatXY scene with colours, 512^3, clipToBounds,
     # /root/reference README.md:24-30) timed in THIS run, next to the headline -- never as `value`: 10 pipelined steps bracketed by
     # synchronisation, and its sampling kernel alone, back to back (16 B/voxel stored + 1/8 B/voxel of sign bits)
@@ -775,12 +802,14 @@ def main():
         samp3_us = e0.elapsed_time(e1) * 1e3 / k3
         for vol in vols:
             vol._free()
+        e3 = timed_elided(step3, drain3, k3)
         bytes3 = n ** 3 * 16 + n ** 3 // 8
         meas3 = load_pmc_traffic("pipeline_step", "repeatxy", n)
         c3 = {"workload": WORKLOADS["repeatxy"] + f", {n}^3", "steps": k3, "ms_per_step": round(s3 * 1e3, 4),
               "mvoxels_per_s": round(n ** 3 / s3 / 1e6, 1), "vertices": nv3, "triangles": ni3 // 3,
               "frac_design_bytes": round((bytes3 + 36 * nv3 + 4 * ni3) / s3 / 1e9 / HBM_PEAK_GBS, 4),
               "frac_measured_bytes": None if not meas3 else round(meas3 / s3 / 1e9 / HBM_PEAK_GBS, 4),
+              "elided_volume_ms_per_step": round(e3 * 1e3, 4),
               "sampler_us_back_to_back": round(samp3_us, 1),
               "sampler_frac": round(bytes3 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
               "what": "BASELINE config C3 in this run: pipelined sample -> mesh of the README scene (colours: 16 B/voxel stored), then its sampling "
@@ -1017,6 +1046,10 @@ def main():
             "kernels_us": kern,
             "roofline": roof,
             "c3_repeatxy": c3,
+            "elided_volume_ms_per_step": None if elided_ms is None else round(elided_ms, 4),
+            "elided_volume_is": "SDFK_OPT_ELIDE_VOLUME = 1 (opt-in): the same K pipelined steps with a volume that is never stored -- the sampler "
+                                "leaves sign bits only, corners and vertex colours are re-evaluated; meshes bit-identical.  Not the contract's "
+                                "step (which includes the 4 B/voxel of stores): reported next to `value`, never as it",
         }
         out.update(extra)
         if dist_extra:

@@ -148,7 +148,13 @@ typedef enum sdfk_option {
     SDFK_OPT_IDLE_PROGRAMS = 15,/* compiled kernel sets are shared by every program of one STRUCTURE (the constants of a program are kernel
                                    arguments, sdfk_program_create); this many structures stay loaded after their last program has been
                                    destroyed (default 32; 0: unloaded at once) -- the next frame of an animation asks for the same one */
-    SDFK_OPT_COUNT_ = 16
+    SDFK_OPT_ELIDE_VOLUME = 16, /* 1: sdfk_sample_march (SdfEx.ToMesh, Sdf.cs:59-63: the Voxels is a temporary nobody sees) on grids above the
+                                   captured-graph limit does not STORE its volume: the sampler leaves the sign bits only, cell corners and
+                                   vertex colours are re-evaluated by the program -- 4 (16 with colours) bytes per voxel of HBM writes less,
+                                   meshes bit-identical.  A volume whose sign words contain case 13 is sampled again with stores (the
+                                   dead-cell test reads voxels).  0 (default): the volume is stored, as the reference does and as the
+                                   headline benchmark's step is defined */
+    SDFK_OPT_COUNT_ = 17
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);
 int sdfk_get_option(int32_t key, int64_t* value);

@@ -584,7 +584,9 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
     }
     __syncthreads();
     const uint32_t n = min(P.counters->n_active, P.cap_active);
-    const bool check_dead = P.counters->n_case13 != 0;
+    // (a volume without storage -- SDFK_OPT_ELIDE_VOLUME -- has no voxels for the dead-cell test to read: the host sees the
+    // same counter, discards this job's result and redoes it on a volume that has them)
+    const bool check_dead = P.counters->n_case13 != 0 && P.values != nullptr;
     const int nchunks = (int)((n + MC_CHUNK - 1u) / MC_CHUNK);
     float* col = s_v + threadIdx.x;
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {

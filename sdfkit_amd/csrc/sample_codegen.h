@@ -100,13 +100,18 @@ __device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float
 //              130 instead of 80 us at 510^3.)
 #define SDFK_ROWS 0
 #define SDFK_FLAT 1
-template <bool CLIP, int MODE>
+// STORE = false (sdfk_sample_signs[_flat], SDFK_OPT_ELIDE_VOLUME): the sign bytes ONLY -- no Values, no Colors.  A volume that
+// sdfk_sample_march creates for itself is a temporary (Sdf.cs:59-63): with the sign bits from here, the corners of the active
+// cells re-evaluated (sdfk_corners_eval) and the vertex colours re-evaluated (sdfk_vertex_colors) the meshing chain never reads
+// it, so the 4 (16) bytes per voxel need not be written at all; the colour arithmetic is dead code the compiler removes.
+// ClipToBounds is then a run-time flag (A.clip) instead of a second instantiation.
+template <bool CLIP, int MODE, bool STORE = true>
 __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const SdfkK& K)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
     __shared__ unsigned char nib[8][64];
 #if SDFK_WRITES_COLOR
-    __shared__ __attribute__((aligned(16))) float cbuf[8 / RPW][768];   // colour staging, one slice per wavefront
+    __shared__ __attribute__((aligned(16))) float cbuf[STORE ? 8 / RPW : 1][STORE ? 768 : 1];   // colour staging, one slice per wavefront
 #endif
     // (a program that only assigns .W has no staging buffer: 0.5 instead of 12.5 KB of LDS per workgroup -- at 8 wavefronts
     // per SIMD the sampler would otherwise hold 100 of a CU's 160 KB, and the marching-cubes kernels of the job before it
@@ -157,12 +162,12 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 sdf_eval(K, px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
-                if (CLIP && (edge_xy || edge_z[k])) w[k] = A.outside;
+                if ((CLIP || (!STORE && A.clip)) && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
             const long o = MODE == SDFK_FLAT ? (long)ix * plane + (f0 + 4 * lane) : ((long)ix * A.ny + iy) * P + z;
-            sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
+            if (STORE) sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
 #if SDFK_WRITES_COLOR
-            if (A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
+            if (STORE && A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
                 sdfk_f4* mine = reinterpret_cast<sdfk_f4*>(cbuf[wave] + 12 * lane);
                 mine[0] = sdfk_f4{cr[0], cg[0], cb[0], cr[1]};
                 mine[1] = sdfk_f4{cg[1], cb[1], cr[2], cg[2]};
@@ -173,7 +178,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
             if (MODE == SDFK_FLAT && z + 3 >= A.nz) n &= z < A.nz ? (1u << (A.nz - z)) - 1u : 0u;   // row padding: 0 bits
         }
         nib[r][lane] = (unsigned char)n;
-        if (A.colors && ix < A.nx) {
+        if (STORE && A.colors && ix < A.nx) {
             // A lane produced 48 contiguous bytes (4 voxels x rgb) of the wavefront's 3 KiB run.
             // Stored as they are, every instruction would touch a third of every line; through
             // the LDS slice they become three full 1 KiB nontemporal stores (lane L writes
@@ -218,9 +223,16 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
     }
 }
 // SDFK_KERNELS: bit mask of the entry points this module contains (the host compiles a program's kernels on demand:
-// bit 0 / 1 = the two instantiations without ClipToBounds, 3 / 4 = with it, 5 = sdfk_vertex_colors, 6 = sdfk_corners_eval, 7 = sdfk_raymarch)
+// bit 0 / 1 = the two instantiations without ClipToBounds, 3 / 4 = with it, 5 = sdfk_vertex_colors, 6 = sdfk_corners_eval, 7 = sdfk_raymarch,
+// 2 / 8 = the sign-bits-only samplers of SDFK_OPT_ELIDE_VOLUME)
 #ifndef SDFK_KERNELS
-#define SDFK_KERNELS 0xff
+#define SDFK_KERNELS 0x1ff
+#endif
+#if SDFK_KERNELS & 0x04
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_signs(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_ROWS, false>(A, K); }
+#endif
+#if SDFK_KERNELS & 0x100
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_signs_flat(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_FLAT, false>(A, K); }
 #endif
 #if SDFK_KERNELS & 0x01
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_ROWS>(A, K); }

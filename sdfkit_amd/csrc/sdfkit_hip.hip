@@ -58,6 +58,7 @@ struct Config {
     int dist_index16 = 0;     // SDFK_OPT_DIST_INDEX16
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
     int idle_programs = 32;   // SDFK_OPT_IDLE_PROGRAMS
+    int elide_volume = 0;     // SDFK_OPT_ELIDE_VOLUME
     int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
     int place_streams = 1;    // SDFK_OPT_STREAM_PLACEMENT
     int idle_lane = 1;        // SDFK_OPT_IDLE_LANE
@@ -762,7 +763,9 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
 // opaque objects
 // ---------------------------------------------------------------------------
 // Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
-enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_VCOLORS = 5, PK_CORNERS = 6, PK_RAYMARCH = 7, PK_COUNT = 8 };
+enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_SIGNS = 2, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_VCOLORS = 5, PK_CORNERS = 6, PK_RAYMARCH = 7,
+                  PK_SIGNS_FLAT = 8, PK_COUNT = 9 };
+static bool pk_is_sampler(int k) { return k <= PK_BITS_CLIP_FLAT || k == PK_SIGNS_FLAT; }
 
 // The compiled kernels of one program STRUCTURE (opcodes, operand ids, outputs -- the generated source; a program's
 // constants are kernel arguments, csrc/sample_codegen.h): shared by every program of that structure, so that a scene whose
@@ -785,6 +788,7 @@ struct sdfk_program {
     int writes_color = 0;
     int refs = 1;   // the caller's handle + volumes it has sampled + queued jobs that launch from its module
     bool orphaned = false;   // the caller's handle is gone (sdfk_program_destroy): captured jobs keyed on it can never be asked for again
+    bool no_elide = false;   // a volume of this program had case-13 sign words (the dead-cell test reads voxels): its volumes are stored from then on
     void* kargs() const { return const_cast<float*>(params.data()); }   // the by-value SdfkK argument of every generated kernel
 };
 
@@ -794,6 +798,10 @@ struct sdfk_volume {
     float gmin[3], gmax[3];
     float* values = nullptr;
     float* colors = nullptr;          // nullptr: colours are all zero
+    // SDFK_OPT_ELIDE_VOLUME: a volume sdfk_sample_march made for itself and never hands out has NO storage for Values / Colors
+    // (values == colors == nullptr): its sampler leaves the sign bits only, corners and vertex colours are re-evaluated.
+    // elided_colors: the program writes colours (the mesh has a colour array although the volume has none).
+    bool elided = false, elided_colors = false;
     // sign bits (value > bits_iso) packed along X, written by the fused sampling kernel;
     // valid until Values change (upload / ClipToBounds)
     uint64_t* bits = nullptr;
@@ -863,6 +871,7 @@ struct sdfk_march_job {
     uint8_t* bits8 = nullptr;            // byte form of the sign bits (k_signbits8 -> k_bits_transpose), job-owned
     sdfk_program* eval_prog = nullptr;   // corners by re-evaluation (holds a reference)
     SampleArgs eval_args;
+    bool colors_elided = false;        // the volume has no colour storage although its program writes colours (SDFK_OPT_ELIDE_VOLUME)
     int slot = -1;                 // index of the pinned result slot (owned until job_release)
     int lane = 0;                  // lane the job's kernels are queued on
     float* bounds_partial = nullptr;   // per-workgroup AABB partials of k_vertices (allocated once per job: launch_emit is allocation-free after)
@@ -916,6 +925,7 @@ static void config_from_env()
     g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0) ? 1 : 0;
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
     g_cfg.idle_programs = ranged("SDFK_IDLE_PROGRAMS", 32, 0, 1024);
+    g_cfg.elide_volume = geti("SDFK_ELIDE_VOLUME", 0) ? 1 : 0;
     g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0) ? 1 : 0;
     g_cfg.place_streams = geti("SDFK_STREAM_PLACEMENT", 1) ? 1 : 0;
     g_cfg.idle_lane = geti("SDFK_IDLE_LANE", 1) ? 1 : 0;
@@ -1112,6 +1122,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_IDLE_LANE: if (!in(0, 1)) break; g_cfg.idle_lane = (int)value; return SDFK_OK;
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
     case SDFK_OPT_IDLE_PROGRAMS: if (!in(0, 1024)) break; g_cfg.idle_programs = (int)value; codes_trim(); return SDFK_OK;
+    case SDFK_OPT_ELIDE_VOLUME: if (!in(0, 1)) break; g_cfg.elide_volume = (int)value; return SDFK_OK;
     case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;
     case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
     default: return fail(SDFK_ERR_INVALID, "sdfk_set_option: unknown option %d", key);
@@ -1138,6 +1149,7 @@ extern "C" int sdfk_get_option(int32_t key, int64_t* value)
     case SDFK_OPT_IDLE_LANE: *value = g_cfg.idle_lane; break;
     case SDFK_OPT_CODE_CACHE: *value = g_cfg.code_cache; break;
     case SDFK_OPT_IDLE_PROGRAMS: *value = g_cfg.idle_programs; break;
+    case SDFK_OPT_ELIDE_VOLUME: *value = g_cfg.elide_volume; break;
     case SDFK_OPT_PREFAULT_HUGE: *value = g_cfg.prefault_huge; break;
     case SDFK_OPT_HW_QUEUES: *value = g_cfg.hw_queues; break;
     default: return fail(SDFK_ERR_INVALID, "sdfk_get_option: unknown option %d", key);
@@ -1380,7 +1392,7 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::vector<char> code;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
     config_from_env();
-    return compile_source(src, 0xfbu, code, false);   // every kernel, a real compile: this IS the check
+    return compile_source(src, 0x1ffu, code, false);   // every kernel, a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -1407,10 +1419,11 @@ int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
     ProgCode* p = cp->code;
     p->last_use = ++g_code_clock;
     if (!p->fn[k]) {
-        static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "", "sdfk_sample_bits_clip",
-                                                    "sdfk_sample_bits_clip_flat", "sdfk_vertex_colors", "sdfk_corners_eval", "sdfk_raymarch"};
+        static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_signs", "sdfk_sample_bits_clip",
+                                                    "sdfk_sample_bits_clip_flat", "sdfk_vertex_colors", "sdfk_corners_eval", "sdfk_raymarch",
+                                                    "sdfk_sample_signs_flat"};
         unsigned mask = 1u << k;
-        if (k <= PK_BITS_CLIP_FLAT && !p->fn[PK_CORNERS]) {   // (and, for a program that writes colours, sdfk_vertex_colors)
+        if (pk_is_sampler(k) && !p->fn[PK_CORNERS]) {   // (and, for a program that writes colours, sdfk_vertex_colors)
             mask |= 1u << PK_CORNERS;
             if (cp->writes_color && !p->fn[PK_VCOLORS]) mask |= 1u << PK_VCOLORS;
         }
@@ -1499,6 +1512,48 @@ extern "C" int sdfk_volume_create(int32_t nx, int32_t ny, int32_t nz, const floa
                                   int32_t with_colors, sdfk_volume** out)
 {
     return sdfk_volume_create_slab(nx, ny, nz, min, max, 0, nz, with_colors, out);
+}
+
+namespace {
+// The temporary volume of a self-contained sample -> mesh job.  With SDFK_OPT_ELIDE_VOLUME (and both re-evaluation paths on) it
+// has no Values / Colors storage at all: nobody can ask for them (the volume never leaves the library).
+int job_volume_create(const sdfk_program* p, int nx, int ny, int nz, const float mn[3], const float mx[3], sdfk_volume** out)
+{
+    const bool elide = g_cfg.elide_volume && g_cfg.corner_eval && g_cfg.vcolor_eval && !p->no_elide;
+    if (!elide) return sdfk_volume_create(nx, ny, nz, mn, mx, p->writes_color ? 1 : 0, out);
+    *out = nullptr;
+    if (nx < 1 || ny < 1 || nz < 1) return fail(SDFK_ERR_INVALID, "sdfk_sample_march: bad dimensions %dx%dx%d", nx, ny, nz);
+    if ((int64_t)nx * ny * ((nz + 3) & ~3) >= (int64_t(1) << 31)) return fail(SDFK_ERR_INVALID, "grid exceeds the reference's int32 linear index (Voxels.cs:82)");
+    sdfk_volume* v = new sdfk_volume();
+    v->nx = nx; v->ny = ny; v->nz = nz; v->nz_global = nz; v->z0 = 0;
+    memcpy(v->gmin, mn, sizeof v->gmin);
+    memcpy(v->gmax, mx, sizeof v->gmax);
+    v->elided = true;
+    v->elided_colors = p->writes_color != 0;
+    *out = v;
+    return SDFK_OK;
+}
+
+// An elided volume gets its storage after all (the rare fall-back: a volume with case-13 sign words needs the dead-cell test of
+// k_resolve, which reads neighbouring voxels) and is sampled again, this time with stores.
+int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, float iso_hint);
+int volume_materialize(sdfk_volume* v)
+{
+    if (!v->elided) return SDFK_OK;
+    sdfk_program* p = v->sampled_by;
+    if (!p) return fail(SDFK_ERR_INVALID, "an elided volume without its program");
+    int r = dev_alloc((void**)&v->values, v->nalloc() * sizeof(float));
+    if (!r && v->elided_colors) r = dev_alloc((void**)&v->colors, v->nalloc() * 3 * sizeof(float));
+    if (r) { dev_free(v->values); v->values = nullptr; return r; }
+    v->elided = false;
+    p->no_elide = true;
+    const int clip = v->sampled_args.clip;
+    const float iso = v->bits_iso;
+    p->refs++;                       // (sample_impl drops the volume's reference before it takes a new one)
+    r = sample_impl(p, v, clip, iso);
+    program_release(p);
+    return r;
+}
 }
 
 extern "C" void sdfk_volume_free(sdfk_volume* v)
@@ -1624,7 +1679,8 @@ static void grid_constants(const sdfk_volume* v, float d[3], float m[3], float* 
     *outside = (v->gmax[0] - v->gmin[0]) / (float)v->nx;
 }
 
-static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, float iso_hint)
+namespace {
+int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, float iso_hint)
 {
     SampleArgs A;
     memset(&A, 0, sizeof A);
@@ -1670,8 +1726,9 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
             if (force == 1 || v->ny > 65535 || v->nx8() > 65535) mode = 1;   // (the row-tiled form has y and x/8 in 16-bit grid dimensions)
             static const char* const names[2][2] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat"}, {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat"}};
             hipFunction_t fn = nullptr;   // (compiled on first use)
-            if (int r = program_fn(p, (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode, &fn)) return r;
-            ProfScope ps(names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
+            const int pk = v->elided ? (mode ? PK_SIGNS_FLAT : PK_SIGNS) : (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode;
+            if (int r = program_fn(p, pk, &fn)) return r;
+            ProfScope ps(v->elided ? (mode ? "sdfk_sample_signs_flat" : "sdfk_sample_signs") : names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
             const size_t plane = (size_t)v->ny * v->pitch();
             phase_token_wait(0);
             if (mode == 1) {
@@ -1699,6 +1756,7 @@ static int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bo
         return SDFK_OK;
     }
 }
+}  // namespace
 
 extern "C" int sdfk_sample(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds)
 {
@@ -1921,6 +1979,11 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     McParams& P = j->P;
     memset(&P, 0, sizeof P);
     P.values = w->values; P.colors = w->colors;
+    j->colors_elided = w->elided && w->elided_colors;
+    if (w->elided && (step != 1 || !w->sampled_by || !g_cfg.corner_eval || (w->elided_colors && !g_cfg.vcolor_eval) || !w->bits_valid || w->bits_iso != iso)) {
+        job_release(j); delete j;
+        return fail(SDFK_ERR_INVALID, "internal: a volume without storage can only be meshed by the program that sampled it (step 1, same iso)");
+    }
     P.nx = w->nx; P.ny = w->ny; P.nz = w->nz;
     P.nzp = w->pitch();
     {   // bit split of the packed cell coordinates: 16 + 16 unless one of nx, ny needs more (the other then needs fewer)
@@ -2007,7 +2070,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     McMeshOut M;
     memset(&M, 0, sizeof M);
     M.vertices = m->vertices; M.colors = m->colors; M.normals = m->normals; M.triangles = m->triangles;
-    m->has_colors = j->P.colors != nullptr;
+    m->has_colors = j->P.colors != nullptr || j->colors_elided;
     M.cap_vertices = (uint32_t)m->cap_v;
     M.cap_indices = m->cap_i;
     M.vertex_base = vertex_base;
@@ -2041,7 +2104,7 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     // Vertex colours of a volume its own program has just sampled: re-evaluated by the program (sdfk_vertex_colors) from
     // the (creator record, edge) descriptors k_vertices leaves, instead of gathered from the colour volume
     const bool no_vcol = !g_cfg.vcolor_eval;   // (SDFK_OPT_VCOLOR_EVAL = 0: the gather path)
-    const bool vcol = j->eval_prog && j->eval_prog->writes_color && j->P.colors && M.colors && j->P.step == 1 && !no_vcol;
+    const bool vcol = j->eval_prog && j->eval_prog->writes_color && (j->P.colors || j->colors_elided) && M.colors && j->P.step == 1 && !no_vcol;
     if (vcol) {
         const size_t need = std::max<size_t>(m->cap_v, 1);
         if (!j->vdesc || j->vdesc_cap < need) {
@@ -2114,6 +2177,14 @@ int march_exact(const sdfk_volume* v, float iso, int step, int layer_begin, int 
     } else {
         r = launch_classify(j, true);
         r = r ? r : wait_counters(j);
+        if (!r && v->elided && j->c.n_case13 != 0) {
+            // case-13 sign words: k_resolve's dead-cell test reads neighbouring VOXELS, and this volume has none
+            // (SDFK_OPT_ELIDE_VOLUME): give it its storage, sample again with stores, start over
+            job_release(j);
+            delete j;
+            if (int r2 = volume_materialize(const_cast<sdfk_volume*>(v))) return r2;
+            return march_exact(v, iso, step, layer_begin, layer_end, vertex_base, key, out);
+        }
         if (!r && j->c.n_active > j->P.cap_active) {   // record list too small: exact size, redo
             r = alloc_records(j, j->c.n_active);
             r = r ? r : launch_classify(j, true);
@@ -2182,7 +2253,10 @@ int mesh_resolve(sdfk_mesh* m)
     m->done = nullptr;
     if (e != hipSuccess) r = fail(SDFK_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
     j->c = g.slots[j->slot].c;
-    const bool fits = j->c.n_active <= j->P.cap_active && j->c.overflow == 0 &&
+    // (an elided volume -- SDFK_OPT_ELIDE_VOLUME -- whose sign words contain case 13 is redone on the exact path, which gives it
+    // its storage first: the dead-cell test of k_resolve reads neighbouring voxels)
+    const bool needs_voxels = m->src && m->src->elided && j->c.n_case13 != 0;
+    const bool fits = !needs_voxels && j->c.n_active <= j->P.cap_active && j->c.overflow == 0 &&
                       (size_t)(j->c.total_v - j->c.nghost) <= m->cap_v && (size_t)j->c.total_t * 3 <= m->cap_i;
     if (!r && fits) {
         if (m->vertex_base + (int64_t)(j->c.total_v - j->c.nghost) >= (int64_t(1) << 31))
@@ -2925,7 +2999,7 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
         if (*out) return SDFK_OK;
     }
     sdfk_volume* v = nullptr;
-    int r = sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
+    int r = step == 1 ? job_volume_create(p, nx, ny, nz, min, max, &v) : sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
     if (r) return r;
     r = require_init();
     {

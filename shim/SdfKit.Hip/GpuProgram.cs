@@ -14,7 +14,7 @@ namespace SdfKit.Hip
     public sealed class GpuProgram : IDisposable
     {
         readonly List<SdfkOp> ops = new List<SdfkOp>();
-        readonly Dictionary<int, int> constants = new Dictionary<int, int>();   // float bits -> value id
+        // (constants are not pooled: see Const)
         public int[] OutRgbw = { -1, -1, -1, -1 };
         public bool WritesColor;
         IntPtr handle;
@@ -35,15 +35,10 @@ namespace SdfKit.Hip
             return ops.Count - 1;
         }
 
-        public int Const(float x)
-        {
-            int bits = BitConverter.SingleToInt32Bits(x);
-            if (!constants.TryGetValue(bits, out int id)) {
-                id = Emit(Op.Const, imm: x);
-                constants[bits] = id;
-            }
-            return id;
-        }
+        /// <summary>One Op.Const per mention, never pooled by VALUE: the constants of a program are kernel arguments and the compiled
+        /// kernels are shared by every program of one structure (sdfk_program_create, include/sdfkit_hip.h) -- the structure must not
+        /// change because two parameters of a scene happen to be equal in one frame of an animation.</summary>
+        public int Const(float x) => Emit(Op.Const, imm: x);
 
         /// <summary>sdfk_program_create on first use (hiprtc, or the library's on-disk code-object cache).</summary>
         public unsafe IntPtr Handle

@@ -31,11 +31,8 @@ class Emitter:
         self.ops.append((op, a, b, c, d, float(imm)))
         return len(self.ops) - 1
 
-    def const(self, x):
-        k = np.float32(x).tobytes()
-        if k not in self.consts:
-            self.consts[k] = self.emit(CONST, imm=float(np.float32(x)))
-        return self.consts[k]
+    def const(self, x):   # GpuProgram.Const: one CONST per mention (constants are kernel arguments: never pooled by value)
+        return self.emit(CONST, imm=float(np.float32(x)))
 
     # Lowering.Length / Visitor.Call("Mod")
     def length(self, x, y, z):
@@ -73,7 +70,7 @@ def readme_scene():
     six = g.const(6.0)
     rhs = [g.emit(DIV, a, six) for a in ab]              # Vector3 / float: scalar broadcast
     mo = [g.emit(SUB, l, r) for l, r in zip(lhs, rhs)]
-    assert one == one3[0]
+    assert one != one3[0]            # (one CONST per mention: GpuProgram.Const does not pool by value)
     return g.ops, mo + [w], True
 
 
@@ -148,9 +145,9 @@ CASES = {
 
 def test_readme_list_is_the_documented_one():
     ops, out, _ = readme_scene()
-    assert len(ops) == 52 and out == [49, 50, 51, 37]
-    assert [o[0] for o in ops[:13]] == [X, Y, Z, CONST, CONST, MUL, ADD, DIV, FLOOR, MUL, SUB, MUL, SUB]
-    assert ops[3][5] == 1.125 and ops[4][5] == 0.5 and ops[12][1:3] == (10, 11)
+    assert len(ops) == 68 and out == [65, 66, 67, 52]      # (52 ops while GpuProgram.Const pooled constants by value: rounds 2-3)
+    assert [o[0] for o in ops[:16]] == [X, Y, Z, CONST, CONST, MUL, ADD, CONST, DIV, FLOOR, MUL, SUB, CONST, CONST, MUL, SUB]
+    assert ops[3][5] == 1.125 and ops[4][5] == 0.5 and ops[7][5] == 1.125 and ops[15][1:3] == (11, 14)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
