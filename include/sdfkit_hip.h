@@ -55,7 +55,8 @@ typedef enum sdfk_status {
  * exceptions are constants one of whose uses the compiler can fold EXACTLY when it sees the value (x * +-1, x / +-1,
  * x / 2^k, x + -0, x - +0, -0 - x): those stay literals and belong to the structure, so that they cost what they always
  * cost; results are bit-identical either way (IEEE-exact foldings only: -ffp-contract=off, no fast-math).  Programs with
- * more than 256 constants keep all of them as literals.  SDFK_OPT_IDLE_PROGRAMS structures stay loaded after their last
+ * more than 28 constants keep ALL of them as literals (arguments live in scalar registers: beyond ~30 the sampler spills them,
+ * csrc/sample_codegen.h has the measurement) -- such a program is its own structure.  SDFK_OPT_IDLE_PROGRAMS structures stay loaded after their last
  * program has been destroyed. */
 typedef enum sdfk_opcode {
     SDFK_OP_CONST = 0,   /* imm (a kernel argument: see above) */

@@ -47,9 +47,54 @@ __device__ __forceinline__ void mc_load_lut_to_lds(int8_t* s_lut /* MCLUT_PADDED
 }
 #endif
 
-// every function below takes `lut` = base of the blob (LDS or constant)
-#define MC_L1(name, i) (lut[MCLUT_OFF_##name + (i)])
-#define MC_L2(name, i, j) (lut[MCLUT_OFF_##name + (i) * MCLUT_DIM1_##name + (j)])
+// ---- the DECISION tables: what the dispatcher reads -------------------------------------------------------------------
+// mc_resolve / mc_test_internal read the case table, the test tables, subconfig13 and (one entry per row of) tiling13_5_1 --
+// 1.1 KB of the 13.5 KB blob; the tiling rows themselves are only read by k_triangles.  They get a blob of their own, built
+// at compile time from the same values, so that k_resolve copies 1.1 KB to LDS per workgroup instead of 13.5 KB (2280
+// workgroups at 512^3: 2.5 instead of 31 MB of L2 -> LDS traffic, 15 instead of 27.5 KB of LDS per workgroup).
+// Triangle-row OFFSETS (Tiling::lut_off) stay offsets into the full blob.
+constexpr int MCDEC_OFF_cases = 0;
+constexpr int MCDEC_OFF_test3 = MCDEC_OFF_cases + MCLUT_DIM0_cases * MCLUT_DIM1_cases;
+constexpr int MCDEC_OFF_test4 = MCDEC_OFF_test3 + MCLUT_DIM0_test3;
+constexpr int MCDEC_OFF_test6 = MCDEC_OFF_test4 + MCLUT_DIM0_test4;
+constexpr int MCDEC_OFF_test7 = MCDEC_OFF_test6 + MCLUT_DIM0_test6 * MCLUT_DIM1_test6;
+constexpr int MCDEC_OFF_test10 = MCDEC_OFF_test7 + MCLUT_DIM0_test7 * MCLUT_DIM1_test7;
+constexpr int MCDEC_OFF_test12 = MCDEC_OFF_test10 + MCLUT_DIM0_test10 * MCLUT_DIM1_test10;
+constexpr int MCDEC_OFF_test13 = MCDEC_OFF_test12 + MCLUT_DIM0_test12 * MCLUT_DIM1_test12;
+constexpr int MCDEC_OFF_subconfig13 = MCDEC_OFF_test13 + MCLUT_DIM0_test13 * MCLUT_DIM1_test13;
+constexpr int MCDEC_OFF_tiling13_5_1 = MCDEC_OFF_subconfig13 + MCLUT_DIM0_subconfig13;
+constexpr int MCDEC_SIZE = MCDEC_OFF_tiling13_5_1 + MCLUT_DIM0_tiling13_5_1 * MCLUT_DIM1_tiling13_5_1 * MCLUT_DIM2_tiling13_5_1;
+constexpr int MCDEC_PADDED = (MCDEC_SIZE + 15) & ~15;   // copied in 16-byte pieces
+struct alignas(16) McDecBlob { int8_t v[MCDEC_PADDED]; };
+constexpr McDecBlob mc_make_dec()
+{
+    constexpr int8_t full[] = {MCLUT_BLOB_VALUES};
+    McDecBlob d{};
+    constexpr int src[10] = {MCLUT_OFF_cases, MCLUT_OFF_test3, MCLUT_OFF_test4, MCLUT_OFF_test6, MCLUT_OFF_test7, MCLUT_OFF_test10,
+                             MCLUT_OFF_test12, MCLUT_OFF_test13, MCLUT_OFF_subconfig13, MCLUT_OFF_tiling13_5_1};
+    constexpr int dst[11] = {MCDEC_OFF_cases, MCDEC_OFF_test3, MCDEC_OFF_test4, MCDEC_OFF_test6, MCDEC_OFF_test7, MCDEC_OFF_test10,
+                             MCDEC_OFF_test12, MCDEC_OFF_test13, MCDEC_OFF_subconfig13, MCDEC_OFF_tiling13_5_1, MCDEC_SIZE};
+    for (int t = 0; t < 10; t++)
+        for (int i = 0; i < dst[t + 1] - dst[t]; i++) d.v[dst[t] + i] = full[src[t] + i];
+    return d;
+}
+__constant__ McDecBlob c_dec = mc_make_dec();
+
+#ifndef MC_HOST_BUILD
+// 256-thread workgroups only
+__device__ __forceinline__ void mc_load_dec_to_lds(int8_t* s_dec /* MCDEC_PADDED bytes, 16-byte aligned */)
+{
+    constexpr int N = MCDEC_PADDED / 16;
+    static_assert(N <= 256, "one round of 256 lanes");
+    if ((int)threadIdx.x < N) reinterpret_cast<uint4*>(s_dec)[threadIdx.x] = reinterpret_cast<const uint4*>(c_dec.v)[threadIdx.x];
+}
+#endif
+
+// every function below takes `lut` = base of the DECISION blob (LDS or constant) for what it reads; triangle-row offsets
+// (MC_ROW2 / MC_ROW3) are offsets into the full blob c_lut
+#define MC_L1(name, i) (lut[MCDEC_OFF_##name + (i)])
+#define MC_L2(name, i, j) (lut[MCDEC_OFF_##name + (i) * MCLUT_DIM1_##name + (j)])
+#define MC_DROW3(name, i, j) (MCDEC_OFF_##name + ((i) * MCLUT_DIM1_##name + (j)) * MCLUT_DIM2_##name)
 #define MC_ROW2(name, i) (MCLUT_OFF_##name + (i) * MCLUT_DIM1_##name)
 #define MC_ROW3(name, i, j) (MCLUT_OFF_##name + ((i) * MCLUT_DIM1_##name + (j)) * MCLUT_DIM2_##name)
 
@@ -148,7 +193,7 @@ __device__ __forceinline__ bool mc_test_internal(const int8_t* lut, const V& v, 
         if (cas == 6) edge = MC_L2(test6, config, 2);
         else if (cas == 7) edge = MC_L2(test7, config, 4);
         else if (cas == 12) edge = MC_L2(test12, config, 3);
-        else edge = lut[MC_ROW3(tiling13_5_1, config, subconfig)];
+        else edge = lut[MC_DROW3(tiling13_5_1, config, subconfig)];
         if (edge >= 0 && edge < 12) {
             const int8_t* e = c_interior_edges[edge];
             t = v[e[0]] / (v[e[0]] - v[e[1]] + MC_EPS);

@@ -569,10 +569,10 @@ __global__ __launch_bounds__(256) void k_gather_corners(McParams P)
 __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
 {
     __shared__ float s_v[8 * 256];   // [corner][thread]: run-time corner indexing without scratch
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
+    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCDEC_PADDED];   // the decision tables only (mc_device.h): 1.1 KB
     __shared__ uint64_t s_wave[4];
     __shared__ uint64_t s_ord[MCLUT_NROWS];
-    mc_load_lut_to_lds(s_lut);
+    mc_load_dec_to_lds(s_lut);
     {   // per-row creation order -> LDS (independent loads per lane)
         const int t = (int)threadIdx.x;
         static_assert(MCLUT_NROWS <= 768, "row table copy assumes <= 3 rounds");

@@ -434,8 +434,12 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_raymarch(RayArgs A, SdfkK
 // Baked as literals (part of the structure): a constant one of whose uses lets the compiler simplify EXACTLY -- x * +-1,
 // x / +-1, x / 2^k (an exact reciprocal), x + -0, x - +0, -0 - x -- so that the common cases cost what they cost as
 // literals; with -ffp-contract=off and no fast-math every such folding is IEEE-exact, results are bit-identical either way.
-// More than kMaxParams constants: all literals (the kernel-argument segment is 4 KB).
-constexpr int kMaxParams = 256;
+// More than kMaxParams constants: ALL literals, as in rounds 1-3.  Arguments live in scalar registers, every evaluation of the
+// program (8 per lane in the sampler) uses all of them, and gfx950 has ~100 SGPRs per wavefront: measured with hipcc on unions of
+// k translated primitives, 29 constants compile without a spill, 36 spill 16 SGPRs into VGPR lanes, 58 (BASELINE config C4, the
+// 8-primitive union) spill 78 -- and that sampler then takes 6.3 instead of 3.6 ms at 1024^3.  Scenes that big change their
+// structure more often than their constants.
+constexpr int kMaxParams = 28;
 
 inline bool sdfk_const_is_baked(const sdfk_op* ops, int n_ops, int i)
 {

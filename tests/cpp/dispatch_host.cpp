@@ -11,7 +11,7 @@ extern "C" {
 int mc_host_resolve(const double* v, int* lut_off, int* nt, int* row)
 {
     const sdfk::CornersPtr c{v};
-    const sdfk::Tiling t = sdfk::mc_resolve(sdfk::c_lut, c);
+    const sdfk::Tiling t = sdfk::mc_resolve(sdfk::c_dec.v, c);
     *lut_off = t.lut_off;
     *nt = t.nt;
     *row = t.row;
@@ -22,7 +22,7 @@ int mc_host_test_face(const double* v, int face) { return sdfk::mc_test_face(sdf
 
 int mc_host_test_internal(const double* v, int cas, int config, int subconfig, int s)
 {
-    return sdfk::mc_test_internal(sdfk::c_lut, sdfk::CornersPtr{v}, cas, config, subconfig, s) ? 1 : 0;
+    return sdfk::mc_test_internal(sdfk::c_dec.v, sdfk::CornersPtr{v}, cas, config, subconfig, s) ? 1 : 0;
 }
 
 int mc_host_interior_edge(int edge, int k) { return sdfk::c_interior_edges[edge][k]; }

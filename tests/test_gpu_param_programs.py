@@ -102,3 +102,14 @@ def test_special_values_as_arguments(gpu):
             ref = (px * np.float32(0.0) + np.float32(0.0)) + np.float32(c)
             got = vol.Values[:, 0, 0]
             assert np.array_equal(got.view(np.uint32), ref.astype(np.float32).view(np.uint32)), c
+
+
+def test_programs_with_many_constants_keep_literals(gpu):
+    """More than 28 constants: all literals (scalar-register budget; csrc/sample_codegen.h) -- the 8-primitive union of
+    BASELINE config C4 is such a program; a 3-primitive union is not."""
+    import bench
+    big = bench.scene_for("union8")[0]
+    assert "K.k[0]" not in big.source() and "struct SdfkK { float k[1]; }" in big.source()
+    a = (SdfExprs.Union(SdfExprs.Sphere(0.6).Translate(-1, 0, 0), SdfExprs.Union(SdfExprs.Box(0.5).Translate(1, 0, 0), SdfExprs.Cylinder(0.4, 0.6)))).ToSdf()
+    b = (SdfExprs.Union(SdfExprs.Sphere(0.55).Translate(-1.25, 0, 0), SdfExprs.Union(SdfExprs.Box(0.45).Translate(1.5, 0, 0), SdfExprs.Cylinder(0.35, 0.65)))).ToSdf()
+    assert a.source() == b.source() and "K.k[" in a.source()
