@@ -762,7 +762,7 @@ def main():
             return (time.perf_counter() - t0) / k
 
     elided_ms = None
-    if not sharded and not args.minimal and n ** 3 > (1 << 24):
+    if not sharded and not args.minimal and n ** 3 > (1 << 24) and os.environ.get("SDFK_BENCH_NO_ELIDED") != "1":
         elided_ms = timed_elided(step, drain, args.steps) * 1e3
 
     # ---- BASELINE config C3 ("HBM roofline run": the README's RepeatXY scene with colours, 512^3, clipToBounds,
@@ -804,14 +804,14 @@ def main():
         samp3_us = e0.elapsed_time(e1) * 1e3 / k3
         for vol in vols:
             vol._free()
-        e3 = timed_elided(step3, drain3, k3)
+        e3 = timed_elided(step3, drain3, k3) if os.environ.get("SDFK_BENCH_NO_ELIDED") != "1" else None
         bytes3 = n ** 3 * 16 + n ** 3 // 8
         meas3 = load_pmc_traffic("pipeline_step", "repeatxy", n)
         c3 = {"workload": WORKLOADS["repeatxy"] + f", {n}^3", "steps": k3, "ms_per_step": round(s3 * 1e3, 4),
               "mvoxels_per_s": round(n ** 3 / s3 / 1e6, 1), "vertices": nv3, "triangles": ni3 // 3,
               "frac_design_bytes": round((bytes3 + 36 * nv3 + 4 * ni3) / s3 / 1e9 / HBM_PEAK_GBS, 4),
               "frac_measured_bytes": None if not meas3 else round(meas3 / s3 / 1e9 / HBM_PEAK_GBS, 4),
-              "elided_volume_ms_per_step": round(e3 * 1e3, 4),
+              "elided_volume_ms_per_step": None if e3 is None else round(e3 * 1e3, 4),
               "sampler_us_back_to_back": round(samp3_us, 1),
               "sampler_frac": round(bytes3 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
               "what": "BASELINE config C3 in this run: pipelined sample -> mesh of the README scene (colours: 16 B/voxel stored), then its sampling "
