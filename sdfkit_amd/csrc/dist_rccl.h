@@ -736,7 +736,7 @@ extern "C" int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int6
             if (idx && !s->idx16) agreed[mode + 2 * idx] = kNever;
         }
     }
-    int best = 1;
+    int best = 0;   // (ties go to the default: ncclAllGather, plain payloads)
     for (int k = 0; k < 4; k++)
         if (agreed[k] < agreed[best]) best = k;
     if (int r = set_form(best >= 2)) return dist_fail(s, r);

@@ -879,60 +879,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const uint32_t out = vi - nghost;
             if (emit && out >= M.cap_vertices) { P.host_counters->overflow = 1u; continue; }
             const int gx = x + mc_edge_ox(e), gy = y + mc_edge_oy(e), gz = z + mc_edge_oz(e);
-            // sharer cells (sweep order): window slot, or -1 = none, or -2-k = record k via the slow path
-            int sl[4] = {-1, -1, -1, -1};
-            if (e != 12) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int cx = gx + mc_share_dx(dir, s), cy = gy + mc_share_dy(dir, s), cz = gz + mc_share_dz(dir, s);
-                    if (cx == x && cy == y && cz == z) { sl[s] = rr; continue; }
-                    if (cx < 0 || cy < 0 || cz < P.lay_count_begin || cx >= P.ncx || cy >= P.ncy || cz >= P.lay_list_end) continue;
-                    const int row = (cz - P.lay_count_begin) * P.ncy + cy;
-                    int w = -1, k = 0;
-                    if (row >= r_f && row - r_f + 1 < nrs) { w = 0; k = row - r_f; }
-                    else if (row >= r_f + P.ncy && row - r_f - P.ncy + 1 < nrs) { w = 1; k = row - r_f - P.ncy; }
-                    bool in_window = false;
-                    if (w >= 0) {
-                        const uint32_t ra = s_rs[w][k], rb = s_rs[w][k + 1];
-                        const uint32_t ws = w ? w2_start : w1_start, wc = w ? w2_cnt : w1_cnt, off = w ? w1_cnt : 0u;
-                        if (ra >= ws && rb <= ws + wc) {
-                            in_window = true;
-                            uint32_t lo = ra - ws + off, hi = rb - ws + off;
-                            while (hi - lo > 4u) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if ((int)(s_wxy[mid] & P.xmask) <= cx) lo = mid; else hi = mid;
-                            }
-                            // (four independent probes: one LDS round trip instead of a dependent scan)
-#pragma unroll
-                            for (uint32_t q = 0; q < 4u; q++) {
-                                const uint32_t idx = min(lo + q, (uint32_t)K4_WMAX - 1u);
-                                const int wx = (int)(s_wxy[idx] & P.xmask);
-                                if (lo + q < hi && wx == cx) sl[s] = (int)idx;
-                            }
-                        }
-                    }
-                    if (!in_window) {
-                        const int g = find_record(P, n, cx, cy, cz);
-                        if (g >= 0) sl[s] = -2 - g;
-                    }
-                }
-            } else {
-                sl[3] = rr;
-            }
-            // push this vertex's id into every live cell around the edge (K5 reads only its own record)
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                if (sl[s] == -1) continue;
-                const uint32_t g = sl[s] >= 0 ? ((uint32_t)sl[s] < w1_cnt ? w1_start + (uint32_t)sl[s] : w2_start + ((uint32_t)sl[s] - w1_cnt))
-                                              : (uint32_t)(-2 - sl[s]);
-                P.rec_vid[(size_t)(e == 12 ? 12 : mc_share_edge(dir, s)) * P.cap_active + g] = vi;
-            }
-            if (!emit) continue;
             const int own_row = (int)(info >> 22);
-            float pos[3], colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
+            float pos[3] = {0.0f, 0.0f, 0.0f}, colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
             const CornersLds v{s_wc + rr, K4_WMAX, iso};   // the creator cell
             if (e == 12) {
+                P.rec_vid[(size_t)12 * P.cap_active + (base + (uint32_t)rr)] = vi;   // (only the cell itself references its centre vertex)
+                if (!emit) continue;
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
                 float fc[3] = {0.0f, 0.0f, 0.0f};
@@ -967,58 +920,98 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 const int occ = (int)((s_occ[own_row] >> 48) & 15ull);
                 for (int o = 0; o < occ; o++) { nrm[0] = nrm[0] + g0; nrm[1] = nrm[1] + g1; nrm[2] = nrm[2] + g2; }
             } else {
-                // Cell.AddFaceFromEdgeIndex, Cell.cs:314-350, in the creator cell's frame.
-                // (index1,index2) of Cell.cs:318-319 are the bit-order ids of the edge's end corners.
-                const int c1 = mc_edge_corner_a(e), c2 = mc_edge_corner_b(e);
-                const double w1 = 1.0 / (MC_EPS + fabs(v[c1]));
-                const double w2 = 1.0 / (MC_EPS + fabs(v[c2]));
-                const double ff = w1 + w2;                       // (0 + w1) + w2
-                const int d1 = dir == 0 ? mc_corner_dx(c1) : (dir == 1 ? mc_corner_dy(c1) : mc_corner_dz(c1));
-                // the two weights by position along the edge: low = base voxel, high = base + 1
-                const double w_lo = d1 ? w2 : w1, w_hi = d1 ? w1 : w2;
-                if (P.step == 1 && ff > 0.0 && isfinite(ff)) {
-                    // stp = 1: off the edge axis both corners share the offset o, so
-                    // (o*w1 + o*w2)/ff is exactly o; on the axis it is w_hi/ff (one division).
-                    const double t = w_hi / ff;
-                    pos[0] = dir == 0 ? (float)((double)gx + t) : (float)(xs + mc_corner_dx(c1));
-                    pos[1] = dir == 1 ? (float)((double)gy + t) : (float)(ys + mc_corner_dy(c1));
-                    pos[2] = dir == 2 ? (float)((double)(gz + P.z0) + t) : (float)(zs + mc_corner_dz(c1));
-                } else {
-                    double fx = 0.0, fy = 0.0, fz = 0.0;
-                    fx += (double)mc_corner_dx(c1) * w1; fy += (double)mc_corner_dy(c1) * w1; fz += (double)mc_corner_dz(c1) * w1;
-                    fx += (double)mc_corner_dx(c2) * w2; fy += (double)mc_corner_dy(c2) * w2; fz += (double)mc_corner_dz(c2) * w2;
-                    pos[0] = (float)((double)xs + stp * fx / ff);
-                    pos[1] = (float)((double)ys + stp * fy / ff);
-                    pos[2] = (float)((double)zs + stp * fz / ff);
-                }
-                if (gather_colors) {
-                    float ca[3], cb[3];
-                    load_corner_color(P, x, y, z, c1, ca);
-                    load_corner_color(P, x, y, z, c2, cb);
-                    const float w1f = (float)w1, w2f = (float)w2;
-#pragma unroll
-                    for (int jj = 0; jj < 3; jj++) {
-                        const float cj = ca[jj] * w1f + cb[jj] * w2f;
-                        colr[jj] = (float)((double)cj / ff);
+                double w_lo = 0.0, w_hi = 0.0;
+                if (emit) {
+                    // Cell.AddFaceFromEdgeIndex, Cell.cs:314-350, in the creator cell's frame.
+                    // (index1,index2) of Cell.cs:318-319 are the bit-order ids of the edge's end corners.
+                    const int c1 = mc_edge_corner_a(e), c2 = mc_edge_corner_b(e);
+                    const double w1 = 1.0 / (MC_EPS + fabs(v[c1]));
+                    const double w2 = 1.0 / (MC_EPS + fabs(v[c2]));
+                    const double ff = w1 + w2;                       // (0 + w1) + w2
+                    const int d1 = dir == 0 ? mc_corner_dx(c1) : (dir == 1 ? mc_corner_dy(c1) : mc_corner_dz(c1));
+                    // the two weights by position along the edge: low = base voxel, high = base + 1
+                    w_lo = d1 ? w2 : w1; w_hi = d1 ? w1 : w2;
+                    if (P.step == 1 && ff > 0.0 && isfinite(ff)) {
+                        // stp = 1: off the edge axis both corners share the offset o, so
+                        // (o*w1 + o*w2)/ff is exactly o; on the axis it is w_hi/ff (one division).
+                        const double t = w_hi / ff;
+                        pos[0] = dir == 0 ? (float)((double)gx + t) : (float)(xs + mc_corner_dx(c1));
+                        pos[1] = dir == 1 ? (float)((double)gy + t) : (float)(ys + mc_corner_dy(c1));
+                        pos[2] = dir == 2 ? (float)((double)(gz + P.z0) + t) : (float)(zs + mc_corner_dz(c1));
+                    } else {
+                        double fx = 0.0, fy = 0.0, fz = 0.0;
+                        fx += (double)mc_corner_dx(c1) * w1; fy += (double)mc_corner_dy(c1) * w1; fz += (double)mc_corner_dz(c1) * w1;
+                        fx += (double)mc_corner_dx(c2) * w2; fy += (double)mc_corner_dy(c2) * w2; fz += (double)mc_corner_dz(c2) * w2;
+                        pos[0] = (float)((double)xs + stp * fx / ff);
+                        pos[1] = (float)((double)ys + stp * fy / ff);
+                        pos[2] = (float)((double)zs + stp * fz / ff);
+                    }
+                    if (gather_colors) {
+                        float ca[3], cb[3];
+                        load_corner_color(P, x, y, z, c1, ca);
+                        load_corner_color(P, x, y, z, c2, cb);
+                        const float w1f = (float)w1, w2f = (float)w2;
+    #pragma unroll
+                        for (int jj = 0; jj < 3; jj++) {
+                            const float cj = ca[jj] * w1f + cb[jj] * w2f;
+                            colr[jj] = (float)((double)cj / ff);
+                        }
                     }
                 }
-                // normal: gather over the cells around the edge, in sweep order.  Every sharer
-                // sees the same two end voxels, so the two weights are computed once.
-#pragma unroll
+                // The cells around the edge in sweep order, ONE at a time -- a loop, not four copies of the search and of the
+                // gradient arithmetic (a quarter of the code, fewer live registers): find it, leave it this vertex's id, add its
+                // share of the normal.
+#pragma unroll 1
                 for (int s = 0; s < 4; s++) {
-                    if (sl[s] == -1) continue;
+                    const int cx = gx + mc_share_dx(dir, s), cy = gy + mc_share_dy(dir, s), cz = gz + mc_share_dz(dir, s);
+                    int sls = -1;   // window slot, or -1 = none, or -2-k = record k via the slow path
+                    if (cx == x && cy == y && cz == z) sls = rr;
+                    else if (!(cx < 0 || cy < 0 || cz < P.lay_count_begin || cx >= P.ncx || cy >= P.ncy || cz >= P.lay_list_end)) {
+                        const int row = (cz - P.lay_count_begin) * P.ncy + cy;
+                        int w = -1, k = 0;
+                        if (row >= r_f && row - r_f + 1 < nrs) { w = 0; k = row - r_f; }
+                        else if (row >= r_f + P.ncy && row - r_f - P.ncy + 1 < nrs) { w = 1; k = row - r_f - P.ncy; }
+                        bool in_window = false;
+                        if (w >= 0) {
+                            const uint32_t ra = s_rs[w][k], rb = s_rs[w][k + 1];
+                            const uint32_t ws = w ? w2_start : w1_start, wc = w ? w2_cnt : w1_cnt, off = w ? w1_cnt : 0u;
+                            if (ra >= ws && rb <= ws + wc) {
+                                in_window = true;
+                                uint32_t lo = ra - ws + off, hi = rb - ws + off;
+                                while (hi - lo > 4u) {
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if ((int)(s_wxy[mid] & P.xmask) <= cx) lo = mid; else hi = mid;
+                                }
+                                // (four independent probes: one LDS round trip instead of a dependent scan)
+#pragma unroll
+                                for (uint32_t q = 0; q < 4u; q++) {
+                                    const uint32_t idx = min(lo + q, (uint32_t)K4_WMAX - 1u);
+                                    const int wx = (int)(s_wxy[idx] & P.xmask);
+                                    if (lo + q < hi && wx == cx) sls = (int)idx;
+                                }
+                            }
+                        }
+                        if (!in_window) {
+                            const int g = find_record(P, n, cx, cy, cz);
+                            if (g >= 0) sls = -2 - g;
+                        }
+                    }
+                    if (sls == -1) continue;
                     const int es = mc_share_edge(dir, s);
-                    if (sl[s] >= 0) {
-                        const uint32_t ti = s_winfo[sl[s]];
+                    const uint32_t g = sls >= 0 ? ((uint32_t)sls < w1_cnt ? w1_start + (uint32_t)sls : w2_start + ((uint32_t)sls - w1_cnt)) : (uint32_t)(-2 - sls);
+                    P.rec_vid[(size_t)es * P.cap_active + g] = vi;   // K5 reads only its own record
+                    if (!emit) continue;
+                    if (sls >= 0) {
+                        const uint32_t ti = s_winfo[sls];
                         const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;
-                        if (occ) add_sharer_gradients(CornersLds{s_wc + sl[s], K4_WMAX, iso}, es, occ, dir, w_lo, w_hi, nrm);
+                        if (occ) add_sharer_gradients(CornersLds{s_wc + sls, K4_WMAX, iso}, es, occ, dir, w_lo, w_hi, nrm);
                     } else {   // outside the staged windows: through global memory
-                        const uint32_t g = (uint32_t)(-2 - sl[s]);
                         const uint32_t ti = P.rec_info[g];
                         const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;
                         if (occ) add_sharer_gradients(CornersGlobal{P.rec_corners + (size_t)g * 8, iso}, es, occ, dir, w_lo, w_hi, nrm);
                     }
                 }
+                if (!emit) continue;
             }
             // Cell.NegativeNormals (Cell.cs:97-109), then Mesh.Transform (Mesh.cs:47-64)
             const float len = v3len(nrm[0], nrm[1], nrm[2]);

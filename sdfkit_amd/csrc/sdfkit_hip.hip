@@ -895,6 +895,7 @@ void drop_source(sdfk_mesh* m);
 void job_release(sdfk_march_job* j, bool kernels_may_be_queued = false);
 void program_release(sdfk_program* p);
 void volume_values_changed(sdfk_volume* v);
+void codes_drop_idle();
 }
 
 // ---------------------------------------------------------------------------
@@ -988,6 +989,7 @@ extern "C" void sdfk_shutdown(void)
     if (!g.inited) return;
     while (!g.pending.empty()) (void)mesh_resolve(g.pending.front());
     graph_jobs_destroy_all();
+    codes_drop_idle();   // (kernel sets no program uses any more; those of live programs go with their last program)
     if (dist_active()) dist_release();   // (sessions that are still alive read as freed: sdfk_dist_session_free after a shutdown only deletes them)
     (void)hipStreamSynchronize(g.stream);
     prof_drain();
@@ -1361,6 +1363,14 @@ void codes_trim()
         if (idle <= (size_t)g_cfg.idle_programs || !oldest) return;
         g_codes.erase(oldest->source);
         code_unload(oldest);
+    }
+}
+
+void codes_drop_idle()
+{
+    for (auto it = g_codes.begin(); it != g_codes.end();) {
+        if (it->second->refs == 0) { ProgCode* c = it->second; it = g_codes.erase(it); code_unload(c); }
+        else ++it;
     }
 }
 

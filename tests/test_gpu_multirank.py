@@ -163,7 +163,7 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
         t = ses.tune(6)
         assert set(t) == {(0, False), (1, False), (0, True), (1, True)} and all(v > 0 for v in t.values()), t
         st = ses.stats()
-        best = min(t, key=lambda k: (t[k], k != (1, False)))
+        best = min(t, key=lambda k: (t[k], k != (0, False)))
         assert (st["exchange_mode"], st["index16"]) == best, (st, t)
         for it in range(7):
             if ses.in_flight == ses.depth:
