@@ -743,8 +743,8 @@ def main():
     # never hands its Voxels out (SdfEx.ToMesh, Sdf.cs:59-63: a temporary), and with the sign bits, re-evaluated corners and
     # re-evaluated vertex colours the meshing chain does not read it.  Meshes are bit-identical (tests/test_gpu_elide_volume.py).
     # The contract's step includes the stores, so the headline keeps them.
-    def timed_elided(step_fn, drain_fn, k):
-        with N.option(N.OPT_ELIDE_VOLUME, 1):
+    def timed_elided(step_fn, drain_fn, k, mode=2):
+        with N.option(N.OPT_ELIDE_VOLUME, mode):
             for _ in range(8):
                 step_fn()
             drain_fn()
@@ -761,9 +761,10 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / k
 
-    elided_ms = None
+    elided_ms = elided1_ms = None
     if not sharded and not args.minimal and n ** 3 > (1 << 24) and os.environ.get("SDFK_BENCH_NO_ELIDED") != "1":
-        elided_ms = timed_elided(step, drain, args.steps) * 1e3
+        elided1_ms = timed_elided(step, drain, args.steps, 1) * 1e3     # every voxel evaluated, nothing stored
+        elided_ms = timed_elided(step, drain, args.steps, 2) * 1e3      # + blocks decided by interval arithmetic
 
     # ---- BASELINE config C3 ("HBM roofline run": the README's RepeatXY scene with colours, 512^3, clipToBounds,
     # /root/reference README.md:24-30) timed in THIS run, next to the headline -- never as `value`: 10 pipelined steps bracketed by
@@ -804,7 +805,10 @@ def main():
         samp3_us = e0.elapsed_time(e1) * 1e3 / k3
         for vol in vols:
             vol._free()
-        e3 = timed_elided(step3, drain3, k3) if os.environ.get("SDFK_BENCH_NO_ELIDED") != "1" else None
+        e3 = e31 = None
+        if os.environ.get("SDFK_BENCH_NO_ELIDED") != "1":
+            e31 = timed_elided(step3, drain3, k3, 1)
+            e3 = timed_elided(step3, drain3, k3, 2)
         bytes3 = n ** 3 * 16 + n ** 3 // 8
         meas3 = load_pmc_traffic("pipeline_step", "repeatxy", n)
         c3 = {"workload": WORKLOADS["repeatxy"] + f", {n}^3", "steps": k3, "ms_per_step": round(s3 * 1e3, 4),
@@ -812,6 +816,7 @@ def main():
               "frac_design_bytes": round((bytes3 + 36 * nv3 + 4 * ni3) / s3 / 1e9 / HBM_PEAK_GBS, 4),
               "frac_measured_bytes": None if not meas3 else round(meas3 / s3 / 1e9 / HBM_PEAK_GBS, 4),
               "elided_volume_ms_per_step": None if e3 is None else round(e3 * 1e3, 4),
+              "elided_volume_no_culling_ms_per_step": None if e31 is None else round(e31 * 1e3, 4),
               "sampler_us_back_to_back": round(samp3_us, 1),
               "sampler_frac": round(bytes3 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
               "what": "BASELINE config C3 in this run: pipelined sample -> mesh of the README scene (colours: 16 B/voxel stored), then its sampling "
@@ -1049,9 +1054,13 @@ def main():
             "roofline": roof,
             "c3_repeatxy": c3,
             "elided_volume_ms_per_step": None if elided_ms is None else round(elided_ms, 4),
-            "elided_volume_is": "SDFK_OPT_ELIDE_VOLUME = 1 (opt-in): the same K pipelined steps with a volume that is never stored -- the sampler "
-                                "leaves sign bits only, corners and vertex colours are re-evaluated; meshes bit-identical.  Not the contract's "
-                                "step (which includes the 4 B/voxel of stores): reported next to `value`, never as it",
+            "elided_volume_no_culling_ms_per_step": None if elided1_ms is None else round(elided1_ms, 4),
+            "elided_volume_is": "SDFK_OPT_ELIDE_VOLUME (opt-in): the same K pipelined steps with a volume that is never stored -- the sampler "
+                                "leaves sign bits only, corners and vertex colours are re-evaluated; meshes bit-identical.  = 2 (the first figure): "
+                                "8 x 4 x 32 blocks whose values provably lie on one side of the iso value -- the program evaluated in interval "
+                                "arithmetic over the block -- get constant sign bytes, only the blocks the surface passes through are evaluated "
+                                "voxel by voxel; = 1 (no_culling): every voxel evaluated.  Not the contract's step (which evaluates and stores "
+                                "every voxel): reported next to `value`, never as it",
         }
         out.update(extra)
         if dist_extra:

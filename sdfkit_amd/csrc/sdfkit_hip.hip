@@ -445,7 +445,7 @@ void prof_drain()
 struct ProfScope {
     ProfSpan s;
     bool on;
-    explicit ProfScope(const char* name) : on(g.prof_on)
+    explicit ProfScope(const char* name) : on(g.prof_on && name != nullptr)   // (nullptr: no span)
     {
         if (on) {
             s.name_id = prof_name_id(name);
@@ -764,8 +764,8 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
 // ---------------------------------------------------------------------------
 // Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
 enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_SIGNS = 2, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_VCOLORS = 5, PK_CORNERS = 6, PK_RAYMARCH = 7,
-                  PK_SIGNS_FLAT = 8, PK_COUNT = 9 };
-static bool pk_is_sampler(int k) { return k <= PK_BITS_CLIP_FLAT || k == PK_SIGNS_FLAT; }
+                  PK_SIGNS_FLAT = 8, PK_CULL = 9, PK_EVAL_BLOCKS = 10, PK_COUNT = 11 };
+static bool pk_is_sampler(int k) { return k <= PK_BITS_CLIP_FLAT || k == PK_SIGNS_FLAT || k == PK_CULL || k == PK_EVAL_BLOCKS; }
 
 // The compiled kernels of one program STRUCTURE (opcodes, operand ids, outputs -- the generated source; a program's
 // constants are kernel arguments, csrc/sample_codegen.h): shared by every program of that structure, so that a scene whose
@@ -802,6 +802,7 @@ struct sdfk_volume {
     // (values == colors == nullptr): its sampler leaves the sign bits only, corners and vertex colours are re-evaluated.
     // elided_colors: the program writes colours (the mesh has a colour array although the volume has none).
     bool elided = false, elided_colors = false;
+    uint32_t* cull_list = nullptr;    // SDFK_OPT_ELIDE_VOLUME = 2: [0] = number of undecided blocks, [16..] = their indices (sdfk_cull_blocks)
     // sign bits (value > bits_iso) packed along X, written by the fused sampling kernel;
     // valid until Values change (upload / ClipToBounds)
     uint64_t* bits = nullptr;
@@ -926,7 +927,7 @@ static void config_from_env()
     g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0) ? 1 : 0;
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
     g_cfg.idle_programs = ranged("SDFK_IDLE_PROGRAMS", 32, 0, 1024);
-    g_cfg.elide_volume = geti("SDFK_ELIDE_VOLUME", 0) ? 1 : 0;
+    g_cfg.elide_volume = ranged("SDFK_ELIDE_VOLUME", 0, 0, 2);
     g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0) ? 1 : 0;
     g_cfg.place_streams = geti("SDFK_STREAM_PLACEMENT", 1) ? 1 : 0;
     g_cfg.idle_lane = geti("SDFK_IDLE_LANE", 1) ? 1 : 0;
@@ -1124,7 +1125,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_IDLE_LANE: if (!in(0, 1)) break; g_cfg.idle_lane = (int)value; return SDFK_OK;
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
     case SDFK_OPT_IDLE_PROGRAMS: if (!in(0, 1024)) break; g_cfg.idle_programs = (int)value; codes_trim(); return SDFK_OK;
-    case SDFK_OPT_ELIDE_VOLUME: if (!in(0, 1)) break; g_cfg.elide_volume = (int)value; return SDFK_OK;
+    case SDFK_OPT_ELIDE_VOLUME: if (!in(0, 2)) break; g_cfg.elide_volume = (int)value; return SDFK_OK;
     case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;
     case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
     default: return fail(SDFK_ERR_INVALID, "sdfk_set_option: unknown option %d", key);
@@ -1402,7 +1403,7 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::vector<char> code;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
     config_from_env();
-    return compile_source(src, 0x1ffu, code, false);   // every kernel, a real compile: this IS the check
+    return compile_source(src, 0x7ffu, code, false);   // every kernel, a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -1431,8 +1432,9 @@ int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
     if (!p->fn[k]) {
         static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_signs", "sdfk_sample_bits_clip",
                                                     "sdfk_sample_bits_clip_flat", "sdfk_vertex_colors", "sdfk_corners_eval", "sdfk_raymarch",
-                                                    "sdfk_sample_signs_flat"};
+                                                    "sdfk_sample_signs_flat", "sdfk_cull_blocks", "sdfk_eval_blocks"};
         unsigned mask = 1u << k;
+        if (k == PK_CULL || k == PK_EVAL_BLOCKS) mask |= (1u << PK_CULL) | (1u << PK_EVAL_BLOCKS);   // (a pair)
         if (pk_is_sampler(k) && !p->fn[PK_CORNERS]) {   // (and, for a program that writes colours, sdfk_vertex_colors)
             mask |= 1u << PK_CORNERS;
             if (cp->writes_color && !p->fn[PK_VCOLORS]) mask |= 1u << PK_VCOLORS;
@@ -1580,6 +1582,7 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
     dev_free(v->colors);
     dev_free(v->bits);
     dev_free(v->bits8);
+    dev_free(v->cull_list);
     delete v;
 }
 
@@ -1737,11 +1740,37 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
             static const char* const names[2][2] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat"}, {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat"}};
             hipFunction_t fn = nullptr;   // (compiled on first use)
             const int pk = v->elided ? (mode ? PK_SIGNS_FLAT : PK_SIGNS) : (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode;
-            if (int r = program_fn(p, pk, &fn)) return r;
-            ProfScope ps(v->elided ? (mode ? "sdfk_sample_signs_flat" : "sdfk_sample_signs") : names[clip_to_bounds ? 1 : 0][mode]);   // (the name rocprofv3 shows for the entry point launched)
+            if (!(v->elided && g_cfg.elide_volume >= 2))
+                if (int r = program_fn(p, pk, &fn)) return r;
+            const bool cull = v->elided && g_cfg.elide_volume >= 2;
+            // (the name rocprofv3 shows for the entry point launched; the two culling kernels have scopes of their own)
+            ProfScope ps(cull ? nullptr : (v->elided ? (mode ? "sdfk_sample_signs_flat" : "sdfk_sample_signs") : names[clip_to_bounds ? 1 : 0][mode]));
             const size_t plane = (size_t)v->ny * v->pitch();
             phase_token_wait(0);
-            if (mode == 1) {
+            if (cull) {
+                // block culling: one lane per 8 x 4 x 32 block decides it by interval arithmetic (constant sign bytes) or lists it;
+                // the listed blocks -- those the surface passes through -- are evaluated voxel by voxel (sample_codegen.h)
+                struct { unsigned* worklist; unsigned* counter; int nbx, nby, nbz; } Cargs;
+                Cargs.nbx = v->nx8(); Cargs.nby = (v->ny + 3) / 4; Cargs.nbz = (v->nz + 31) / 32;
+                const size_t nblocks = (size_t)Cargs.nbx * Cargs.nby * Cargs.nbz;
+                if (!v->cull_list) {
+                    if (int r = dev_alloc((void**)&v->cull_list, (nblocks + 16) * sizeof(uint32_t))) return r;
+                }
+                Cargs.counter = v->cull_list; Cargs.worklist = v->cull_list + 16;
+                hipFunction_t fn_cull = nullptr, fn_eval = nullptr;
+                if (int r = program_fn(p, PK_CULL, &fn_cull)) return r;
+                if (int r = program_fn(p, PK_EVAL_BLOCKS, &fn_eval)) return r;
+                HIPCHK(hipMemsetAsync(v->cull_list, 0, sizeof(uint32_t), g.stream));
+                void* cparams[] = {&A, &Cargs, p->kargs()};
+                {
+                    ProfScope ps2("sdfk_cull_blocks");
+                    HIPCHK(hipModuleLaunchKernel(fn_cull, (unsigned)((nblocks + 255) / 256), 1, 1, 256, 1, 1, 0, g.stream, cparams, nullptr));
+                }
+                {
+                    ProfScope ps2("sdfk_eval_blocks");
+                    HIPCHK(hipModuleLaunchKernel(fn_eval, (unsigned)std::min<size_t>((nblocks + 3) / 4, 4096), 1, 1, 256, 1, 1, 0, g.stream, cparams, nullptr));
+                }
+            } else if (mode == 1) {
                 const dim3 fg = flat_grid(plane, v->nx8());
                 HIPCHK(hipModuleLaunchKernel(fn, fg.x, fg.y, fg.z, tpb, 1, 1, 0, g.stream, params, nullptr));
             }

@@ -35,20 +35,29 @@ def _kernels_launched(fn):
     return out, {k for k, v in N.profile_snapshot().items() if v[1]}
 
 
-# grids above the captured-graph limit (2^24 voxels) take the elided path; every row shape of the sampler (z tiles, plane chunks)
+def _sampler_ran(ran, mode):
+    """mode 1: the sign-only sampler; mode 2: block culling by interval arithmetic + the listed blocks voxel by voxel"""
+    if mode == 1:
+        return any(k.startswith("sdfk_sample_signs") for k in ran) and "sdfk_cull_blocks" not in ran
+    return "sdfk_cull_blocks" in ran and "sdfk_eval_blocks" in ran and not any(k.startswith("sdfk_sample_signs") for k in ran)
+
+
+# grids above the captured-graph limit (2^24 voxels) take the elided path; every row shape of the sampler (z tiles, plane chunks;
+# 300 x 236 x 250: partial blocks of the culling pass on every upper face)
 @pytest.mark.parametrize("name", sorted(S.CATALOGUE))
 @pytest.mark.parametrize("dims", [(264, 260, 256), (300, 236, 250)])
-def test_elided_mesh_is_the_oracles(gpu, name, dims):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_elided_mesh_is_the_oracles(gpu, name, dims, mode):
     scene, sdf = S.CATALOGUE[name]()
     mn, mx = [-2.8125] * 3, [2.8125] * 3
     ov, oc = O.sample(scene, mn, mx, *dims)
     O.clip_to_bounds(ov, mn, mx)
     om = O.march(ov, oc, mn, mx)
-    with N.option(N.OPT_ELIDE_VOLUME, 1):
+    with N.option(N.OPT_ELIDE_VOLUME, mode):
         for rep in range(3):      # exact two-phase path first, then the speculative one
             mesh, ran = _kernels_launched(lambda: sdf.ToMesh(mn, mx, *dims))
             assert_mesh_equal(mesh, om)
-            assert any(k.startswith("sdfk_sample_signs") for k in ran) and not any(k.startswith("sdfk_sample_bits") for k in ran), ran
+            assert _sampler_ran(ran, mode) and not any(k.startswith("sdfk_sample_bits") for k in ran), ran
             assert "k_gather_corners" not in ran and "k_signbits" not in ran
     with N.option(N.OPT_ELIDE_VOLUME, 0):                                 # the default: the volume is stored
         mesh, ran = _kernels_launched(lambda: sdf.ToMesh(mn, mx, *dims))
@@ -56,15 +65,52 @@ def test_elided_mesh_is_the_oracles(gpu, name, dims):
         assert any(k.startswith("sdfk_sample_bits") for k in ran)
 
 
-def test_no_clip_and_other_iso(gpu):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_no_clip_and_other_iso(gpu, mode):
     mn, mx, dims = [-1.5] * 3, [1.5] * 3, (272, 264, 256)
     s = O.Scene(); s.sphere_w(1.0)
     ov, oc = O.sample(s, mn, mx, *dims)
-    for iso in (0.0, 0.125):
+    for iso in (0.0, 0.125, -0.25):
         om = O.march(ov, oc, mn, mx, iso=iso)
-        with N.option(N.OPT_ELIDE_VOLUME, 1):
+        with N.option(N.OPT_ELIDE_VOLUME, mode):
             for rep in range(2):
                 assert_mesh_equal(Sdfs.Sphere(1.0).ToMesh(mn, mx, *dims, clipToBounds=False, isoValue=iso), om)
+
+
+def _same_mesh(a, b):
+    # (bit patterns: the colours of a random program may be NaN)
+    same = lambda x, y: x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    return (np.array_equal(a.Triangles, b.Triangles) and same(a.Vertices, b.Vertices) and same(a.Colors, b.Colors) and
+            same(a.Normals, b.Normals) and same(a.Min, b.Min) and same(a.Max, b.Max))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_block_culling_is_sound_on_random_programs(gpu, seed):
+    """Random op DAGs over all 17 opcodes (NaN, infinities, signed zeros, denormals, divisions by intervals that contain zero,
+    square roots of negative numbers, selects on unknown operands flow through): whatever the interval pass decides for a block
+    must be what the voxel-by-voxel evaluation gives -- the mesh with block culling is the mesh without it, bit for bit.  (That the
+    latter is the reference's is the business of the stored path's own parity tests.)"""
+    from oracle import ir_interp as I
+    from sdfkit_amd.api import Sdf
+    ops, out = I.random_program(seed)
+    arr = (N.Op * len(ops))()
+    for i, (op, a, b, c, d, imm) in enumerate(ops):
+        arr[i].opcode, arr[i].a, arr[i].b, arr[i].c, arr[i].d, arr[i].imm = op, a, b, c, d, imm
+    sdf = Sdf(None, True)
+    sdf._ir = (arr, len(ops), (C.c_int32 * 4)(*out))
+    mn, mx, dims = [-2.0, -1.5, -2.5], [2.0, 2.5, 1.5], (264, 260, 256)
+    # iso values: 0, and the median of the field (so that a surface does pass through the grid, whatever the program is)
+    w = I.sample(ops, out, True, mn, mx, 33, 33, 32)[0]
+    fin = w[np.isfinite(w)]
+    isos = [0.0] + ([float(np.float32(np.median(fin)))] if fin.size else [])
+    for iso in isos:
+        for clip in (True, False):
+            with N.option(N.OPT_ELIDE_VOLUME, 0):
+                ref = sdf.ToMesh(mn, mx, *dims, clipToBounds=clip, isoValue=iso)
+            with N.option(N.OPT_ELIDE_VOLUME, 2):
+                got, ran = _kernels_launched(lambda: sdf.ToMesh(mn, mx, *dims, clipToBounds=clip, isoValue=iso))
+            assert _same_mesh(got, ref), (seed, iso, clip, len(ref.Vertices), len(got.Vertices))
+            assert len(ref.Vertices) < 40_000_000
 
 
 def test_case_13_sign_words_fall_back_to_a_stored_volume(gpu):
@@ -89,11 +135,11 @@ def test_case_13_sign_words_fall_back_to_a_stored_volume(gpu):
     ov, oc = I.sample(ops, out, False, mn, mx, *dims)                 # the same float32 program, op for op
     om = O.march(ov, oc, mn, mx)
     assert len(om.vertices) > 100000
-    with N.option(N.OPT_ELIDE_VOLUME, 1):
+    with N.option(N.OPT_ELIDE_VOLUME, 2):
         for rep in range(3):
             mesh, ran = _kernels_launched(lambda: sdf.ToMesh(mn, mx, *dims, clipToBounds=False))
             assert_mesh_equal(mesh, om)
             if rep == 0:
-                assert any(k.startswith("sdfk_sample_signs") for k in ran) and any(k.startswith("sdfk_sample_bits") for k in ran), ran
+                assert "sdfk_cull_blocks" in ran and any(k.startswith("sdfk_sample_bits") for k in ran), ran
             else:
-                assert not any(k.startswith("sdfk_sample_signs") for k in ran), ran      # stored from the start now
+                assert "sdfk_cull_blocks" not in ran and not any(k.startswith("sdfk_sample_signs") for k in ran), ran      # stored from the start now
