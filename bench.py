@@ -1057,8 +1057,8 @@ def main():
             "elided_volume_no_culling_ms_per_step": None if elided1_ms is None else round(elided1_ms, 4),
             "elided_volume_is": "SDFK_OPT_ELIDE_VOLUME (opt-in): the same K pipelined steps with a volume that is never stored -- the sampler "
                                 "leaves sign bits only, corners and vertex colours are re-evaluated; meshes bit-identical.  = 2 (the first figure): "
-                                "8 x 4 x 32 blocks whose values provably lie on one side of the iso value -- the program evaluated in interval "
-                                "arithmetic over the block -- get constant sign bytes, only the blocks the surface passes through are evaluated "
+                                "64 x 4 x 4 blocks whose values provably lie on one side of the iso value -- the program evaluated in interval "
+                                "arithmetic over the block -- get constant sign words, only the blocks the surface passes through are evaluated "
                                 "voxel by voxel; = 1 (no_culling): every voxel evaluated.  Not the contract's step (which evaluates and stores "
                                 "every voxel): reported next to `value`, never as it",
         }

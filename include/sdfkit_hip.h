@@ -153,10 +153,10 @@ typedef enum sdfk_option {
                                    captured-graph limit does not STORE its volume: the sampler leaves the sign bits only, cell corners and
                                    vertex colours are re-evaluated by the program -- 4 (16 with colours) bytes per voxel of HBM writes less,
                                    meshes bit-identical.  A volume whose sign words contain case 13 is sampled again with stores (the
-                                   dead-cell test reads voxels).  2: in addition most voxels are not even EVALUATED: 8 x 4 x 32 blocks whose
+                                   dead-cell test reads voxels).  2: in addition most voxels are not even EVALUATED: 64 x 4 x 4 blocks whose
                                    values provably lie on one side of the iso value (the program evaluated in interval arithmetic over the
                                    block: rigorous for the float operations themselves, no assumption about the SDF) get constant sign
-                                   bytes, only the blocks the surface passes through are evaluated voxel by voxel.  0 (default): the volume
+                                   words, only the blocks the surface passes through are evaluated voxel by voxel.  0 (default): the volume
                                    is evaluated and stored, as the reference does and as the headline benchmark's step is defined */
     SDFK_OPT_COUNT_ = 17
 } sdfk_option;

@@ -73,6 +73,17 @@ __device__ __forceinline__ sdfk_iv iv_mul(sdfk_iv a, sdfk_iv b)
     r.hi = sdfk_max_ieee(sdfk_max_ieee(p0, p1), sdfk_max_ieee(p2, p3));
     return r;
 }
+// a * a of ONE value (x * x in every Length): the product form would treat the two factors as independent and give [-|lo hi|, ..]
+// for an interval around zero -- a negative lower bound under the square root, i.e. "unknown" for every block that a coordinate
+// plane of some primitive's centre passes through.  fl(x * x) is monotone in |x|.
+__device__ __forceinline__ sdfk_iv iv_sqr(sdfk_iv a)
+{
+    const float p0 = a.lo * a.lo, p1 = a.hi * a.hi;
+    sdfk_iv r;
+    r.hi = sdfk_max_ieee(p0, p1);
+    r.lo = (a.lo >= 0.0f || a.hi <= 0.0f) ? sdfk_min_ieee(p0, p1) : (r.hi == r.hi ? 0.0f : r.hi);
+    return r;
+}
 __device__ __forceinline__ sdfk_iv iv_div(sdfk_iv a, sdfk_iv b)
 {
     const float q0 = a.lo / b.lo, q1 = a.lo / b.hi, q2 = a.hi / b.lo, q3 = a.hi / b.hi;
@@ -299,16 +310,18 @@ extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<true, SDFK_FLAT>(A, K); }
 #endif
 
-// ---- SDFK_OPT_ELIDE_VOLUME, block culling: the sign bits without evaluating most voxels ----------------------------------------
+// ---- SDFK_OPT_ELIDE_VOLUME = 2, block culling: the sign bits without evaluating most voxels ---------------------------------
 // The sign-only sampler above is pure arithmetic (74 us for the sphere at 512^3).  But a block of voxels whose values provably
 // all lie on one side of the iso value needs no evaluation at all: sdf_interval() below is the program evaluated over a BOX of
 // sample points in the interval form of every operation (prelude), and a box whose result interval excludes the iso value gets
-// its sign bytes written as constants.  No assumption about the SDF (no Lipschitz bound): the intervals contain every float
-// the per-voxel evaluation can produce, NaN = unknown = evaluate.  A block = 8 x (one byte of bits8) x 4 y x 32 z (one 32-byte
-// sector per y row): 1024 voxels, one lane of sdfk_cull_blocks each; blocks it cannot decide go to a work list (order
-// irrelevant: every byte has its place) that sdfk_eval_blocks evaluates, one wavefront a block -- lane = x + 8 (y + 4 (z / 16)),
-// so that the 64-bit ballot of "value > iso" for the k-th voxel of every lane IS eight output bytes.
-struct CullArgs { unsigned* worklist; unsigned* counter; int nbx, nby, nbz; };
+// its sign bits written as constants.  No assumption about the SDF (no Lipschitz bound): the intervals contain every float
+// the per-voxel evaluation can produce, NaN = unknown = evaluate.
+// A block = 64 x (ONE word of the X-packed sign array the marching-cubes classifier reads) x 4 y x 4 z = 1024 voxels, 16 words.
+// sdfk_cull_blocks: one LANE per block decides it (16 constant words) or appends it to a work list (order irrelevant: every word
+// has its place).  sdfk_eval_blocks: one WAVEFRONT per listed block, lane = x -- the 64-bit ballot of "value > iso" over the lanes
+// IS the sign word of a (y, z) row, sixteen evaluations and sixteen ballots a block.  Both write bits[z][y][xw] directly: this
+// path has no byte form and no k_bits_transpose.
+struct CullArgs { unsigned long long* bits; unsigned* worklist; unsigned* counter; int nbx, nby, nbz; };
 #if SDFK_KERNELS & 0x600
 __device__ __forceinline__ float sdfk_coord(float m, int i, float d) { return m + (float)i * d; }
 #endif
@@ -317,36 +330,40 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_cull_blocks(SampleArgs A,
 {
     const int nb = C.nbx * C.nby * C.nbz;
     const int b = blockIdx.x * 256 + threadIdx.x;
-    int decided = -1;   // -1: not a block; 0 / 1: every voxel's bit; 2: evaluate
+    int decided = -1;   // -1: not a block; 1: `word` is the sign word of all 16 rows of the block; 2: evaluate
+    unsigned long long word = 0;
     int bx = 0, by = 0, bz = 0;
     if (b < nb) {
-        bz = b % C.nbz;                      // (z fastest: neighbouring lanes write neighbouring 32-byte runs of one byte row)
-        const int t = b / C.nbz;
-        bx = t % C.nbx;
-        by = t / C.nbx;
-        const int x0 = bx * 8, y0 = by * 4, z0 = bz * 32;
+        bx = b % C.nbx;                      // (x words fastest: neighbouring lanes write neighbouring words of a (y, z) row)
+        const int t = b / C.nbx;
+        by = t % C.nby;
+        bz = t / C.nby;
+        const int x0 = bx * 64, y0 = by * 4, z0 = bz * 4;
         decided = 2;
         // only whole blocks away from the clipped faces are candidates (the others are O(n^2) few)
-        const bool whole = x0 + 8 <= A.nx && y0 + 4 <= A.ny && z0 + 32 <= A.nz;
-        const bool faces = A.clip && (x0 == 0 || x0 + 8 >= A.nx || y0 == 0 || y0 + 4 >= A.ny || A.z0 + z0 == 0 || A.z0 + z0 + 32 >= A.nz_global);
+        const bool whole = x0 + 64 <= A.nx && y0 + 4 <= A.ny && z0 + 4 <= A.nz;
+        const bool faces = A.clip && (x0 == 0 || x0 + 64 >= A.nx || y0 == 0 || y0 + 4 >= A.ny || A.z0 + z0 == 0 || A.z0 + z0 + 4 >= A.nz_global);
         if (whole && !faces) {
-            const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0, A.dx), sdfk_coord(A.mx, x0 + 7, A.dx));
+            // eight sub-boxes of 8 x each -- one BYTE of the word each: a box of 64 x is too wide for scenes that repeat along x (the
+            // interval of mod(x, period) covers the whole period), and the interval pass is 1 % of the sampler's work either way
             const sdfk_iv Y = iv_make(sdfk_coord(A.my, y0, A.dy), sdfk_coord(A.my, y0 + 3, A.dy));
-            const sdfk_iv Z = iv_make(sdfk_coord(A.mz, A.z0 + z0, A.dz), sdfk_coord(A.mz, A.z0 + z0 + 31, A.dz));
-            const sdfk_iv W = sdf_interval(K, X, Y, Z);
-            if (W.lo > A.iso) decided = 1;                       // (false for NaN)
-            else if (W.hi <= A.iso && W.lo == W.lo) decided = 0;
+            const sdfk_iv Z = iv_make(sdfk_coord(A.mz, A.z0 + z0, A.dz), sdfk_coord(A.mz, A.z0 + z0 + 3, A.dz));
+            decided = 1;
+#pragma unroll 1
+            for (int sx = 0; sx < 8; sx++) {
+                const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0 + 8 * sx, A.dx), sdfk_coord(A.mx, x0 + 8 * sx + 7, A.dx));
+                const sdfk_iv W = sdf_interval(K, X, Y, Z);
+                if (W.lo > A.iso) word |= 0xffull << (8 * sx);                 // (false for NaN)
+                else if (!(W.hi <= A.iso && W.lo == W.lo)) { decided = 2; break; }
+            }
         }
     }
-    if (decided == 0 || decided == 1) {
-        typedef unsigned sdfk_u4 __attribute__((ext_vector_type(4), aligned(4)));   // (byte rows are only 4-byte aligned in general)
-        const unsigned v = decided ? 0xffffffffu : 0u;
-        const sdfk_u4 q = {v, v, v, v};
-        for (int yy = 0; yy < 4; yy++) {
-            unsigned char* row = A.bits8 + ((long)(by * 4 + yy) * A.nx8 + bx) * A.pitch8 + bz * 32;
-            reinterpret_cast<sdfk_u4*>(row)[0] = q;
-            reinterpret_cast<sdfk_u4*>(row)[1] = q;
-        }
+    if (decided == 1) {
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++)
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+                C.bits[((long)(bz * 4 + zz) * A.ny + (by * 4 + yy)) * C.nbx + bx] = word;
     }
     // the undecided blocks of this wavefront: one atomic for all of them
     const unsigned long long need = __builtin_amdgcn_ballot_w64(decided == 2);
@@ -362,40 +379,35 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_cull_blocks(SampleArgs A,
 #if SDFK_KERNELS & 0x400
 extern "C" __global__ __launch_bounds__(256) void sdfk_eval_blocks(SampleArgs A, CullArgs C, SdfkK K)
 {
-    __shared__ unsigned long long s_ballot[4][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned count = *C.counter;
     for (unsigned e = blockIdx.x * 4u + (unsigned)wave; e < count; e += gridDim.x * 4u) {
         const int b = (int)C.worklist[e];
-        const int bz = b % C.nbz, t = b / C.nbz, bx = t % C.nbx, by = t / C.nbx;
-        const int ix = bx * 8 + (lane & 7), iy = by * 4 + ((lane >> 3) & 3), izb = bz * 32 + (lane >> 5) * 16;
-        const float px = sdfk_coord(A.mx, ix, A.dx), py = sdfk_coord(A.my, iy, A.dy);
-        const bool edge_xy = (ix == 0) | (ix == A.nx - 1) | (iy == 0) | (iy == A.ny - 1);
-        const bool in_xy = ix < A.nx && iy < A.ny;
+        const int bx = b % C.nbx, t = b / C.nbx, by = t % C.nby, bz = t / C.nby;
+        const int ix = bx * 64 + lane;
+        const float px = sdfk_coord(A.mx, ix, A.dx);
+        const bool edge_x = (ix == 0) | (ix == A.nx - 1);
+        unsigned long long word = 0;   // (this lane's word of the block: lane 4 zz + yy keeps row (yy, zz))
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int iz = izb + k, zg = A.z0 + iz;
-            float r, g, bl, w;
-            sdf_eval(K, px, py, sdfk_coord(A.mz, zg, A.dz), r, g, bl, w);
-            if (A.clip && (edge_xy || zg == 0 || zg == A.nz_global - 1)) w = A.outside;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(in_xy && iz < A.nz && w > A.iso);
-            if (lane == 0) s_ballot[wave][k] = m;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // lanes 0..31: y = lane / 8, four consecutive z each -> one dword of the byte row (y, x / 8)
-        if (lane < 32) {
-            const int yy = lane >> 3, zq = (lane & 7) * 4;
-            unsigned out = 0;
+        for (int zz = 0; zz < 4; zz++) {
+            const int iz = bz * 4 + zz, zg = A.z0 + iz;
+            const float pz = sdfk_coord(A.mz, zg, A.dz);
+            const bool edge_z = (zg == 0) | (zg == A.nz_global - 1);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int z = zq + j;
-                const unsigned char* src = reinterpret_cast<const unsigned char*>(&s_ballot[wave][z & 15]);
-                out |= (unsigned)src[yy + 4 * (z >> 4)] << (8 * j);
+            for (int yy = 0; yy < 4; yy++) {
+                const int iy = by * 4 + yy;
+                float r, g, bl, w;
+                sdf_eval(K, px, sdfk_coord(A.my, iy, A.dy), pz, r, g, bl, w);
+                if (A.clip && (edge_x || edge_z || iy == 0 || iy == A.ny - 1)) w = A.outside;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(ix < A.nx && w > A.iso);   // bits of x >= nx stay 0
+                if (lane == 4 * zz + yy) word = m;
             }
-            if (by * 4 + yy < A.ny && bz * 32 + zq < A.pitch8)
-                *reinterpret_cast<unsigned*>(A.bits8 + ((long)(by * 4 + yy) * A.nx8 + bx) * A.pitch8 + bz * 32 + zq) = out;
         }
-        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) {
+            const int yy = lane & 3, zz = lane >> 2;
+            if (by * 4 + yy < A.ny && bz * 4 + zz < A.nz)
+                C.bits[((long)(bz * 4 + zz) * A.ny + (by * 4 + yy)) * C.nbx + bx] = word;
+        }
     }
 }
 #endif
@@ -695,7 +707,8 @@ inline bool generate_sample_source(const sdfk_op* ops, int n_ops, const int32_t 
         {   // the same operation on intervals
             static const char* const ifn[] = {nullptr, nullptr, nullptr, nullptr, "iv_add", "iv_sub", "iv_mul", "iv_div", "iv_neg", "iv_abs", "iv_sqrt",
                                               "iv_floor", "iv_min", "iv_max", "iv_min", "iv_max", "iv_sel_lt"};
-            if (arity == 1) snprintf(buf, sizeof buf, "    const sdfk_iv i%d = %s(i%d);\n", i, ifn[o.opcode], o.a);
+            if (o.opcode == SDFK_OP_MUL && o.a == o.b) snprintf(buf, sizeof buf, "    const sdfk_iv i%d = iv_sqr(i%d);\n", i, o.a);
+            else if (arity == 1) snprintf(buf, sizeof buf, "    const sdfk_iv i%d = %s(i%d);\n", i, ifn[o.opcode], o.a);
             else if (arity <= 3) snprintf(buf, sizeof buf, "    const sdfk_iv i%d = %s(i%d, i%d);\n", i, ifn[o.opcode], o.a, o.b);
             else snprintf(buf, sizeof buf, "    const sdfk_iv i%d = %s(i%d, i%d, i%d, i%d);\n", i, ifn[o.opcode], o.a, o.b, o.c, o.d);
             ibody += buf;

@@ -1722,7 +1722,7 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
         if (!v->bits) {
             if (int r = dev_alloc((void**)&v->bits, v->nbitwords() * sizeof(uint64_t))) return r;
         }
-        if (!v->bits8) {
+        if (!v->bits8 && !(v->elided && g_cfg.elide_volume >= 2)) {   // (block culling writes the words directly: no byte form)
             if (int r = dev_alloc((void**)&v->bits8, (size_t)v->ny * v->nx8() * v->pitch8() + 64)) return r;
         }
         A.bits8 = v->bits8;
@@ -1748,10 +1748,12 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
             const size_t plane = (size_t)v->ny * v->pitch();
             phase_token_wait(0);
             if (cull) {
-                // block culling: one lane per 8 x 4 x 32 block decides it by interval arithmetic (constant sign bytes) or lists it;
-                // the listed blocks -- those the surface passes through -- are evaluated voxel by voxel (sample_codegen.h)
-                struct { unsigned* worklist; unsigned* counter; int nbx, nby, nbz; } Cargs;
-                Cargs.nbx = v->nx8(); Cargs.nby = (v->ny + 3) / 4; Cargs.nbz = (v->nz + 31) / 32;
+                // block culling: one lane per 64 x 4 x 4 block decides it by interval arithmetic (constant sign words) or lists it; the
+                // listed blocks -- those the surface passes through -- are evaluated voxel by voxel; both write the X-packed sign
+                // words themselves (sample_codegen.h): no byte form, no transposer
+                struct { unsigned long long* bits; unsigned* worklist; unsigned* counter; int nbx, nby, nbz; } Cargs;
+                Cargs.bits = (unsigned long long*)v->bits;
+                Cargs.nbx = v->nxw(); Cargs.nby = (v->ny + 3) / 4; Cargs.nbz = (v->nz + 3) / 4;
                 const size_t nblocks = (size_t)Cargs.nbx * Cargs.nby * Cargs.nbz;
                 if (!v->cull_list) {
                     if (int r = dev_alloc((void**)&v->cull_list, (nblocks + 16) * sizeof(uint32_t))) return r;
@@ -1783,7 +1785,7 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
             v->bits_valid = false;
             return SDFK_OK;
         }
-        {
+        if (!(v->elided && g_cfg.elide_volume >= 2)) {   // (the block-culling kernels write the words themselves)
             ProfScope ps("k_bits_transpose");
             hipLaunchKernelGGL(k_bits_transpose, transpose_grid(v->nz, v->ny, v->nxw()), dim3(256), 0, g.stream,
                                v->bits8, v->bits, v->nx8(), v->ny, v->nz, v->nxw(), v->pitch8());

@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu():
     N.init(0)
+    if not (N.get_option(N.OPT_CORNER_EVAL) and N.get_option(N.OPT_VCOLOR_EVAL)):
+        pytest.skip("a volume without storage needs both re-evaluation paths (SDFK_NO_CORNER_EVAL / SDFK_NO_VCOLOR_EVAL are set)")
     return True
 
 

@@ -70,7 +70,9 @@ def test_bench_gpus_n_started_as_plain_python(gpu, world):
     assert 0 < sh["slab_kernels_only_ms"] and sh["xgmi"]["receive_bound_ms"] > 0
     for k in ("latency_ms_single_stream", "first_call_ms", "first_call", "value_is", "pipeline_frac_is"):
         assert k in one
-    assert one["latency_ms_single_stream"] >= one["ms_per_step"] * 0.8
+    # (one call at a time is not faster than the pipelined steady state -- with the lanes off, SDFK_LANES=0, the two are the same
+    # thing measured twice, hence the slack)
+    assert one["latency_ms_single_stream"] >= one["ms_per_step"] * 0.5
 
 
 def _gpu_count():
@@ -116,7 +118,9 @@ buf = (C.c_ubyte * 128)()
 N.check(L.sdfk_dist_unique_id(buf))
 N.check(L.sdfk_dist_init(1, 0, buf))
 assert D.info() == (1, 0, 1)
-assert N.get_option(N.OPT_DIST_EXCHANGE) == 0 and N.get_option(N.OPT_DIST_INDEX16) == 0    # the defaults: the plainest collective
+import os
+if "SDFK_DIST_EXCHANGE" not in os.environ and "SDFK_DIST_INDEX16" not in os.environ:
+    assert N.get_option(N.OPT_DIST_EXCHANGE) == 0 and N.get_option(N.OPT_DIST_INDEX16) == 0    # the defaults: the plainest collective
 for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64))):
     scene, sdf = S.CATALOGUE[name]()
     mn, mx = [-2.8125] * 3, [2.8125] * 3

@@ -1,0 +1,15 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"; export TMPDIR=/tmp
+O=gpurun_out/alt; mkdir -p $O
+run() {
+  tag=$1; shift
+  env "$@" timeout 1500 python3 -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/$tag.log 2>&1
+  echo "$tag ($*): rc $? -- $(tail -1 $O/$tag.log)"
+}
+run elide_cull SDFK_ELIDE_VOLUME=2
+run lanes0 SDFK_LANES=0
+run dist_index16 SDFK_DIST_INDEX16=1 SDFK_DIST_EXCHANGE=2
+run gather_paths SDFK_NO_CORNER_EVAL=1 SDFK_NO_VCOLOR_EVAL=1
+run dist_direct SDFK_DIST_EXCHANGE=1
+timeout 600 python3 tools/elide_kernels_probe.py 2>/dev/null | tee gpurun_out/r04h/elide_kernels.txt
