@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPU soak test: a random interleaving of the API (fused ToMesh jobs read late / never read,
-two-stage volumes with explicit clip and edits, other iso values and steps, ray-marched frames)
-for SECONDS (default 60), every result checked against oracle results computed up front."""
+two-stage volumes with explicit clip and edits, other iso values and steps, ray-marched frames,
+large grids under a randomly chosen SDFK_OPT_ELIDE_VOLUME, programs of one structure with new constants,
+recycled mesh arrays) for SECONDS (default 60), every result checked against oracle results computed up front."""
 import ctypes as C
 import os
 import sys
@@ -25,6 +26,13 @@ for name in ("readme_repeat_xy", "union8", "sphere_w", "sdf_with_color", "repeat
         v, c = O.sample(scene, MN, MX, *dims)
         O.clip_to_bounds(v, MN, MX)
         CASES.append(dict(name=name, dims=dims, sdf=sdf, scene=scene, v=v, c=c, m=O.march(v, c, MN, MX), m25=None, ray=None))
+# grids above the captured-graph limit: the only ones SDFK_OPT_ELIDE_VOLUME applies to (0 stored, 1 sign-only, 2 block culling)
+BIG = []
+for name, dims in (("readme_repeat_xy", (264, 260, 256)), ("sphere_w", (272, 250, 260)), ("union8", (260, 264, 256))):
+    scene, sdf = S.CATALOGUE[name]()
+    v, c = O.sample(scene, MN, MX, *dims)
+    O.clip_to_bounds(v, MN, MX)
+    BIG.append(dict(name=name, dims=dims, sdf=sdf, m=O.march(v, c, MN, MX)))
 N.init()
 L = N.lib()
 
@@ -42,9 +50,28 @@ def raw(case):
 
 held, ops, t0 = [], 0, time.time()
 while time.time() - t0 < secs:
-    k = int(rng.integers(0, 8))
+    k = int(rng.integers(0, 11))
     case = CASES[int(rng.integers(0, len(CASES)))]
-    if k <= 2:                                   # queue a fused job, read it later (or never)
+    if k == 8:                                   # a large grid under a random volume-elision mode, mesh arrays recycled
+        big = BIG[int(rng.integers(0, len(BIG)))]
+        with N.option(N.OPT_ELIDE_VOLUME, int(rng.integers(0, 3))):
+            mesh = big["sdf"].ToMesh(MN, MX, *big["dims"])
+        assert same(mesh, big["m"]), ("big", big["name"], N.get_option(N.OPT_ELIDE_VOLUME))
+        mesh.Recycle()
+    elif k == 9:                                 # the sphere's structure with a radius nobody has seen: no compile, the oracle's mesh
+        from sdfkit_amd import Sdfs
+        r = float(np.float32(0.4 + 0.9 * rng.random()))
+        dims = ((40, 36, 44), (64, 64, 64))[int(rng.integers(0, 2))]
+        sc = O.Scene(); sc.sphere_w(r)
+        v, c = O.sample(sc, MN, MX, *dims)
+        O.clip_to_bounds(v, MN, MX)
+        assert same(Sdfs.Sphere(r).ToMesh(MN, MX, *dims), O.march(v, c, MN, MX)), ("radius", r, dims)
+    elif k == 10 and held:                       # read a held mesh and hand its arrays back at once
+        case2, h = held.pop(int(rng.integers(0, len(held))))
+        mesh = Mesh._from_handle(h)
+        assert same(mesh, case2["m"]), ("late read + recycle", case2["name"], case2["dims"])
+        mesh.Recycle()
+    elif k <= 2:                                 # queue a fused job, read it later (or never)
         held.append((case, raw(case)))
     elif k == 3 and held:                        # read one of the held meshes, out of order
         case2, h = held.pop(int(rng.integers(0, len(held))))
