@@ -944,13 +944,14 @@ def main():
             d2h = {}
             colors_written = bool(sdf.writes_color)
             for kind in ("pooled", "pinned", "managed", "managed_recycled", "numpy"):
-                ts = [one_call(kind) for _ in range(5)]
+                ts = [one_call(kind) for _ in range(8)]
                 d2h[kind] = {"median_ms": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "all_ms": [round(t, 3) for t in ts]}
             d2h["pooled"]["pool"] = {"hits": pooled.hits, "misses": pooled.misses}
             extra["one_step_incl_mesh_d2h_ms"] = d2h["pooled"]["median_ms"]
             extra["one_step_incl_mesh_d2h"] = {
                 "what": "sdfk_sample_march + sdfk_mesh_counts + sdfk_mesh_copy of V/C/N/T to the host + sdfk_mesh_bounds, one call at a time; "
-                        "median of 4 calls after a warm-up call.  pooled (the headline figure: what a host that meshes a grid shape "
+                        "median of 7 calls after a warm-up call (the second copy into an address is still slow -- the runtime maps the pages "
+                        "for its first direct copy -- from the third on it is the steady state).  pooled (the headline figure: what a host that meshes a grid shape "
                         "repeatedly gets BY DESIGN) = the four exact-length arrays rented from a pool of arrays that earlier meshes of the "
                         "same size handed back (Mesh.Recycle; shim: MeshArrayPool), a miss -- the warm-up call here -- allocating "
                         "untouched memory; incl. all four arrays, bounds and stats, and the colour array cleared by the library.  "
