@@ -38,8 +38,25 @@
 
 namespace sdfk {
 
-constexpr int K4_WMAX = 640;   // k_vertices: record-window slots staged in LDS (both windows together)
-constexpr int K4_RMAX = 288;   // k_vertices: rowstart entries staged per window
+// k_vertices stages, per chunk of MC_CHUNK records, two windows of the record list (K4_WMAX slots of 40 B together) and the
+// rowstart[] slices that map a row to its records (2 x K4_RMAX entries).  Whatever falls outside is still found -- through
+// global memory, at several dependent round trips per lookup -- so the sizes decide how often that happens
+// (tools/experiments/r04_vertices_counters.patch counts it):
+//   rows: a chunk that straddles two layers spans the EMPTY rows between the last surface row of one layer and the first of the
+//         next, ncy - (rows the surface occupies) of them.  With 288 entries 7 % of the 512^3 sphere's vertices (the second
+//         layer's part of every such chunk) took the global path; with ncy + 100 or more none do.  1152 covers ncy <= ~1050.
+//   slots: rows near a horizontal tangent hold long runs of records, so the next layer's rows can hold far more than the
+//         chunk's own (README scene: 1.4 % of the vertices outside 640 slots, 0.5 % outside 752).
+// 52.8 KB of LDS per workgroup in all: three workgroups per CU, as the 162 VGPRs allow anyway.
+#ifndef SDFK_K4_WMAX
+#define SDFK_K4_WMAX 752
+#endif
+#ifndef SDFK_K4_RMAX
+#define SDFK_K4_RMAX 1152
+#endif
+constexpr int K4_WMAX = SDFK_K4_WMAX;   // k_vertices: record-window slots staged in LDS (both windows together)
+constexpr int K4_RMAX = SDFK_K4_RMAX;   // k_vertices: rowstart entries staged per window
+static_assert(K4_WMAX <= 768 && K4_WMAX >= 512, "k_vertices stages the windows in three rounds of 256 slots");
 
 // ---------------------------------------------------------------------------
 // K1: sign bits
