@@ -2134,7 +2134,10 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
         const float inv_det = 1.0f / det;
         M.inv[0] = yz * inv_det; M.inv[1] = xz * inv_det; M.inv[2] = xy * inv_det;
     }
-    constexpr int vcap = 256 * 8, tcap = 256 * 8;   // (persistent-workgroup caps were measured: +-2 us, noise)
+#ifndef SDFK_KV_GRIDCAP
+#define SDFK_KV_GRIDCAP (256 * 8)
+#endif
+    constexpr int vcap = SDFK_KV_GRIDCAP, tcap = 256 * 8;   // (persistent-workgroup caps were measured: +-2 us, noise)
     const int vgrid = grid_for(j->P.cap_active, (int)MC_CHUNK, vcap);
     if (!j->bounds_partial || j->bounds_blocks != vgrid) {
         if (int rr = job_alloc(j, &j->bounds_partial, (size_t)vgrid * 6)) return rr;
