@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCDEC_PADDED];   // the decision tables only (mc_device.h): 1.1 KB
     __shared__ uint64_t s_wave[4];
     __shared__ uint64_t s_ord[MCLUT_NROWS];
+    __shared__ uint32_t s_rows[2][2];   // [chunk parity][first, last]: row of the chunk's first / last record
     mc_load_dec_to_lds(s_lut);
     {   // per-row creation order -> LDS (independent loads per lane)
         const int t = (int)threadIdx.x;
@@ -603,17 +604,21 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     // (a volume without storage -- SDFK_OPT_ELIDE_VOLUME -- has no voxels for the dead-cell test to read: the host sees the
     // same counter, discards this job's result and redoes it on a volume that has them)
-    const bool check_dead = P.counters->n_case13 != 0 && P.values != nullptr;
+    const bool any13 = P.counters->n_case13 != 0;
+    const bool check_dead = any13 && P.values != nullptr;
     const int nchunks = (int)((n + MC_CHUNK - 1u) / MC_CHUNK);
     float* col = s_v + threadIdx.x;
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    int parity = 0;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x, parity ^= 1) {
         const uint32_t i = (uint32_t)c * MC_CHUNK + threadIdx.x;
         const bool mine_rec = threadIdx.x < MC_CHUNK && i < n;   // (lanes MC_CHUNK..255 idle here: see MC_CHUNK)
         uint32_t nown = 0, nt_emit = 0, info = 0, dead = 0;
         uint64_t own = 0;
+        int ry = 0, rz = 0;
         if (mine_rec) {
             const uint32_t xy = P.rec_xy[i];
             const int x = (int)(xy & P.xmask), y = (int)(xy >> P.xbits), z = (int)P.rec_z[i];
+            ry = y; rz = z;
             corners_to_column(*reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8),
                               *reinterpret_cast<const float4*>(P.rec_corners + (size_t)i * 8 + 4), col);
             const CornersLds v{col, 256, (double)P.iso};
@@ -642,29 +647,41 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
                 dead = 1;
             }
         }
+        // rows spanned by the chunk (lets K4 fetch its windows without first reading records): its first and last record are
+        // lanes 0 and cnt - 1, which hold their coordinates already
+        const uint32_t first = (uint32_t)c * MC_CHUNK, last = min(first + MC_CHUNK - 1u, n - 1u);
+        if (mine_rec && (i == first || i == last)) {
+            const uint32_t row = (uint32_t)(rz - P.lay_count_begin) * (uint32_t)P.ncy + (uint32_t)ry;
+            // (two buffers: the next chunk's rows are written before a barrier separates them from this chunk's reads)
+            if (i == first) s_rows[parity][0] = row;
+            if (i == last) s_rows[parity][1] = row;
+        }
         // in-chunk prefix and chunk total of (created vertices, triangles), packed v << 31 | t
         uint64_t total;
-        const uint64_t pre = block_excl_scan_u64(((uint64_t)nown << 31) | nt_emit, s_wave, &total);
+        const uint64_t pre = block_excl_scan_u64(((uint64_t)nown << 31) | nt_emit, s_wave, &total);   // (syncs: s_rows is complete)
+        // ... and the record ranges of its two neighbour windows (see k_vertices): three rowstart loads, one per lane, issued
+        // HERE so that they are in flight during the stores and the second scan below (thread 0 loading them one after the
+        // other at the very end left every workgroup waiting for two more L2 round trips)
+        const uint32_t rf = s_rows[parity][0], rl = s_rows[parity][1];
+        const uint32_t nrows = (uint32_t)((P.lay_list_end - P.lay_count_begin) * P.ncy);
+        const uint32_t nrs = min(rl - rf + 3u, (uint32_t)K4_RMAX);
+        uint32_t wrow = 0;
+        if (threadIdx.x < 3) {
+            const uint32_t r = threadIdx.x == 0 ? rf + nrs - 1u : (threadIdx.x == 1 ? rf + (uint32_t)P.ncy : rf + (uint32_t)P.ncy + nrs - 1u);
+            wrow = min(P.rowstart[min(r, nrows)], n);
+        }
         if (mine_rec) {
             P.rec_info[i] = info;
             P.rec_own[i] = own;
             P.rec_pre[i] = (uint32_t)(pre >> 31) | ((uint32_t)(pre & 0x7fffffffull) << 16);
         }
-        uint64_t ndead;
-        (void)block_excl_scan_u64(dead, s_wave, &ndead);
+        // "impossible case 13" cells of the chunk: only volumes that have such sign words at all need the count
+        uint64_t ndead = 0;
+        if (any13) (void)block_excl_scan_u64(dead, s_wave, &ndead);
+        const uint32_t w1e = __shfl(wrow, 0), w2s = __shfl(wrow, 1), w2e = __shfl(wrow, 2);
         if (threadIdx.x == 0) {
             P.chunktot[c] = total;
             P.chunkdead[c] = (uint32_t)ndead;
-            // rows spanned by the chunk: lets K4 fetch its windows without first reading records
-            const uint32_t first = (uint32_t)c * MC_CHUNK, last = min(first + MC_CHUNK - 1u, n - 1u);
-            const uint32_t rf = (P.rec_z[first] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[first] >> P.xbits);
-            const uint32_t rl = (P.rec_z[last] - (uint32_t)P.lay_count_begin) * (uint32_t)P.ncy + (P.rec_xy[last] >> P.xbits);
-            // ... and the record ranges of its two neighbour windows (see k_vertices)
-            const uint32_t nrows = (uint32_t)((P.lay_list_end - P.lay_count_begin) * P.ncy);
-            const uint32_t nrs = min(rl - rf + 3u, (uint32_t)K4_RMAX);
-            const uint32_t w1e = min(P.rowstart[min(rf + nrs - 1u, nrows)], n);
-            const uint32_t w2s = min(P.rowstart[min(rf + (uint32_t)P.ncy, nrows)], n);
-            const uint32_t w2e = min(P.rowstart[min(rf + (uint32_t)P.ncy + nrs - 1u, nrows)], n);
             P.chunkwin[c] = make_uint4(rf, rl, w1e, w2s);
             P.chunkwin2[c] = w2e;
         }
