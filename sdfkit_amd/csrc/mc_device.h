@@ -123,12 +123,16 @@ __constant__ uint64_t c_roword[MCLUT_NROWS] = {MCLUT_ROWORD_VALUES};
 // per-thread register array indexed that way is demoted to scratch memory by the compiler,
 // so kernels keep each thread's corners in its own LDS column instead (conflict-free:
 // consecutive lanes -> consecutive banks) and hand the decision functions an accessor.
-struct CornersLds {          // float voxels in LDS, [corner][thread] with `stride` threads
+// (ISO0: the iso value is known to be +0.0 -- x - 0.0 is x for every x, -0.0 and NaN included, so the subtraction, one f64
+// operation per corner read, is left out; k_vertices reads ~58 corners per vertex)
+template <bool ISO0>
+struct CornersLdsT {          // float voxels in LDS, [corner][thread] with `stride` threads
     const float* p;
     int stride;
     double iso;
-    __device__ __forceinline__ double operator[](int k) const { return (double)p[k * stride] - iso; }
+    __device__ __forceinline__ double operator[](int k) const { return ISO0 ? (double)p[k * stride] : (double)p[k * stride] - iso; }
 };
+using CornersLds = CornersLdsT<false>;
 // Corners of one cell inside a 3x3x3 voxel block staged per thread in LDS
 // ([(lx*3+ly)*3+lz][256 threads]); (ox,oy,oz) = the cell's origin inside the block.
 struct CornersNbr {

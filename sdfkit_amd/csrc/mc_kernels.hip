@@ -790,6 +790,7 @@ __device__ __forceinline__ void add_sharer_gradients(const V& vs, int es, int oc
     }
 }
 
+template <bool ISO0>   // ISO0: P.iso == +0.0 (CornersLdsT, mc_device.h)
 __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
 {
     __shared__ float s_wc[8 * K4_WMAX];          // window corner values: [corner][slot]
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int own_row = (int)(info >> 22);
             float pos[3] = {0.0f, 0.0f, 0.0f}, colr[3] = {0.0f, 0.0f, 0.0f}, nrm[3] = {0.0f, 0.0f, 0.0f};
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
-            const CornersLds v{s_wc + rr, K4_WMAX, iso};   // the creator cell
+            const CornersLdsT<ISO0> v{s_wc + rr, K4_WMAX, iso};   // the creator cell
             if (e == 12) {
                 P.rec_vid[(size_t)12 * P.cap_active + (base + (uint32_t)rr)] = vi;   // (only the cell itself references its centre vertex)
                 if (!emit) continue;
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     if (sls >= 0) {
                         const uint32_t ti = s_winfo[sls];
                         const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;
-                        if (occ) add_sharer_gradients(CornersLds{s_wc + sls, K4_WMAX, iso}, es, occ, dir, w_lo, w_hi, nrm);
+                        if (occ) add_sharer_gradients(CornersLdsT<ISO0>{s_wc + sls, K4_WMAX, iso}, es, occ, dir, w_lo, w_hi, nrm);
                     } else {   // outside the staged windows: through global memory
                         const uint32_t ti = P.rec_info[g];
                         const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;

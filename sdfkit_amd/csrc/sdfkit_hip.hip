@@ -2162,7 +2162,10 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     phase_token_wait(1);
     {
         ProfScope ps("k_vertices");
-        hipLaunchKernelGGL(k_vertices, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
+        uint32_t iso_bits;
+        memcpy(&iso_bits, &j->P.iso, 4);
+        if (iso_bits == 0u) hipLaunchKernelGGL(k_vertices<true>, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);   // (+0.0: the usual iso value)
+        else hipLaunchKernelGGL(k_vertices<false>, dim3(vgrid), dim3(256), 0, g.stream, j->P, M);
         HIPCHK(hipGetLastError());
     }
     phase_token_pass(1);
