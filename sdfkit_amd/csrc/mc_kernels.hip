@@ -798,7 +798,6 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     __shared__ uint32_t s_rs[2][K4_RMAX];
     __shared__ uint64_t s_occ[MCLUT_NROWS];
     __shared__ uint32_t s_pre[257];
-    __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_own[256];
     __shared__ uint32_t s_z[256];
     __shared__ uint8_t s_creator[256 * 13];   // creator record (slot in the chunk) of each vertex of the chunk
@@ -849,8 +848,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         const uint32_t w1_cnt = min(max(cw.z, base + cnt) - w1_start, (uint32_t)K4_WMAX);
         const uint32_t w2_start = cw.w;
         const uint32_t w2_cnt = min(P.chunkwin2[ci] - w2_start, (uint32_t)K4_WMAX - w1_cnt);
+        // (the in-chunk prefix of the created vertices and the chunk's total were left by k_resolve -- rec_pre, chunktot --: two
+        // more loads in this batch instead of a workgroup scan, three barriers, after it)
+        uint32_t my_pre = 0;
+        const uint32_t total = (uint32_t)(P.chunktot[ci] >> 31);
         if (threadIdx.x < cnt) {
             my_nown = (P.rec_info[irec] >> 18) & 15u;
+            my_pre = P.rec_pre[irec] & 0xffffu;
             s_own[threadIdx.x] = P.rec_own[irec];
             s_z[threadIdx.x] = P.rec_z[irec];
         }
@@ -893,12 +897,11 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         chunk_prefix += chunk_totals_block(prefix_lane, s_part);
         prefix_upto = ci;
         if (threadIdx.x == 0) P.chunkpre[ci] = chunk_prefix;
-        const uint32_t total = block_exclusive_scan_256(my_nown, s_pre, s_wave);   // (syncs: LDS is complete)
-        {   // vertex -> creator table (a cell creates at most 13): one LDS read per vertex instead of a search
-            const uint32_t p0 = s_pre[threadIdx.x];
-            for (uint32_t k = 0; k < my_nown; k++) s_creator[p0 + k] = (uint8_t)threadIdx.x;
-        }
-        __syncthreads();
+        s_pre[threadIdx.x] = threadIdx.x < cnt ? my_pre : total;
+        if (threadIdx.x == 255) s_pre[256] = total;
+        // vertex -> creator table (a cell creates at most 13): one LDS read per vertex instead of a search
+        for (uint32_t k = 0; k < my_nown; k++) s_creator[my_pre + k] = (uint8_t)threadIdx.x;
+        __syncthreads();   // (LDS is complete)
         const uint32_t chunk_vbase = (uint32_t)(chunk_prefix >> 31);
         // ---- per created vertex
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {
@@ -1165,7 +1168,6 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
     __shared__ uint32_t s_pre[257];
-    __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_lo[256];
     __shared__ uint8_t s_cell[256 * 12];   // record (slot in the chunk) of each triangle of the chunk (<= 12 triangles a cell)
     mc_load_lut_to_lds(s_lut);
@@ -1196,16 +1198,19 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
         uint32_t my_ni = 0;
         __syncthreads();
         const uint64_t chunk_pre = P.chunkpre[base / MC_CHUNK];   // left by k_vertices (loaded with the records: not a round trip of its own after the scan)
+        // (in-chunk prefix and chunk total of the triangles: left by k_resolve, as in k_vertices -- no workgroup scan)
+        const uint32_t total = 3u * (uint32_t)(P.chunktot[base / MC_CHUNK] & 0x7fffffffull);
+        uint32_t t0 = 0;
         if (threadIdx.x < MC_CHUNK && irec < n) {
             const uint32_t info = P.rec_info[irec];
             my_ni = 3u * ((info >> 14) & 15u);
+            t0 = P.rec_pre[irec] >> 16;
             s_lo[threadIdx.x] = info & 0x3fffu;
         }
-        const uint32_t total = block_exclusive_scan_256(my_ni, s_pre, s_wave);
-        {   // triangle -> cell table: one LDS read per index instead of a search over the prefix
-            const uint32_t t0 = s_pre[threadIdx.x] / 3u;   // (the prefix counts indices: multiples of 3)
-            for (uint32_t k = 0; 3u * k < my_ni; k++) s_cell[t0 + k] = (uint8_t)threadIdx.x;
-        }
+        s_pre[threadIdx.x] = (threadIdx.x < MC_CHUNK && irec < n) ? 3u * t0 : total;   // (the prefix counts indices)
+        if (threadIdx.x == 255) s_pre[256] = total;
+        // triangle -> cell table: one LDS read per index instead of a search over the prefix
+        for (uint32_t k = 0; 3u * k < my_ni; k++) s_cell[t0 + k] = (uint8_t)threadIdx.x;
         __syncthreads();
         const size_t chunk_ibase = (size_t)(chunk_pre & 0x7fffffffull) * 3;
         for (uint32_t j = threadIdx.x; j < total; j += 256u) {   // one lane per triangle index
