@@ -337,29 +337,34 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     // words, read cooperatively: cheaper than a separate scan launch)
     uint32_t total;
     const uint32_t pre = block_excl_scan_u32(cnt, before, &total);   // also reduces `before` over the workgroup
-    if (b == (int)gridDim.x - 1) {   // the last block publishes the totals and the layer marks
-        uint64_t ghost = 0, upto_emit_end = 0, all13 = 0;
+    if (b == 0) {
+        // The FIRST block publishes the totals and the layer marks: everything here follows from the count pass's blockcnt[], the
+        // first block starts first and its extra work hides behind the rest of the launch (the last block, which did this in
+        // rounds 1-3, starts last and was the launch's tail)
+        uint64_t ghost = 0, upto_emit_end = 0, all13 = 0, all = 0;
         const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.bpl, ge = (P.lay_emit_end - P.lay_count_begin) * P.bpl;
         for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
             const uint64_t w = P.blockcnt[i];
             const uint64_t c = w & 0xffffffffull;
+            all += c;
             if (i < gb) ghost += c;
             if (i < ge) upto_emit_end += c;
             all13 += w >> 32;
         }
-        __shared__ uint64_t s_sum[3][4];
-        ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13);
+        __shared__ uint64_t s_sum[4][4];
+        ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13); all = wave_sum_u64(all);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; }
+        if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; s_sum[3][wave] = all; }
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint64_t ng = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
             const uint64_t ue = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
-            P.counters->n_active = before + total;
+            const uint32_t nall = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
+            P.counters->n_active = nall;
             P.counters->n_ghost_cells = (uint32_t)ng;
             P.counters->n_emit_cells = (uint32_t)(ue - ng);
             P.counters->n_case13 = (uint32_t)(s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]);
-            P.rowstart[(size_t)(lay + 1) * P.ncy] = before + total;   // sentinel
+            P.rowstart[(size_t)((int)gridDim.x / P.bpl) * P.ncy] = nall;   // sentinel after the last layer's rows
         }
     }
     if (i0 < nseg) {
