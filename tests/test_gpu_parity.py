@@ -329,6 +329,18 @@ def test_sparse_rows_volume(gpu):
     assert len(om.vertices) > 2000
     m = MarchingCubes.CreateMesh(Voxels(v, c, [-1] * 3, [1] * 3))
     assert_mesh_equal(m, om)
+    # ... and with cell rows by the thousand: k_vertices stages 1152 rowstart entries per window (mc_kernels.hip), so only a
+    # chunk whose records are spread over more rows than that still cuts its windows and takes the global-memory path
+    shape = (19, 2000, 9)
+    v = np.full(shape, -1.0, np.float32) - rng.uniform(0, 1, shape).astype(np.float32)
+    c = rng.uniform(0, 1, shape + (3,)).astype(np.float32)
+    for x in range(2, shape[0] - 3, 4):
+        for y in range(2, shape[1] - 3, 150):
+            for z in range(1, shape[2] - 2, 2):
+                v[x:x + 2, y:y + 2, z] = rng.uniform(0.2, 2.0, (2, 2))
+    om = O.march(v, c, [-1] * 3, [1] * 3)
+    assert len(om.vertices) > 2000
+    assert_mesh_equal(MarchingCubes.CreateMesh(Voxels(v, c, [-1] * 3, [1] * 3)), om)
     # and a surface with exactly one active cell per cell row (a plane x = const)
     scene, sdf = S.plane_w((1.0, 0.0, 0.0), 0.013)
     mn, mx, n = [-1] * 3, [1] * 3, (33, 90, 47)
