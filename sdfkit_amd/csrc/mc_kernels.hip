@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
                 float fc[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
+#pragma unroll 1
                 for (int k = 0; k < 8; k++) {
                     const double wk = 1.0 / (MC_EPS + fabs(v[k]));
                     fx += (double)mc_corner_dx(k) * wk;
