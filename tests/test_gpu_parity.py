@@ -770,7 +770,7 @@ def test_special_values_in_host_volumes(gpu, seed):
     v.ravel()[idx] = specials[rng.integers(0, len(specials), len(idx))]
     c = rng.uniform(0, 1, dims + (3,)).astype(np.float32)
     mn, mx = [-1.0, -1.25, -1.5], [1.0, 1.25, 1.5]
-    for iso in (0.0, 0.125):
+    for iso in (0.0, 0.125, -0.0):   # (+0.0 takes k_vertices<ISO0>, which leaves `- iso` out; -0.0 must not: -0.0 - -0.0 = +0.0)
         om = O.march(v, c, mn, mx, iso=iso)
         m = MarchingCubes.CreateMesh(Voxels(v.copy(), c.copy(), mn, mx), iso)
         assert len(m.Vertices) == len(om.vertices) and np.array_equal(m.Triangles, om.triangles)
