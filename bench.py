@@ -947,12 +947,16 @@ def main():
                 ts = [one_call(kind) for _ in range(8)]
                 d2h[kind] = {"median_ms": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "all_ms": [round(t, 3) for t in ts]}
             d2h["pooled"]["pool"] = {"hits": pooled.hits, "misses": pooled.misses}
-            extra["one_step_incl_mesh_d2h_ms"] = d2h["pooled"]["median_ms"]
+            # (the key every round has carried = the DEFAULT API path: a caller of the reference-shaped API never recycles, so its four
+            # arrays are fresh managed memory; the pooled figure -- the opt-in Mesh.Recycle(), not in the reference -- has its own key)
+            extra["one_step_incl_mesh_d2h_ms"] = d2h["managed"]["median_ms"]
+            extra["one_step_incl_mesh_d2h_pooled_ms"] = d2h["pooled"]["median_ms"]
             extra["one_step_incl_mesh_d2h"] = {
                 "what": "sdfk_sample_march + sdfk_mesh_counts + sdfk_mesh_copy of V/C/N/T to the host + sdfk_mesh_bounds, one call at a time; "
                         "median of 7 calls after a warm-up call (the second copy into an address is still slow -- the runtime maps the pages "
-                        "for its first direct copy -- from the third on it is the steady state).  pooled (the headline figure: what a host that meshes a grid shape "
-                        "repeatedly gets BY DESIGN) = the four exact-length arrays rented from a pool of arrays that earlier meshes of the "
+                        "for its first direct copy -- from the third on it is the steady state).  one_step_incl_mesh_d2h_ms = managed (the default API "
+                        "path, comparable with rounds 1-3); one_step_incl_mesh_d2h_pooled_ms = pooled (what a host that meshes a grid shape "
+                        "repeatedly and calls the opt-in Mesh.Recycle() gets) = the four exact-length arrays rented from a pool of arrays that earlier meshes of the "
                         "same size handed back (Mesh.Recycle; shim: MeshArrayPool), a miss -- the warm-up call here -- allocating "
                         "untouched memory; incl. all four arrays, bounds and stats, and the colour array cleared by the library.  "
                         "managed (the worst case of a C# caller, Mesh.cs:10-13) "

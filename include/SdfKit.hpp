@@ -310,8 +310,11 @@ public:
         }
     }
     void WriteObj(const std::string& path) const { std::ofstream f(path); WriteObj(f); }
-    // invariant-culture System.Single.ToString(): shortest round-trip digits, scientific
-    // ("d.dddE+XX") when the decimal exponent is < -4 or >= 7
+    // invariant-culture System.Single.ToString() of .NET Core 3.0+ (the runtime global.json pins): shortest round-trip
+    // digits through format 'G'; scientific ("d.dddE+XX") when the decimal-point position (decimal exponent + 1) is
+    // greater than max(number of digits, 7) or below -3 -- Number.Formatting.cs: nMaxDigits = Math.Max(number.DigitsCount,
+    // SinglePrecision), then FormatGeneral's `digPos > nMaxDigits || digPos < -3`.  So 12345678f prints "12345678" (8 digits,
+    // position 8), 1e7f prints "1E+07" (1 digit, position 8 > 7), 1e-5f prints "1E-05".
     static std::string FormatSingle(float x)
     {
         if (std::isnan(x)) return "NaN";
@@ -327,7 +330,8 @@ public:
         std::string digits;
         for (char c : mant) if (c >= '0' && c <= '9') digits.push_back(c);
         std::string out;
-        if (e > -5 && e < 7) {
+        const int max_digits = (int)std::max<size_t>(digits.size(), 7);
+        if (e > -5 && e < max_digits) {
             if (e >= 0) {
                 std::string ip = digits.substr(0, std::min(digits.size(), (size_t)e + 1));
                 ip.append((size_t)e + 1 - ip.size(), '0');

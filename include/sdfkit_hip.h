@@ -25,7 +25,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SDFK_ABI_VERSION 4   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint */
+#define SDFK_ABI_VERSION 5   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint;
+                                5: SDFK_OPT_ELIDE_VOLUME defaults to 2 (the temporary volume of sdfk_sample_march is not stored) */
 
 typedef enum sdfk_status {
     SDFK_OK = 0,
@@ -149,15 +150,18 @@ typedef enum sdfk_option {
     SDFK_OPT_IDLE_PROGRAMS = 15,/* compiled kernel sets are shared by every program of one STRUCTURE (the constants of a program are kernel
                                    arguments, sdfk_program_create); this many structures stay loaded after their last program has been
                                    destroyed (default 32; 0: unloaded at once) -- the next frame of an animation asks for the same one */
-    SDFK_OPT_ELIDE_VOLUME = 16, /* 1: sdfk_sample_march (SdfEx.ToMesh, Sdf.cs:59-63: the Voxels is a temporary nobody sees) on grids above the
-                                   captured-graph limit does not STORE its volume: the sampler leaves the sign bits only, cell corners and
-                                   vertex colours are re-evaluated by the program -- 4 (16 with colours) bytes per voxel of HBM writes less,
-                                   meshes bit-identical.  A volume whose sign words contain case 13 is sampled again with stores (the
-                                   dead-cell test reads voxels).  2: in addition most voxels are not even EVALUATED: 64 x 4 x 4 blocks whose
-                                   values provably lie on one side of the iso value (the program evaluated in interval arithmetic over the
-                                   block: rigorous for the float operations themselves, no assumption about the SDF) get constant sign
-                                   words, only the blocks the surface passes through are evaluated voxel by voxel.  0 (default): the volume
-                                   is evaluated and stored, as the reference does and as the headline benchmark's step is defined */
+    SDFK_OPT_ELIDE_VOLUME = 16, /* The temporary volume of sdfk_sample_march (SdfEx.ToMesh, Sdf.cs:59-63: the Voxels is a local nobody sees),
+                                   on grids above the captured-graph limit.  2 (DEFAULT since ABI 5): it is neither stored nor, for the most
+                                   part, even evaluated -- 64 x 4 x 4 blocks whose values provably lie on one side of the iso value (the
+                                   program evaluated in interval arithmetic over the block: rigorous for the float operations themselves,
+                                   no assumption about the SDF) get constant sign words, only the blocks the surface passes through are
+                                   evaluated voxel by voxel; cell corners and vertex colours are re-evaluated by the program.  1: every
+                                   voxel is evaluated, nothing but the sign bits is stored (4, or 16 with colours, bytes per voxel of HBM
+                                   writes less than 0).  0: the volume is evaluated and stored, as the reference does and as the headline
+                                   benchmark's step is defined (bench.py sets 0 for its headline).  Meshes are bit-identical in all three.
+                                   Never elided: a volume the caller can see (sdfk_sample / sdfk_sample_march_slab / Voxels.SampleSdf:
+                                   those always store), step > 1, a NaN iso value, a program one of whose volumes had case-13 sign words
+                                   (the dead-cell test of the meshing reads voxels: that job is redone on a stored volume) */
     SDFK_OPT_COUNT_ = 17
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);

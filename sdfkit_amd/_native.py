@@ -119,6 +119,9 @@ SIGNATURES = {
 # sdfk_allgather_fn: int (*)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
+# enum sdfk_status
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_COMPILE, ERR_NOMEM, ERR_UNSUPPORTED = 0, 1, 2, 3, 4, 5, 6
+
 # enum sdfk_option
 OPT_LANES, OPT_TOKENS, OPT_GRAPHS, OPT_COPY_MODE, OPT_CORNER_EVAL, OPT_VCOLOR_EVAL = 1, 2, 3, 4, 5, 6
 OPT_DIST_EXCHANGE, OPT_DIST_LANES, OPT_HW_QUEUES, OPT_CODE_CACHE, OPT_PREFAULT_HUGE, OPT_DIST_INDEX16, OPT_STREAM_PLACEMENT, OPT_IDLE_LANE = 7, 8, 9, 10, 11, 12, 13, 14

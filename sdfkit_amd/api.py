@@ -664,8 +664,10 @@ class Mesh:
 
 
 def _fmt_single(x):
-    """Invariant-culture System.Single.ToString() (.NET Core 3.0+: shortest round-trip digits;
-    scientific when the decimal exponent is < -4 or >= 7, the Single default precision)."""
+    """Invariant-culture System.Single.ToString() of .NET Core 3.0+ (the runtime the reference's global.json pins): the
+    shortest round-trip digits through format 'G'; scientific (d.dddE+XX) when the decimal-point position (decimal exponent
+    + 1) exceeds max(number of digits, 7) or is below -3 -- Number.Formatting.cs: nMaxDigits = Math.Max(number.DigitsCount,
+    SinglePrecision), FormatGeneral: digPos > nMaxDigits || digPos < -3.  12345678f -> "12345678", 1e7f -> "1E+07"."""
     x = np.float32(x)
     if np.isnan(x):
         return "NaN"
@@ -678,7 +680,7 @@ def _fmt_single(x):
     e = int(exp)
     neg = mant.startswith("-")
     digits = mant.lstrip("-").replace(".", "")
-    if -5 < e < 7:
+    if -5 < e < max(len(digits), 7):
         if e >= 0:
             ip, fp = digits[:e + 1].ljust(e + 1, "0"), digits[e + 1:]
         else:

@@ -61,17 +61,37 @@ __device__ __forceinline__ float sdfk_sqrt(float x)
 // maximum propagate it (IEEE 754:2019 minimum / maximum), an interval whose divisor contains zero is made NaN, a square root of
 // an interval reaching below zero is NaN by itself, and the caller evaluates every voxel of a block whose result is NaN.
 struct sdfk_iv { float lo, hi; };
+// "Unknown" is a property of the WHOLE interval: an operation that can produce NaN for SOME operand pair inside the box poisons both
+// endpoints, never one (a half-poisoned [NaN, 2] would pass `hi < x` tests although the points whose value is NaN compare false).
+// That covers: NaN endpoints; sqrt of an interval reaching below zero; a divisor interval containing zero; inf - inf, inf + -inf and
+// 0 * inf, which need not show at the corners of the operand box ([-1, 1] * [inf, inf] has corner products -inf and +inf only).
+__device__ __forceinline__ sdfk_iv iv_nan() { sdfk_iv r; r.lo = __builtin_nanf(""); r.hi = r.lo; return r; }
+__device__ __forceinline__ sdfk_iv iv_whole(sdfk_iv r) { if (r.lo != r.lo || r.hi != r.hi) return iv_nan(); return r; }
+__device__ __forceinline__ bool iv_unknown(sdfk_iv a) { return a.lo != a.lo || a.hi != a.hi; }
+__device__ __forceinline__ bool iv_has_zero(sdfk_iv a) { return a.lo <= 0.0f && a.hi >= 0.0f; }
+__device__ __forceinline__ bool iv_has_inf(sdfk_iv a) { return __builtin_isinf(a.lo) || __builtin_isinf(a.hi); }
 __device__ __forceinline__ sdfk_iv iv_make(float a, float b) { sdfk_iv r; r.lo = sdfk_min_ieee(a, b); r.hi = sdfk_max_ieee(a, b); return r; }
 __device__ __forceinline__ sdfk_iv iv_const(float c) { sdfk_iv r; r.lo = c; r.hi = c; return r; }
-__device__ __forceinline__ sdfk_iv iv_add(sdfk_iv a, sdfk_iv b) { sdfk_iv r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; }
-__device__ __forceinline__ sdfk_iv iv_sub(sdfk_iv a, sdfk_iv b) { sdfk_iv r; r.lo = a.lo - b.hi; r.hi = a.hi - b.lo; return r; }
+__device__ __forceinline__ sdfk_iv iv_add(sdfk_iv a, sdfk_iv b)
+{
+    const float inf = __builtin_inff();
+    if ((a.hi == inf && b.lo == -inf) || (a.lo == -inf && b.hi == inf)) return iv_nan();   // inf + -inf somewhere in the box
+    sdfk_iv r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return iv_whole(r);
+}
+__device__ __forceinline__ sdfk_iv iv_sub(sdfk_iv a, sdfk_iv b)
+{
+    const float inf = __builtin_inff();
+    if ((a.hi == inf && b.hi == inf) || (a.lo == -inf && b.lo == -inf)) return iv_nan();   // inf - inf somewhere in the box
+    sdfk_iv r; r.lo = a.lo - b.hi; r.hi = a.hi - b.lo; return iv_whole(r);
+}
 __device__ __forceinline__ sdfk_iv iv_mul(sdfk_iv a, sdfk_iv b)
 {
+    if ((iv_has_inf(a) && iv_has_zero(b)) || (iv_has_inf(b) && iv_has_zero(a))) return iv_nan();   // 0 * inf somewhere in the box
     const float p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
     sdfk_iv r;
     r.lo = sdfk_min_ieee(sdfk_min_ieee(p0, p1), sdfk_min_ieee(p2, p3));
     r.hi = sdfk_max_ieee(sdfk_max_ieee(p0, p1), sdfk_max_ieee(p2, p3));
-    return r;
+    return iv_whole(r);
 }
 // a * a of ONE value (x * x in every Length): the product form would treat the two factors as independent and give [-|lo hi|, ..]
 // for an interval around zero -- a negative lower bound under the square root, i.e. "unknown" for every block that a coordinate
@@ -81,41 +101,45 @@ __device__ __forceinline__ sdfk_iv iv_sqr(sdfk_iv a)
     const float p0 = a.lo * a.lo, p1 = a.hi * a.hi;
     sdfk_iv r;
     r.hi = sdfk_max_ieee(p0, p1);
-    r.lo = (a.lo >= 0.0f || a.hi <= 0.0f) ? sdfk_min_ieee(p0, p1) : (r.hi == r.hi ? 0.0f : r.hi);
-    return r;
+    r.lo = (a.lo >= 0.0f || a.hi <= 0.0f) ? sdfk_min_ieee(p0, p1) : 0.0f;
+    return iv_whole(r);
 }
 __device__ __forceinline__ sdfk_iv iv_div(sdfk_iv a, sdfk_iv b)
 {
+    if (!(b.lo > 0.0f) && !(b.hi < 0.0f)) return iv_nan();   // the divisor may be zero (or is unknown)
+    if (iv_has_inf(a) && iv_has_inf(b)) return iv_nan();      // inf / inf somewhere in the box
     const float q0 = a.lo / b.lo, q1 = a.lo / b.hi, q2 = a.hi / b.lo, q3 = a.hi / b.hi;
     sdfk_iv r;
     r.lo = sdfk_min_ieee(sdfk_min_ieee(q0, q1), sdfk_min_ieee(q2, q3));
     r.hi = sdfk_max_ieee(sdfk_max_ieee(q0, q1), sdfk_max_ieee(q2, q3));
-    if (!(b.lo > 0.0f) && !(b.hi < 0.0f)) { r.lo = __builtin_nanf(""); r.hi = r.lo; }   // the divisor may be zero (or is unknown)
-    return r;
+    return iv_whole(r);
 }
-__device__ __forceinline__ sdfk_iv iv_neg(sdfk_iv a) { sdfk_iv r; r.lo = -a.hi; r.hi = -a.lo; return r; }
+__device__ __forceinline__ sdfk_iv iv_neg(sdfk_iv a) { sdfk_iv r; r.lo = -a.hi; r.hi = -a.lo; return iv_whole(r); }
 __device__ __forceinline__ sdfk_iv iv_abs(sdfk_iv a)
 {
     const float x = __builtin_fabsf(a.lo), y = __builtin_fabsf(a.hi);
     sdfk_iv r;
     r.hi = sdfk_max_ieee(x, y);
-    r.lo = (a.lo >= 0.0f || a.hi <= 0.0f) ? sdfk_min_ieee(x, y) : (r.hi == r.hi ? 0.0f : r.hi);   // zero inside: [0, max]
-    return r;
+    r.lo = (a.lo >= 0.0f || a.hi <= 0.0f) ? sdfk_min_ieee(x, y) : 0.0f;   // zero inside: [0, max]
+    return iv_whole(r);
 }
-__device__ __forceinline__ sdfk_iv iv_sqrt(sdfk_iv a) { sdfk_iv r; r.lo = sdfk_sqrt(a.lo); r.hi = sdfk_sqrt(a.hi); return r; }
-__device__ __forceinline__ sdfk_iv iv_floor(sdfk_iv a) { sdfk_iv r; r.lo = __builtin_floorf(a.lo); r.hi = __builtin_floorf(a.hi); return r; }
+// (an interval that reaches below zero holds points whose root is NaN: unknown as a whole, not [NaN, sqrt(hi)])
+__device__ __forceinline__ sdfk_iv iv_sqrt(sdfk_iv a) { sdfk_iv r; r.lo = sdfk_sqrt(a.lo); r.hi = sdfk_sqrt(a.hi); return iv_whole(r); }
+__device__ __forceinline__ sdfk_iv iv_floor(sdfk_iv a) { sdfk_iv r; r.lo = __builtin_floorf(a.lo); r.hi = __builtin_floorf(a.hi); return iv_whole(r); }
 // (a < b) ? a : b, Math.Min: both are min(a, b) when no NaN is involved, and minimum() makes the result unknown when one is
-__device__ __forceinline__ sdfk_iv iv_min(sdfk_iv a, sdfk_iv b) { sdfk_iv r; r.lo = sdfk_min_ieee(a.lo, b.lo); r.hi = sdfk_min_ieee(a.hi, b.hi); return r; }
-__device__ __forceinline__ sdfk_iv iv_max(sdfk_iv a, sdfk_iv b) { sdfk_iv r; r.lo = sdfk_max_ieee(a.lo, b.lo); r.hi = sdfk_max_ieee(a.hi, b.hi); return r; }
+__device__ __forceinline__ sdfk_iv iv_min(sdfk_iv a, sdfk_iv b) { sdfk_iv r; r.lo = sdfk_min_ieee(a.lo, b.lo); r.hi = sdfk_min_ieee(a.hi, b.hi); return iv_whole(r); }
+__device__ __forceinline__ sdfk_iv iv_max(sdfk_iv a, sdfk_iv b) { sdfk_iv r; r.lo = sdfk_max_ieee(a.lo, b.lo); r.hi = sdfk_max_ieee(a.hi, b.hi); return iv_whole(r); }
 // (a < b) ? c : d
 __device__ __forceinline__ sdfk_iv iv_sel_lt(sdfk_iv a, sdfk_iv b, sdfk_iv c, sdfk_iv d)
 {
-    if (a.hi < b.lo) return c;          // a < b for every operand pair
-    if (a.lo >= b.hi) return d;         // never
-    sdfk_iv r;                          // either (also when a or b is unknown: a comparison with NaN is false, which is d)
+    if (!iv_unknown(a) && !iv_unknown(b)) {   // (an unknown operand may be NaN at some points -- the comparison is false there, which is d -- and anything elsewhere)
+        if (a.hi < b.lo) return c;            // a < b for every operand pair
+        if (a.lo >= b.hi) return d;           // never
+    }
+    sdfk_iv r;                                // either
     r.lo = sdfk_min_ieee(c.lo, d.lo);
     r.hi = sdfk_max_ieee(c.hi, d.hi);
-    return r;
+    return iv_whole(r);
 }
 )SRC";
 
@@ -353,8 +377,9 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_cull_blocks(SampleArgs A,
             for (int sx = 0; sx < 8; sx++) {
                 const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0 + 8 * sx, A.dx), sdfk_coord(A.mx, x0 + 8 * sx + 7, A.dx));
                 const sdfk_iv W = sdf_interval(K, X, Y, Z);
-                if (W.lo > A.iso) word |= 0xffull << (8 * sx);                 // (false for NaN)
-                else if (!(W.hi <= A.iso && W.lo == W.lo)) { decided = 2; break; }
+                // (decided only by an interval that is known as a whole: both comparisons are false for NaN)
+                if (W.lo > A.iso && W.hi >= W.lo) word |= 0xffull << (8 * sx);
+                else if (!(W.hi <= A.iso && W.lo <= W.hi)) { decided = 2; break; }
             }
         }
     }

@@ -58,7 +58,7 @@ struct Config {
     int dist_index16 = 0;     // SDFK_OPT_DIST_INDEX16
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
     int idle_programs = 32;   // SDFK_OPT_IDLE_PROGRAMS
-    int elide_volume = 0;     // SDFK_OPT_ELIDE_VOLUME
+    int elide_volume = 2;     // SDFK_OPT_ELIDE_VOLUME (default: the temporary volume of sdfk_sample_march is not stored, blocks are culled)
     int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
     int place_streams = 1;    // SDFK_OPT_STREAM_PLACEMENT
     int idle_lane = 1;        // SDFK_OPT_IDLE_LANE
@@ -927,7 +927,7 @@ static void config_from_env()
     g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0) ? 1 : 0;
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
     g_cfg.idle_programs = ranged("SDFK_IDLE_PROGRAMS", 32, 0, 1024);
-    g_cfg.elide_volume = ranged("SDFK_ELIDE_VOLUME", 0, 0, 2);
+    g_cfg.elide_volume = ranged("SDFK_ELIDE_VOLUME", 2, 0, 2);
     g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0) ? 1 : 0;
     g_cfg.place_streams = geti("SDFK_STREAM_PLACEMENT", 1) ? 1 : 0;
     g_cfg.idle_lane = geti("SDFK_IDLE_LANE", 1) ? 1 : 0;
@@ -1529,9 +1529,13 @@ extern "C" int sdfk_volume_create(int32_t nx, int32_t ny, int32_t nz, const floa
 namespace {
 // The temporary volume of a self-contained sample -> mesh job.  With SDFK_OPT_ELIDE_VOLUME (and both re-evaluation paths on) it
 // has no Values / Colors storage at all: nobody can ask for them (the volume never leaves the library).
-int job_volume_create(const sdfk_program* p, int nx, int ny, int nz, const float mn[3], const float mx[3], sdfk_volume** out)
+int job_volume_create(const sdfk_program* p, int nx, int ny, int nz, const float mn[3], const float mx[3], float iso, sdfk_volume** out)
 {
-    const bool elide = g_cfg.elide_volume && g_cfg.corner_eval && g_cfg.vcolor_eval && !p->no_elide;
+    if (!out || !mn || !mx) return fail(SDFK_ERR_INVALID, "sdfk_sample_march: null argument");   // (as sdfk_volume_create_slab answers on the stored path)
+    // Not elided: a NaN iso value (it never compares equal, so the cached sign bits never match and the sign-bit pass of the
+    // meshing job would have to READ the voxels: the stored path returns its empty mesh) and the sampler-only measurement mode
+    // (sdfk_profile_enable(2) leaves no valid sign bits behind) -- the option must never change a status code.
+    const bool elide = g_cfg.elide_volume && g_cfg.corner_eval && g_cfg.vcolor_eval && !p->no_elide && iso == iso && !g.sampler_only;
     if (!elide) return sdfk_volume_create(nx, ny, nz, mn, mx, p->writes_color ? 1 : 0, out);
     *out = nullptr;
     if (nx < 1 || ny < 1 || nz < 1) return fail(SDFK_ERR_INVALID, "sdfk_sample_march: bad dimensions %dx%dx%d", nx, ny, nz);
@@ -3046,7 +3050,7 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
         if (*out) return SDFK_OK;
     }
     sdfk_volume* v = nullptr;
-    int r = step == 1 ? job_volume_create(p, nx, ny, nz, min, max, &v) : sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
+    int r = step == 1 ? job_volume_create(p, nx, ny, nz, min, max, iso_value, &v) : sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
     if (r) return r;
     r = require_init();
     {

@@ -162,6 +162,22 @@ namespace SdfKit
             return GC.AllocateUninitializedArray<T>((int)n);
         }
 
+        /// <summary>A recycled array of exactly n elements, or null -- without allocating on a miss (for callers that want a
+        /// ZEROED array then: `new T[n]`, not the uninitialised one Rent would hand out).</summary>
+        public static T[]? TryRent<T>(long n) where T : unmanaged
+        {
+            lock (gate) {
+                if (free.TryGetValue((typeof(T), (int)n), out var st) && st.Count > 0) {
+                    var a = (T[])st.Pop();
+                    bytes -= n * System.Runtime.CompilerServices.Unsafe.SizeOf<T>();
+                    Hits++;
+                    return a;
+                }
+                Misses++;
+            }
+            return null;
+        }
+
         public static void Return<T>(T[]? a) where T : unmanaged
         {
             if (a == null || a.Length == 0) return;
@@ -195,11 +211,12 @@ namespace SdfKit
             // no colour destination is passed, the library has nothing to clear or to fault in (0.7 of 2.4 ms at 512^3); a recycled
             // one holds an old mesh's colours: it is passed, and the library clears it (resident pages: a memset on its pool)
             Vector3[] c;
-            bool clear;
-            if (colors) { c = MeshArrayPool.Rent<Vector3>(nv, out _); clear = true; }
+            bool clear = true;
+            if (colors) c = MeshArrayPool.Rent<Vector3>(nv, out _);
             else {
-                c = MeshArrayPool.Rent<Vector3>(nv, out clear);
-                if (!clear) c = new Vector3[nv];     // (a miss gave an UNINITIALISED array: take a zeroed one instead)
+                var recycled = MeshArrayPool.TryRent<Vector3>(nv);   // (no allocation on a miss: a ZEROED array is wanted then)
+                clear = recycled != null;
+                c = recycled ?? new Vector3[nv];
             }
             fixed (Vector3* pv = v, pc = c, pn = n) fixed (int* pt = t)
                 Native.Check(Native.sdfk_mesh_copy(h, (float*)pv, clear ? (float*)pc : null, (float*)pn, pt));
@@ -210,10 +227,16 @@ namespace SdfKit
 
         /// <summary>Hands the four arrays to <see cref="MeshArrayPool"/>: the next mesh of the same size gets them instead of new,
         /// untouched memory.  Not in the reference (a Mesh is simply collected); opt-in for hosts that mesh repeatedly.  The mesh
-        /// and its arrays must not be used afterwards.</summary>
+        /// and its arrays must not be used afterwards.  A second call on the same mesh does nothing (the arrays go to the pool ONCE:
+        /// pushed twice, two later meshes would be handed the same memory); two Mesh objects built over the SAME arrays must not
+        /// both be recycled -- the pool cannot see that (the Python mirror empties the mesh instead: Vertices etc. are get-only here,
+        /// Mesh.cs:10-13).</summary>
         public void Recycle()
         {
+            if (recycled) return;
+            recycled = true;
             MeshArrayPool.Return(Vertices); MeshArrayPool.Return(Colors); MeshArrayPool.Return(Normals); MeshArrayPool.Return(Triangles);
         }
+        bool recycled;
     }
 }

@@ -1,9 +1,12 @@
-// dispatch_host.cpp -- test shim (g++ -shared -DMC_HOST_BUILD): the product's case dispatcher, csrc/mc_device.h's
-// mc_resolve / mc_test_face / mc_test_internal, compiled for the host from the very header the kernels include, with the
+// dispatch_host.cpp -- test shim (g++ -shared): the product's case dispatcher, csrc/mc_decide.h's mc_resolve / mc_test_face /
+// mc_test_internal, compiled for the host from the very header the kernels include (through csrc/mc_device.h), with the
 // lookup blob of csrc/mc_luts.h.  tests/test_dispatch_manifest.py compares every decision it takes with the manifest
 // extracted mechanically from MarchingCubes.cs:94-546 (tools/gen_dispatch.py).
-#define MC_HOST_BUILD 1
-#include "../../sdfkit_amd/csrc/mc_device.h"
+// The header takes its qualifiers from its includer -- <hip/hip_runtime.h> in the product; a host compiler gets them HERE:
+#define __device__
+#define __forceinline__ inline
+#define __constant__ static const
+#include "../../sdfkit_amd/csrc/mc_decide.h"
 
 extern "C" {
 

@@ -217,7 +217,18 @@ TEST(MeshWriteObjFormat)   // Mesh.cs:66-97 + invariant-culture Single.ToString(
     ARE_EQUAL(true, Mesh::FormatSingle(1e-5f) == "1E-05");
     ARE_EQUAL(true, Mesh::FormatSingle(0.0001f) == "0.0001");
     ARE_EQUAL(true, Mesh::FormatSingle(1234567.0f) == "1234567");
-    ARE_EQUAL(true, Mesh::FormatSingle(12345678.0f) == "1.2345678E+07");
+    // .NET Core 3.0+: scientific iff the decimal-point position > max(digits, 7) or < -3 (Number.Formatting.cs)
+    ARE_EQUAL(true, Mesh::FormatSingle(12345678.0f) == "12345678");          // 8 digits, position 8: fixed
+    ARE_EQUAL(true, Mesh::FormatSingle(16777216.0f) == "16777216");
+    ARE_EQUAL(true, Mesh::FormatSingle(1e7f) == "1E+07");                    // 1 digit, position 8 > 7
+    ARE_EQUAL(true, Mesh::FormatSingle(1.5e7f) == "1.5E+07");
+    ARE_EQUAL(true, Mesh::FormatSingle(123456792.0f) == "1.2345679E+08");    // 8 digits, position 9 > 8: scientific
+    ARE_EQUAL(true, Mesh::FormatSingle(100000008.0f) == "1.0000001E+08");
+    ARE_EQUAL(true, Mesh::FormatSingle(105242136.0f) == "105242136");        // 9 digits, position 9: fixed
+    ARE_EQUAL(true, Mesh::FormatSingle(1052421360.0f) == "1.0524214E+09");
+    ARE_EQUAL(true, Mesh::FormatSingle(-12345678.0f) == "-12345678");
+    ARE_EQUAL(true, Mesh::FormatSingle(0.00012345678f) == "0.00012345678");  // position -3: fixed
+    ARE_EQUAL(true, Mesh::FormatSingle(0.000012345678f) == "1.2345678E-05");
     ARE_EQUAL(true, Mesh::FormatSingle(0.33333334f) == "0.33333334");
     ARE_EQUAL(true, Mesh::FormatSingle(100.0f) == "100");
     auto mesh = Sdfs::Sphere(1.0f).ToMesh(Vector3(-1.5f, -1.5f, -1.5f), Vector3(1.5f, 1.5f, 1.5f), 5, 5, 5, 2048, -1, false);

@@ -145,3 +145,82 @@ def test_case_13_sign_words_fall_back_to_a_stored_volume(gpu):
                 assert "sdfk_cull_blocks" in ran and any(k.startswith("sdfk_sample_bits") for k in ran), ran
             else:
                 assert "sdfk_cull_blocks" not in ran and not any(k.startswith("sdfk_sample_signs") for k in ran), ran      # stored from the start now
+
+
+def test_elision_is_the_default_and_never_changes_a_status(gpu):
+    """ABI 5: SDFK_OPT_ELIDE_VOLUME defaults to 2 (unless the environment says otherwise).  And the option must never change what a
+    call RETURNS: null bounds are SDFK_ERR_INVALID either way, a NaN iso value gives the stored path's empty mesh, the
+    sampler-only measurement mode (sdfk_profile_enable(2)) still works."""
+    import os
+    L = N.lib()
+    if "SDFK_ELIDE_VOLUME" not in os.environ:
+        assert N.get_option(N.OPT_ELIDE_VOLUME) == 2
+    sdf = Sdfs.Sphere(1.0)
+    prog = sdf.program()
+    mn, mx, n = N.f3([-1.5] * 3), N.f3([1.5] * 3), 264
+    for mode in (0, 1, 2):
+        with N.option(N.OPT_ELIDE_VOLUME, mode):
+            m = C.c_void_p()
+            assert L.sdfk_sample_march(prog, None, mx, n, n, n, 0, C.c_float(0.0), 1, C.byref(m)) == N.ERR_INVALID and not m.value
+            assert L.sdfk_sample_march(prog, mn, None, n, n, n, 0, C.c_float(0.0), 1, C.byref(m)) == N.ERR_INVALID and not m.value
+            # NaN never compares: no voxel is "> iso", no cell is active (MarchingCubes.cs:74: index 0 everywhere)
+            for rep in range(2):
+                mesh = sdf.ToMesh([-1.5] * 3, [1.5] * 3, n, n, n, clipToBounds=False, isoValue=float("nan"))
+                assert len(mesh.Vertices) == 0 and len(mesh.Triangles) == 0
+            N.check(L.sdfk_profile_enable(2))
+            try:
+                N.check(L.sdfk_sample_march(prog, mn, mx, n, n, n, 0, C.c_float(0.0), 1, C.byref(m)))
+                a, b = C.c_int64(), C.c_int64()
+                N.check(L.sdfk_mesh_counts(m, C.byref(a), C.byref(b)))
+                L.sdfk_mesh_free(m)
+            finally:
+                N.check(L.sdfk_profile_enable(0))
+
+
+def test_block_culling_with_nan_producing_programs(gpu):
+    """Programs that give NaN at SOME voxels of a block -- the root of a negative number, inf - inf, 0 * inf, inf / inf -- whose
+    interval form has ordinary corner values: the interval must read "unknown" as a whole (a half-poisoned [NaN, x] used to pass
+    `hi < y` tests), so every such block is evaluated voxel by voxel and the sign words are the per-voxel sampler's (`NaN > iso`
+    is false: bit 0)."""
+    from oracle import ir_interp as I
+    from sdfkit_amd.expr import select_lt, trace
+    big = 3.0e38
+
+    def root_of_negative(p):        # sqrt(x) - 0.5: NaN for x < 0, an ordinary surface at x = 0.25
+        return Vec4.of((0, 0, 0), MathF.Sqrt(p.x) - 0.5 + 0.0 * p.y)
+
+    def select_on_half_nan(p):      # (sqrt(x) - 3 < -1) ? sphere : 1: the comparison is false where x < 0
+        s = MathF.Sqrt((p.x * p.x + p.y * p.y) + p.z * p.z) - 0.8
+        return Vec4.of((0, 0, 0), select_lt(MathF.Sqrt(p.x) - 3.0, -1.0, s, 1.0 + 0.0 * p.y))
+
+    def inf_minus_inf(p):           # (x * big) * 4 overflows to +-inf for |x| > 0.28: its difference with itself is NaN there, 0 inside
+        h = (p.x * big) * 4.0
+        return Vec4.of((0, 0, 0), (h - h) + (p.y - 0.1))
+
+    def zero_times_inf(p):          # y * inf: NaN on the plane y == 0 (no sample point lies there: rows are at (i + 0.5) d) and +-inf elsewhere
+        h = (MathF.Abs(p.x) + 1.0) * big * big
+        return Vec4.of((0, 0, 0), p.y * h)
+
+    def inf_over_inf(p):            # |x| * big * 4 is +inf for |x| > 0.28: h / h is NaN there, 1 inside
+        h = MathF.Abs(p.x) * big * 4.0
+        return Vec4.of((0, 0, 0), h / h + (p.z - 1.2))
+
+    mn, mx, dims = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], (264, 260, 256)
+    for field in (root_of_negative, select_on_half_nan, inf_minus_inf, zero_times_inf, inf_over_inf):
+        sdf = Sdf(field, False)
+        for iso in (0.0, 0.25):
+            for clip in (False, True):
+                with N.option(N.OPT_ELIDE_VOLUME, 0):
+                    ref = sdf.ToMesh(mn, mx, *dims, clipToBounds=clip, isoValue=iso)
+                with N.option(N.OPT_ELIDE_VOLUME, 1):
+                    one = sdf.ToMesh(mn, mx, *dims, clipToBounds=clip, isoValue=iso)
+                with N.option(N.OPT_ELIDE_VOLUME, 2):
+                    got = sdf.ToMesh(mn, mx, *dims, clipToBounds=clip, isoValue=iso)
+                assert _same_mesh(one, ref), (field.__name__, iso, clip, len(ref.Vertices), len(one.Vertices))
+                assert _same_mesh(got, ref), (field.__name__, iso, clip, len(ref.Vertices), len(got.Vertices))
+    # and the stored path of the first one is the IR interpreter's field under the oracle's sweep
+    ops, out = trace(root_of_negative, False)
+    ov, oc = I.sample(ops, out, False, mn, mx, *dims)
+    om = O.march(ov, oc, mn, mx)
+    with N.option(N.OPT_ELIDE_VOLUME, 2):
+        assert_mesh_equal(Sdf(root_of_negative, False).ToMesh(mn, mx, *dims, clipToBounds=False), om)

@@ -17,5 +17,5 @@ run dist_conservative SDFK_DIST_LANES=0 SDFK_DIST_EXCHANGE=0
 run dist_index16 SDFK_DIST_INDEX16=1 SDFK_DIST_EXCHANGE=2
 run gather_paths SDFK_NO_CORNER_EVAL=1 SDFK_NO_VCOLOR_EVAL=1
 run elide_volume SDFK_ELIDE_VOLUME=1
-run elide_cull SDFK_ELIDE_VOLUME=2
+run stored_volume SDFK_ELIDE_VOLUME=0
 run dist_direct SDFK_DIST_EXCHANGE=1

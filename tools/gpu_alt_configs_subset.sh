@@ -10,7 +10,7 @@ run() {
   echo "$tag ($*): rc $? -- $(tail -1 $O/$tag.log)"
 }
 run default SDFK_UNUSED=0
-run elide_cull SDFK_ELIDE_VOLUME=2
+run stored_volume SDFK_ELIDE_VOLUME=0
 run lanes0 SDFK_LANES=0
 run graphs_off SDFK_GRAPHS=0
 run dist_index16 SDFK_DIST_INDEX16=1 SDFK_DIST_EXCHANGE=2
