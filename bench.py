@@ -575,13 +575,20 @@ def main():
     for _ in range(n_clock):
         nv, ni = step()
     nv, ni = drain()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nv, ni = step()
-    nv, ni = drain()   # every queued step has completed and been checked before the clock stops
-    barrier()
-    dt = time.perf_counter() - t0
+    # The timed region, R times over: every block is EXACTLY K steps bracketed by barrier + torch.cuda.synchronize() on both sides (the
+    # contract's measurement), max over ranks; `value` is the MEDIAN block, min / max / all blocks are on the line (`blocks`).  One
+    # block is 3 ms at 512^3: a single sample says little (box to box 0.147-0.154 ms in round 4).  SDFK_BENCH_BLOCKS=1: one block.
+    n_blocks = max(1, int(os.environ.get("SDFK_BENCH_BLOCKS", "11")))
+    block_dts = []
+    for _ in range(n_blocks):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            nv, ni = step()
+        nv, ni = drain()   # every queued step has completed and been checked before the clock stops
+        barrier()
+        block_dts.append(max_over_ranks(time.perf_counter() - t0))
+    dt = sorted(block_dts)[len(block_dts) // 2]
     gc.enable()
     # The same K steps with COLD clocks: the GPU idles long enough to drop its clocks, then W warm-up steps and K timed ones
     # -- what the driver's command measures without the clock warm-up above (the headline `value` has it, and says so).
@@ -601,8 +608,7 @@ def main():
     if sharded:   # per-rank counts -> totals of the whole mesh (from the gathered headers of the last step)
         per_rank = [list(c) for c in worker.counts()]
         nv, ni = sum(p[0] for p in per_rank), sum(p[1] for p in per_rank)
-    dt = max_over_ranks(dt)
-    ms_step = dt / args.steps * 1e3
+    ms_step = dt / args.steps * 1e3   # (each block already is the max over ranks)
 
     # ---- the sharded step without its exchange: this rank's slab kernels alone, queued back to back
     # (what "kernel-only" means at N > 1); max over ranks
@@ -824,6 +830,47 @@ def main():
                       "voxel + the mesh; measured: profiles/pmc_traffic.json)"}
         del sdf3
 
+    # ---- BASELINE config C5 (stretch: RayMarcher.Render, RayMarcher.cs:45-211) in THIS run: 1920 x 1080, 256 depth iterations, the README
+    # scene, camera (-2, 2, 4) -> origin (Perf/Program.cs:54-58), images device-resident; never `value`.  ALU-bound (no HBM traffic to
+    # speak of): the roofline figure is the share of the vector-issue time, from the committed SQ counter pass (profiles/pmc_traffic.json)
+    c5 = None
+    if not sharded and not args.minimal and args.scene == "sphere" and n == 512 and os.environ.get("SDFK_BENCH_NO_C5") != "1":
+        from sdfkit_amd import Matrix4x4, RayMarcher
+        w5, h5, it5, k5 = 1920, 1080, 256, 10
+        sdf5 = scene_for("repeatxy")[0]
+        rm = RayMarcher(w5, h5, sdf5)
+        rm.DepthIterations = it5
+        rm.ViewTransform = Matrix4x4.CreateLookAt((-2, 2, 4), (0, 0, 0), (0, 1, 0))
+        pos5, vpi5 = rm.camera()
+        rgb5 = torch.empty((h5, w5, 3), dtype=torch.float32, device=dev)
+        a5 = (sdf5.program(), w5, h5, N.f3(pos5), (C.c_float * 16)(*[float(x) for x in vpi5.ravel()]), C.c_float(1.0), C.c_float(100.0), it5,
+              None, C.c_void_p(rgb5.data_ptr()))
+        for _ in range(3):          # (Perf/Program.cs:43-62: the first loop is discarded; here also the clocks)
+            N.check(L.sdfk_raymarch_device(*a5))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(k5):
+            N.check(L.sdfk_raymarch_device(*a5))
+        e1.record(stream)
+        torch.cuda.synchronize()
+        f5 = e0.elapsed_time(e1) * 1e-3 / k5
+        evals5 = w5 * h5 * (it5 + 6)
+        sq5 = load_pmc_traffic("sdfk_raymarch:SQ_ACTIVE_INST_VALU", "c5", 1080)     # quad-cycles of vector issue per launch, summed over the chip
+        iv5 = load_pmc_traffic("sdfk_raymarch:SQ_INSTS_VALU", "c5", 1080)           # wave-level vector instructions per launch
+        c5 = {"workload": "RayMarcher.Render 1920 x 1080, 256 depth iterations + 6 evaluations for the normal, README RepeatXY scene, camera (-2,2,4) -> origin",
+              "frames": k5, "ms_per_frame": round(f5 * 1e3, 4), "mrays_per_s": round(w5 * h5 / f5 / 1e6, 1), "gevals_per_s": round(evals5 / f5 / 1e9, 2),
+              # share of the frame's time in which the 1024 SIMDs issue vector instructions: SQ_ACTIVE_INST_VALU counts quad-cycles summed
+              # over the chip, 2.4 GHz peak clock (the clock the chip holds under load is lower: the fraction is a lower bound)
+              "valu_issue_frac": None if not sq5 else round(sq5 * 4 / 1024 / 2.4e9 / f5, 4),
+              "valu_insts_per_eval": None if not iv5 else round(iv5 * 64 / evals5, 1),
+              "checksum": float(torch.nan_to_num(rgb5.double()).sum().item()),
+              "what": "BASELINE config C5 in this run: K frames back to back, one HIP event pair on the launch stream; bound = vector ALU issue (the scene costs "
+                      "two IEEE divisions and a square root per evaluation); valu_issue_frac from the committed SQ counter pass of tools/bench_raymarch.py "
+                      "(profiles/pmc_traffic.json: sdfk_raymarch:SQ_ACTIVE_INST_VALU@c5@1080), not re-measured here; depth and colour images are "
+                      "bit-identical to the oracle's (tests/test_raymarch.py)"}
+        del rgb5, sdf5
+
     # context figures, outside the timed region, rank 0 only: what this box
     # reaches with a plain device fill / copy, and one step including the mesh copy to the host
     extra = {}
@@ -943,10 +990,34 @@ def main():
                 del host_values, host_colors
             d2h = {}
             colors_written = bool(sdf.writes_color)
+
+            def pipelined_handoff(k):
+                """Hand-off THROUGHPUT: the next job is queued before the previous mesh is copied out, so the copy of mesh i (DMA + the
+                host's share) overlaps the kernels of job i + 1 on the library's lanes -- what a host that meshes frame after frame
+                gets per mesh with the reference-shaped calls in this order, pooled arrays (Mesh.Recycle)."""
+                def submit():
+                    m = C.c_void_p()
+                    N.check(L.sdfk_sample_march(prog, N.f3(mn), N.f3(mx), n, n, n, 1 if clip else 0, C.c_float(0.0), 1, C.byref(m)))
+                    return m
+                prev = submit()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    nxt = submit()
+                    hm = Mesh._from_handle(prev, pool=pooled)
+                    hm.Recycle()
+                    prev = nxt
+                Mesh._from_handle(prev, pool=pooled).Recycle()
+                return (time.perf_counter() - t1) / (k + 1) * 1e3
             for kind in ("pooled", "pinned", "managed", "managed_recycled", "numpy"):
                 ts = [one_call(kind) for _ in range(8)]
                 d2h[kind] = {"median_ms": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "all_ms": [round(t, 3) for t in ts]}
             d2h["pooled"]["pool"] = {"hits": pooled.hits, "misses": pooled.misses}
+            pipelined_handoff(3)
+            extra["pipelined_handoff_ms_per_mesh"] = round(pipelined_handoff(10), 3)
+            extra["pipelined_handoff_is"] = ("sample -> mesh -> the four arrays on the host, per mesh, when the next job is queued BEFORE the previous mesh is copied "
+                                             "out (the copy overlaps the next job's kernels): 10 meshes, pooled exact-length arrays; "
+                                             f"{(36 * nv + 4 * ni if colors_written else 24 * nv + 4 * ni) / 1e6:.1f} MB over PCIe per mesh")
             # (the key every round has carried = the DEFAULT API path: a caller of the reference-shaped API never recycles, so its four
             # arrays are fresh managed memory; the pooled figure -- the opt-in Mesh.Recycle(), not in the reference -- has its own key)
             extra["one_step_incl_mesh_d2h_ms"] = d2h["managed"]["median_ms"]
@@ -1010,8 +1081,17 @@ def main():
                       else f"Mvoxels/s, {n}^3 {args.scene} SDF sample->mesh",
             "value": round(n ** 3 / step_s / 1e6, 1),
             "unit": "Mvoxels/s",
+            # (first among the extras: what the driver's command measures WITHOUT the clock warm-up `value` has -- the GPU idles, then
+            # W warm-up steps and K timed ones)
+            "value_cold_clocks": round(n ** 3 / (dt_cold / args.steps) / 1e6, 1),
+            "ms_per_step_cold_clocks": round(dt_cold / args.steps * 1e3, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
+            "blocks": {"n": len(block_dts), "ms_per_step_median": round(ms_step, 4),
+                       "ms_per_step_min": round(min(block_dts) / args.steps * 1e3, 4), "ms_per_step_max": round(max(block_dts) / args.steps * 1e3, 4),
+                       "ms_per_step_all": [round(b / args.steps * 1e3, 4) for b in block_dts],
+                       "what": f"{len(block_dts)} timed blocks of K = {args.steps} steps, each bracketed by barrier + synchronize on both sides (max over "
+                               "ranks); `value` / `ms_per_step` = the median block"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -1022,12 +1102,10 @@ def main():
                        "grid": [n, n, n], "vertices": nv, "triangles": ni // 3,
                        "parallelism": "1 GPU" if world == 1 else
                                       f"z-slab x{world}, slab meshes exchanged by the library over " + ("RCCL" if D.info()[2] == 1 else "its host transport (gloo; ranks share one GPU)")},
-            "value_is": ("throughput of the pipelined steady state with warm clocks: " +
+            "value_is": ("throughput of the pipelined steady state with warm clocks, median of the timed blocks (`blocks`): " +
                          ("five identical jobs in flight on the library's three internal streams" if not sharded else "three sharded steps in flight") +
                          ", buffers sized from the previous mesh of the shape; value_cold_clocks = the same K steps after the GPU idled (no clock "
                          "warm-up); latency_ms_single_stream / frac_single_call = one call at a time; first_call_ms = the first call"),
-            "value_cold_clocks": round(n ** 3 / (dt_cold / args.steps) / 1e6, 1),
-            "ms_per_step_cold_clocks": round(dt_cold / args.steps * 1e3, 4),
             "untimed_steps_before_timing": {"warmup": n_warm + n_est, "clock_warmup": n_clock,
                                             "why": "W + 4 steps fill the allocator's pools; then the same step runs for ~80 ms so that the GPU is at "
                                                    "its sustained clocks when the K timed steps start (after idling it needs 10-15 ms of load: "
@@ -1058,6 +1136,7 @@ def main():
             "kernels_us": kern,
             "roofline": roof,
             "c3_repeatxy": c3,
+            "c5_raymarch": c5,
             "elided_volume_ms_per_step": None if elided_ms is None else round(elided_ms, 4),
             "elided_volume_no_culling_ms_per_step": None if elided1_ms is None else round(elided1_ms, 4),
             "elided_volume_is": "SDFK_OPT_ELIDE_VOLUME (opt-in): the same K pipelined steps with a volume that is never stored -- the sampler "

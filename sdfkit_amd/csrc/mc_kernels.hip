@@ -57,6 +57,14 @@ namespace sdfk {
 constexpr int K4_WMAX = SDFK_K4_WMAX;   // k_vertices: record-window slots staged in LDS (both windows together)
 constexpr int K4_RMAX = SDFK_K4_RMAX;   // k_vertices: rowstart entries staged per window
 static_assert(K4_WMAX <= 768 && K4_WMAX >= 512, "k_vertices stages the windows in three rounds of 256 slots");
+// k_triangles stages the chunk's block of vertex ids (rec_vid, MC_VSTRIDE slots at most) in LDS: a smooth surface uses 3.5 slots per
+// record (840 per chunk), 1536 cover 6.4 per record; what a noisier chunk has beyond that is read from global memory (19.4 KB of
+// LDS in all: eight workgroups per CU)
+#ifndef SDFK_K5_VMAX
+#define SDFK_K5_VMAX 1536
+#endif
+constexpr int K5_VMAX = SDFK_K5_VMAX;
+static_assert(K5_VMAX % 256 == 0 && K5_VMAX >= 256, "k_triangles loads the block in rounds of 256 slots");
 
 // ---------------------------------------------------------------------------
 // K1: sign bits
@@ -269,124 +277,177 @@ __device__ __forceinline__ uint64_t segment_mask(uint64_t a, uint64_t an, uint64
 // 4 consecutive segments and keeps their words in registers (20 words, five 16/8-byte loads per
 // voxel row).  WRITE = false: count the active cells of the block; WRITE = true: write them at
 // (sum of the earlier blocks) + in-block prefix.
+// A WORKGROUP takes the same 1024 segments of K2_LPB consecutive layers -- K2_LPB logical blocks -- and keeps all K2_LPB + 1
+// sign planes it needs in registers: plane z + 1 of one layer is plane z of the next, so a plane is fetched (K2_LPB + 1) / K2_LPB
+// times per pass instead of twice (one workgroup per logical block, rounds 1-4: the second fetch came from another XCD's
+// workgroup and missed its L2 -- 34 MB through the fabric for a 16.8 MB array).  All loads of a lane are issued up front.
+#ifndef SDFK_COMPACT_LPB
+#define SDFK_COMPACT_LPB 4
+#endif
+constexpr int K2_LPB = SDFK_COMPACT_LPB;
+static_assert(K2_LPB >= 1 && K2_LPB <= 8, "sign planes per workgroup are held in registers");
+
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_compact(McParams P)
 {
-    const int b = blockIdx.x;
-    const int lay = b / P.bpl;
-    const int z = P.lay_count_begin + lay;
+    const int nlay = P.lay_list_end - P.lay_count_begin;
+    const int nlog = nlay * P.bpl;                           // logical blocks: [layer][part]
+    const int part = (int)blockIdx.x % P.bpl, lay0 = ((int)blockIdx.x / P.bpl) * K2_LPB;
+    const int nl = min(K2_LPB, nlay - lay0);                 // layers of this workgroup
+    const int b0 = lay0 * P.bpl + part;                      // logical block of its first layer; layer l: b0 + l * bpl
     const int nseg = P.ncy * P.nxw;
-    const int i0 = (b - lay * P.bpl) * 1024 + 4 * (int)threadIdx.x;
-    uint64_t m[4] = {0, 0, 0, 0};
-    uint32_t cnt = 0, n13 = 0;
-    int y = 0, xw = 0;
-    // the count pass recorded which wavefronts found nothing: those skip the sign words here
-    const bool look = !WRITE || P.wavecnt[b * 4 + (int)(threadIdx.x >> 6)] != 0;
-    // write pass: this lane's share of the counts of all earlier blocks, loaded HERE (four independent loads per trip, in
+    const int i0 = part * 1024 + 4 * (int)threadIdx.x;
+    const int wave = (int)(threadIdx.x >> 6);
+    // the count pass recorded which wavefronts found nothing in which layer: those skip the sign words here
+    bool look[K2_LPB];
+#pragma unroll
+    for (int l = 0; l < K2_LPB; l++) look[l] = l < nl && (!WRITE || P.wavecnt[(b0 + l * P.bpl) * 4 + wave] != 0);
+    // write pass: this lane's share of the counts of all blocks before b0, loaded HERE (four independent loads per trip, in
     // flight together with the sign words below) -- a plain "load; add" loop after the words cost up to eight dependent L2
-    // round trips for the last blocks of a 512^3 grid
-    uint32_t before = 0;
+    // round trips for the last blocks of a 512^3 grid --, and of the bpl blocks between two consecutive layers of this workgroup
+    uint32_t before[K2_LPB];
+#pragma unroll
+    for (int l = 0; l < K2_LPB; l++) before[l] = 0;
     if (WRITE) {
-        for (int i = threadIdx.x; i < b; i += 1024) {
+        for (int i = threadIdx.x; i < b0; i += 1024) {
             const uint32_t c0 = (uint32_t)P.blockcnt[i];
-            const uint32_t c1 = i + 256 < b ? (uint32_t)P.blockcnt[i + 256] : 0u;
-            const uint32_t c2 = i + 512 < b ? (uint32_t)P.blockcnt[i + 512] : 0u;
-            const uint32_t c3 = i + 768 < b ? (uint32_t)P.blockcnt[i + 768] : 0u;
-            before += (c0 + c1) + (c2 + c3);
+            const uint32_t c1 = i + 256 < b0 ? (uint32_t)P.blockcnt[i + 256] : 0u;
+            const uint32_t c2 = i + 512 < b0 ? (uint32_t)P.blockcnt[i + 512] : 0u;
+            const uint32_t c3 = i + 768 < b0 ? (uint32_t)P.blockcnt[i + 768] : 0u;
+            before[0] += (c0 + c1) + (c2 + c3);
+        }
+#pragma unroll
+        for (int l = 1; l < K2_LPB; l++)
+            if (l < nl)
+                for (int i = threadIdx.x; i < P.bpl; i += 256) before[l] += (uint32_t)P.blockcnt[b0 + (l - 1) * P.bpl + i];
+    }
+    int y0 = 0, xw0 = 0;
+    if (i0 < nseg) {
+        y0 = i0 / P.nxw;
+        xw0 = i0 - y0 * P.nxw;
+    }
+    // sign planes lay0 .. lay0 + nl of this lane's two voxel rows: plane p serves layers p - 1 and p
+    uint64_t w[K2_LPB + 1][2][5];
+    {
+        const size_t plane = (size_t)P.ny * P.nxw;
+        const uint64_t* f0 = P.bits + (size_t)(P.lay_count_begin + lay0) * plane + i0;
+#pragma unroll
+        for (int p = 0; p <= K2_LPB; p++) {
+            const bool need = i0 < nseg && ((p > 0 && look[p - 1]) || (p < K2_LPB && look[p]));
+            if (need) {
+                load_words5(f0 + (size_t)p * plane, w[p][0]);
+                load_words5(f0 + (size_t)p * plane + P.nxw, w[p][1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) w[p][0][k] = w[p][1][k] = 0;
+            }
         }
     }
-    if (i0 < nseg) {
-        y = i0 / P.nxw;
-        xw = i0 - y * P.nxw;
-    }
-    if (look && i0 < nseg) {
-        const size_t plane = (size_t)P.ny * P.nxw;
-        const uint64_t* f0 = P.bits + (size_t)z * plane + i0;
-        uint64_t wa[5], wb[5], wc[5], wd[5];
-        load_words5(f0, wa);
-        load_words5(f0 + P.nxw, wb);
-        load_words5(f0 + plane, wc);
-        load_words5(f0 + plane + P.nxw, wd);
-        int xk = xw;
+    uint32_t cnts[K2_LPB], n13s[K2_LPB];
+    uint32_t base_acc = 0;   // (write pass) records before the current layer's block
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int rem = (i0 + k < nseg) ? P.ncx - xk * 64 : 0;
-            uint64_t m13;
-            m[k] = segment_mask(wa[k], wa[k + 1], wb[k], wb[k + 1], wc[k], wc[k + 1], wd[k], wd[k + 1], rem, m13);
-            cnt += (uint32_t)__popcll(m[k]);
-            n13 += (uint32_t)__popcll(m13);
-            if (++xk == P.nxw) xk = 0;
+    for (int l = 0; l < K2_LPB; l++) {
+        cnts[l] = n13s[l] = 0;
+        if (l >= nl) continue;   // (uniform over the workgroup)
+        uint64_t m[4] = {0, 0, 0, 0};
+        uint32_t cnt = 0, n13 = 0;
+        if (look[l] && i0 < nseg) {
+            int xk = xw0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int rem = (i0 + k < nseg) ? P.ncx - xk * 64 : 0;
+                uint64_t m13;
+                m[k] = segment_mask(w[l][0][k], w[l][0][k + 1], w[l][1][k], w[l][1][k + 1], w[l + 1][0][k], w[l + 1][0][k + 1],
+                                    w[l + 1][1][k], w[l + 1][1][k + 1], rem, m13);
+                cnt += (uint32_t)__popcll(m[k]);
+                n13 += (uint32_t)__popcll(m13);
+                if (++xk == P.nxw) xk = 0;
+            }
+        }
+        if (!WRITE) { cnts[l] = cnt; n13s[l] = n13; continue; }
+        // exclusive prefix of this block = sum of the counts of all earlier blocks (a few thousand
+        // words, read cooperatively: cheaper than a separate scan launch)
+        uint32_t total, red = before[l];
+        const uint32_t pre = block_excl_scan_u32(cnt, red, &total);   // also reduces `red` over the workgroup
+        base_acc += red;
+        const int lay = lay0 + l, z = P.lay_count_begin + lay;
+        if (b0 == 0 && l == 0) {
+            // The FIRST block publishes the totals and the layer marks: everything here follows from the count pass's blockcnt[], the
+            // first block starts first and its extra work hides behind the rest of the launch (the last block, which did this in
+            // rounds 1-3, starts last and was the launch's tail)
+            uint64_t ghost = 0, upto_emit_end = 0, all13 = 0, all = 0;
+            const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.bpl, ge = (P.lay_emit_end - P.lay_count_begin) * P.bpl;
+            for (int i = threadIdx.x; i < nlog; i += 256) {
+                const uint64_t wv = P.blockcnt[i];
+                const uint64_t c = wv & 0xffffffffull;
+                all += c;
+                if (i < gb) ghost += c;
+                if (i < ge) upto_emit_end += c;
+                all13 += wv >> 32;
+            }
+            __shared__ uint64_t s_sum[4][4];
+            ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13); all = wave_sum_u64(all);
+            const int lane = threadIdx.x & 63;
+            if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; s_sum[3][wave] = all; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint64_t ng = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
+                const uint64_t ue = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
+                const uint32_t nall = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
+                P.counters->n_active = nall;
+                P.counters->n_ghost_cells = (uint32_t)ng;
+                P.counters->n_emit_cells = (uint32_t)(ue - ng);
+                P.counters->n_case13 = (uint32_t)(s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]);
+                P.rowstart[(size_t)nlay * P.ncy] = nall;   // sentinel after the last layer's rows
+            }
+        }
+        if (i0 < nseg) {
+            uint32_t pos = base_acc + pre;
+            uint32_t* rowstart = P.rowstart + (size_t)lay * P.ncy;
+            int y = y0, xw = xw0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i0 + k < nseg) {
+                    if (xw == 0) rowstart[y] = pos;   // first record of cell row (z, y)
+                    const uint32_t yz = (uint32_t)y << P.xbits;
+                    uint64_t mk = m[k];
+                    while (mk) {
+                        const int bit = __builtin_ctzll(mk);
+                        mk &= mk - 1;
+                        if (pos < P.cap_active) {
+                            P.rec_xy[pos] = (uint32_t)(xw * 64 + bit) | yz;
+                            P.rec_z[pos] = (uint32_t)z;
+                        }
+                        pos++;
+                    }
+                    if (++xw == P.nxw) { xw = 0; y++; }
+                }
+            }
         }
     }
     if (!WRITE) {
         // low 32 bits: active cells of the block; high 32 bits: its case-13 sign words (rare)
-        __shared__ uint32_t s_cnt[4], s_n13;
-        if (threadIdx.x == 0) s_n13 = 0;
-        const uint32_t wsum = wave_sum_u32(cnt);
+        __shared__ uint32_t s_cnt[K2_LPB][4], s_n13[K2_LPB];
+        if (threadIdx.x < K2_LPB) s_n13[threadIdx.x] = 0;
+        uint32_t wsum[K2_LPB];
+#pragma unroll
+        for (int l = 0; l < K2_LPB; l++) wsum[l] = wave_sum_u32(cnts[l]);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) {
-            s_cnt[threadIdx.x >> 6] = wsum;
-            P.wavecnt[b * 4 + (threadIdx.x >> 6)] = wsum;   // lets the write pass skip empty wavefronts
-        }
-        if (n13) atomicAdd(&s_n13, n13);
-        __syncthreads();
-        if (threadIdx.x == 0) P.blockcnt[b] = (uint64_t)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]) | ((uint64_t)s_n13 << 32);
-        return;
-    }
-    // exclusive prefix of this block = sum of the counts of all earlier blocks (a few thousand
-    // words, read cooperatively: cheaper than a separate scan launch)
-    uint32_t total;
-    const uint32_t pre = block_excl_scan_u32(cnt, before, &total);   // also reduces `before` over the workgroup
-    if (b == 0) {
-        // The FIRST block publishes the totals and the layer marks: everything here follows from the count pass's blockcnt[], the
-        // first block starts first and its extra work hides behind the rest of the launch (the last block, which did this in
-        // rounds 1-3, starts last and was the launch's tail)
-        uint64_t ghost = 0, upto_emit_end = 0, all13 = 0, all = 0;
-        const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.bpl, ge = (P.lay_emit_end - P.lay_count_begin) * P.bpl;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
-            const uint64_t w = P.blockcnt[i];
-            const uint64_t c = w & 0xffffffffull;
-            all += c;
-            if (i < gb) ghost += c;
-            if (i < ge) upto_emit_end += c;
-            all13 += w >> 32;
-        }
-        __shared__ uint64_t s_sum[4][4];
-        ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13); all = wave_sum_u64(all);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; s_sum[3][wave] = all; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint64_t ng = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
-            const uint64_t ue = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
-            const uint32_t nall = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
-            P.counters->n_active = nall;
-            P.counters->n_ghost_cells = (uint32_t)ng;
-            P.counters->n_emit_cells = (uint32_t)(ue - ng);
-            P.counters->n_case13 = (uint32_t)(s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]);
-            P.rowstart[(size_t)((int)gridDim.x / P.bpl) * P.ncy] = nall;   // sentinel after the last layer's rows
-        }
-    }
-    if (i0 < nseg) {
-        uint32_t pos = before + pre;
-        uint32_t* rowstart = P.rowstart + (size_t)lay * P.ncy;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < nseg) {
-                if (xw == 0) rowstart[y] = pos;   // first record of cell row (z, y)
-                const uint32_t yz = (uint32_t)y << P.xbits;
-                uint64_t mk = m[k];
-                while (mk) {
-                    const int bit = __builtin_ctzll(mk);
-                    mk &= mk - 1;
-                    if (pos < P.cap_active) {
-                        P.rec_xy[pos] = (uint32_t)(xw * 64 + bit) | yz;
-                        P.rec_z[pos] = (uint32_t)z;
-                    }
-                    pos++;
+            for (int l = 0; l < K2_LPB; l++)
+                if (l < nl) {
+                    s_cnt[l][wave] = wsum[l];
+                    P.wavecnt[(b0 + l * P.bpl) * 4 + wave] = wsum[l];   // lets the write pass skip empty wavefronts
                 }
-                if (++xw == P.nxw) { xw = 0; y++; }
-            }
+        }
+#pragma unroll
+        for (int l = 0; l < K2_LPB; l++)
+            if (n13s[l]) atomicAdd(&s_n13[l], n13s[l]);
+        __syncthreads();
+        if ((int)threadIdx.x < nl) {
+            const int l = (int)threadIdx.x;
+            P.blockcnt[b0 + l * P.bpl] = (uint64_t)(s_cnt[l][0] + s_cnt[l][1] + s_cnt[l][2] + s_cnt[l][3]) | ((uint64_t)s_n13[l] << 32);
         }
     }
 }
@@ -617,7 +678,7 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x, parity ^= 1) {
         const uint32_t i = (uint32_t)c * MC_CHUNK + threadIdx.x;
         const bool mine_rec = threadIdx.x < MC_CHUNK && i < n;   // (lanes MC_CHUNK..255 idle here: see MC_CHUNK)
-        uint32_t nown = 0, nt_emit = 0, info = 0, dead = 0;
+        uint32_t nown = 0, nt_emit = 0, nslots = 0, info = 0, dead = 0;
         uint64_t own = 0;
         int ry = 0, rz = 0;
         if (mine_rec) {
@@ -631,10 +692,10 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
             const bool counted = z < P.lay_emit_end;     // the layer above is context only
             const bool emit = counted && z >= P.lay_emit_begin;
             if (t.nt > 0) {
+                const uint64_t ord = s_ord[t.row];   // the row's vertex ids in the order of their first reference = creation order
+                const int nd = (int)(ord >> 60);     // ... and their number
                 if (counted) {
                     const unsigned pmask = positional_own_mask(x > 0, y > 0, P.z0 + z > 0) | (1u << 12);
-                    const uint64_t ord = s_ord[t.row];   // the row's vertex ids in the order of their first reference = creation order
-                    const int nd = (int)(ord >> 60);
                     for (int k = 0; k < nd; k++) {
                         const int e = (int)((ord >> (4 * k)) & 15ull);
                         bool mine = (pmask >> e) & 1u;
@@ -647,7 +708,8 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
                     }
                 }
                 nt_emit = emit ? (uint32_t)t.nt : 0u;
-                info = (uint32_t)t.lut_off | (nt_emit << 14) | (nown << 18) | ((uint32_t)t.row << 22);
+                nslots = emit ? (uint32_t)nd : 0u;   // one vertex-id slot per distinct id of the row (mc_device.h): only k_triangles reads them
+                info = (1u << 13) | (nt_emit << 14) | (nown << 18) | ((uint32_t)t.row << 22);   // (+ the slot prefix, below)
             } else if (emit && (t.index == 0xA5 || t.index == 0x5A)) {
                 dead = 1;
             }
@@ -661,9 +723,9 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
             if (i == first) s_rows[parity][0] = row;
             if (i == last) s_rows[parity][1] = row;
         }
-        // in-chunk prefix and chunk total of (created vertices, triangles), packed v << 31 | t
+        // in-chunk prefix and chunk total of (vertex-id slots, created vertices, triangles): 21 bits each (at most 13 * 256 per chunk)
         uint64_t total;
-        const uint64_t pre = block_excl_scan_u64(((uint64_t)nown << 31) | nt_emit, s_wave, &total);   // (syncs: s_rows is complete)
+        const uint64_t pre = block_excl_scan_u64(((uint64_t)nslots << 42) | ((uint64_t)nown << 21) | nt_emit, s_wave, &total);   // (syncs: s_rows is complete)
         // ... and the record ranges of its two neighbour windows (see k_vertices): three rowstart loads, one per lane, issued
         // HERE so that they are in flight during the stores and the second scan below (thread 0 loading them one after the
         // other at the very end left every workgroup waiting for two more L2 round trips)
@@ -676,16 +738,17 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
             wrow = min(P.rowstart[min(r, nrows)], n);
         }
         if (mine_rec) {
-            P.rec_info[i] = info;
+            P.rec_info[i] = info ? info | (uint32_t)(pre >> 42) : 0u;
             P.rec_own[i] = own;
-            P.rec_pre[i] = (uint32_t)(pre >> 31) | ((uint32_t)(pre & 0x7fffffffull) << 16);
+            P.rec_pre[i] = (uint32_t)((pre >> 21) & 0x1fffffull) | ((uint32_t)(pre & 0x1fffffull) << 16);
         }
         // "impossible case 13" cells of the chunk: only volumes that have such sign words at all need the count
         uint64_t ndead = 0;
         if (any13) (void)block_excl_scan_u64(dead, s_wave, &ndead);
         const uint32_t w1e = __shfl(wrow, 0), w2s = __shfl(wrow, 1), w2e = __shfl(wrow, 2);
         if (threadIdx.x == 0) {
-            P.chunktot[c] = total;
+            P.chunktot[c] = (((total >> 21) & 0x1fffffull) << 31) | (total & 0x1fffffull);   // v << 31 | t, as every consumer sums them
+            P.chunkslots[c] = (uint32_t)(total >> 42);
             P.chunkdead[c] = (uint32_t)ndead;
             P.chunkwin[c] = make_uint4(rf, rl, w1e, w2s);
             P.chunkwin2[c] = w2e;
@@ -927,7 +990,9 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
             const int xs = x * P.step, ys = y * P.step, zs = (z + P.z0) * P.step;
             const CornersLdsT<ISO0> v{s_wc + rr, K4_WMAX, iso};   // the creator cell
             if (e == 12) {
-                P.rec_vid[(size_t)12 * P.cap_active + (base + (uint32_t)rr)] = vi;   // (only the cell itself references its centre vertex)
+                // (only the cell itself references its centre vertex: the last of its slots -- 12 is the highest id)
+                if ((info >> 14) & 15u)
+                    P.rec_vid[(size_t)ci * MC_VSTRIDE + (info & 0xfffu) + mc_slot_of(s_occ[own_row], 12)] = vi;
                 if (!emit) continue;
                 // Cell.CalculateCenterVertex, Cell.cs:501-549
                 double fx = 0.0, fy = 0.0, fz = 0.0, ff = 0.0, gsum[3] = {0.0, 0.0, 0.0};
@@ -1046,16 +1111,15 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                     if (sls == -1) continue;
                     const int es = mc_share_edge(dir, s);
                     const uint32_t g = sls >= 0 ? ((uint32_t)sls < w1_cnt ? w1_start + (uint32_t)sls : w2_start + ((uint32_t)sls - w1_cnt)) : (uint32_t)(-2 - sls);
-                    P.rec_vid[(size_t)es * P.cap_active + g] = vi;   // K5 reads only its own record
+                    const uint32_t ti = sls >= 0 ? s_winfo[sls] : P.rec_info[g];   // (sls < 0: outside the staged windows, through global memory)
+                    const uint64_t tocc = ti ? s_occ[ti >> 22] : 0ull;
+                    // the sharer's slot for this vertex id (only cells that emit triangles have slots: K5 reads only its own chunk's block)
+                    if ((ti >> 14) & 15u) P.rec_vid[(size_t)(g / MC_CHUNK) * MC_VSTRIDE + (ti & 0xfffu) + mc_slot_of(tocc, es)] = vi;
                     if (!emit) continue;
-                    if (sls >= 0) {
-                        const uint32_t ti = s_winfo[sls];
-                        const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;
-                        if (occ) add_sharer_gradients(CornersLdsT<ISO0>{s_wc + sls, K4_WMAX, iso}, es, occ, dir, w_lo, w_hi, nrm);
-                    } else {   // outside the staged windows: through global memory
-                        const uint32_t ti = P.rec_info[g];
-                        const int occ = ti ? (int)((s_occ[ti >> 22] >> (4 * es)) & 15ull) : 0;
-                        if (occ) add_sharer_gradients(CornersGlobal{P.rec_corners + (size_t)g * 8, iso}, es, occ, dir, w_lo, w_hi, nrm);
+                    const int occ = (int)((tocc >> (4 * es)) & 15ull);
+                    if (occ) {
+                        if (sls >= 0) add_sharer_gradients(CornersLdsT<ISO0>{s_wc + sls, K4_WMAX, iso}, es, occ, dir, w_lo, w_hi, nrm);
+                        else add_sharer_gradients(CornersGlobal{P.rec_corners + (size_t)g * 8, iso}, es, occ, dir, w_lo, w_hi, nrm);
                     }
                 }
                 if (!emit) continue;
@@ -1171,11 +1235,13 @@ static_assert(sizeof(SlabHeader) == 64, "SDFK_SLAB_HEADER_BYTES");
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
 {
-    __shared__ __attribute__((aligned(16))) int8_t s_lut[MCLUT_PADDED];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lut[MCSLOT_BYTES];   // the SLOT form of the triangle rows, 4 bits an entry (mc_device.h)
+    __shared__ uint16_t s_rowoff[MCLUT_NROWS];
+    __shared__ uint32_t s_vid[K5_VMAX];    // the chunk's block of vertex ids (what lies beyond K5_VMAX slots is read from global memory)
     __shared__ uint32_t s_pre[257];
-    __shared__ uint32_t s_lo[256];
+    __shared__ uint16_t s_lo[256], s_sp[256];   // per record: start of its triangle row in the blob, first of its slots in the block
     __shared__ uint8_t s_cell[256 * 12];   // record (slot in the chunk) of each triangle of the chunk (<= 12 triangles a cell)
-    mc_load_lut_to_lds(s_lut);
+    mc_load_slotlut_to_lds(s_lut, s_rowoff);
     const uint32_t n = min(P.counters->n_active, P.cap_active);
     const uint32_t nghost = P.counters->nghost;
     if (blockIdx.x == 0) {   // K4 has completed (stream order): finish Mesh.Measure
@@ -1198,20 +1264,35 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             *reinterpret_cast<SlabHeader*>(M.slab_header) = h;
         }
     }
+    __syncthreads();   // (s_rowoff is read below)
     for (uint32_t base = blockIdx.x * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
         const uint32_t irec = base + threadIdx.x;
+        const uint32_t ci = base / MC_CHUNK;
         uint32_t my_ni = 0;
         __syncthreads();
-        const uint64_t chunk_pre = P.chunkpre[base / MC_CHUNK];   // left by k_vertices (loaded with the records: not a round trip of its own after the scan)
+        const uint64_t chunk_pre = P.chunkpre[ci];   // left by k_vertices (loaded with the records: not a round trip of its own after the scan)
         // (in-chunk prefix and chunk total of the triangles: left by k_resolve, as in k_vertices -- no workgroup scan)
-        const uint32_t total = 3u * (uint32_t)(P.chunktot[base / MC_CHUNK] & 0x7fffffffull);
-        uint32_t t0 = 0;
+        const uint32_t total = 3u * (uint32_t)(P.chunktot[ci] & 0x7fffffffull);
+        // the chunk's block of vertex ids, pushed by the creators in k_vertices: contiguous, loaded with coalesced loads (all of a
+        // lane's loads are issued before the first LDS store)
+        const uint32_t nvid = min(P.chunkslots[ci], (uint32_t)K5_VMAX);
+        const uint32_t* vblock = P.rec_vid + (size_t)ci * MC_VSTRIDE;
+        uint32_t vv[K5_VMAX / 256];
+#pragma unroll
+        for (int q = 0; q < K5_VMAX / 256; q++) {
+            const uint32_t k = threadIdx.x + 256u * q;
+            vv[q] = k < nvid ? vblock[k] : 0u;
+        }
+        uint32_t t0 = 0, info = 0;
         if (threadIdx.x < MC_CHUNK && irec < n) {
-            const uint32_t info = P.rec_info[irec];
+            info = P.rec_info[irec];
             my_ni = 3u * ((info >> 14) & 15u);
             t0 = P.rec_pre[irec] >> 16;
-            s_lo[threadIdx.x] = info & 0x3fffu;
         }
+#pragma unroll
+        for (int q = 0; q < K5_VMAX / 256; q++) s_vid[threadIdx.x + 256u * q] = vv[q];
+        s_lo[threadIdx.x] = s_rowoff[min(info >> 22, (uint32_t)MCLUT_NROWS - 1u)];
+        s_sp[threadIdx.x] = (uint16_t)(info & 0xfffu);
         s_pre[threadIdx.x] = (threadIdx.x < MC_CHUNK && irec < n) ? 3u * t0 : total;   // (the prefix counts indices)
         if (threadIdx.x == 255) s_pre[256] = total;
         // triangle -> cell table: one LDS read per index instead of a search over the prefix
@@ -1223,8 +1304,8 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
             if (o >= M.cap_indices) { P.host_counters->overflow = 1u; continue; }
             const int rr = (int)s_cell[j / 3u];
             const uint32_t k = j - s_pre[rr];
-            const int e = s_lut[s_lo[rr] + k];
-            const uint32_t vi = P.rec_vid[(size_t)e * P.cap_active + (base + (uint32_t)rr)];   // pushed by the creator (K4)
+            const uint32_t slot = (uint32_t)s_sp[rr] + mc_slot_entry(s_lut, (uint32_t)s_lo[rr] + k);   // the record's slot of this triangle corner's vertex id
+            const uint32_t vi = slot < (uint32_t)K5_VMAX ? s_vid[slot] : vblock[slot];             // pushed by the creator (K4)
             M.triangles[o] = (int32_t)((int64_t)vi - (int64_t)nghost + M.vertex_base);
         }
     }

@@ -15,6 +15,9 @@ namespace sdfk {
 #endif
 constexpr uint32_t MC_CHUNK = MC_CHUNK_RECORDS;
 static_assert(MC_CHUNK >= 64 && MC_CHUNK <= 256, "one 256-thread workgroup per chunk");
+// vertex-id slots per chunk (rec_vid): a record references at most 13 distinct vertex ids (12 edges + the centre vertex)
+constexpr uint32_t MC_VSTRIDE = MC_CHUNK * 13u;
+static_assert(MC_VSTRIDE <= 4096, "the in-chunk slot prefix has 12 bits in rec_info");
 
 struct McCounters {
     uint32_t n_active;     // active cells listed (may exceed the list capacity)
@@ -57,12 +60,14 @@ struct McParams {
     uint32_t xmask;        // (1 << xbits) - 1
     uint32_t* rec_z;       // z (local layer)
     uint32_t* rowstart;    // [(z - lay_count_begin) * ncy + y] = first record of cell row (z,y); +1 sentinel
-    uint32_t* rec_info;    // lut_off | nt_emitted << 14 | n_created << 18 | row_id << 22   (0 = emits nothing)
+    uint32_t* rec_info;    // in-chunk slot prefix (12 bits) | 1 << 13 | nt_emitted << 14 | n_created << 18 | row_id << 22   (0 = emits nothing)
     uint64_t* rec_own;     // created edge ids, 4 bits each, creation order
     uint32_t* rec_pre;     // in-chunk exclusive prefix: created vertices | triangles << 16
     float* rec_corners;    // 8 corner voxel values (v0..v7), 32 bytes per record
-    uint32_t* rec_vid;     // [edge 0..12][cap_active]: vertex id of the cell's edge e, pushed by the creator (edge-major:
-                           // consecutive vertices push into consecutive records of the same few edge planes)
+    uint32_t* rec_vid;     // [chunk][MC_VSTRIDE]: the vertex ids the chunk's emitting records reference, one slot per distinct id of a
+                           // record's tiling row in increasing id order, records back to back (rec_info: slot prefix); pushed by the
+                           // creators (k_vertices), loaded as one contiguous block per chunk by k_triangles (mc_device.h, "vertex-id SLOTS")
+    uint32_t* chunkslots;  // slots used per chunk
     uint32_t* chunkdead;   // "impossible case 13" cells per MC_CHUNK-record chunk
     uint4* chunkwin;       // per chunk: (first row, last row, end of window 1, start of window 2) (K4 set-up)
     uint32_t* chunkwin2;   // per chunk: end of window 2

@@ -197,6 +197,14 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
     __shared__ unsigned char nib[8][64];
+#ifdef SDFK_SAMPLE_VREG
+    // (occupancy cap of the sampling kernels: naming vector register N as clobbered makes the kernel's allocation N + 1 registers,
+    // i.e. at most 512 / (N + 1) wavefronts per SIMD -- 95: five, 127: four -- so that the marching-cubes kernels of the jobs on the
+    // other lanes find wavefront slots and registers next to a running sampler; see DESIGN.md "places")
+#define SDFK_S2_(x) #x
+#define SDFK_S1_(x) SDFK_S2_(x)
+    asm volatile("" ::: "v" SDFK_S1_(SDFK_SAMPLE_VREG));
+#endif
 #if SDFK_WRITES_COLOR
     __shared__ __attribute__((aligned(16))) float cbuf[STORE ? 8 / RPW : 1][STORE ? 768 : 1];   // colour staging, one slice per wavefront
 #endif

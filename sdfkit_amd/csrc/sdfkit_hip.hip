@@ -850,6 +850,8 @@ struct sdfk_mesh {
     int status = 0;                     // sticky error of a failed resolution
     std::string error;
     bool has_colors = true;             // false: the source volume had no colours (Colors are all zero)
+    bool colors_valid = true;           // false: has_colors is false AND the device array `colors` was never written (k_vertices skips the
+                                        // all-zero colour stores, 12 bytes per vertex): whoever hands device colours out zeroes them first
     bool external = false;              // V / C / N / T are sections of a caller-owned slab payload (not freed here)
     struct GraphJob* graph_job = nullptr;   // the job came from a captured launch graph: `pending` and (while `borrowed`) the buffers are its
     bool borrowed = false;
@@ -1917,7 +1919,8 @@ int alloc_records(sdfk_march_job* j, size_t c)
     rr = rr ? rr : job_alloc(j, &P.rec_own, c);
     rr = rr ? rr : job_alloc(j, &P.rec_pre, c);
     rr = rr ? rr : job_alloc(j, &P.rec_corners, c * 8);
-    rr = rr ? rr : job_alloc(j, &P.rec_vid, c * 13);
+    rr = rr ? rr : job_alloc(j, &P.rec_vid, (c / MC_CHUNK + 1) * (size_t)MC_VSTRIDE);
+    rr = rr ? rr : job_alloc(j, &P.chunkslots, c / MC_CHUNK + 2);
     rr = rr ? rr : job_alloc(j, &P.chunktot, c / MC_CHUNK + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkpre, c / MC_CHUNK + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkdead, c / MC_CHUNK + 2);
@@ -1949,9 +1952,10 @@ int launch_classify(sdfk_march_job* j, bool publish)
     }
     {
         ProfScope ps("k_compact");
-        const int nlog = (P.lay_list_end - P.lay_count_begin) * P.bpl;
-        hipLaunchKernelGGL(k_compact<false>, dim3(nlog), dim3(256), 0, g.stream, P);
-        hipLaunchKernelGGL(k_compact<true>, dim3(nlog), dim3(256), 0, g.stream, P);
+        // (a workgroup takes the same 1024 segments of K2_LPB consecutive layers: mc_kernels.hip)
+        const int nwg = ((P.lay_list_end - P.lay_count_begin + K2_LPB - 1) / K2_LPB) * P.bpl;
+        hipLaunchKernelGGL(k_compact<false>, dim3(nwg), dim3(256), 0, g.stream, P);
+        hipLaunchKernelGGL(k_compact<true>, dim3(nwg), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     const int nchunks = (int)((P.cap_active + MC_CHUNK - 1u) / MC_CHUNK);
@@ -2116,6 +2120,10 @@ int launch_emit(sdfk_march_job* j, sdfk_mesh* m, int64_t vertex_base)
     memset(&M, 0, sizeof M);
     M.vertices = m->vertices; M.colors = m->colors; M.normals = m->normals; M.triangles = m->triangles;
     m->has_colors = j->P.colors != nullptr || j->colors_elided;
+    if (!m->has_colors) {   // a .W-only program: every colour is (0,0,0) (Voxels.cs:88-92) -- nothing is stored, sdfk_mesh_copy clears the host array
+        M.colors = nullptr;
+        m->colors_valid = false;
+    }
     M.cap_vertices = (uint32_t)m->cap_v;
     M.cap_indices = m->cap_i;
     M.vertex_base = vertex_base;
@@ -2336,6 +2344,7 @@ int mesh_resolve(sdfk_mesh* m)
             m->n_active = x->n_active; m->n_case13 = x->n_case13;
             m->cap_v = x->cap_v; m->cap_i = x->cap_i;
             m->has_colors = x->has_colors;
+            m->colors_valid = x->colors_valid;
             delete x;
         }
     }
@@ -2644,7 +2653,7 @@ int graph_sample_march(const sdfk_program* p, const float mn[3], const float mx[
     sdfk_mesh* m = new sdfk_mesh();
     const sdfk_mesh* pr = q->proto;
     m->vertices = pr->vertices; m->colors = pr->colors; m->normals = pr->normals; m->triangles = pr->triangles; m->bounds = pr->bounds;
-    m->cap_v = pr->cap_v; m->cap_i = pr->cap_i; m->has_colors = pr->has_colors; m->lane = lane;
+    m->cap_v = pr->cap_v; m->cap_i = pr->cap_i; m->has_colors = pr->has_colors; m->colors_valid = pr->colors_valid; m->lane = lane;
     m->borrowed = true;
     m->graph_job = q;
     q->borrower = m;
@@ -3050,7 +3059,11 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
         if (*out) return SDFK_OK;
     }
     sdfk_volume* v = nullptr;
-    int r = step == 1 ? job_volume_create(p, nx, ny, nz, min, max, iso_value, &v) : sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
+    // (SDFK_OPT_ELIDE_VOLUME applies to grids above the captured-graph limit: a launch-bound grid gains nothing from one launch more
+    // and 4 bytes per voxel less, and its captured job -- built on the second sighting of a key -- stores its volume: one kernel
+    // set per program structure either way)
+    const bool elidable = step == 1 && !graphs_enabled((int64_t)nx * ny * nz);
+    int r = elidable ? job_volume_create(p, nx, ny, nz, min, max, iso_value, &v) : sdfk_volume_create(nx, ny, nz, min, max, p->writes_color ? 1 : 0, &v);
     if (r) return r;
     r = require_init();
     {
@@ -3139,9 +3152,12 @@ extern "C" int sdfk_host_alloc(int64_t n_bytes, void** out)
     *out = nullptr;
     if (int r = require_init()) return r;
     const size_t c = size_class((size_t)std::max<int64_t>(n_bytes, 1));
-    auto it = g.host_free.find(c);
+    // (the block of this size class that was freed LAST: equal keys keep their insertion order, so it is the one before the upper
+    // bound -- its pages are the likeliest to be in the host's caches and TLBs)
+    auto it = g.host_free.upper_bound(c);
     void* p = nullptr;
-    if (it != g.host_free.end()) {
+    if (it != g.host_free.begin() && std::prev(it)->first == c) {
+        --it;
         p = it->second;
         g.host_free.erase(it);
     } else if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) {
@@ -3307,7 +3323,10 @@ extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* 
     const_cast<sdfk_mesh*>(m)->used_on_main = true;
     const size_t vb = (size_t)m->nv * 3 * sizeof(float);
     if (vertices3 && vb) HIPCHK(hipMemcpyAsync(vertices3, m->vertices, vb, hipMemcpyDeviceToDevice, g.stream));
-    if (colors3 && vb) HIPCHK(hipMemcpyAsync(colors3, m->colors, vb, hipMemcpyDeviceToDevice, g.stream));
+    if (colors3 && vb) {
+        if (m->has_colors || m->colors_valid) HIPCHK(hipMemcpyAsync(colors3, m->colors, vb, hipMemcpyDeviceToDevice, g.stream));
+        else HIPCHK(hipMemsetAsync(colors3, 0, vb, g.stream));   // (all zero, never stored: colors_valid)
+    }
     if (normals3 && vb) HIPCHK(hipMemcpyAsync(normals3, m->normals, vb, hipMemcpyDeviceToDevice, g.stream));
     if (triangles && m->ni) HIPCHK(hipMemcpyAsync(triangles, m->triangles, (size_t)m->ni * sizeof(int32_t), hipMemcpyDeviceToDevice, g.stream));
     return SDFK_OK;
@@ -3320,6 +3339,11 @@ extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void*
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = mesh_resolve(const_cast<sdfk_mesh*>(m))) return r;   // (the buffers may be replaced by an exact re-run)
     const_cast<sdfk_mesh*>(m)->used_on_main = true;
+    if (colors3 && !m->has_colors && !m->colors_valid && m->colors && m->nv > 0) {   // the all-zero colours were never stored: now they are asked for
+        if (int r = require_init()) return r;
+        HIPCHK(hipMemsetAsync(m->colors, 0, (size_t)m->nv * 3 * sizeof(float), g.stream));
+        const_cast<sdfk_mesh*>(m)->colors_valid = true;
+    }
     if (vertices3) *vertices3 = m->vertices;
     if (colors3) *colors3 = m->colors;
     if (normals3) *normals3 = m->normals;
