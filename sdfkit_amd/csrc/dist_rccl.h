@@ -15,41 +15,12 @@
 // opt-ins: none of them has run between two GPUs yet (one GPU per development box).
 #pragma once
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include "slab_protocol.h"
 
 namespace {
 
-struct RcclApi {
-    void* handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
-
-struct DistContext {
-    int backend = 0;   // 0: none, 1: RCCL, 2: host transport
-    int world = 1, rank = 0;
-    RcclApi nccl;
-    ncclComm_t comm = nullptr;
-    hipStream_t stream = nullptr;        // the exchange stream
-    bool stream_owned = false;           // (created here, not one of the placed streams of sdfkit_hip.hip)
-    sdfk_allgather_fn host_fn = nullptr;
-    void* host_ctx = nullptr;
-    int64_t* agree_dev = nullptr;        // [1 + world]
-    int64_t* agree_host = nullptr;       // pinned, [1 + world]
-    char* stage = nullptr;               // host transport: pinned staging, (1 + world) x stage_stride
-    int64_t stage_stride = 0;
-    int sessions = 0;
-};
-DistContext gd;
+// (struct RcclApi, struct DistContext and the per-context `gd`: sdfkit_hip.hip, "device contexts")
 
 int rccl_load()
 {

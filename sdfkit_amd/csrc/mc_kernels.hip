@@ -279,10 +279,14 @@ __device__ __forceinline__ uint64_t segment_mask(uint64_t a, uint64_t an, uint64
 // (sum of the earlier blocks) + in-block prefix.
 // A WORKGROUP takes the same 1024 segments of K2_LPB consecutive layers -- K2_LPB logical blocks -- and keeps all K2_LPB + 1
 // sign planes it needs in registers: plane z + 1 of one layer is plane z of the next, so a plane is fetched (K2_LPB + 1) / K2_LPB
-// times per pass instead of twice (one workgroup per logical block, rounds 1-4: the second fetch came from another XCD's
-// workgroup and missed its L2 -- 34 MB through the fabric for a 16.8 MB array).  All loads of a lane are issued up front.
+// times per pass instead of twice (with one workgroup per logical block the second fetch comes from another XCD's workgroup
+// and misses its L2: 34 MB through the fabric for a 16.8 MB array).  All loads of a lane are issued up front.
+// K2_LPB = 1 is the product: measured at 512^3 (round 5, profiles/r05_ab_compact_layers.txt), both passes together take 25.9 us
+// with 1, 30.1 with 2 and 41.3 with 4 layers per workgroup -- a quarter of the workgroups, each lane four layers in a row with a
+// workgroup scan per layer -- and the pipelined step does not move (0.1399 / 0.1391 / 0.1449 ms): the fabric serves the second
+// fetch at no visible cost, the longer workgroups cost what they cost.
 #ifndef SDFK_COMPACT_LPB
-#define SDFK_COMPACT_LPB 4
+#define SDFK_COMPACT_LPB 1
 #endif
 constexpr int K2_LPB = SDFK_COMPACT_LPB;
 static_assert(K2_LPB >= 1 && K2_LPB <= 8, "sign planes per workgroup are held in registers");

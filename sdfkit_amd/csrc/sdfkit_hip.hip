@@ -28,6 +28,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <rccl/rccl.h>   // (types only: the library is loaded with dlopen when a process shards, dist_rccl.h)
+
 #include "../../include/sdfkit_hip.h"
 #include "mc_kernels.hip"
 #include "sample_codegen.h"
@@ -94,6 +96,7 @@ static int fail(int code, const char* fmt, ...)
 // ---------------------------------------------------------------------------
 struct sdfk_mesh;
 struct sdfk_volume;
+struct ProgCode;
 
 namespace {
 
@@ -176,8 +179,67 @@ struct Context {
     std::map<uint64_t, uint32_t> graph_sightings;   // full job key (+ lane) -> times asked for without a captured job
 };
 
-Context g;
-std::recursive_mutex g_mu;
+// ---- the sharding state of a device context (dist_rccl.h) ----------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+struct DistContext {
+    int backend = 0;   // 0: none, 1: RCCL, 2: host transport
+    int world = 1, rank = 0;
+    RcclApi nccl;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;        // the exchange stream
+    bool stream_owned = false;           // (created here, not one of the placed streams of sdfkit_hip.hip)
+    sdfk_allgather_fn host_fn = nullptr;
+    void* host_ctx = nullptr;
+    int64_t* agree_dev = nullptr;        // [1 + world]
+    int64_t* agree_host = nullptr;       // pinned, [1 + world]
+    char* stage = nullptr;               // host transport: pinned staging, (1 + world) x stage_stride
+    int64_t stage_stride = 0;
+    int sessions = 0;
+};
+
+// ---- device contexts --------------------------------------------------------------------------------------------------------
+// Everything the library keeps per GPU -- streams, lanes, pools, result slots, captured jobs, loaded kernel modules, the sharding
+// state -- lives in a DeviceState, and every THREAD has a current one, exactly like the HIP runtime's current device: sdfk_init(d)
+// creates the context of device d (once) and makes it the calling thread's; a thread that never called sdfk_init uses the context
+// of the first device the process initialised (a host whose calls arrive on thread-pool threads keeps working as in rounds 1-4).
+// Handles (programs, volumes, meshes, sessions) belong to the context they were made in and are used by threads whose current
+// context that is.  One process can therefore drive several GPUs, one host thread per device (sdfk_node_*, dist_rccl.h; the
+// reference is a library one .NET process calls: Sdf.cs:59-63); each context has its own lock, so the threads do not serialise.
+struct DeviceState {
+    Context ctx;
+    std::recursive_mutex mu;
+    DistContext dist;
+    std::unordered_map<std::string, ProgCode*> codes;   // kernel sets of the program structures loaded on this device (modules are per device)
+    uint64_t code_clock = 0;
+    int graph_build_failures = 0;
+    int claimed_device = -1;   // the device sdfk_init is making / has made this context for (-1: free); under g_registry_mu
+    bool listed = true;        // found by sdfk_init(device) (false: the private context of a local node's virtual rank)
+};
+DeviceState g_state0;                                   // the first device's context (storage; `inited` says whether it is in use)
+DeviceState* g_default_state = &g_state0;               // current context of threads that never chose one
+std::mutex g_registry_mu;                               // guards g_states / g_default_state / process-wide settings
+std::vector<DeviceState*> g_states{&g_state0};          // the contexts sdfk_init made, by device (a local node's private ones are not listed)
+thread_local DeviceState* t_state = nullptr;
+inline DeviceState& cur_state() { return *(t_state ? t_state : g_default_state); }
+// (the names the rest of this file has always used for "the" context, its lock and its sharding state)
+#define g (cur_state().ctx)
+#define g_mu (cur_state().mu)
+#define gd (cur_state().dist)
+#define g_codes (cur_state().codes)
+#define g_code_clock (cur_state().code_clock)
+#define g_graph_build_failures (cur_state().graph_build_failures)
 
 size_t size_class(size_t n)
 {
@@ -583,6 +645,7 @@ public:
     }
 };
 HostPool g_pool;
+std::recursive_mutex g_pool_mu;   // one client at a time (the pool is shared by the device contexts of the process)
 
 // Makes the pages of [p, p + n) present and writable before the copy lands in them: slices are
 // 2 MiB-aligned so that two threads never fault into the same page-table page (or the same
@@ -645,12 +708,15 @@ int64_t g_copy_stats[5] = {0, 0, 0, 0, 0};   // last staged copy: bytes, ns unti
 // pageable memory is never handed to the HIP runtime: its pin-on-the-fly path measured anywhere
 // between 0.8 and 26 ms for the same 33 MB, depending on page size and history (tools/host_io_probe.py).
 // mode 0: pre-fault on the pool, then the runtime's own copy; mode 2: the runtime's copy alone.
-int copy_to_host(const std::vector<CopyPiece>& pieces)
+// `beside`: host work that does not touch the destinations (clearing the colour array of a mesh without colours): done while the
+// DMA transfers are in flight where the copy is the runtime's own (resident / pinned destinations), before the copy otherwise
+int copy_to_host(const std::vector<CopyPiece>& pieces, const std::function<void()>& beside = nullptr)
 {
+    std::lock_guard<std::recursive_mutex> pool_lk(g_pool_mu);
     int mode = g_cfg.copy_mode;   // SDFK_OPT_COPY_MODE
     size_t total = 0;
     for (auto& p : pieces) total += p.bytes;
-    if (total == 0) return SDFK_OK;
+    if (total == 0) { if (beside) beside(); return SDFK_OK; }
     bool pinned = true;   // every destination inside a block of the library's pinned arena: plain DMA, nothing to pre-fault
     for (auto& p : pieces) {
         if (!p.bytes) continue;
@@ -679,11 +745,15 @@ int copy_to_host(const std::vector<CopyPiece>& pieces)
     g_copy_stats[0] = (int64_t)total;
     g_copy_stats[1] = g_copy_stats[2] = g_copy_stats[3] = g_copy_stats[4] = resident ? -1 : 0;
     if (total < (size_t(1) << 20) || mode == 2 || pinned || resident) {   // small: nothing to gain from helpers
+        hipError_t e = hipSuccess;
         for (auto& p : pieces)
-            if (p.bytes) HIPCHK(hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
+            if (p.bytes && e == hipSuccess) e = hipMemcpyAsync(p.dst, p.src, p.bytes, hipMemcpyDeviceToHost, g.stream);
+        if (beside) beside();   // (while the transfers run)
+        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        if (e != hipSuccess) return fail(SDFK_ERR_HIP, "device-to-host copy: %s", hipGetErrorString(e));
         return SDFK_OK;
     }
+    if (beside) beside();
     if (mode == 1 && stage_reserve() != SDFK_OK) mode = 0;   // no pinned memory to be had: the runtime's copy still works
     if (mode == 1) {
         const auto tp0 = std::chrono::steady_clock::now();
@@ -909,9 +979,14 @@ extern "C" int sdfk_abi_version(void) { return SDFK_ABI_VERSION; }
 extern "C" const char* sdfk_last_error(void) { return t_err.c_str(); }
 
 // The ONE place the environment is read (see Config): start-up defaults of the options, the cache location, debugging aids.
+static void config_from_env_once();
 static void config_from_env()
 {
-    if (g_cfg.loaded) return;
+    static std::once_flag once;
+    std::call_once(once, config_from_env_once);
+}
+static void config_from_env_once()
+{
     g_cfg.loaded = true;
     auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
     auto gets = [](const char* name) { const char* e = getenv(name); return std::string(e ? e : ""); };
@@ -943,14 +1018,12 @@ static void config_from_env()
     g_cfg.rccl_lib = gets("SDFK_RCCL_LIB");
 }
 
-extern "C" int sdfk_init(int device)
+namespace {
+// initialises the calling thread's current context (t_state is set) on `device`
+int context_init(int device)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (g.inited) {
-        if (device != g.device) return fail(SDFK_ERR_INVALID, "already initialised on device %d", g.device);
-        return SDFK_OK;
-    }
-    config_from_env();
+    if (g.inited) return SDFK_OK;
     // The library's lanes, the caller's stream and the exchange stream must not share hardware queues: the HIP runtime maps
     // all streams of a process onto GPU_MAX_HW_QUEUES (default 4) in-order queues, and a stream that waits for an event (a
     // lane section's end, a collective) then holds up every OTHER stream behind it in the same queue.  Nor may two of them
@@ -983,6 +1056,58 @@ extern "C" int sdfk_init(int device)
     t_bound_device = device;
     g.inited = true;
     return SDFK_OK;
+}
+
+// a context for `device` becomes the calling thread's current one: the one sdfk_init made for that device before, a free one, or a new one
+DeviceState* context_claim(int device, bool listed)
+{
+    std::lock_guard<std::mutex> rl(g_registry_mu);
+    DeviceState* st = nullptr;
+    if (listed)
+        for (DeviceState* q : g_states)
+            if (q->listed && q->claimed_device == device) st = q;
+    if (!st)
+        for (DeviceState* q : g_states)
+            if (q->claimed_device < 0) { st = q; break; }
+    if (!st) {
+        st = new DeviceState();
+        g_states.push_back(st);
+    }
+    st->claimed_device = device;
+    st->listed = listed;
+    if (listed && g_default_state->claimed_device < 0) g_default_state = st;   // (the first context in use serves the threads that never chose)
+    return st;
+}
+
+void context_unclaim(DeviceState* st)
+{
+    std::lock_guard<std::mutex> rl(g_registry_mu);
+    st->claimed_device = -1;
+    st->listed = true;
+    if (g_default_state == st)
+        for (DeviceState* q : g_states)
+            if (q->listed && q->claimed_device >= 0) { g_default_state = q; break; }
+}
+}  // namespace
+
+// sdfk_init(device): the context of `device` -- created and initialised on first use -- becomes the CALLING THREAD's current
+// context (like hipSetDevice).  A process that only ever names one device behaves as in ABI 1-4; naming a second device no
+// longer fails: one process may drive several GPUs, one host thread each (or one thread that switches with sdfk_init).
+extern "C" int sdfk_init(int device)
+{
+    config_from_env();
+    if (device < 0) return fail(SDFK_ERR_INVALID, "device %d out of range", device);
+    DeviceState* prev = t_state;
+    DeviceState* st = context_claim(device, true);
+    t_state = st;
+    const int r = context_init(device);
+    if (r) {   // nothing half-made stays behind; the thread keeps the context it had
+        bool inited;
+        { std::lock_guard<std::recursive_mutex> lk(st->mu); inited = st->ctx.inited; }
+        if (!inited) context_unclaim(st);
+        t_state = prev;
+    }
+    return r;
 }
 
 extern "C" void sdfk_shutdown(void)
@@ -1045,6 +1170,8 @@ extern "C" void sdfk_shutdown(void)
     g.own_stream = nullptr;
     g.stream = g.user_stream = nullptr;
     g.inited = false;
+    g.device = -1;
+    context_unclaim(&cur_state());   // (the context object stays, free for the next sdfk_init)
 }
 
 extern "C" int sdfk_set_stream(void* hip_stream)
@@ -1185,7 +1312,7 @@ extern "C" int sdfk_set_cache_dir(const char* path)
 // hit compares the whole key text, so a hash collision cannot return foreign code.  Files appear
 // atomically (write to a temporary, rename).  SDFK_NO_CACHE=1 switches it off.
 namespace {
-struct JitStats { int64_t compiled = 0, cache_hits = 0; double compile_ms = 0.0; } g_jit;
+struct JitStats { std::atomic<int64_t> compiled{0}, cache_hits{0}; std::atomic<int64_t> compile_us{0}; } g_jit;   // (process-wide: hiprtc may run for two devices at once)
 
 uint64_t fnv1a64(const std::string& s, uint64_t h)
 {
@@ -1314,7 +1441,7 @@ static int compile_source(const std::string& src, unsigned mask, std::vector<cha
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
     g_jit.compiled++;
-    g_jit.compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g_jit.compile_us += (int64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if (!path.empty()) cache_store(path, key, code);
     return SDFK_OK;
 }
@@ -1324,14 +1451,12 @@ extern "C" int sdfk_jit_stats(int64_t* n_compiled, int64_t* n_cache_hits, double
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (n_compiled) *n_compiled = g_jit.compiled;
     if (n_cache_hits) *n_cache_hits = g_jit.cache_hits;
-    if (compile_ms_total) *compile_ms_total = g_jit.compile_ms;
+    if (compile_ms_total) *compile_ms_total = (double)g_jit.compile_us.load() * 1e-3;
     return SDFK_OK;
 }
 
 namespace {
 // structures with loaded modules, keyed by the generated source (the whole text is the key: no collisions)
-std::unordered_map<std::string, ProgCode*> g_codes;
-uint64_t g_code_clock = 0;
 
 void code_unload(ProgCode* c)
 {
@@ -1648,6 +1773,7 @@ extern "C" int sdfk_volume_download(const sdfk_volume* v, float* values, float* 
     if (values) pieces.push_back({dense_v ? dense_v : v->values, values, v->nvox() * sizeof(float)});
     if (colors3 && v->colors) pieces.push_back({dense_c ? dense_c : v->colors, colors3, v->nvox() * 3 * sizeof(float)});
     if (colors3 && !v->colors) {   // colours that were never written are zero (Voxels.cs:88-92): cleared on the pool
+        std::lock_guard<std::recursive_mutex> pool_lk(g_pool_mu);
         const size_t nb = v->nvox() * 3 * sizeof(float), per = size_t(2) << 20;
         char* c = (char*)colors3;
         g_pool.start((int)((nb + per - 1) / per), [=](int t) { const size_t a = (size_t)t * per; memset(c + a, 0, std::min(per, nb - a)); });
@@ -2485,7 +2611,6 @@ struct GraphJob {
     size_t bytes = 0;
     uint64_t last_use = 0;
 };
-int g_graph_build_failures = 0;
 
 void graph_job_destroy(GraphJob* q)
 {
@@ -3216,7 +3341,7 @@ extern "C" int sdfk_host_prefault(void* p, int64_t n_bytes)
 {
     if (n_bytes < 0) return fail(SDFK_ERR_INVALID, "sdfk_host_prefault: bad size");
     if (!p || n_bytes == 0) return SDFK_OK;
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    std::lock_guard<std::recursive_mutex> pool_lk(g_pool_mu);
     config_from_env();
     prefault_start(p, (size_t)n_bytes);
     g_pool.wait();
@@ -3305,13 +3430,16 @@ extern "C" int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* color
     if (normals3 && vb) pieces.push_back({m->normals, normals3, vb});
     if (triangles && m->ni) pieces.push_back({m->triangles, triangles, (size_t)m->ni * sizeof(int32_t)});
     if (m->lane != g.cur_lane) const_cast<sdfk_mesh*>(m)->used_on_main = true;
-    if (colors3 && vb && !m->has_colors) {   // zero-fill (and first touch) on the pool
-        const size_t per = size_t(2) << 20, nt = (vb + per - 1) / per;
-        char* c = (char*)colors3;
-        g_pool.start((int)nt, [=](int t) { const size_t a = (size_t)t * per; memset(c + a, 0, std::min(per, vb - a)); });
-        g_pool.wait();
-    }
-    return copy_to_host(pieces);
+    std::function<void()> clear_colors;
+    if (colors3 && vb && !m->has_colors)   // zero-fill (and first touch) on the pool, beside the transfers of the other arrays
+        clear_colors = [=]() {
+            std::lock_guard<std::recursive_mutex> pool_lk(g_pool_mu);
+            const size_t per = size_t(2) << 20, nt = (vb + per - 1) / per;
+            char* c = (char*)colors3;
+            g_pool.start((int)nt, [=](int t) { const size_t a = (size_t)t * per; memset(c + a, 0, std::min(per, vb - a)); });
+            g_pool.wait();
+        };
+    return copy_to_host(pieces, clear_colors);
 }
 
 extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* colors3, void* normals3, void* triangles)
