@@ -860,9 +860,13 @@ def main():
         iv5 = load_pmc_traffic("sdfk_raymarch:SQ_INSTS_VALU", "c5", 1080)           # wave-level vector instructions per launch
         c5 = {"workload": "RayMarcher.Render 1920 x 1080, 256 depth iterations + 6 evaluations for the normal, README RepeatXY scene, camera (-2,2,4) -> origin",
               "frames": k5, "ms_per_frame": round(f5 * 1e3, 4), "mrays_per_s": round(w5 * h5 / f5 / 1e6, 1), "gevals_per_s": round(evals5 / f5 / 1e9, 2),
-              # share of the frame's time in which the 1024 SIMDs issue vector instructions: SQ_ACTIVE_INST_VALU counts quad-cycles summed
-              # over the chip, 2.4 GHz peak clock (the clock the chip holds under load is lower: the fraction is a lower bound)
-              "valu_issue_frac": None if not sq5 else round(sq5 * 4 / 1024 / 2.4e9 / f5, 4),
+              # share of the vector ALUs' peak issue rate: a SIMD issues one wave64 vector instruction per 2 cycles at full rate (157 TFLOP/s
+              # fp32 = 1024 SIMDs x 32 FMA lanes x 2.4 GHz), so wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz x frame time) -- a LOWER
+              # bound: the quarter-rate instructions of the divisions and square roots count as full-rate ones, and the clock the chip
+              # holds under this load is below 2.4 GHz (SQ_BUSY_CYCLES of the same pass: ~2.2 GHz)
+              "valu_issue_frac": None if not iv5 else round(iv5 * 2 / 1024 / 2.4e9 / f5, 4),
+              # wavefront-cycles with a vector instruction in flight / SIMD-cycles (can exceed 1: two wavefronts of a SIMD overlap in the pipeline)
+              "valu_active_frac": None if not sq5 else round(sq5 * 4 / 1024 / 2.4e9 / f5, 4),
               "valu_insts_per_eval": None if not iv5 else round(iv5 * 64 / evals5, 1),
               "checksum": float(torch.nan_to_num(rgb5.double()).sum().item()),
               "what": "BASELINE config C5 in this run: K frames back to back, one HIP event pair on the launch stream; bound = vector ALU issue (the scene costs "

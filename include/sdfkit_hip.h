@@ -26,7 +26,8 @@ extern "C" {
 #endif
 
 #define SDFK_ABI_VERSION 5   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint;
-                                5: SDFK_OPT_ELIDE_VOLUME defaults to 2 (the temporary volume of sdfk_sample_march is not stored) */
+                                5: SDFK_OPT_ELIDE_VOLUME defaults to 2 (the temporary volume of sdfk_sample_march is not stored); sdfk_init makes a
+                                   context per device and per-thread current; sdfk_node_* (several GPUs from one process) */
 
 typedef enum sdfk_status {
     SDFK_OK = 0,
@@ -84,7 +85,12 @@ typedef struct sdfk_march_job sdfk_march_job;
 
 /* ---- lifetime -------------------------------------------------------------- */
 int sdfk_abi_version(void);
-/* Select HIP device `device` (ordinal) and create the library stream. Idempotent. */
+/* The library's context of HIP device `device` (ordinal) -- created on first use: stream, lanes, pools -- becomes the CALLING THREAD's
+ * current context, like hipSetDevice: everything the thread creates afterwards lives on that device.  Idempotent.  A thread that
+ * never called sdfk_init works in the context of the first device the process initialised (a host whose calls arrive on pool
+ * threads needs nothing else).  Since ABI 5 a second device is not an error: one process may drive several GPUs, one host thread
+ * per device (handles are used by threads whose current context is the one they were made in; a mesh's accessors work from any
+ * thread).  sdfk_node_open below does exactly that for a whole node.  sdfk_shutdown releases the calling thread's current context. */
 int sdfk_init(int device);
 void sdfk_shutdown(void);
 /* Run on a caller-owned hipStream_t; NULL = the library's own (non-blocking) stream.  NB: the
@@ -379,6 +385,27 @@ void sdfk_dist_session_free(sdfk_dist_session* s);
 /* SdfEx.ToMesh (Sdf.cs:59-63) over all ranks, one call: every rank gets the full mesh. */
 int sdfk_dist_to_mesh(const sdfk_program* p, const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz,
                       int32_t clip_to_bounds, float iso_value, sdfk_mesh** out);
+
+/* ---- one process, several GPUs (SdfEx.ToMesh, Sdf.cs:59-63: a library call of ONE host process) --------------------------------
+ * The sharded step above wants one rank per GPU; a managed host is one process.  A NODE gives every listed device a context of its
+ * own and a host thread of the library's own that is the rank: the threads join one RCCL communicator per device (ncclCommInitRank
+ * on a shared id -- what one process per GPU does) and run the same Z-slab step side by side (sdfk_dist_session_*: same
+ * partition, same exchange, same protocol); the caller posts a scene and gets the WHOLE mesh back as an ordinary sdfk_mesh on
+ * the first device (its accessors -- counts, copy, bounds, transform, free -- work from the calling thread).
+ *   devices / n_devices: the HIP ordinals of the ranks, in rank order; NULL / 0 = every device of the process.  A device listed
+ *   more than once makes ranks that share a GPU: they exchange through host memory (RCCL refuses two ranks on one device) --
+ *   for bring-up and tests on a one-GPU box.
+ * sdfk_node_to_mesh takes the SDF program as its op list (each rank compiles / loads it on its own device; a repeated scene keeps
+ * its programs and its session: the second call is one sharded step).  One call at a time per node.  Free every mesh before
+ * sdfk_node_close.  The node's contexts are private: a thread's own sdfk_init context on the same device is independent of them. */
+typedef struct sdfk_node sdfk_node;
+int sdfk_node_open(const int32_t* devices, int32_t n_devices, sdfk_node** out);
+/* world = ranks; backend = 1: RCCL between the ranks, 2: the host transport (ranks share a device) */
+int sdfk_node_info(const sdfk_node* node, int32_t* world, int32_t* backend);
+int sdfk_node_to_mesh(sdfk_node* node, const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
+                      const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz,
+                      int32_t clip_to_bounds, float iso_value, sdfk_mesh** out);
+void sdfk_node_close(sdfk_node* node);
 
 /* ---- RayMarcher (RayMarcher.cs:45-211) ---------------------------------------
  * RenderDepth (depth != NULL) and / or Render (rgb != NULL) of the program's SDF by sphere

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsdfkit_hip.so")
 SOURCES = ["sdfkit_hip.hip"]
-DEPS = ["exports.map", "sdfkit_hip.hip", "mc_kernels.hip", "mc_device.h", "mc_decide.h", "mc_params.h", "mc_luts.h", "sample_codegen.h", "dist_rccl.h", "slab_protocol.h",
+DEPS = ["exports.map", "sdfkit_hip.hip", "mc_kernels.hip", "mc_device.h", "mc_decide.h", "mc_params.h", "mc_luts.h", "sample_codegen.h", "dist_rccl.h", "node_local.h", "slab_protocol.h",
         os.path.join("..", "..", "include", "sdfkit_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

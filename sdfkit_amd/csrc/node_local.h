@@ -1,0 +1,269 @@
+// node_local.h -- several GPUs from ONE process (include/sdfkit_hip.h, "one process, several GPUs"): sdfk_node_*.
+//
+// The reference is a library that a single .NET process calls (Sdf.cs:59-63: `sdf.ToMesh(...)`); the Z-slab sharded step of
+// dist_rccl.h wants one RANK per GPU.  A node gives every GPU a device context of its own (sdfkit_hip.hip, "device contexts") and a
+// host THREAD of the library's own that is the rank: the threads join one RCCL communicator per device (ncclCommInitRank on a shared
+// id, exactly what one process per GPU does) and run the very same sharded step -- sdfk_dist_session_* -- side by side; the calling
+// thread posts a command and gets rank 0's whole mesh back as an ordinary sdfk_mesh (its accessors work from any thread: the mesh
+// remembers its context).  Nothing else is new: partition, exchange, rebase and extraction are dist_rccl.h's.
+// Ranks that share a device (a device listed twice: tests on a one-GPU box, RCCL refuses two ranks on one device) exchange through
+// host memory between the threads (the library's host transport, sdfk_dist_init_host).
+// Included by sdfkit_hip.hip after dist_rccl.h.
+#pragma once
+#include <condition_variable>
+#include <thread>
+
+namespace {
+struct NodeBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 1, count = 0;
+    uint64_t gen = 0;
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t my = gen;
+        if (++count == n) { count = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != my; });
+    }
+};
+}  // namespace
+
+struct sdfk_node {
+    struct Worker {
+        sdfk_node* node = nullptr;
+        std::thread th;
+        int device = 0, rank = 0;
+        DeviceState* st = nullptr;
+        // the scene the rank holds a session for (a host that meshes frame after frame asks for the same one again)
+        std::string key;
+        sdfk_program* prog = nullptr;
+        sdfk_dist_session* sess = nullptr;
+        int status = SDFK_OK;
+        std::string error;
+    };
+    int world = 1;
+    bool host_transport = false;
+    std::vector<Worker> workers;
+    std::mutex mu;
+    std::condition_variable cv_cmd, cv_done;
+    uint64_t cmd_gen = 0;
+    int cmd = 0;      // 1: to_mesh, 2: stop
+    int done = 0;
+    // command
+    std::vector<sdfk_op> ops;
+    int32_t out_rgbw[4] = {0, 0, 0, 0};
+    int32_t writes_color = 0, nx = 0, ny = 0, nz = 0, clip = 0;
+    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, iso = 0.0f;
+    sdfk_mesh* mesh0 = nullptr;
+    // start-up rendezvous
+    unsigned char uid[SDFK_DIST_ID_BYTES] = {};
+    NodeBarrier bar;
+    std::vector<const void*> send_ptrs;   // host transport: every rank's send buffer of the all-gather in progress
+    std::mutex call_mu;                   // one sdfk_node_to_mesh at a time
+};
+
+namespace {
+
+// the host transport between the threads of a node: everybody publishes its send buffer, then copies everybody's
+int node_allgather(void* ctx, const void* send, void* recv, int64_t bytes)
+{
+    sdfk_node::Worker* w = (sdfk_node::Worker*)ctx;
+    sdfk_node* n = w->node;
+    n->send_ptrs[(size_t)w->rank] = send;
+    n->bar.wait();
+    for (int q = 0; q < n->world; q++) memcpy((char*)recv + (size_t)q * (size_t)bytes, n->send_ptrs[(size_t)q], (size_t)bytes);
+    n->bar.wait();   // (nobody overwrites its send buffer before everybody has read it)
+    return 0;
+}
+
+void node_worker_release(sdfk_node::Worker* w)
+{
+    if (w->sess) sdfk_dist_session_free(w->sess);
+    w->sess = nullptr;
+    if (w->prog) sdfk_program_destroy(w->prog);
+    w->prog = nullptr;
+    w->key.clear();
+}
+
+int node_worker_to_mesh(sdfk_node::Worker* w, sdfk_mesh** out)
+{
+    sdfk_node* n = w->node;
+    *out = nullptr;
+    std::string key((const char*)n->ops.data(), n->ops.size() * sizeof(sdfk_op));
+    key.append((const char*)n->out_rgbw, sizeof n->out_rgbw);
+    const int32_t dims[5] = {n->writes_color, n->nx, n->ny, n->nz, n->clip};
+    key.append((const char*)dims, sizeof dims);
+    key.append((const char*)n->mn, 12);
+    key.append((const char*)n->mx, 12);
+    key.append((const char*)&n->iso, 4);
+    if (key != w->key || !w->sess) {
+        node_worker_release(w);
+        if (int r = sdfk_program_create(n->ops.data(), (int32_t)n->ops.size(), n->out_rgbw, n->writes_color, &w->prog)) return r;
+        if (int r = sdfk_dist_session_create(w->prog, n->mn, n->mx, n->nx, n->ny, n->nz, n->clip, n->iso, 1, &w->sess)) return r;
+        w->key = key;
+    }
+    int r = sdfk_dist_submit(w->sess);
+    if (!r) r = sdfk_dist_collect(w->sess, nullptr, nullptr);
+    if (!r && w->rank == 0) r = sdfk_dist_mesh(w->sess, out);   // (every rank holds the gathered slabs; rank 0's copy becomes the mesh)
+    return r;
+}
+
+void node_worker_main(sdfk_node::Worker* w)
+{
+    sdfk_node* n = w->node;
+    // ---- start-up: a private context on the device, then the communicator (all ranks together)
+    w->st = context_claim(w->device, false);
+    t_state = w->st;
+    w->status = context_init(w->device);
+    if (w->status) w->error = t_err;
+    n->bar.wait();                                   // (1) every context is up (or has failed)
+    bool ok = true;
+    for (auto& q : n->workers) ok = ok && q.status == SDFK_OK;
+    if (ok && !n->host_transport && w->rank == 0) {
+        w->status = sdfk_dist_unique_id(n->uid);
+        if (w->status) w->error = t_err;
+    }
+    n->bar.wait();                                   // (2) the id is there
+    ok = true;
+    for (auto& q : n->workers) ok = ok && q.status == SDFK_OK;
+    if (ok) {
+        w->status = n->host_transport ? sdfk_dist_init_host(n->world, w->rank, node_allgather, w) : sdfk_dist_init(n->world, w->rank, n->uid);
+        if (w->status) w->error = t_err;
+    }
+    n->bar.wait();                                   // (3) the communicator is up (or somebody failed: the opener reads the statuses)
+    ok = true;
+    for (auto& q : n->workers) ok = ok && q.status == SDFK_OK;
+    // ---- commands
+    uint64_t seen = 0;
+    for (;;) {
+        int cmd;
+        {
+            std::unique_lock<std::mutex> lk(n->mu);
+            n->cv_cmd.wait(lk, [&] { return n->cmd_gen != seen; });
+            seen = n->cmd_gen;
+            cmd = n->cmd;
+        }
+        if (cmd == 1 && ok) {
+            sdfk_mesh* m = nullptr;
+            w->status = node_worker_to_mesh(w, &m);
+            w->error = w->status ? t_err : std::string();
+            if (w->rank == 0) n->mesh0 = m;
+            else if (m) sdfk_mesh_free(m);
+        }
+        if (cmd == 2) {
+            node_worker_release(w);
+            sdfk_dist_shutdown();
+            sdfk_shutdown();          // (this thread's context: frees everything it holds and gives the context back)
+        }
+        {
+            std::lock_guard<std::mutex> lk(n->mu);
+            if (++n->done == n->world) n->cv_done.notify_all();
+        }
+        if (cmd == 2) return;
+    }
+}
+
+int node_post(sdfk_node* n, int cmd)
+{
+    std::unique_lock<std::mutex> lk(n->mu);
+    n->cmd = cmd;
+    n->done = 0;
+    n->cmd_gen++;
+    n->cv_cmd.notify_all();
+    n->cv_done.wait(lk, [&] { return n->done == n->world; });
+    return SDFK_OK;
+}
+
+}  // namespace
+
+extern "C" int sdfk_node_open(const int32_t* devices, int32_t n_devices, sdfk_node** out)
+{
+    if (!out) return fail(SDFK_ERR_INVALID, "sdfk_node_open: null argument");
+    *out = nullptr;
+    config_from_env();
+    int have = 0;
+    const hipError_t e = hipGetDeviceCount(&have);
+    if (e != hipSuccess || have <= 0) return fail(SDFK_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    std::vector<int> devs;
+    if (!devices || n_devices <= 0)
+        for (int d = 0; d < have; d++) devs.push_back(d);
+    else
+        for (int i = 0; i < n_devices; i++) devs.push_back(devices[i]);
+    if (devs.size() > 64) return fail(SDFK_ERR_INVALID, "sdfk_node_open: more than 64 ranks");
+    bool shared = false;
+    for (size_t i = 0; i < devs.size(); i++) {
+        if (devs[i] < 0 || devs[i] >= have) return fail(SDFK_ERR_INVALID, "sdfk_node_open: device %d out of range (%d devices)", devs[i], have);
+        for (size_t k = 0; k < i; k++) shared = shared || devs[k] == devs[i];
+    }
+    sdfk_node* n = new sdfk_node();
+    n->world = (int)devs.size();
+    n->host_transport = shared;   // (RCCL refuses two ranks on one device: ranks that share one exchange through the host)
+    n->workers.resize(devs.size());
+    n->send_ptrs.assign(devs.size(), nullptr);
+    n->bar.n = n->world;
+    for (size_t i = 0; i < devs.size(); i++) {
+        n->workers[i].node = n;
+        n->workers[i].device = devs[i];
+        n->workers[i].rank = (int)i;
+    }
+    for (auto& w : n->workers) w.th = std::thread(node_worker_main, &w);
+    // the workers rendezvous among themselves; a no-op command tells when all of them are through their start-up
+    node_post(n, 0);
+    for (auto& w : n->workers)
+        if (w.status) {
+            const int r = w.status;
+            const std::string why = "sdfk_node_open: rank " + std::to_string(w.rank) + " (device " + std::to_string(w.device) + "): " + w.error;
+            node_post(n, 2);
+            for (auto& q : n->workers) q.th.join();
+            delete n;
+            return fail(r, "%s", why.c_str());
+        }
+    *out = n;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_node_info(const sdfk_node* n, int32_t* world, int32_t* backend)
+{
+    if (!n) return fail(SDFK_ERR_INVALID, "sdfk_node_info: null node");
+    if (world) *world = n->world;
+    if (backend) *backend = n->host_transport ? 2 : 1;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_node_to_mesh(sdfk_node* n, const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
+                                 const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz,
+                                 int32_t clip_to_bounds, float iso_value, sdfk_mesh** out)
+{
+    if (!n || !ops || n_ops <= 0 || !out_rgbw || !min || !max || !out) return fail(SDFK_ERR_INVALID, "sdfk_node_to_mesh: null/empty argument");
+    *out = nullptr;
+    std::lock_guard<std::mutex> one(n->call_mu);
+    n->ops.assign(ops, ops + n_ops);
+    memcpy(n->out_rgbw, out_rgbw, sizeof n->out_rgbw);
+    n->writes_color = writes_color;
+    memcpy(n->mn, min, 12);
+    memcpy(n->mx, max, 12);
+    n->nx = nx; n->ny = ny; n->nz = nz; n->clip = clip_to_bounds ? 1 : 0; n->iso = iso_value;
+    n->mesh0 = nullptr;
+    node_post(n, 1);
+    for (auto& w : n->workers)
+        if (w.status) {
+            if (n->mesh0) sdfk_mesh_free(n->mesh0);
+            n->mesh0 = nullptr;
+            return fail(w.status, "sdfk_node_to_mesh: rank %d (device %d): %s", w.rank, w.device, w.error.c_str());
+        }
+    *out = n->mesh0;
+    n->mesh0 = nullptr;
+    return SDFK_OK;
+}
+
+extern "C" void sdfk_node_close(sdfk_node* n)
+{
+    if (!n) return;
+    {
+        std::lock_guard<std::mutex> one(n->call_mu);
+        node_post(n, 2);
+    }
+    for (auto& w : n->workers) w.th.join();
+    delete n;
+}

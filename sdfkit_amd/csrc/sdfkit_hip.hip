@@ -240,6 +240,13 @@ inline DeviceState& cur_state() { return *(t_state ? t_state : g_default_state);
 #define g_codes (cur_state().codes)
 #define g_code_clock (cur_state().code_clock)
 #define g_graph_build_failures (cur_state().graph_build_failures)
+// the calling thread works in context `st` for the lifetime of the scope (accessors of a handle that belongs to another thread's
+// context: the mesh a local node hands back, sdfk_node_to_mesh)
+struct StateScope {
+    DeviceState* saved;
+    explicit StateScope(DeviceState* st) : saved(t_state) { if (st) t_state = st; }
+    ~StateScope() { t_state = saved; }
+};
 
 size_t size_class(size_t n)
 {
@@ -896,6 +903,7 @@ struct sdfk_volume {
 };
 
 struct sdfk_mesh {
+    DeviceState* owner = &cur_state();   // the device context the mesh was made in: its accessors work there, whichever thread calls them
     int64_t nv = 0, ni = 0;
     float* vertices = nullptr;
     float* colors = nullptr;
@@ -3010,6 +3018,7 @@ extern "C" int sdfk_sample_march_slab(const sdfk_program* p, sdfk_volume* slab, 
 
 extern "C" int sdfk_mesh_pack(const sdfk_mesh* m, void* dst, int64_t capacity_bytes, int64_t* needed_bytes)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m || !dst) return fail(SDFK_ERR_INVALID, "sdfk_mesh_pack: null argument");
     if (int r = require_init()) return r;
@@ -3357,6 +3366,7 @@ extern "C" int sdfk_host_prefault(void* p, int64_t n_bytes)
 // its counts.  *exact = 1 in the second case.
 extern "C" int sdfk_mesh_size_hint(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices, int32_t* exact)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     int64_t nv = m->nv, ni = m->ni;
@@ -3375,6 +3385,7 @@ extern "C" int sdfk_mesh_size_hint(const sdfk_mesh* m, int64_t* n_vertices, int6
 
 extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t* n_indices)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     bind_thread();
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
@@ -3386,6 +3397,7 @@ extern "C" int sdfk_mesh_counts(const sdfk_mesh* m, int64_t* n_vertices, int64_t
 
 extern "C" int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int64_t* n_case13_cells)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     bind_thread();
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
@@ -3397,6 +3409,7 @@ extern "C" int sdfk_mesh_stats(const sdfk_mesh* m, int64_t* n_active_cells, int6
 
 extern "C" int sdfk_mesh_bounds(const sdfk_mesh* mc, float min[3], float max[3])
 {
+    StateScope in_owner_context(mc ? mc->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     sdfk_mesh* m = const_cast<sdfk_mesh*>(mc);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
@@ -3416,6 +3429,7 @@ extern "C" int sdfk_mesh_bounds(const sdfk_mesh* mc, float min[3], float max[3])
 
 extern "C" int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* colors3, float* normals3, int32_t* triangles)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = require_init()) return r;
@@ -3444,6 +3458,7 @@ extern "C" int sdfk_mesh_copy(const sdfk_mesh* m, float* vertices3, float* color
 
 extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* colors3, void* normals3, void* triangles)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
     if (int r = require_init()) return r;
@@ -3462,6 +3477,7 @@ extern "C" int sdfk_mesh_copy_device(const sdfk_mesh* m, void* vertices3, void* 
 
 extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void** colors3, void** normals3, void** triangles)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     bind_thread();
     if (!m) return fail(SDFK_ERR_INVALID, "null mesh");
@@ -3482,6 +3498,7 @@ extern "C" int sdfk_mesh_device_ptrs(const sdfk_mesh* m, void** vertices3, void*
 // Mesh.Transform(Matrix4x4) (Mesh.cs:47-64) on the device-resident mesh, in place.
 extern "C" int sdfk_mesh_transform(sdfk_mesh* m, const float matrix[16], const float normal_matrix[16])
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!m || !matrix || !normal_matrix) return fail(SDFK_ERR_INVALID, "sdfk_mesh_transform: null argument");
     if (int r = require_init()) return r;
@@ -3509,6 +3526,7 @@ extern "C" int sdfk_mesh_transform(sdfk_mesh* m, const float matrix[16], const f
 
 extern "C" void sdfk_mesh_free(sdfk_mesh* m)
 {
+    StateScope in_owner_context(m ? m->owner : nullptr);
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     bind_thread();
     if (!m) return;
@@ -3584,3 +3602,4 @@ extern "C" int sdfk_profile_get(int32_t i, const char** name, double* total_ms, 
 // Z-slab sharding: sdfk_dist_* (RCCL called by the library itself)
 // ---------------------------------------------------------------------------
 #include "dist_rccl.h"
+#include "node_local.h"

@@ -216,3 +216,48 @@ def unpack_self_describing(g):
     mx = np.max(np.stack(maxs), axis=0) if maxs else np.zeros(3, np.float32)
     return (np.concatenate(V), np.concatenate(Cc), np.concatenate(Nn), np.concatenate(T),
             mn.astype(np.float32), mx.astype(np.float32))
+
+
+class Node:
+    """Several GPUs from ONE process (sdfk_node_*, include/sdfkit_hip.h): every listed device gets a context of its own and a host
+    thread of the library's own that is its rank; `to_mesh` is SdfEx.ToMesh (Sdf.cs:59-63) over all of them, called from one
+    thread -- what a managed host, which is one process, needs (the one-process-per-GPU form is `init` + `sharded_to_mesh`).
+
+        node = D.Node()                      # every GPU of the process; D.Node([0, 0]) = two ranks sharing GPU 0 (host transport)
+        mesh = node.to_mesh(sdf, mn, mx, nx, ny, nz)
+        node.close()
+    """
+
+    def __init__(self, devices=None):
+        self._h = C.c_void_p()
+        L = N.lib()
+        if devices is None:
+            N.check(L.sdfk_node_open(None, 0, C.byref(self._h)))
+        else:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            N.check(L.sdfk_node_open(arr, len(devices), C.byref(self._h)))
+        w, b = C.c_int32(), C.c_int32()
+        N.check(L.sdfk_node_info(self._h, C.byref(w), C.byref(b)))
+        self.world, self.backend = w.value, b.value
+
+    def to_mesh_handle(self, sdf, mn, mx, nx, ny, nz, clipToBounds=True, isoValue=0.0):
+        arr, n, out = sdf.ir()
+        h = C.c_void_p()
+        N.check(N.lib().sdfk_node_to_mesh(self._h, arr, n, out, int(sdf.writes_color), N.f3(mn), N.f3(mx), nx, ny, nz,
+                                          1 if clipToBounds else 0, C.c_float(isoValue), C.byref(h)))
+        return h
+
+    def to_mesh(self, sdf, mn, mx, nx, ny, nz, clipToBounds=True, isoValue=0.0):
+        from .api import Mesh
+        return Mesh._from_handle(self.to_mesh_handle(sdf, mn, mx, nx, ny, nz, clipToBounds, isoValue))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            N.lib().sdfk_node_close(self._h)
+        self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

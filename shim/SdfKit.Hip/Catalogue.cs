@@ -41,6 +41,12 @@ namespace SdfKit
                 return ToVoxels(sdf, min, max, nx, ny, nz, batchSize, maxDegreeOfParallelism, clipToBounds).ToMesh(isoValue, step, progress);
             // one process per GPU with Dist.Init done: the same call shards the grid by Z slab over the GPUs of the node and
             // every rank gets the whole mesh (collective: every rank makes the call) -- Dist.cs, sdfk_dist_to_mesh
+            // a node of several GPUs opened by THIS process (new Node()): one call from this thread uses all of them -- Dist.cs, sdfk_node_to_mesh
+            if (Node.Current != null && Node.Current.World > 1 && step == 1 && (long)nx * ny * nz >= Node.MinVoxels) {
+                var whole = Node.Current.ToMesh(prog, min, max, nx, ny, nz, clipToBounds, isoValue);
+                MarchingCubes.ReportProgress(progress, nz, step);
+                return whole;
+            }
             if (Dist.World > 1 && step == 1) {
                 var whole = Dist.ToMesh(prog, min, max, nx, ny, nz, clipToBounds, isoValue);
                 MarchingCubes.ReportProgress(progress, nz, step);

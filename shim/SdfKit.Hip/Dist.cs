@@ -1,4 +1,5 @@
-// Dist.cs -- SdfEx.ToMesh (Sdf.cs:59-63) over the GPUs of one node: one process per GPU, the grid cut into Z slabs, the
+// Dist.cs -- SdfEx.ToMesh (Sdf.cs:59-63) over the GPUs of one node.  Two forms: `Node` (bottom of the file) = several GPUs from THIS
+// process, one call from one managed thread; `Dist` = one process per GPU, the grid cut into Z slabs, the
 // slab meshes exchanged by the LIBRARY (it calls RCCL itself; include/sdfkit_hip.h, "Z-slab sharding").  What is left for
 // the host is what only the host can do: start one process per GPU and hand the 128-byte RCCL id from rank 0 to the others.
 // UNCOMPILED IN THIS REPOSITORY (no .NET toolchain in the build image); the same calls, in the same order, are what
@@ -84,6 +85,50 @@ namespace SdfKit.Hip
                 if (h != IntPtr.Zero) Native.sdfk_dist_session_free(h);
                 h = IntPtr.Zero;
             }
+        }
+    }
+
+    /// <summary>Several GPUs from THIS process (sdfk_node_*): the library gives every device a context of its own and a host thread
+    /// of its own that is the Z-slab rank; the threads join RCCL exactly as one process per GPU would.  `SdfEx.ToMesh` (Sdf.cs:59-63)
+    /// dispatches here when a node is open: one call from one managed thread uses the whole node.
+    /// <code>using var node = new Node();            // every GPU of the process
+    /// var mesh = node.ToMesh(program, min, max, 1024, 1024, 1024);</code></summary>
+    public sealed unsafe class Node : IDisposable
+    {
+        IntPtr h;
+        public int World { get; }
+        public static Node? Current { get; private set; }      // what the SdfEx.ToMesh facade consults (Catalogue.cs)
+        /// <summary>Grids below this stay on one GPU: a sharded step costs an exchange of the whole mesh between the GPUs (DESIGN.md,
+        /// "the fabric bound": at 512^3 every rank receives 23 MB over xGMI, more than one GPU needs for the whole job).</summary>
+        public static long MinVoxels = 1L << 28;
+
+        public Node(int[]? devices = null)
+        {
+            if (devices == null || devices.Length == 0) Native.Check(Native.sdfk_node_open(null, 0, out h));
+            else fixed (int* d = devices) Native.Check(Native.sdfk_node_open(d, devices.Length, out h));
+            Native.Check(Native.sdfk_node_info(h, out var world, out _));
+            World = world;
+            Current = this;
+        }
+
+        public Mesh ToMesh(GpuProgram program, Vector3 min, Vector3 max, int nx, int ny, int nz, bool clipToBounds = true, float isoValue = 0)
+        {
+            float* mn = stackalloc float[3] { min.X, min.Y, min.Z };
+            float* mx = stackalloc float[3] { max.X, max.Y, max.Z };
+            var ops = new SdfkOp[program.Ops.Count];
+            for (int i = 0; i < ops.Length; i++) ops[i] = program.Ops[i];
+            IntPtr mesh;
+            fixed (SdfkOp* po = ops) fixed (int* o = program.OutRgbw)
+                Native.Check(Native.sdfk_node_to_mesh(h, po, ops.Length, o, program.WritesColor ? 1 : 0, mn, mx, nx, ny, nz, clipToBounds ? 1 : 0, isoValue, out mesh));
+            // (the mesh lives in rank 0's context; its accessors work from this thread)
+            try { return SdfKit.Mesh.FromNative(mesh, program.WritesColor); } finally { Native.sdfk_mesh_free(mesh); }
+        }
+
+        public void Dispose()
+        {
+            if (Current == this) Current = null;
+            if (h != IntPtr.Zero) Native.sdfk_node_close(h);
+            h = IntPtr.Zero;
         }
     }
 }

@@ -75,6 +75,12 @@ namespace SdfKit.Hip
         [DllImport(Lib)] public static extern int sdfk_dist_tune(IntPtr session, int stepsPerMode, long* nsPerConfig4);
         [DllImport(Lib)] public static extern int sdfk_dist_stats(IntPtr session, long* stats8);
         [DllImport(Lib)] public static extern void sdfk_dist_session_free(IntPtr session);
+        // several GPUs from ONE process (the managed host is one process): include/sdfkit_hip.h, "one process, several GPUs"
+        [DllImport(Lib)] public static extern int sdfk_node_open(int* devices, int nDevices, out IntPtr node);
+        [DllImport(Lib)] public static extern int sdfk_node_info(IntPtr node, out int world, out int backend);
+        [DllImport(Lib)] public static extern int sdfk_node_to_mesh(IntPtr node, SdfkOp* ops, int nOps, int* outRgbw, int writesColor, float* min, float* max,
+                                                                    int nx, int ny, int nz, int clip, float iso, out IntPtr mesh);
+        [DllImport(Lib)] public static extern void sdfk_node_close(IntPtr node);
         // RayMarcher (RayMarcher.cs:45-211)
         [DllImport(Lib)] public static extern int sdfk_raymarch(IntPtr program, int width, int height, float* cameraPosition, float* viewProjectionInverse,
                                                                 float near, float far, int depthIterations, float* depth, float* rgb);

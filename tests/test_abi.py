@@ -83,6 +83,13 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(N.SdfKitNativeError) as e:
         Sdfs.Sphere(1.0).ToMesh([-1] * 3, [1] * 3, 8, 8, 8)
     assert e.value.status == 2  # SDFK_ERR_NO_DEVICE: there is no CPU fallback
+    # the same for the several-GPUs-from-one-process form: no device, no node (and no worker thread left behind)
+    import ctypes as C
+    import threading
+    before = threading.active_count()
+    h = C.c_void_p()
+    assert N.lib().sdfk_node_open(None, 0, C.byref(h)) == 2 and not h.value
+    assert threading.active_count() == before
 
 
 def test_product_does_not_reference_the_oracle():
