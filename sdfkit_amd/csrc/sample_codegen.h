@@ -349,7 +349,7 @@ extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_
 // its sign bits written as constants.  No assumption about the SDF (no Lipschitz bound): the intervals contain every float
 // the per-voxel evaluation can produce, NaN = unknown = evaluate.
 // A block = 64 x (ONE word of the X-packed sign array the marching-cubes classifier reads) x 4 y x 4 z = 1024 voxels, 16 words.
-// sdfk_cull_blocks: one LANE per block decides it (16 constant words) or appends it to a work list (order irrelevant: every word
+// sdfk_cull_blocks: eight LANES per block decide it (16 constant words) or append it to a work list (order irrelevant: every word
 // has its place).  sdfk_eval_blocks: one WAVEFRONT per listed block, lane = x -- the 64-bit ballot of "value > iso" over the lanes
 // IS the sign word of a (y, z) row, sixteen evaluations and sixteen ballots a block.  Both write bits[z][y][xw] directly: this
 // path has no byte form and no k_bits_transpose.
@@ -358,55 +358,73 @@ struct CullArgs { unsigned long long* bits; unsigned* worklist; unsigned* counte
 __device__ __forceinline__ float sdfk_coord(float m, int i, float d) { return m + (float)i * d; }
 #endif
 #if SDFK_KERNELS & 0x200
-extern "C" __global__ __launch_bounds__(256) void sdfk_cull_blocks(SampleArgs A, CullArgs C, SdfkK K)
+// EIGHT lanes per block, one per 8-x sub-box -- one BYTE of the block's sign word each: a box of 64 x is too wide for scenes that repeat
+// along x (the interval of mod(x, period) covers the whole period).  (Round 4 gave a block ONE lane that walked the eight sub-boxes
+// in a row: 131 072 lanes at 512^3, two wavefronts per SIMD, each a chain of eight interval evaluations -- 19 us of latency for 3 us
+// of vector work.)  The eight lanes combine their bytes with three butterfly steps; each then stores two of the block's sixteen rows.
+extern "C" __global__ __launch_bounds__(1024) void sdfk_cull_blocks(SampleArgs A, CullArgs C, SdfkK K)
 {
+    __shared__ unsigned s_cnt[16], s_base;
     const int nb = C.nbx * C.nby * C.nbz;
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    int decided = -1;   // -1: not a block; 1: `word` is the sign word of all 16 rows of the block; 2: evaluate
-    unsigned long long word = 0;
+    const int gid = blockIdx.x * 1024 + threadIdx.x;
+    const int b = gid >> 3, sx = gid & 7;
+    int cls = -1;   // -1: not a block; 0 / 1: every voxel of this lane's sub-box is <= iso / > iso; 2: evaluate the block
     int bx = 0, by = 0, bz = 0;
     if (b < nb) {
-        bx = b % C.nbx;                      // (x words fastest: neighbouring lanes write neighbouring words of a (y, z) row)
+        bx = b % C.nbx;                      // (x words fastest: neighbouring blocks write neighbouring words of a (y, z) row)
         const int t = b / C.nbx;
         by = t % C.nby;
         bz = t / C.nby;
         const int x0 = bx * 64, y0 = by * 4, z0 = bz * 4;
-        decided = 2;
+        cls = 2;
         // only whole blocks away from the clipped faces are candidates (the others are O(n^2) few)
         const bool whole = x0 + 64 <= A.nx && y0 + 4 <= A.ny && z0 + 4 <= A.nz;
         const bool faces = A.clip && (x0 == 0 || x0 + 64 >= A.nx || y0 == 0 || y0 + 4 >= A.ny || A.z0 + z0 == 0 || A.z0 + z0 + 4 >= A.nz_global);
         if (whole && !faces) {
-            // eight sub-boxes of 8 x each -- one BYTE of the word each: a box of 64 x is too wide for scenes that repeat along x (the
-            // interval of mod(x, period) covers the whole period), and the interval pass is 1 % of the sampler's work either way
+            const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0 + 8 * sx, A.dx), sdfk_coord(A.mx, x0 + 8 * sx + 7, A.dx));
             const sdfk_iv Y = iv_make(sdfk_coord(A.my, y0, A.dy), sdfk_coord(A.my, y0 + 3, A.dy));
             const sdfk_iv Z = iv_make(sdfk_coord(A.mz, A.z0 + z0, A.dz), sdfk_coord(A.mz, A.z0 + z0 + 3, A.dz));
-            decided = 1;
-#pragma unroll 1
-            for (int sx = 0; sx < 8; sx++) {
-                const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0 + 8 * sx, A.dx), sdfk_coord(A.mx, x0 + 8 * sx + 7, A.dx));
-                const sdfk_iv W = sdf_interval(K, X, Y, Z);
-                // (decided only by an interval that is known as a whole: both comparisons are false for NaN)
-                if (W.lo > A.iso && W.hi >= W.lo) word |= 0xffull << (8 * sx);
-                else if (!(W.hi <= A.iso && W.lo <= W.hi)) { decided = 2; break; }
-            }
+            const sdfk_iv W = sdf_interval(K, X, Y, Z);
+            // (decided only by an interval that is known as a whole: both comparisons are false for NaN)
+            if (W.lo > A.iso && W.hi >= W.lo) cls = 1;
+            else if (W.hi <= A.iso && W.lo <= W.hi) cls = 0;
         }
     }
-    if (decided == 1) {
+    // the block's word (byte sx = 0xff where the sub-box lies above the iso value) and "some sub-box is undecided", over the 8 lanes of the block
+    unsigned lo = (cls == 1 && sx < 4) ? 0xffu << (8 * sx) : 0u, hi = (cls == 1 && sx >= 4) ? 0xffu << (8 * (sx - 4)) : 0u;
+    unsigned und = cls == 2 ? 1u : 0u;
+    // (ds_swizzle in bit mode: and 0x1f, or 0, xor 1 / 2 / 4 -- lanes 8 k .. 8 k + 7 exchange among themselves)
+#define SDFK_OR8(v)                                                              \
+    v |= (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (1 << 10) | 0x1f);        \
+    v |= (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (2 << 10) | 0x1f);        \
+    v |= (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);
+    SDFK_OR8(lo) SDFK_OR8(hi) SDFK_OR8(und)
+#undef SDFK_OR8
+    if (cls >= 0 && !und) {
+        const unsigned long long word = (unsigned long long)lo | ((unsigned long long)hi << 32);
 #pragma unroll
-        for (int zz = 0; zz < 4; zz++)
+        for (int q = 0; q < 2; q++) {        // rows 2 sx and 2 sx + 1 of the block's sixteen (zz, yy) rows
+            const int row = 2 * sx + q, zz = row >> 2, yy = row & 3;
+            C.bits[((long)(bz * 4 + zz) * A.ny + (by * 4 + yy)) * C.nbx + bx] = word;
+        }
+    }
+    // the undecided blocks of this WORKGROUP (128 blocks, their first lanes): ONE atomic for all of them -- every atomic goes to the
+    // same counter, and same-address atomics serialise (one per wavefront, 8 blocks each, made this kernel 73 us at 512^3)
+    const bool listed = cls >= 0 && und && sx == 0;
+    const unsigned long long need = __builtin_amdgcn_ballot_w64(listed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (unsigned)__builtin_popcountll(need);
+    __syncthreads();
+    unsigned before = 0, total = 0;
 #pragma unroll
-            for (int yy = 0; yy < 4; yy++)
-                C.bits[((long)(bz * 4 + zz) * A.ny + (by * 4 + yy)) * C.nbx + bx] = word;
+    for (int w = 0; w < 16; w++) {
+        const unsigned c = s_cnt[w];
+        before += w < wave ? c : 0u;
+        total += c;
     }
-    // the undecided blocks of this wavefront: one atomic for all of them
-    const unsigned long long need = __builtin_amdgcn_ballot_w64(decided == 2);
-    if (need) {
-        const int lane = threadIdx.x & 63;
-        unsigned first = 0;
-        if (lane == 0) first = atomicAdd(C.counter, (unsigned)__builtin_popcountll(need));
-        first = __builtin_amdgcn_readfirstlane(first);
-        if (decided == 2) C.worklist[first + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull))] = (unsigned)b;
-    }
+    if (threadIdx.x == 0 && total) s_base = atomicAdd(C.counter, total);
+    __syncthreads();
+    if (listed) C.worklist[s_base + before + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull))] = (unsigned)b;
 }
 #endif
 #if SDFK_KERNELS & 0x400

@@ -1906,7 +1906,7 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
                 void* cparams[] = {&A, &Cargs, p->kargs()};
                 {
                     ProfScope ps2("sdfk_cull_blocks");
-                    HIPCHK(hipModuleLaunchKernel(fn_cull, (unsigned)((nblocks + 255) / 256), 1, 1, 256, 1, 1, 0, g.stream, cparams, nullptr));
+                    HIPCHK(hipModuleLaunchKernel(fn_cull, (unsigned)((nblocks * 8 + 1023) / 1024), 1, 1, 1024, 1, 1, 0, g.stream, cparams, nullptr));   // (eight lanes per block)
                 }
                 {
                     ProfScope ps2("sdfk_eval_blocks");

@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: everything profiles/ needs for a round.  usage: tools/gpu_round_profiles.sh r04
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; export TMPDIR=/tmp
 O=gpurun_out/profiles_$tag; mkdir -p $O
