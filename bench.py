@@ -648,7 +648,7 @@ def main():
         ring_bound_ms = recv / (XGMI_LINK_GBS_PER_DIRECTION * 1e9) * 1e3 if world > 1 else 0.0
         dist_extra = {"world": world, "backend": backend,
                       "exchange": {-1: "host transport", 0: "ncclAllGather (in place)", 1: "grouped ncclSend / ncclRecv to every peer (all xGMI links at once)",
-                                   2: "grouped sends to rank 0 only (headers to everybody)"}[mode],
+                                   2: "grouped sends to rank 0 only (headers to everybody)", 3: "headers only: the mesh stays sharded (payloads on demand)"}[mode],
                       "exchange_tuned_ns": tuned,
                       "payload": ("compact: indices as 16-bit offsets against one int32 base per 1024 indices, decoded by the step into the whole "
                                   "mesh's int32 index array" if st["index16"] else "plain: int32 indices, rebased in place by the step") +
@@ -676,6 +676,10 @@ def main():
                       "speedup_ceiling_is": "single_gpu_ms_per_step / xgmi.receive_bound_ms: the most the z-slab + all-gather contract allows on this "
                                             "grid with this payload form, reached only if the slab kernels hide entirely behind an exchange that runs "
                                             "at the links' peak",
+                      # ... and what lifts it: SDFK_OPT_DIST_EXCHANGE = 3, the mesh stays sharded (a step moves the 64-byte headers only;
+                      # sdfk_dist_slab_mesh / sdfk_dist_mesh fetch payloads on demand): the step is then bound by the slowest rank's slab
+                      # kernels, measured above without the exchange
+                      "speedup_ceiling_mesh_stays_sharded": None if not (single_ms and tk) else round(single_ms / (tk / args.steps * 1e3), 2),
                       "single_gpu_ms_per_step": None if single_ms is None else round(single_ms, 4),
                       "speedup_measured": None if not single_ms else round(single_ms / ms_step, 3),
                       "steps_redone_on_the_exact_path": st["redone"], "stride_regrowths": st["regrown"]}

@@ -27,7 +27,8 @@ extern "C" {
 
 #define SDFK_ABI_VERSION 5   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint;
                                 5: SDFK_OPT_ELIDE_VOLUME defaults to 2 (the temporary volume of sdfk_sample_march is not stored); sdfk_init makes a
-                                   context per device and per-thread current; sdfk_node_* (several GPUs from one process) */
+                                   context per device and per-thread current; sdfk_node_* (several GPUs from one process); sdfk_dist_slab_mesh and exchange
+                                   mode 3 (the mesh stays sharded); sdfk_eval_points (SdfEx.Sample) */
 
 typedef enum sdfk_status {
     SDFK_OK = 0,
@@ -129,7 +130,11 @@ typedef enum sdfk_option {
     SDFK_OPT_CORNER_EVAL = 5,   /* 1 (default): cell corners of a freshly sampled volume are re-evaluated; 0: gathered */
     SDFK_OPT_VCOLOR_EVAL = 6,   /* 1 (default): vertex colours of a freshly sampled volume are re-evaluated; 0: gathered */
     SDFK_OPT_DIST_EXCHANGE = 7, /* sharded step: 0 (default) ncclAllGather, in place -- the plainest collective; opt-ins: 1 grouped
-                                   ncclSend/ncclRecv to every peer (all xGMI links at once), 2 payloads to rank 0 only (headers to all).
+                                   ncclSend/ncclRecv to every peer (all xGMI links at once), 2 payloads to rank 0 only (headers to all),
+                                   3 THE MESH STAYS SHARDED: only the 64-byte headers travel in a step (the counts of every slab on every
+                                   rank), the slab payloads stay on their GPUs -- sdfk_dist_slab_mesh hands out a rank's own slab,
+                                   sdfk_dist_mesh runs the payload exchange of that one step on demand (collective).  A step is then
+                                   no longer bound by what every rank has to receive over xGMI.
                                    sdfk_dist_tune measures 0 against 1 on the node it runs on */
     SDFK_OPT_DIST_LANES = 8,    /* sharded step: internal streams consecutive steps rotate over: 0..3, default 3 (measured: a step on an
                                    8-rank slab of 512^3 takes 82 / 46 / 35 us with 1 / 2 / 3; a fourth shares a hardware queue: 98 us) */
@@ -363,8 +368,13 @@ int sdfk_dist_collect(sdfk_dist_session* s, int64_t* n_vertices_mine, int64_t* n
 /* Per-rank (vertices, indices) of the step collected last: counts[2 * world]. */
 int sdfk_dist_counts(const sdfk_dist_session* s, int64_t* counts);
 /* The whole mesh of the step collected last (valid call until the next submit reuses that slot): the slab sections of the
- * gather buffer concatenated into an ordinary device-resident mesh -- identical to the single-GPU sdfk_sample_march. */
+ * gather buffer concatenated into an ordinary device-resident mesh -- identical to the single-GPU sdfk_sample_march.
+ * (Exchange mode 3: the payloads of that step are exchanged HERE, so the call is collective -- every rank makes it.) */
 int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out);
+/* This rank's OWN slab of the step collected last as a mesh of its own (indices global: + the vertex counts of the slabs before it).
+ * Not collective, no payload exchange: with SDFK_OPT_DIST_EXCHANGE = 3 a host assembles the whole mesh from the ranks' slabs, each
+ * copied over its own PCIe link to the offsets sdfk_dist_counts gives (vertices: sum of nv of the ranks before; likewise indices). */
+int sdfk_dist_slab_mesh(sdfk_dist_session* s, sdfk_mesh** out);
 /* The raw gather buffer of the step collected last: world payloads of stride_bytes each (header + sections, indices
  * rebased), device memory owned by the session. */
 int sdfk_dist_gathered(const sdfk_dist_session* s, void** device_ptr, int64_t* stride_bytes);
@@ -405,7 +415,25 @@ int sdfk_node_info(const sdfk_node* node, int32_t* world, int32_t* backend);
 int sdfk_node_to_mesh(sdfk_node* node, const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
                       const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz,
                       int32_t clip_to_bounds, float iso_value, sdfk_mesh** out);
+/* The mesh on the HOST, in the two phases every managed caller needs (Mesh.cs:10-13: four exact-length arrays): begin runs the
+ * sharded step and returns the totals; copy fills the caller's arrays -- every rank copies ITS slab into its slice (indices global)
+ * over its own PCIe link, all ranks at once.  The node's steps leave the mesh sharded (SDFK_OPT_DIST_EXCHANGE = 3 semantics: only
+ * the 64-byte headers cross xGMI), so nothing is bound by what a rank would have to receive from the others.  colors3 may be NULL
+ * (has_colors = 0: every colour is zero); min / max = Mesh.Measure over the slabs (may be NULL). */
+int sdfk_node_mesh_begin(sdfk_node* node, const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
+                         const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds,
+                         float iso_value, int64_t* n_vertices, int64_t* n_indices, int32_t* has_colors);
+int sdfk_node_mesh_copy(sdfk_node* node, float* vertices3, float* colors3, float* normals3, int32_t* triangles, float min[3], float max[3]);
 void sdfk_node_close(sdfk_node* node);
+
+/* ---- SdfEx.Sample (Sdf.cs:22-47) ----------------------------------------------
+ * The SDF at `n` arbitrary points (x, y, z triples): rgbw4[4 i .. 4 i + 3] = (colour, distance) of point i, exactly what the
+ * delegate writes into the caller's Vector4 buffer -- a program that only assigns .W (Sdfs.Sphere, Sdf.cs:211) leaves X, Y, Z of
+ * every element as the caller had them.  batchSize / maxDegreeOfParallelism of the reference have no meaning here.
+ * sdfk_eval_points: host arrays, synchronous; sdfk_eval_points_device: caller-owned device buffers, asynchronous on the
+ * library stream. */
+int sdfk_eval_points(const sdfk_program* p, const float* points3, int64_t n, float* rgbw4);
+int sdfk_eval_points_device(const sdfk_program* p, const void* points3_dev, int64_t n, void* rgbw4_dev);
 
 /* ---- RayMarcher (RayMarcher.cs:45-211) ---------------------------------------
  * RenderDepth (depth != NULL) and / or Render (rgb != NULL) of the program's SDF by sphere

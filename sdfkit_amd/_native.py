@@ -105,15 +105,20 @@ SIGNATURES = {
     "sdfk_dist_collect": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "sdfk_dist_counts": (C.c_int, [_vp, C.POINTER(_i64)]),
     "sdfk_dist_mesh": (C.c_int, [_vp, _vpp]),
+    "sdfk_dist_slab_mesh": (C.c_int, [_vp, _vpp]),
     "sdfk_dist_gathered": (C.c_int, [_vp, _vpp, C.POINTER(_i64)]),
     "sdfk_dist_stats": (C.c_int, [_vp, C.POINTER(_i64)]),
     "sdfk_dist_enqueue_only": (C.c_int, [_vp]),
     "sdfk_dist_tune": (C.c_int, [_vp, _i32, C.POINTER(_i64)]),
     "sdfk_dist_session_free": (None, [_vp]),
     "sdfk_dist_to_mesh": (C.c_int, [_vp, _fp, _fp, _i32, _i32, _i32, _i32, _f, _vpp]),
+    "sdfk_eval_points": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sdfk_eval_points_device": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sdfk_node_open": (C.c_int, [C.POINTER(_i32), _i32, _vpp]),
     "sdfk_node_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "sdfk_node_to_mesh": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), _i32, _fp, _fp, _i32, _i32, _i32, _i32, _f, _vpp]),
+    "sdfk_node_mesh_begin": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32), _i32, _fp, _fp, _i32, _i32, _i32, _i32, _f, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "sdfk_node_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _fp, _fp]),
     "sdfk_node_close": (None, [_vp]),
     "sdfk_profile_count": (C.c_int, []),
     "sdfk_profile_get": (C.c_int, [_i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),

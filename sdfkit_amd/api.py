@@ -85,6 +85,20 @@ class Sdf:
         v._sample(self, clip=clipToBounds)
         return v
 
+    def Sample(self, points, colorsAndDistances=None, batchSize=DefaultBatchSize, maxDegreeOfParallelism=-1):
+        """SdfEx.Sample (Sdf.cs:22-47): the SDF at arbitrary points.  points [n, 3] float32; returns (and, when given, fills)
+        colorsAndDistances [n, 4] = (r, g, b, distance) per point.  Like the reference's delegates, an SDF that only assigns .W
+        leaves X, Y, Z of the caller's elements untouched (zeros in a fresh array).  batchSize / maxDegreeOfParallelism are
+        accepted and ignored (one lane per point on the GPU)."""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        out = colorsAndDistances
+        if out is None:
+            out = np.zeros((len(pts), 4), np.float32)
+        if out.dtype != np.float32 or not out.flags.c_contiguous or out.shape != (len(pts), 4):
+            raise ValueError("colorsAndDistances must be a C-contiguous float32 array of shape [n, 4]")
+        N.check(N.lib().sdfk_eval_points(self.program(), pts.ctypes.data, len(pts), out.ctypes.data))
+        return out
+
     def ToImage(self, width, height, *camera, **kw):
         """SdfEx.ToImage (Sdf.cs:65-99): camera = viewTransform, or position, target, up."""
         from .raymarch import to_image

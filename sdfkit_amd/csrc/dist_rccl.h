@@ -168,6 +168,48 @@ __global__ __launch_bounds__(256) void k_slabs_concat(ConcatArgs A)
     }
 }
 
+// ONE slab of a gather buffer as a mesh of its own: sections -> dense arrays, indices + ibias (the vertex counts of the slabs before
+// it when the step left them slab-local -- exchange mode 3 --, 0 when the step's own kernel has rebased them already).
+struct SlabExtractArgs {
+    const char* section;   // the slab's payload (header first)
+    float* vertices;
+    float* colors;
+    float* normals;
+    int32_t* triangles;
+    float* bounds;
+    int32_t ibias;
+};
+
+__global__ __launch_bounds__(256) void k_slab_extract(SlabExtractArgs A)
+{
+    using sdfk::SlabHeader;
+    const SlabHeader* h = reinterpret_cast<const SlabHeader*>(A.section);
+    const int64_t nv = h->nv, ni = h->ni, capv = h->cap_v > 0 ? (int64_t)h->cap_v : nv;
+    const bool wc = h->vbytes == 36;
+    const char* sec = A.section + sizeof(SlabHeader);
+    const uint32_t* sv = reinterpret_cast<const uint32_t*>(sec);
+    const uint32_t* sc = reinterpret_cast<const uint32_t*>(sec + 12 * capv);
+    const uint32_t* sn = reinterpret_cast<const uint32_t*>(sec + (wc ? 24 : 12) * capv);
+    const int32_t* st = reinterpret_cast<const int32_t*>(sec + (int64_t)h->vbytes * capv);
+    const bool c16 = h->idx_bits == 16;
+    const uint16_t* t16 = reinterpret_cast<const uint16_t*>(st);
+    const int32_t* bases = reinterpret_cast<const int32_t*>(sec + (int64_t)h->vbytes * capv + ((2 * ni + 3) & ~int64_t(3)));
+    uint32_t* dv = reinterpret_cast<uint32_t*>(A.vertices);
+    uint32_t* dc = reinterpret_cast<uint32_t*>(A.colors);
+    uint32_t* dn = reinterpret_cast<uint32_t*>(A.normals);
+    const int64_t nf = 3 * nv, total = 3 * nf + ni;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < nf) dv[i] = sv[i];
+        else if (i < 2 * nf) dc[i - nf] = wc ? sc[i - nf] : 0u;
+        else if (i < 3 * nf) dn[i - 2 * nf] = sn[i - 2 * nf];
+        else {
+            const int64_t k = i - 3 * nf;
+            A.triangles[k] = (c16 ? bases[k / sdfk::SLAB_IDX_BLOCK] + (int32_t)t16[k] : st[k]) + A.ibias;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 6) A.bounds[threadIdx.x] = nv > 0 ? (threadIdx.x < 3 ? h->bmin[threadIdx.x] : h->bmax[threadIdx.x - 3]) : 0.0f;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -200,6 +242,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         int32_t* decoded = nullptr;       // idx16: the whole mesh's int32 indices, decoded by the step (k_slabs_decode16)
         int64_t decoded_cap = 0;
         bool ready_valid = false, read_valid = false;
+        bool payloads_gathered = false;   // the last exchange of this slot moved the slab payloads (false: headers only, exchange mode 3)
         sdfk_mesh* exact = nullptr;       // mesh of run_exact until pack_exact
     };
     std::vector<Slot> slots;
@@ -375,28 +418,42 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         return SDFK_OK;
     }
 
-    int exchange(int k) override
+    int exchange(int k) override { return exchange_as(k, exchange_mode); }
+
+    // mode 3 ("the mesh stays sharded"): only the 64-byte HEADERS travel -- every decision of the protocol needs them, nothing else
+    // does -- and the slab payloads stay where they were emitted until somebody asks for the whole mesh (sdfk_dist_mesh then runs
+    // the payload exchange of that one step, exchange_as(k, 0)); sdfk_dist_slab_mesh hands out a rank's own slab without any exchange.
+    // What every rank has to RECEIVE per step drops from (world - 1) slab meshes to (world - 1) x 64 bytes: the step is no longer
+    // bound by the fabric ("the fabric bound").
+    int exchange_as(int k, int mode)
     {
         Slot& s = slots[k];
         if (int r = have_buffers(s, "exchange")) return r;
         const int w = gd.world, me = gd.rank;
         hipStream_t cs = gd.stream;
+        s.payloads_gathered = mode != 3 || w == 1;
         if (gd.backend == 2) {
             // host transport: device -> pinned, the host's own all-gather, pinned -> device (synchronous: a test / bring-up path)
             char* hs = gd.stage;
             char* hr = gd.stage + stride;
+            const int64_t piece = mode == 3 ? (int64_t)SDFK_SLAB_HEADER_BYTES : stride;   // (mode 3: the headers only)
             hipError_t e = hipEventSynchronize(s.packed);
-            if (e == hipSuccess) e = hipMemcpyAsync(hs, send_buf(s), (size_t)stride, hipMemcpyDeviceToHost, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(hs, send_buf(s), (size_t)piece, hipMemcpyDeviceToHost, cs);
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
             if (e != hipSuccess) return keep(fail(SDFK_ERR_HIP, "host transport: %s", hipGetErrorString(e)));
-            if (gd.host_fn(gd.host_ctx, hs, hr, stride) != 0) return keep(fail(SDFK_ERR_HIP, "the host transport's all-gather failed"));
-            e = hipMemcpyAsync(s.gathered, hr, (size_t)w * (size_t)stride, hipMemcpyHostToDevice, cs);
+            if (gd.host_fn(gd.host_ctx, hs, hr, piece) != 0) return keep(fail(SDFK_ERR_HIP, "the host transport's all-gather failed"));
+            if (mode == 3) {   // header q -> the head of section q (this rank's own section keeps its payload)
+                for (int q = 0; q < w && e == hipSuccess; q++)
+                    if (q != me) e = hipMemcpyAsync(s.gathered + (size_t)q * stride, hr + (size_t)q * piece, (size_t)piece, hipMemcpyHostToDevice, cs);
+            } else
+                e = hipMemcpyAsync(s.gathered, hr, (size_t)w * (size_t)stride, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipStreamSynchronize(cs);   // (the staging block is reused by the next exchange)
             if (e != hipSuccess) return keep(fail(SDFK_ERR_HIP, "host transport: %s", hipGetErrorString(e)));
         } else {
             if (hipStreamWaitEvent(cs, s.packed, 0) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "hipStreamWaitEvent failed"));
             const RcclApi& N = gd.nccl;
             ncclResult_t nr = ncclSuccess;
+            const int exchange_mode = mode;   // (the mode of THIS exchange)
             if (exchange_mode == 0 || w == 1) {
                 nr = N.AllGather(send_buf(s), s.gathered, (size_t)stride, ncclChar, gd.comm, cs);   // in place
             } else {
@@ -405,7 +462,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
                 nr = N.GroupStart();
                 for (int q = 0; q < w && nr == ncclSuccess; q++) {
                     if (q == me) continue;
-                    const bool full_to_q = exchange_mode == 1 || q == 0, full_from_q = exchange_mode == 1 || me == 0;
+                    const bool full_to_q = exchange_mode == 1 || (exchange_mode == 2 && q == 0), full_from_q = exchange_mode == 1 || (exchange_mode == 2 && me == 0);
                     nr = N.Send(send_buf(s), full_to_q ? (size_t)stride : (size_t)SDFK_SLAB_HEADER_BYTES, ncclChar, q, gd.comm, cs);
                     if (nr == ncclSuccess)
                         nr = N.Recv(s.gathered + (size_t)q * stride, full_from_q ? (size_t)stride : (size_t)SDFK_SLAB_HEADER_BYTES, ncclChar, q, gd.comm, cs);
@@ -419,7 +476,7 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         }
         // indices of slab r += vertices of slabs 0..r-1; the headers land in pinned host memory (one event, no copy).
         // (mode 2 on a rank other than 0: there are no foreign payloads to rebase -- the kernel sees header-only slabs)
-        const bool headers_only = exchange_mode == 2 && me != 0 && gd.backend == 1 && w > 1;
+        const bool headers_only = w > 1 && ((mode == 2 && me != 0 && gd.backend == 1) || mode == 3);
         if (idx16 && !headers_only)   // compact slabs: decode into the whole mesh's int32 index array (+ the header mirror)
             hipLaunchKernelGGL(sdfk::k_slabs_decode16, dim3(64, w), dim3(256), 0, cs, (const char*)s.gathered, w, stride, (sdfk::SlabHeader*)s.hdr_dev,
                                s.decoded, s.decoded_cap);
@@ -745,9 +802,16 @@ extern "C" int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out)
         }
     }
     if (nv >= (int64_t(1) << 31)) return fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])");
+    sdfk_dist_session::Slot& sl = s->slots[k];
+    if (!sl.payloads_gathered) {
+        // exchange mode 3: the step moved the headers only.  The whole mesh is asked for now: the payload exchange of THIS step
+        // (collective: every rank makes this call), then the usual extraction
+        int r = s->exchange_as(k, 0);
+        if (!r && hipEventSynchronize(sl.ready) != hipSuccess) r = fail(SDFK_ERR_HIP, "sdfk_dist_mesh: waiting for the payload exchange failed");
+        if (r) { if (!s->err.empty()) t_err = s->err; return r; }
+    }
     sdfk_mesh* m = nullptr;
     if (int r = alloc_mesh(&m, (size_t)nv, (size_t)ni)) return r;
-    sdfk_dist_session::Slot& sl = s->slots[k];
     ConcatArgs A{sl.gathered, gd.world, s->stride, m->vertices, m->colors, m->normals, m->triangles, m->bounds,
                  (s->idx16 && ni <= sl.decoded_cap) ? sl.decoded : nullptr};
     // (the slot's exchange has completed: collect waited for its `ready` event)
@@ -761,6 +825,48 @@ extern "C" int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out)
     m->nv = nv; m->ni = ni;
     memcpy(m->h_min, bmin, 12);
     memcpy(m->h_max, bmax, 12);
+    m->bounds_valid = true;
+    m->has_colors = s->vbytes == 36;
+    *out = m;
+    return SDFK_OK;
+}
+
+// This rank's OWN slab of the step collected last as a mesh of its own, indices global (+ the vertex counts of the slabs before it,
+// from the gathered headers): what a host assembles the whole mesh from without any payload exchange (exchange mode 3) -- every
+// rank copies its slab to the host over its own PCIe link, to the offsets sdfk_dist_counts gives.  Not collective.
+extern "C" int sdfk_dist_slab_mesh(sdfk_dist_session* s, sdfk_mesh** out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!s || !out) return fail(SDFK_ERR_INVALID, "sdfk_dist_slab_mesh: null argument");
+    *out = nullptr;
+    if (int r = require_init()) return r;
+    const int k = s->proto.last_slot();
+    const int64_t* h = s->proto.last_headers();
+    if (k < 0 || !h) return fail(SDFK_ERR_INVALID, "sdfk_dist_slab_mesh: no collected step (or its slot has been resubmitted)");
+    int64_t vbase = 0;
+    for (int q = 0; q < gd.world; q++) {
+        const int64_t* hq = h + q * sdfk::kSlabHeaderWords;
+        if (hq[0] < 0 || hq[1] < 0) return fail(SDFK_ERR_INVALID, "sdfk_dist_slab_mesh: the collected step has an unresolved slab");
+        if (q < gd.rank) vbase += hq[0];
+    }
+    const int64_t* me = h + gd.rank * sdfk::kSlabHeaderWords;
+    const int64_t nv = me[0], ni = me[1];
+    if (vbase + nv >= (int64_t(1) << 31)) return fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])");
+    sdfk_mesh* m = nullptr;
+    if (int r = alloc_mesh(&m, (size_t)nv, (size_t)ni)) return r;
+    sdfk_dist_session::Slot& sl = s->slots[k];
+    // (indices in this rank's section: still slab-local after a headers-only step or in the compact form, rebased in place otherwise)
+    const bool local_ids = !sl.payloads_gathered || s->idx16;
+    SlabExtractArgs A{s->send_buf(sl), m->vertices, m->colors, m->normals, m->triangles, m->bounds, local_ids ? (int32_t)vbase : 0};
+    const int64_t words = 9 * nv + ni;
+    hipLaunchKernelGGL(k_slab_extract, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((words + 1023) / 1024, 1024))), dim3(256), 0, g.stream, A);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(sl.read, g.stream);
+    if (e != hipSuccess) { sdfk_mesh_free(m); return fail(SDFK_ERR_HIP, "sdfk_dist_slab_mesh: %s", hipGetErrorString(e)); }
+    sl.read_valid = true;
+    m->nv = nv; m->ni = ni;
+    const float* b = reinterpret_cast<const float*>(me + 2);
+    if (nv > 0) { memcpy(m->h_min, b, 12); memcpy(m->h_max, b + 3, 12); }
     m->bounds_valid = true;
     m->has_colors = s->vbytes == 36;
     *out = m;

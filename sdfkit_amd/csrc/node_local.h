@@ -56,6 +56,13 @@ struct sdfk_node {
     int32_t writes_color = 0, nx = 0, ny = 0, nz = 0, clip = 0;
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, iso = 0.0f;
     sdfk_mesh* mesh0 = nullptr;
+    // host-array form (sdfk_node_mesh_begin / sdfk_node_mesh_copy): totals of the step in flight, the caller's arrays
+    int64_t total_v = 0, total_i = 0;
+    int32_t has_colors = 0;
+    float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+    bool step_open = false;
+    float *dst_v = nullptr, *dst_c = nullptr, *dst_n = nullptr;
+    int32_t* dst_t = nullptr;
     // start-up rendezvous
     unsigned char uid[SDFK_DIST_ID_BYTES] = {};
     NodeBarrier bar;
@@ -86,10 +93,76 @@ void node_worker_release(sdfk_node::Worker* w)
     w->key.clear();
 }
 
+// the rank's session for the scene of the current command (kept while the scene stays the same)
+int node_worker_session(sdfk_node::Worker* w);
+
 int node_worker_to_mesh(sdfk_node::Worker* w, sdfk_mesh** out)
 {
-    sdfk_node* n = w->node;
     *out = nullptr;
+    if (int r = node_worker_session(w)) return r;
+    int r = sdfk_dist_submit(w->sess);
+    if (!r) r = sdfk_dist_collect(w->sess, nullptr, nullptr);
+    // (the node's sessions leave the mesh sharded -- exchange mode 3 --: asking for the WHOLE mesh gathers the payloads of this step,
+    // which is collective; rank 0's copy is the one handed out)
+    sdfk_mesh* m = nullptr;
+    if (!r) r = sdfk_dist_mesh(w->sess, &m);
+    if (w->rank == 0) *out = m;
+    else if (m) sdfk_mesh_free(m);
+    return r;
+}
+
+// host-array form, phase 1: the step; every rank then knows every slab's counts (the headers) -- rank 0 publishes the totals
+int node_worker_begin(sdfk_node::Worker* w)
+{
+    sdfk_node* n = w->node;
+    if (int r = node_worker_session(w)) return r;
+    int r = sdfk_dist_submit(w->sess);
+    if (!r) r = sdfk_dist_collect(w->sess, nullptr, nullptr);
+    if (r || w->rank != 0) return r;
+    const int64_t* h = w->sess->proto.last_headers();
+    if (!h) return fail(SDFK_ERR_INVALID, "sdfk_node_mesh_begin: no collected step");
+    n->total_v = n->total_i = 0;
+    bool any = false;
+    for (int q = 0; q < n->world; q++) {
+        const int64_t* hq = h + q * sdfk::kSlabHeaderWords;
+        if (hq[0] < 0 || hq[1] < 0) return fail(SDFK_ERR_INVALID, "sdfk_node_mesh_begin: the step has an unresolved slab");
+        n->total_v += hq[0];
+        n->total_i += hq[1];
+        const float* b = reinterpret_cast<const float*>(hq + 2);
+        if (hq[0] > 0) {   // Mesh.Measure (Mesh.cs:30-45) over the slabs that have vertices
+            for (int c = 0; c < 3; c++) {
+                n->bmin[c] = any ? std::min(n->bmin[c], b[c]) : b[c];
+                n->bmax[c] = any ? std::max(n->bmax[c], b[3 + c]) : b[3 + c];
+            }
+            any = true;
+        }
+    }
+    if (!any) for (int c = 0; c < 3; c++) n->bmin[c] = n->bmax[c] = 0.0f;
+    if (n->total_v >= (int64_t(1) << 31)) return fail(SDFK_ERR_UNSUPPORTED, "vertex index exceeds int32 (Mesh.Triangles is int[])");
+    n->has_colors = w->sess->vbytes == 36;
+    return SDFK_OK;
+}
+
+// phase 2: every rank copies ITS slab into its slice of the caller's arrays -- over its own PCIe link, all ranks at once, no exchange
+// between the GPUs at all (the mesh stayed sharded)
+int node_worker_copy(sdfk_node::Worker* w)
+{
+    sdfk_node* n = w->node;
+    const int64_t* h = w->sess ? w->sess->proto.last_headers() : nullptr;
+    if (!h) return fail(SDFK_ERR_INVALID, "sdfk_node_mesh_copy: no step to copy (call sdfk_node_mesh_begin first)");
+    int64_t vb = 0, ib = 0;
+    for (int q = 0; q < w->rank; q++) { vb += h[q * sdfk::kSlabHeaderWords]; ib += h[q * sdfk::kSlabHeaderWords + 1]; }
+    sdfk_mesh* m = nullptr;
+    if (int r = sdfk_dist_slab_mesh(w->sess, &m)) return r;
+    const int r = sdfk_mesh_copy(m, n->dst_v ? n->dst_v + 3 * vb : nullptr, n->dst_c ? n->dst_c + 3 * vb : nullptr,
+                                 n->dst_n ? n->dst_n + 3 * vb : nullptr, n->dst_t ? n->dst_t + ib : nullptr);
+    sdfk_mesh_free(m);
+    return r;
+}
+
+int node_worker_session(sdfk_node::Worker* w)
+{
+    sdfk_node* n = w->node;
     std::string key((const char*)n->ops.data(), n->ops.size() * sizeof(sdfk_op));
     key.append((const char*)n->out_rgbw, sizeof n->out_rgbw);
     const int32_t dims[5] = {n->writes_color, n->nx, n->ny, n->nz, n->clip};
@@ -101,12 +174,10 @@ int node_worker_to_mesh(sdfk_node::Worker* w, sdfk_mesh** out)
         node_worker_release(w);
         if (int r = sdfk_program_create(n->ops.data(), (int32_t)n->ops.size(), n->out_rgbw, n->writes_color, &w->prog)) return r;
         if (int r = sdfk_dist_session_create(w->prog, n->mn, n->mx, n->nx, n->ny, n->nz, n->clip, n->iso, 1, &w->sess)) return r;
+        w->sess->exchange_mode = 3;   // the mesh stays sharded: a step moves the headers only, payloads travel when (and where) they are asked for
         w->key = key;
     }
-    int r = sdfk_dist_submit(w->sess);
-    if (!r) r = sdfk_dist_collect(w->sess, nullptr, nullptr);
-    if (!r && w->rank == 0) r = sdfk_dist_mesh(w->sess, out);   // (every rank holds the gathered slabs; rank 0's copy becomes the mesh)
-    return r;
+    return SDFK_OK;
 }
 
 void node_worker_main(sdfk_node::Worker* w)
@@ -151,6 +222,10 @@ void node_worker_main(sdfk_node::Worker* w)
             if (w->rank == 0) n->mesh0 = m;
             else if (m) sdfk_mesh_free(m);
         }
+        if ((cmd == 3 || cmd == 4) && ok) {
+            w->status = cmd == 3 ? node_worker_begin(w) : node_worker_copy(w);
+            w->error = w->status ? t_err : std::string();
+        }
         if (cmd == 2) {
             node_worker_release(w);
             sdfk_dist_shutdown();
@@ -175,6 +250,25 @@ int node_post(sdfk_node* n, int cmd)
     return SDFK_OK;
 }
 
+}  // namespace
+
+namespace {
+void node_set_scene(sdfk_node* n, const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color, const float min[3],
+                    const float max[3], int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds, float iso_value)
+{
+    n->ops.assign(ops, ops + n_ops);
+    memcpy(n->out_rgbw, out_rgbw, sizeof n->out_rgbw);
+    n->writes_color = writes_color;
+    memcpy(n->mn, min, 12);
+    memcpy(n->mx, max, 12);
+    n->nx = nx; n->ny = ny; n->nz = nz; n->clip = clip_to_bounds ? 1 : 0; n->iso = iso_value;
+}
+int node_first_error(sdfk_node* n, const char* what)
+{
+    for (auto& w : n->workers)
+        if (w.status) return fail(w.status, "%s: rank %d (device %d): %s", what, w.rank, w.device, w.error.c_str());
+    return SDFK_OK;
+}
 }  // namespace
 
 extern "C" int sdfk_node_open(const int32_t* devices, int32_t n_devices, sdfk_node** out)
@@ -238,13 +332,9 @@ extern "C" int sdfk_node_to_mesh(sdfk_node* n, const sdfk_op* ops, int32_t n_ops
     if (!n || !ops || n_ops <= 0 || !out_rgbw || !min || !max || !out) return fail(SDFK_ERR_INVALID, "sdfk_node_to_mesh: null/empty argument");
     *out = nullptr;
     std::lock_guard<std::mutex> one(n->call_mu);
-    n->ops.assign(ops, ops + n_ops);
-    memcpy(n->out_rgbw, out_rgbw, sizeof n->out_rgbw);
-    n->writes_color = writes_color;
-    memcpy(n->mn, min, 12);
-    memcpy(n->mx, max, 12);
-    n->nx = nx; n->ny = ny; n->nz = nz; n->clip = clip_to_bounds ? 1 : 0; n->iso = iso_value;
+    node_set_scene(n, ops, n_ops, out_rgbw, writes_color, min, max, nx, ny, nz, clip_to_bounds, iso_value);
     n->mesh0 = nullptr;
+    n->step_open = false;
     node_post(n, 1);
     for (auto& w : n->workers)
         if (w.status) {
@@ -254,6 +344,41 @@ extern "C" int sdfk_node_to_mesh(sdfk_node* n, const sdfk_op* ops, int32_t n_ops
         }
     *out = n->mesh0;
     n->mesh0 = nullptr;
+    return SDFK_OK;
+}
+
+
+// The mesh on the HOST, in two phases like every managed caller needs it (Mesh.cs:10-13: four exact-length arrays): begin runs the
+// sharded step and returns the totals; copy fills the caller's arrays -- every rank copies its own slab into its slice over its own
+// PCIe link, all at once; the slabs never cross xGMI.
+extern "C" int sdfk_node_mesh_begin(sdfk_node* n, const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color,
+                                    const float min[3], const float max[3], int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds,
+                                    float iso_value, int64_t* n_vertices, int64_t* n_indices, int32_t* has_colors)
+{
+    if (!n || !ops || n_ops <= 0 || !out_rgbw || !min || !max) return fail(SDFK_ERR_INVALID, "sdfk_node_mesh_begin: null/empty argument");
+    std::lock_guard<std::mutex> one(n->call_mu);
+    node_set_scene(n, ops, n_ops, out_rgbw, writes_color, min, max, nx, ny, nz, clip_to_bounds, iso_value);
+    n->step_open = false;
+    node_post(n, 3);
+    if (int r = node_first_error(n, "sdfk_node_mesh_begin")) return r;
+    n->step_open = true;
+    if (n_vertices) *n_vertices = n->total_v;
+    if (n_indices) *n_indices = n->total_i;
+    if (has_colors) *has_colors = n->has_colors;
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_node_mesh_copy(sdfk_node* n, float* vertices3, float* colors3, float* normals3, int32_t* triangles, float min[3], float max[3])
+{
+    if (!n) return fail(SDFK_ERR_INVALID, "sdfk_node_mesh_copy: null node");
+    std::lock_guard<std::mutex> one(n->call_mu);
+    if (!n->step_open) return fail(SDFK_ERR_INVALID, "sdfk_node_mesh_copy: no step to copy (call sdfk_node_mesh_begin first)");
+    n->dst_v = vertices3; n->dst_c = colors3; n->dst_n = normals3; n->dst_t = triangles;
+    node_post(n, 4);
+    n->dst_v = n->dst_c = n->dst_n = nullptr; n->dst_t = nullptr;
+    if (int r = node_first_error(n, "sdfk_node_mesh_copy")) return r;
+    if (min) memcpy(min, n->bmin, 12);
+    if (max) memcpy(max, n->bmax, 12);
     return SDFK_OK;
 }
 

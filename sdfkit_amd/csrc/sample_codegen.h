@@ -319,9 +319,9 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
 }
 // SDFK_KERNELS: bit mask of the entry points this module contains (the host compiles a program's kernels on demand:
 // bit 0 / 1 = the two instantiations without ClipToBounds, 3 / 4 = with it, 5 = sdfk_vertex_colors, 6 = sdfk_corners_eval, 7 = sdfk_raymarch,
-// 2 / 8 = the sign-bits-only samplers of SDFK_OPT_ELIDE_VOLUME, 9 / 10 = its block culling: sdfk_cull_blocks / sdfk_eval_blocks)
+// 2 / 8 = the sign-bits-only samplers of SDFK_OPT_ELIDE_VOLUME, 9 / 10 = its block culling: sdfk_cull_blocks / sdfk_eval_blocks, 11 = sdfk_eval_points)
 #ifndef SDFK_KERNELS
-#define SDFK_KERNELS 0x7ff
+#define SDFK_KERNELS 0xfff
 #endif
 #if SDFK_KERNELS & 0x04
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_signs(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_ROWS, false>(A, K); }
@@ -566,6 +566,23 @@ extern "C" __global__ __launch_bounds__(256) void sdfk_vertex_colors(SampleArgs 
         float* c = V.colors + 3ul * o;
         c[0] = out[0]; c[1] = out[1]; c[2] = out[2];
     }
+}
+#endif
+
+// SdfEx.Sample (Sdf.cs:22-47): the SDF at arbitrary points, one lane per point.  The delegate writes into the caller's Vector4 buffer:
+// a delegate that only assigns .W (Sdfs.Sphere, Sdf.cs:211) leaves X, Y, Z of every element as the caller had them -- here too.
+struct PointArgs { const float* points; float* rgbw; long n; };
+#if SDFK_KERNELS & 0x800
+extern "C" __global__ __launch_bounds__(256) void sdfk_eval_points(PointArgs A, SdfkK K)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    float r, g, b, w;
+    sdf_eval(K, A.points[3 * i], A.points[3 * i + 1], A.points[3 * i + 2], r, g, b, w);
+#if SDFK_WRITES_COLOR
+    A.rgbw[4 * i] = r; A.rgbw[4 * i + 1] = g; A.rgbw[4 * i + 2] = b;
+#endif
+    A.rgbw[4 * i + 3] = w;
 }
 #endif
 

@@ -719,7 +719,6 @@ int64_t g_copy_stats[5] = {0, 0, 0, 0, 0};   // last staged copy: bytes, ns unti
 // DMA transfers are in flight where the copy is the runtime's own (resident / pinned destinations), before the copy otherwise
 int copy_to_host(const std::vector<CopyPiece>& pieces, const std::function<void()>& beside = nullptr)
 {
-    std::lock_guard<std::recursive_mutex> pool_lk(g_pool_mu);
     int mode = g_cfg.copy_mode;   // SDFK_OPT_COPY_MODE
     size_t total = 0;
     for (auto& p : pieces) total += p.bytes;
@@ -761,6 +760,9 @@ int copy_to_host(const std::vector<CopyPiece>& pieces, const std::function<void(
         return SDFK_OK;
     }
     if (beside) beside();
+    // (from here on the shared thread pool works for this copy: one client at a time.  The runtime's own copy above needs no pool:
+    // the ranks of a local node copy their slabs side by side, each over its own PCIe link)
+    std::lock_guard<std::recursive_mutex> pool_lk(g_pool_mu);
     if (mode == 1 && stage_reserve() != SDFK_OK) mode = 0;   // no pinned memory to be had: the runtime's copy still works
     if (mode == 1) {
         const auto tp0 = std::chrono::steady_clock::now();
@@ -841,7 +843,7 @@ int copy_to_host(const std::vector<CopyPiece>& pieces, const std::function<void(
 // ---------------------------------------------------------------------------
 // Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
 enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_SIGNS = 2, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_VCOLORS = 5, PK_CORNERS = 6, PK_RAYMARCH = 7,
-                  PK_SIGNS_FLAT = 8, PK_CULL = 9, PK_EVAL_BLOCKS = 10, PK_COUNT = 11 };
+                  PK_SIGNS_FLAT = 8, PK_CULL = 9, PK_EVAL_BLOCKS = 10, PK_POINTS = 11, PK_COUNT = 12 };
 static bool pk_is_sampler(int k) { return k <= PK_BITS_CLIP_FLAT || k == PK_SIGNS_FLAT || k == PK_CULL || k == PK_EVAL_BLOCKS; }
 
 // The compiled kernels of one program STRUCTURE (opcodes, operand ids, outputs -- the generated source; a program's
@@ -1007,7 +1009,7 @@ static void config_from_env_once()
     g_cfg.copy_threads = ranged("SDFK_COPY_THREADS", 0, 0, 256);
     g_cfg.corner_eval = geti("SDFK_NO_CORNER_EVAL", 0) ? 0 : 1;
     g_cfg.vcolor_eval = geti("SDFK_NO_VCOLOR_EVAL", 0) ? 0 : 1;
-    g_cfg.dist_exchange = ranged("SDFK_DIST_EXCHANGE", 0, 0, 2);
+    g_cfg.dist_exchange = ranged("SDFK_DIST_EXCHANGE", 0, 0, 3);
     g_cfg.dist_lanes = ranged("SDFK_DIST_LANES", 3, 0, 3);
     g_cfg.dist_index16 = geti("SDFK_DIST_INDEX16", 0) ? 1 : 0;
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
@@ -1255,7 +1257,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_COPY_MODE: if (!in(0, 2)) break; g_cfg.copy_mode = (int)value; return SDFK_OK;
     case SDFK_OPT_CORNER_EVAL: if (!in(0, 1)) break; g_cfg.corner_eval = (int)value; return SDFK_OK;
     case SDFK_OPT_VCOLOR_EVAL: if (!in(0, 1)) break; g_cfg.vcolor_eval = (int)value; return SDFK_OK;
-    case SDFK_OPT_DIST_EXCHANGE: if (!in(0, 2)) break; g_cfg.dist_exchange = (int)value; return SDFK_OK;
+    case SDFK_OPT_DIST_EXCHANGE: if (!in(0, 3)) break; g_cfg.dist_exchange = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_LANES: if (!in(0, 3)) break; g_cfg.dist_lanes = (int)value; return SDFK_OK;
     case SDFK_OPT_DIST_INDEX16: if (!in(0, 1)) break; g_cfg.dist_index16 = (int)value; return SDFK_OK;
     case SDFK_OPT_STREAM_PLACEMENT: if (!in(0, 1)) break; g_cfg.place_streams = (int)value; return SDFK_OK;
@@ -1538,7 +1540,7 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::vector<char> code;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
     config_from_env();
-    return compile_source(src, 0x7ffu, code, false);   // every kernel, a real compile: this IS the check
+    return compile_source(src, 0xfffu, code, false);   // every kernel, a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -1567,7 +1569,7 @@ int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
     if (!p->fn[k]) {
         static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_signs", "sdfk_sample_bits_clip",
                                                     "sdfk_sample_bits_clip_flat", "sdfk_vertex_colors", "sdfk_corners_eval", "sdfk_raymarch",
-                                                    "sdfk_sample_signs_flat", "sdfk_cull_blocks", "sdfk_eval_blocks"};
+                                                    "sdfk_sample_signs_flat", "sdfk_cull_blocks", "sdfk_eval_blocks", "sdfk_eval_points"};
         unsigned mask = 1u << k;
         if (k == PK_CULL || k == PK_EVAL_BLOCKS) mask |= (1u << PK_CULL) | (1u << PK_EVAL_BLOCKS);   // (a pair)
         if (pk_is_sampler(k) && !p->fn[PK_CORNERS]) {   // (and, for a program that writes colours, sdfk_vertex_colors)
@@ -3214,6 +3216,55 @@ extern "C" int sdfk_sample_march(const sdfk_program* p, const float min[3], cons
     if (!r && (*out)->pending && (*out)->src == v) (*out)->owns_src = true;   // freed when the mesh is resolved
     else sdfk_volume_free(v);
     return r;
+}
+
+// ---------------------------------------------------------------------------
+// SdfEx.Sample (Sdf.cs:22-47): the SDF at arbitrary points
+// ---------------------------------------------------------------------------
+static int eval_points_launch(const sdfk_program* p, const float* points_dev, int64_t n, float* rgbw_dev)
+{
+    struct { const float* points; float* rgbw; long n; } A{points_dev, rgbw_dev, (long)n};   // (= PointArgs of sample_codegen.h)
+    hipFunction_t fn = nullptr;
+    if (int r = program_fn(p, PK_POINTS, &fn)) return r;
+    void* params[] = {&A, p->kargs()};
+    ProfScope ps("sdfk_eval_points");
+    HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, g.stream, params, nullptr));
+    return SDFK_OK;
+}
+
+extern "C" int sdfk_eval_points_device(const sdfk_program* p, const void* points3_dev, int64_t n, void* rgbw4_dev)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || n < 0 || (n > 0 && (!points3_dev || !rgbw4_dev))) return fail(SDFK_ERR_INVALID, "sdfk_eval_points: null / negative argument");
+    if (n >= (int64_t(1) << 31) * 256) return fail(SDFK_ERR_INVALID, "sdfk_eval_points: too many points");
+    if (int r = require_init()) return r;
+    if (n == 0) return SDFK_OK;
+    return eval_points_launch(p, (const float*)points3_dev, n, (float*)rgbw4_dev);
+}
+
+extern "C" int sdfk_eval_points(const sdfk_program* p, const float* points3, int64_t n, float* rgbw4)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!p || n < 0 || (n > 0 && (!points3 || !rgbw4))) return fail(SDFK_ERR_INVALID, "sdfk_eval_points: null / negative argument");
+    if (n >= (int64_t(1) << 31) * 256) return fail(SDFK_ERR_INVALID, "sdfk_eval_points: too many points");
+    if (int r = require_init()) return r;
+    if (n == 0) return SDFK_OK;
+    float* pd = nullptr;
+    float* od = nullptr;
+    int r = dev_alloc((void**)&pd, (size_t)n * 3 * sizeof(float));
+    if (!r) r = dev_alloc((void**)&od, (size_t)n * 4 * sizeof(float));
+    hipError_t e = hipSuccess;
+    if (!r) e = hipMemcpyAsync(pd, points3, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, g.stream);
+    // (a program that only assigns .W leaves X, Y, Z of the caller's elements alone, as the reference's delegates do: they travel there and back)
+    if (!r && e == hipSuccess && !p->writes_color) e = hipMemcpyAsync(od, rgbw4, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, g.stream);
+    if (!r && e == hipSuccess) r = eval_points_launch(p, pd, n, od);
+    if (!r && e == hipSuccess) e = hipMemcpyAsync(rgbw4, od, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, g.stream);
+    const hipError_t es = hipStreamSynchronize(g.stream);   // (the caller's arrays are not retained; the pool is stream-ordered)
+    dev_free(pd);
+    dev_free(od);
+    if (r) return r;
+    if (e != hipSuccess || es != hipSuccess) return fail(SDFK_ERR_HIP, "sdfk_eval_points: %s", hipGetErrorString(e != hipSuccess ? e : es));
+    return SDFK_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -160,6 +160,14 @@ class SlabSession:
         """This rank's slab kernels without the exchange (measurement)."""
         N.check(self.L.sdfk_dist_enqueue_only(self.h))
 
+    def slab_mesh(self):
+        """Host copy of THIS rank's slab of the step collected last, indices global (sdfk_dist_slab_mesh: no payload exchange --
+        with SDFK_OPT_DIST_EXCHANGE = 3 the whole mesh is the ranks' slabs in rank order)."""
+        from .api import Mesh
+        m = C.c_void_p()
+        N.check(self.L.sdfk_dist_slab_mesh(self.h, C.byref(m)))
+        return Mesh._from_handle(m)
+
     def mesh(self):
         """Host copy of the whole mesh of the step collected last."""
         from .api import Mesh
@@ -250,6 +258,26 @@ class Node:
     def to_mesh(self, sdf, mn, mx, nx, ny, nz, clipToBounds=True, isoValue=0.0):
         from .api import Mesh
         return Mesh._from_handle(self.to_mesh_handle(sdf, mn, mx, nx, ny, nz, clipToBounds, isoValue))
+
+    def to_mesh_host(self, sdf, mn, mx, nx, ny, nz, clipToBounds=True, isoValue=0.0):
+        """The same mesh assembled on the HOST: sdfk_node_mesh_begin (the sharded step, totals) + sdfk_node_mesh_copy (every rank copies
+        its own slab into its slice of the four exact-length arrays, all PCIe links at once; the slabs never cross xGMI)."""
+        from .api import Mesh, MeshArrayPool
+        import numpy as np
+        arr, n, out = sdf.ir()
+        nv, ni, hc = C.c_int64(), C.c_int64(), C.c_int32()
+        N.check(N.lib().sdfk_node_mesh_begin(self._h, arr, n, out, int(sdf.writes_color), N.f3(mn), N.f3(mx), nx, ny, nz,
+                                             1 if clipToBounds else 0, C.c_float(isoValue), C.byref(nv), C.byref(ni), C.byref(hc)))
+        if Mesh.Pool is None:
+            Mesh.Pool = MeshArrayPool()
+        pool = Mesh.Pool
+        v, c, nn = (pool.rent((nv.value, 3), np.float32) for _ in range(3))
+        t = pool.rent((ni.value,), np.int32)
+        lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
+        N.check(N.lib().sdfk_node_mesh_copy(self._h, v.ctypes.data, c.ctypes.data, nn.ctypes.data, t.ctypes.data, lo, hi))
+        m = Mesh(v, c, nn, t, np.array(lo[:], np.float32), np.array(hi[:], np.float32))
+        m._pool = pool
+        return m
 
     def close(self):
         if self._h is not None and self._h.value:

@@ -30,6 +30,17 @@ namespace SdfKit
             return inner == null ? cpu : GpuSdf.Tag(cpu, GpuSdf.WithColor(inner, color));
         }
 
+        // Sdf.cs:22-47: the SDF at arbitrary points.  A tagged SDF goes to the GPU in one call (sdfk_eval_points: the delegate's
+        // contract exactly -- a .W-only SDF leaves X, Y, Z of the caller's elements alone); an opaque delegate keeps the reference's
+        // batched Parallel.For (SampleCpu = the reference body, renamed).  Small batches stay on the CPU: a PCIe round trip costs more.
+        public static unsafe void Sample(this Sdf sdf, Memory<Vector3> points, Memory<Vector4> distances, int batchSize = SdfConfig.DefaultBatchSize, int maxDegreeOfParallelism = -1)
+        {
+            var prog = GpuSdf.ProgramOf(sdf);
+            if (prog == null || distances.Length < 4096) { SampleCpu(sdf, points, distances, batchSize, maxDegreeOfParallelism); return; }
+            using var hp = points.Pin(); using var hd = distances.Pin();
+            Native.Check(Native.sdfk_eval_points(prog.Handle, (float*)hp.Pointer, distances.Length, (float*)hd.Pointer));
+        }
+
         // Sdf.cs:59-63.  With a tagged SDF the whole chain stays on the device: ONE native call
         // (sample + ClipToBounds + sign bits fused, marching cubes, mesh left in HBM), then the copy into the
         // managed Mesh arrays.  batchSize / maxDegreeOfParallelism have no GPU meaning.

@@ -117,11 +117,20 @@ namespace SdfKit.Hip
             float* mx = stackalloc float[3] { max.X, max.Y, max.Z };
             var ops = new SdfkOp[program.Ops.Count];
             for (int i = 0; i < ops.Length; i++) ops[i] = program.Ops[i];
-            IntPtr mesh;
+            // two phases, as every managed mesh needs them (Mesh.cs:10-13: exact-length arrays): the sharded step + totals, then every GPU
+            // copies its own slab into its slice of the arrays over its own PCIe link (the slabs never cross xGMI)
+            long nv, ni; int hasColors;
             fixed (SdfkOp* po = ops) fixed (int* o = program.OutRgbw)
-                Native.Check(Native.sdfk_node_to_mesh(h, po, ops.Length, o, program.WritesColor ? 1 : 0, mn, mx, nx, ny, nz, clipToBounds ? 1 : 0, isoValue, out mesh));
-            // (the mesh lives in rank 0's context; its accessors work from this thread)
-            try { return SdfKit.Mesh.FromNative(mesh, program.WritesColor); } finally { Native.sdfk_mesh_free(mesh); }
+                Native.Check(Native.sdfk_node_mesh_begin(h, po, ops.Length, o, program.WritesColor ? 1 : 0, mn, mx, nx, ny, nz, clipToBounds ? 1 : 0, isoValue,
+                                                         out nv, out ni, out hasColors));
+            var v = MeshArrayPool.Rent<Vector3>(nv, out _); var nrm = MeshArrayPool.Rent<Vector3>(nv, out _); var t = MeshArrayPool.Rent<int>(ni, out _);
+            var recycled = hasColors != 0 ? MeshArrayPool.Rent<Vector3>(nv, out _) : MeshArrayPool.TryRent<Vector3>(nv);
+            var c = recycled ?? new Vector3[nv];                        // (no colours and no recycled array: a NEW array is zero already)
+            bool passColors = hasColors != 0 || recycled != null;       // (a recycled one is cleared by the library)
+            Vector3 lo, hi;
+            fixed (Vector3* pv = v, pc = c, pn = nrm) fixed (int* pt = t)
+                Native.Check(Native.sdfk_node_mesh_copy(h, (float*)pv, passColors ? (float*)pc : null, (float*)pn, pt, (float*)&lo, (float*)&hi));
+            return new Mesh(v, c, nrm, t, lo, hi);                      // (the internal constructor that skips Measure: Voxels.Hip.cs)
         }
 
         public void Dispose()

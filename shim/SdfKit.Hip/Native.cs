@@ -74,12 +74,17 @@ namespace SdfKit.Hip
         [DllImport(Lib)] public static extern int sdfk_dist_mesh(IntPtr session, out IntPtr mesh);
         [DllImport(Lib)] public static extern int sdfk_dist_tune(IntPtr session, int stepsPerMode, long* nsPerConfig4);
         [DllImport(Lib)] public static extern int sdfk_dist_stats(IntPtr session, long* stats8);
+        [DllImport(Lib)] public static extern int sdfk_dist_slab_mesh(IntPtr session, out IntPtr mesh);
         [DllImport(Lib)] public static extern void sdfk_dist_session_free(IntPtr session);
+        [DllImport(Lib)] public static extern int sdfk_eval_points(IntPtr program, float* points3, long n, float* rgbw4);   // SdfEx.Sample, Sdf.cs:22-47
         // several GPUs from ONE process (the managed host is one process): include/sdfkit_hip.h, "one process, several GPUs"
         [DllImport(Lib)] public static extern int sdfk_node_open(int* devices, int nDevices, out IntPtr node);
         [DllImport(Lib)] public static extern int sdfk_node_info(IntPtr node, out int world, out int backend);
         [DllImport(Lib)] public static extern int sdfk_node_to_mesh(IntPtr node, SdfkOp* ops, int nOps, int* outRgbw, int writesColor, float* min, float* max,
                                                                     int nx, int ny, int nz, int clip, float iso, out IntPtr mesh);
+        [DllImport(Lib)] public static extern int sdfk_node_mesh_begin(IntPtr node, SdfkOp* ops, int nOps, int* outRgbw, int writesColor, float* min, float* max,
+                                                                       int nx, int ny, int nz, int clip, float iso, out long nVertices, out long nIndices, out int hasColors);
+        [DllImport(Lib)] public static extern int sdfk_node_mesh_copy(IntPtr node, float* vertices3, float* colors3, float* normals3, int* triangles, float* min, float* max);
         [DllImport(Lib)] public static extern void sdfk_node_close(IntPtr node);
         // RayMarcher (RayMarcher.cs:45-211)
         [DllImport(Lib)] public static extern int sdfk_raymarch(IntPtr program, int width, int height, float* cameraPosition, float* viewProjectionInverse,

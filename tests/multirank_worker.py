@@ -35,7 +35,7 @@ if REAL:
     D.init(device=DEVICE)
 else:
     D.init_host(device=0)
-MODE = N.get_option(N.OPT_DIST_EXCHANGE) if REAL else -1
+MODE = N.get_option(N.OPT_DIST_EXCHANGE) if REAL else -1      # (the host transport reports -1; SDFK_DIST_EXCHANGE=3 still means "headers only")
 HOLDS_MESH = not (REAL and MODE == 2 and dist.get_rank() != 0)   # gather-to-root: only rank 0 holds the whole mesh
 graphs_on = N.get_option(N.OPT_GRAPHS) != 0 and N.get_option(N.OPT_DIST_LANES) != 0
 
@@ -57,12 +57,26 @@ elif REAL:   # (collective: every rank makes the call; the ranks that hold no me
         ok = False
     except N.SdfKitNativeError as e:
         ok = "only rank 0 holds the mesh" in str(e)
+def own_slab_is_its_slice(ses):
+    """sdfk_dist_slab_mesh: this rank's slab, indices global = the slice of the whole (oracle) mesh the headers' counts delimit"""
+    counts, r = ses.counts(), dist.get_rank()
+    vb, ib = sum(c[0] for c in counts[:r]), sum(c[1] for c in counts[:r])
+    nv, ni = counts[r]
+    sm = ses.slab_mesh()
+    return bool(np.array_equal(sm.Vertices, om.vertices[vb:vb + nv]) and np.array_equal(sm.Triangles, om.triangles[ib:ib + ni]) and
+                np.array_equal(sm.Colors, om.colors[vb:vb + nv]) and np.array_equal(sm.Normals, om.normals[vb:vb + nv], equal_nan=True))
+
+
 ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=3)
 for it in range(16):
     if ses.in_flight == ses.depth:
         ses.collect()
+        if it % 3 == 0:
+            ok &= own_slab_is_its_slice(ses)      # (before the whole mesh is asked for: exchange mode 3 has moved no payload yet)
         if HOLDS_MESH:
             ok &= same(ses.mesh())
+        if it % 3 == 1:
+            ok &= own_slab_is_its_slice(ses)      # (and after: the payloads have been gathered and rebased in place)
     ses.submit()
 while ses.in_flight:
     ses.collect()

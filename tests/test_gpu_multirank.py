@@ -131,7 +131,7 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims), om)
     # (exchange, payload form, internal streams, steps in flight): the default, the opt-ins, the CONSERVATIVE retry grades of
     # bench.py (one step in flight; no lanes at all) and the compact gather-to-root form (tools/gpu_alt_configs.sh)
-    for mode, idx16, lanes, depth in ((0, 0, 3, 3), (1, 0, 3, 3), (2, 0, 3, 3), (1, 1, 3, 3), (0, 1, 3, 3), (0, 0, 3, 1), (0, 0, 0, 1), (2, 1, 3, 3), (2, 1, 0, 1)):
+    for mode, idx16, lanes, depth in ((0, 0, 3, 3), (1, 0, 3, 3), (2, 0, 3, 3), (1, 1, 3, 3), (0, 1, 3, 3), (0, 0, 3, 1), (0, 0, 0, 1), (2, 1, 3, 3), (2, 1, 0, 1), (3, 0, 3, 3), (3, 1, 3, 1)):
         N.set_option(N.OPT_DIST_EXCHANGE, mode)
         N.set_option(N.OPT_DIST_INDEX16, idx16)
         N.set_option(N.OPT_DIST_LANES, lanes)
@@ -264,14 +264,17 @@ def test_sharded_step_host_cost_world_one(gpu):
     assert d["config"]["vertices"] > 10000
 
 
-@pytest.mark.parametrize("world,name,dims,idx16", [(2, "readme_repeat_xy", (40, 36, 44), 0), (3, "union8", (36, 40, 50), 0), (4, "sphere_w", (64, 64, 64), 0),
-                                                   (3, "readme_repeat_xy", (40, 36, 44), 1), (2, "sphere_w", (64, 64, 64), 1)])
-def test_pipelined_session_full_parity_multi_rank(gpu, world, name, dims, idx16):
+@pytest.mark.parametrize("world,name,dims,idx16,exchange", [(2, "readme_repeat_xy", (40, 36, 44), 0, 0), (3, "union8", (36, 40, 50), 0, 0), (4, "sphere_w", (64, 64, 64), 0, 0),
+                                                            (3, "readme_repeat_xy", (40, 36, 44), 1, 0), (2, "sphere_w", (64, 64, 64), 1, 0),
+                                                            (3, "readme_repeat_xy", (40, 36, 44), 0, 3), (2, "union8", (36, 40, 50), 1, 3), (4, "sphere_w", (64, 64, 64), 0, 3)])
+def test_pipelined_session_full_parity_multi_rank(gpu, world, name, dims, idx16, exchange):
     """2-4 ranks (one GPU, the library's host transport over gloo), real kernels: every rank's whole mesh == the oracle's, bit
-    for bit -- with int32 indices rebased by the step, and with the compact 16-bit index payloads decoded by sdfk_dist_mesh."""
+    for bit -- with int32 indices rebased by the step, and with the compact 16-bit index payloads decoded by sdfk_dist_mesh.
+    exchange 3 = the mesh stays sharded: a step moves the 64-byte headers only; every rank's OWN slab (sdfk_dist_slab_mesh, global
+    indices) is its slice of the oracle's mesh, and sdfk_dist_mesh gathers the payloads of that step on demand."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join("tests", "multirank_worker.py"), name] + [str(d) for d in dims]
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, SDFK_DIST_INDEX16=str(idx16)))
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, SDFK_DIST_INDEX16=str(idx16), SDFK_DIST_EXCHANGE=str(exchange)))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count("identical") == world
 

@@ -52,6 +52,10 @@ def test_node_meshes_are_the_oracles(gpu, devices):
         for rep in range(2):
             assert_mesh_equal(node.to_mesh(sdf2, mn2, mx2, *dims, clipToBounds=True), ref2)
         assert_mesh_equal(node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False), ref)
+        # the host-array form: begin (the step, totals) + copy (every rank its own slab into its slice; nothing crosses between the GPUs)
+        for rep in range(2):
+            assert_mesh_equal(node.to_mesh_host(sdf2, mn2, mx2, *dims, clipToBounds=True), ref2)
+            assert_mesh_equal(node.to_mesh_host(sdf, mn, mx, *dims, clipToBounds=False), ref)
         # the calling thread's own context is untouched by the node's private ones
         assert_mesh_equal(sdf.ToMesh(mn, mx, *dims, clipToBounds=False), ref)
         # a mesh handle of the node is an ordinary handle: accessors from this thread, device-side transform included
