@@ -456,6 +456,129 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
     }
 }
 
+// The write pass with the lanes' segments INTERLEAVED (SDFK_COMPACT_STRIDED): lane L of a block takes segments L, L + 256, L + 512 and
+// L + 768 of the block's 1024 instead of four consecutive ones.  A run of busy segments -- a row near a tangent of the surface
+// holds up to 64 records per segment -- then spreads over neighbouring lanes instead of piling up to 256 records on one lane, whose
+// serial walk over its set bits was the tail of the launch (round 4's timeline: writing 1.0 us for the first wavefront, up to 5 us of
+// waiting for the slowest).  Quarter k of the block is exactly what wavefront k of the COUNT pass covered, so "nothing there" is a
+// wave-uniform test per quarter.  One 64-bit workgroup scan of the four packed per-quarter counts (a quarter holds at most
+// 256 x 64 = 2^14 records) gives every segment its place in sweep order.
+__global__ __launch_bounds__(256) void k_compact_write(McParams P)
+{
+    const int b = (int)blockIdx.x;                 // logical block = (layer, part)
+    const int lay = b / P.bpl, part = b - lay * P.bpl;
+    const int z = P.lay_count_begin + lay;
+    const int nlay = P.lay_list_end - P.lay_count_begin, nlog = nlay * P.bpl;
+    const int nseg = P.ncy * P.nxw;
+    const int s0 = part * 1024 + (int)threadIdx.x;
+    // this lane's share of the counts of all blocks before b (in flight together with the sign words below)
+    uint32_t before = 0;
+    for (int i = threadIdx.x; i < b; i += 1024) {
+        const uint32_t c0 = (uint32_t)P.blockcnt[i];
+        const uint32_t c1 = i + 256 < b ? (uint32_t)P.blockcnt[i + 256] : 0u;
+        const uint32_t c2 = i + 512 < b ? (uint32_t)P.blockcnt[i + 512] : 0u;
+        const uint32_t c3 = i + 768 < b ? (uint32_t)P.blockcnt[i + 768] : 0u;
+        before += (c0 + c1) + (c2 + c3);
+    }
+    bool look[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) look[k] = P.wavecnt[b * 4 + k] != 0;   // (uniform over the workgroup)
+    uint64_t m[4] = {0, 0, 0, 0};
+    int ys[4] = {0, 0, 0, 0}, xws[4] = {0, 0, 0, 0};
+    {
+        const size_t plane = (size_t)P.ny * P.nxw;
+        const uint64_t* f0 = P.bits + (size_t)z * plane;
+        u64x2u wa[4], wb[4], wc[4], wd[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {      // all loads first
+            const int s = s0 + 256 * k;
+            wa[k] = wb[k] = wc[k] = wd[k] = u64x2u{0, 0};
+            if (look[k] && s < nseg) {
+                const uint64_t* q = f0 + s;
+                wa[k] = *reinterpret_cast<const u64x2u*>(q);
+                wb[k] = *reinterpret_cast<const u64x2u*>(q + P.nxw);
+                wc[k] = *reinterpret_cast<const u64x2u*>(q + plane);
+                wd[k] = *reinterpret_cast<const u64x2u*>(q + plane + P.nxw);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = s0 + 256 * k;
+            if (s < nseg) {
+                ys[k] = s / P.nxw;
+                xws[k] = s - ys[k] * P.nxw;
+                if (look[k]) {
+                    uint64_t m13;
+                    m[k] = segment_mask(wa[k].x, wa[k].y, wb[k].x, wb[k].y, wc[k].x, wc[k].y, wd[k].x, wd[k].y, P.ncx - xws[k] * 64, m13);
+                }
+            }
+        }
+    }
+    // segment order within the block = (quarter k, lane): exclusive prefix of the packed per-quarter counts over the lanes, then the
+    // totals of the quarters before
+    __shared__ uint64_t s_wave[4];
+    const uint64_t mine = (uint64_t)__popcll(m[0]) | ((uint64_t)__popcll(m[1]) << 16) | ((uint64_t)__popcll(m[2]) << 32) | ((uint64_t)__popcll(m[3]) << 48);
+    uint64_t total;
+    const uint64_t pre = block_excl_scan_u64(mine, s_wave, &total);
+    __shared__ uint32_t s_before[4];
+    {
+        const uint32_t r = wave_sum_u32(before);
+        if ((threadIdx.x & 63) == 0) s_before[threadIdx.x >> 6] = r;
+    }
+    __syncthreads();
+    const uint32_t base = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+    if (b == 0) {
+        // the first block publishes the totals and the layer marks (everything follows from the count pass's blockcnt[])
+        uint64_t ghost = 0, upto_emit_end = 0, all13 = 0, all = 0;
+        const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.bpl, ge = (P.lay_emit_end - P.lay_count_begin) * P.bpl;
+        for (int i = threadIdx.x; i < nlog; i += 256) {
+            const uint64_t wv = P.blockcnt[i];
+            const uint64_t c = wv & 0xffffffffull;
+            all += c;
+            if (i < gb) ghost += c;
+            if (i < ge) upto_emit_end += c;
+            all13 += wv >> 32;
+        }
+        __shared__ uint64_t s_sum[4][4];
+        ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13); all = wave_sum_u64(all);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; s_sum[3][wave] = all; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t ng = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
+            const uint64_t ue = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
+            const uint32_t nall = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
+            P.counters->n_active = nall;
+            P.counters->n_ghost_cells = (uint32_t)ng;
+            P.counters->n_emit_cells = (uint32_t)(ue - ng);
+            P.counters->n_case13 = (uint32_t)(s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]);
+            P.rowstart[(size_t)nlay * P.ncy] = nall;   // sentinel after the last layer's rows
+        }
+    }
+    uint32_t* rowstart = P.rowstart + (size_t)lay * P.ncy;
+    uint32_t qbase = base;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int s = s0 + 256 * k;
+        if (s < nseg) {
+            uint32_t pos = qbase + (uint32_t)((pre >> (16 * k)) & 0xffffull);
+            if (xws[k] == 0) rowstart[ys[k]] = pos;   // first record of cell row (z, y)
+            const uint32_t yz = (uint32_t)ys[k] << P.xbits;
+            uint64_t mk = m[k];
+            while (mk) {
+                const int bit = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                if (pos < P.cap_active) {
+                    P.rec_xy[pos] = (uint32_t)(xws[k] * 64 + bit) | yz;
+                    P.rec_z[pos] = (uint32_t)z;
+                }
+                pos++;
+            }
+        }
+        qbase += (uint32_t)((total >> (16 * k)) & 0xffffull);
+    }
+}
+
 // Sum of the per-chunk (vertices << 31 | triangles) totals of chunks [from, to) over the
 // workgroup (a few thousand words at most, L2 resident): every workgroup derives the prefix of
 // its own chunk this way instead of waiting for a separate scan launch.

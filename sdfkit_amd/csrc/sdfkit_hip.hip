@@ -2091,7 +2091,13 @@ int launch_classify(sdfk_march_job* j, bool publish)
         // (a workgroup takes the same 1024 segments of K2_LPB consecutive layers: mc_kernels.hip)
         const int nwg = ((P.lay_list_end - P.lay_count_begin + K2_LPB - 1) / K2_LPB) * P.bpl;
         hipLaunchKernelGGL(k_compact<false>, dim3(nwg), dim3(256), 0, g.stream, P);
-        hipLaunchKernelGGL(k_compact<true>, dim3(nwg), dim3(256), 0, g.stream, P);
+#ifndef SDFK_COMPACT_STRIDED
+#define SDFK_COMPACT_STRIDED 1
+#endif
+        if (SDFK_COMPACT_STRIDED && K2_LPB == 1)   // (the write pass with interleaved segments: mc_kernels.hip)
+            hipLaunchKernelGGL(k_compact_write, dim3((P.lay_list_end - P.lay_count_begin) * P.bpl), dim3(256), 0, g.stream, P);
+        else
+            hipLaunchKernelGGL(k_compact<true>, dim3(nwg), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
     }
     const int nchunks = (int)((P.cap_active + MC_CHUNK - 1u) / MC_CHUNK);
