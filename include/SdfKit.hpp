@@ -37,6 +37,11 @@ struct Vector3 {
     static Vector3 Zero() { return Vector3(0, 0, 0); }
     float Length() const { return std::sqrt((X * X + Y * Y) + Z * Z); }
 };
+struct Vector4 {   // (colour, distance) of a sample: what an Sdf delegate writes per point (Sdf.cs:8)
+    float X = 0, Y = 0, Z = 0, W = 0;
+    Vector4() = default;
+    Vector4(float x, float y, float z, float w) : X(x), Y(y), Z(z), W(w) {}
+};
 inline Vector3 operator+(Vector3 a, Vector3 b) { return {a.X + b.X, a.Y + b.Y, a.Z + b.Z}; }
 inline Vector3 operator-(Vector3 a, Vector3 b) { return {a.X - b.X, a.Y - b.Y, a.Z - b.Z}; }
 inline Vector3 operator*(Vector3 a, float s) { return {a.X * s, a.Y * s, a.Z * s}; }
@@ -191,6 +196,14 @@ public:
     // SdfEx.WithColor (Sdf.cs:101-115)
     Sdf WithColor(Vector3 color) const { PointFn f = st_->fn; return Sdf([f, color](Vec3 p) { return Vec4(Vec3(color), f(p).W); }, true); }
     Sdf WithColor(float r, float g, float b) const { return WithColor(Vector3(r, g, b)); }
+    // SdfEx.Sample (Sdf.cs:22-47): the SDF at arbitrary points; out[i] = (colour, distance) of points[i] -- an SDF that only assigns .W leaves
+    // X, Y, Z of the caller's elements alone, like the reference's delegates.  batchSize / maxDegreeOfParallelism have no GPU meaning.
+    void Sample(const std::vector<Vector3>& points, std::vector<Vector4>& out, int /*batchSize*/ = 2048, int /*maxDegreeOfParallelism*/ = -1) const
+    {
+        if (out.size() != points.size()) out.resize(points.size());
+        static_assert(sizeof(Vector3) == 12 && sizeof(Vector4) == 16, "plain float triples / quadruples");
+        Check(sdfk_eval_points(Program(), points.empty() ? nullptr : &points[0].X, (int64_t)points.size(), out.empty() ? nullptr : &out[0].X));
+    }
     // SdfEx.ToVoxels / ToMesh (Sdf.cs:49-63)
     inline Voxels ToVoxels(Vector3 min, Vector3 max, int nx, int ny, int nz, int batchSize = 2048, int maxDegreeOfParallelism = -1, bool clipToBounds = true) const;
     inline Mesh ToMesh(Vector3 min, Vector3 max, int nx, int ny, int nz, int batchSize = 2048, int maxDegreeOfParallelism = -1,

@@ -162,8 +162,7 @@ struct Context {
     size_t stage_bytes = 0;
     // pinned host arena (sdfk_host_alloc): size-class free lists like the device pool; a block in
     // `host_live` is in the caller's hands
-    std::multimap<size_t, void*> host_free;
-    std::map<void*, size_t> host_live;
+    // (the arena itself is process-wide: HostArena below -- a block may be freed, or be the destination of a copy, in any context)
     // sizes seen last time for a (shape, iso-independent) key: lets a repeat call launch the
     // whole pipeline speculatively and synchronise once
     struct Hint { uint32_t n_active, nv, ni; };
@@ -240,6 +239,14 @@ inline DeviceState& cur_state() { return *(t_state ? t_state : g_default_state);
 #define g_codes (cur_state().codes)
 #define g_code_clock (cur_state().code_clock)
 #define g_graph_build_failures (cur_state().graph_build_failures)
+// Pinned host arena (sdfk_host_alloc): process-wide -- pinned memory belongs to no device context (hipHostMallocPortable), and a host
+// may free a block, or name it as the destination of a copy, from a thread whose current context is another one than the allocator's.
+struct HostArena {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;   // size-class free lists, equal keys in order of return
+    std::map<void*, size_t> live;               // blocks in the callers' hands
+};
+HostArena g_arena;
 // the calling thread works in context `st` for the lifetime of the scope (accessors of a handle that belongs to another thread's
 // context: the mesh a local node hands back, sdfk_node_to_mesh)
 struct StateScope {
@@ -726,8 +733,9 @@ int copy_to_host(const std::vector<CopyPiece>& pieces, const std::function<void(
     bool pinned = true;   // every destination inside a block of the library's pinned arena: plain DMA, nothing to pre-fault
     for (auto& p : pieces) {
         if (!p.bytes) continue;
-        auto it = g.host_live.upper_bound(p.dst);
-        if (it == g.host_live.begin()) { pinned = false; break; }
+        std::lock_guard<std::mutex> al(g_arena.mu);
+        auto it = g_arena.live.upper_bound(p.dst);
+        if (it == g_arena.live.begin()) { pinned = false; break; }
         --it;
         if ((const char*)p.dst + p.bytes > (const char*)it->first + it->second) { pinned = false; break; }
     }
@@ -1169,9 +1177,20 @@ extern "C" void sdfk_shutdown(void)
     if (g.stage) (void)hipHostFree(g.stage);
     g.stage = nullptr;
     g.stage_bytes = 0;
-    for (auto& kv : g.host_free) (void)hipHostFree(kv.second);
-    g.host_free.clear();
-    g.host_live.clear();   // blocks still in their owners' hands stay mapped (arrays of the host mirror may outlive the library state): leaked, not freed
+    {   // the pinned arena goes with the LAST context of the process (blocks still in their owners' hands stay mapped -- arrays of the
+        // host mirror may outlive the library state --: leaked, not freed)
+        bool last = true;
+        {
+            std::lock_guard<std::mutex> rl(g_registry_mu);
+            for (DeviceState* q : g_states) last = last && (q == &cur_state() || q->claimed_device < 0);
+        }
+        if (last) {
+            std::lock_guard<std::mutex> al(g_arena.mu);
+            for (auto& kv : g_arena.free_blocks) (void)hipHostFree(kv.second);
+            g_arena.free_blocks.clear();
+            g_arena.live.clear();
+        }
+    }
     if (g.slots) (void)hipHostFree(g.slots);
     g.slots = nullptr;
     g.slots_dev = nullptr;
@@ -3338,37 +3357,41 @@ extern "C" int sdfk_raymarch(const sdfk_program* p, int32_t width, int32_t heigh
 // ---------------------------------------------------------------------------
 extern "C" int sdfk_host_alloc(int64_t n_bytes, void** out)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!out || n_bytes < 0) return fail(SDFK_ERR_INVALID, "sdfk_host_alloc: bad argument");
     *out = nullptr;
-    if (int r = require_init()) return r;
+    {
+        std::lock_guard<std::recursive_mutex> lk(g_mu);
+        if (int r = require_init()) return r;
+    }
     const size_t c = size_class((size_t)std::max<int64_t>(n_bytes, 1));
+    std::lock_guard<std::mutex> al(g_arena.mu);
     // (the block of this size class that was freed LAST: equal keys keep their insertion order, so it is the one before the upper
     // bound -- its pages are the likeliest to be in the host's caches and TLBs)
-    auto it = g.host_free.upper_bound(c);
+    auto it = g_arena.free_blocks.upper_bound(c);
     void* p = nullptr;
-    if (it != g.host_free.begin() && std::prev(it)->first == c) {
+    if (it != g_arena.free_blocks.begin() && std::prev(it)->first == c) {
         --it;
         p = it->second;
-        g.host_free.erase(it);
-    } else if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) {
-        for (auto& kv : g.host_free) (void)hipHostFree(kv.second);   // drop the cache and retry once
-        g.host_free.clear();
-        if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) return fail(SDFK_ERR_NOMEM, "hipHostMalloc(%zu) failed", c);
+        g_arena.free_blocks.erase(it);
+    } else if (hipHostMalloc(&p, c, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        for (auto& kv : g_arena.free_blocks) (void)hipHostFree(kv.second);   // drop the cache and retry once
+        g_arena.free_blocks.clear();
+        if (hipHostMalloc(&p, c, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return fail(SDFK_ERR_NOMEM, "hipHostMalloc(%zu) failed", c); }
     }
-    g.host_live[p] = c;
+    g_arena.live[p] = c;
     *out = p;
     return SDFK_OK;
 }
 
 extern "C" void sdfk_host_free(void* p)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!p) return;
-    auto it = g.host_live.find(p);
-    if (it == g.host_live.end()) return;
-    g.host_free.emplace(it->second, p);   // back to the arena
-    g.host_live.erase(it);
+    std::lock_guard<std::mutex> al(g_arena.mu);
+    auto it = g_arena.live.find(p);
+    if (it == g_arena.live.end()) return;
+    g_arena.free_blocks.emplace(it->second, p);   // back to the arena
+    g_arena.live.erase(it);
 }
 
 // Makes [p, p + n_bytes) of the caller's (pageable) memory present and writable on the library's thread pool: what

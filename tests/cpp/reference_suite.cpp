@@ -242,9 +242,22 @@ TEST(MeshWriteObjFormat)   // Mesh.cs:66-97 + invariant-culture Single.ToString(
     IS_TRUE(txt.find("\nvn ") != std::string::npos && txt.find("\nf 1//1 ") != std::string::npos);
 }
 
+TEST(SdfSamplePoints)   // SdfEx.Sample (Sdf.cs:22-47): the value at the centre of a sphere of radius 0.5 is -0.5 (VolumeTests.cs:83-106 asserts the same of the grid)
+{
+    auto sdf = Sdfs::Sphere(0.5f);
+    std::vector<Vector3> pts = {Vector3(0, 0, 0), Vector3(0.5f, 0, 0), Vector3(0, 2, 0), Vector3(3, 4, 0)};
+    std::vector<Vector4> out(pts.size(), Vector4(9, 8, 7, 6));
+    sdf.Sample(pts, out);
+    IS_TRUE(out[0].W == -0.5f && out[1].W == 0.0f && out[2].W == 1.5f && out[3].W == 4.5f);
+    IS_TRUE(out[0].X == 9 && out[2].Y == 8 && out[3].Z == 7);      // a .W-only delegate leaves X, Y, Z alone (Sdf.cs:211)
+    auto col = sdf.WithColor(0.25f, 0.5f, 0.75f);
+    col.Sample(pts, out);
+    IS_TRUE(out[3].W == 4.5f && out[3].X == 0.25f && out[3].Y == 0.5f && out[3].Z == 0.75f);
+}
+
 int main()
 {
-    run_MeshWriteObjFormat();
+    run_MeshWriteObjFormat(); run_SdfSamplePoints();
     run_RayMarcherSphereDepth(); run_RayMarcherBoxDepth(); run_RayMarcherCylinderDepth(); run_RayMarcherPlaneDepth(); run_RayMarcherSphereRepeat();
     run_ColoredSpheres(); run_Sphere5(); run_Sphere10(); run_UnclippedSphere10(); run_ClippedSphere10(); run_Box10();
     run_Cylinder50(); run_Sphere128Progress(); run_CreateVolumeSphere(); run_CreateMeshSphere(); run_SolidSphere();

@@ -2,7 +2,7 @@
 """GPU soak test: a random interleaving of the API (fused ToMesh jobs read late / never read,
 two-stage volumes with explicit clip and edits, other iso values and steps, ray-marched frames,
 large grids under a randomly chosen SDFK_OPT_ELIDE_VOLUME, programs of one structure with new constants,
-recycled mesh arrays) for SECONDS (default 60), every result checked against oracle results computed up front."""
+recycled mesh arrays, the SDF at random points, a local node of two ranks sharing the GPU -- device mesh and host-array form) for SECONDS (default 60), every result checked against oracle results computed up front."""
 import ctypes as C
 import os
 import sys
@@ -48,11 +48,21 @@ def raw(case):
     return h
 
 
+from sdfkit_amd import dist as D
+node = D.Node([0, 0])                            # two ranks (threads of the library, a device context each) sharing GPU 0
 held, ops, t0 = [], 0, time.time()
 while time.time() - t0 < secs:
-    k = int(rng.integers(0, 11))
+    k = int(rng.integers(0, 13))
     case = CASES[int(rng.integers(0, len(CASES)))]
-    if k == 8:                                   # a large grid under a random volume-elision mode, mesh arrays recycled
+    if k == 11:                                  # the node: the whole mesh on the first rank's device, or straight into host arrays
+        mesh = (node.to_mesh if rng.random() < 0.5 else node.to_mesh_host)(case["sdf"], MN, MX, *case["dims"])
+        assert same(mesh, case["m"]), ("node", case["name"], case["dims"])
+    elif k == 12:                                # SdfEx.Sample at random points
+        pts = rng.uniform(-3, 3, (257, 3)).astype(np.float32)
+        got = case["sdf"].Sample(pts)
+        want = np.stack([O.eval_point(case["scene"], p) for p in pts[:64]])
+        assert np.array_equal(got[:64, 3].view(np.uint32), want[:, 3].view(np.uint32)), ("points", case["name"])
+    elif k == 8:                                   # a large grid under a random volume-elision mode, mesh arrays recycled
         big = BIG[int(rng.integers(0, len(BIG)))]
         with N.option(N.OPT_ELIDE_VOLUME, int(rng.integers(0, 3))):
             mesh = big["sdf"].ToMesh(MN, MX, *big["dims"])
@@ -102,4 +112,5 @@ while time.time() - t0 < secs:
     ops += 1
 for case2, h in held:
     assert same(Mesh._from_handle(h), case2["m"])
+node.close()
 print(f"stress ok: {ops} operations in {time.time() - t0:.1f} s")
