@@ -706,7 +706,7 @@ def main():
     # ---- latency of ONE call, nothing else in flight, everything on one stream: sdfk_sample_march,
     # then the accessor that waits for it (what a caller that needs each mesh before it builds the
     # next one gets; the headline `value` is the pipelined steady state)
-    latency_ms = None
+    latency_ms = latency_default_ms = None
     if not sharded and not args.minimal:
         for _ in range(3):
             sample_march_once()
@@ -715,6 +715,17 @@ def main():
         for _ in range(args.steps):
             sample_march_once()
         latency_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        # ... and the same with the PRODUCT default (SDFK_OPT_ELIDE_VOLUME = 2: the temporary volume is not stored, blocks away from the
+        # surface are not evaluated): what one synchronous sdf.ToMesh costs a caller who changes nothing
+        if n ** 3 > (1 << 24):
+            with N.option(N.OPT_ELIDE_VOLUME, 2):
+                for _ in range(3):
+                    sample_march_once()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    sample_march_once()
+                latency_default_ms = (time.perf_counter() - t0) / args.steps * 1e3
     N.set_option(N.OPT_LANES, lanes_before)
 
     # The roofline kernel on its own: K back-to-back launches of the fused sampling kernel into a
@@ -828,7 +839,8 @@ def main():
               "elided_volume_ms_per_step": None if e3 is None else round(e3 * 1e3, 4),
               "elided_volume_no_culling_ms_per_step": None if e31 is None else round(e31 * 1e3, 4),
               "sampler_us_back_to_back": round(samp3_us, 1),
-              "sampler_frac": round(bytes3 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+              "sampler_frac": round(n ** 3 * 16 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),            # algorithmic: 16 B/voxel stored
+              "sampler_frac_design_bytes": round(bytes3 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),   # + 1/8 B/voxel of sign bytes
               "what": "BASELINE config C3 in this run: pipelined sample -> mesh of the README scene (colours: 16 B/voxel stored), then its sampling "
                       "kernel alone, launched back to back into two resident volumes; fractions = bytes / time / 8 TB/s (design: 16 + 1/8 B per "
                       "voxel + the mesh; measured: profiles/pmc_traffic.json)"}
@@ -1048,12 +1060,14 @@ def main():
     if rank == 0:
         nvox_rank = n * n * (D.slab(n, world, rank)[3] if world > 1 else n)
         colors = bool(sdf.writes_color)
-        # algorithmic bytes per launch: sample stores 4 B/voxel (+12 B colour),
-        # signbits loads 4 B/voxel; candidates for "dominant kernel"
-        cands = {}
-        for k in kern:  # sdfk_sample_bits[_clip][_anynz]: whichever entry point of the fused sampler ran
-            if k.startswith("sdfk_sample_bits"):  # stores: 4 B/voxel distance (+12 B colour) + 1/8 B/voxel sign bits
-                cands[k] = nvox_rank * (16 if colors else 4) + nvox_rank // 8
+        # ALGORITHMIC bytes per launch of the dominant kernel = SURVEY.md section 8(d)'s per-unit figure x the voxels of one launch: the
+        # sampling kernel STORES 4 B/voxel of distance (+ 12 B/voxel of colour).  The 1/8 B/voxel of sign bytes the fused kernel also
+        # leaves are this design's own (design_bytes_per_launch, and what the PMC `traffic` contains): not counted in `achieved`
+        cands, design = {}, {}
+        for k in kern:  # sdfk_sample_bits[_clip][_flat]: whichever entry point of the fused sampler ran
+            if k.startswith("sdfk_sample_bits"):
+                cands[k] = nvox_rank * (16 if colors else 4)
+                design[k] = cands[k] + nvox_rank // 8
         dom = max(cands, key=lambda k: kern[k]["avg_us"]) if cands else None
         roof = None
         if dom:
@@ -1063,7 +1077,8 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(dom, args.scene, n),
                     "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command, committed; not re-measured in this run)",
-                    "algorithmic_bytes_per_launch": cands[dom], "avg_launch_us": round(us, 2),
+                    "algorithmic_bytes_per_launch": cands[dom], "design_bytes_per_launch": design[dom],
+                    "frac_design_bytes_per_launch": round(design[dom] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 2),
                     "method": ("one HIP event pair on the launch stream around K back-to-back launches of the kernel alone (four resident "
                                "volumes in turn), divided by K" if own else
                                "hipEvent pairs around each launch on the launch stream, K-step pipeline pass on ONE in-order stream")
@@ -1121,6 +1136,7 @@ def main():
                                                    "value_cold_clocks is the figure without it"},
             "mtris_per_s": round(ni / 3 / step_s / 1e6, 2),
             "latency_ms_single_stream": None if latency_ms is None else round(latency_ms, 4),
+            "latency_ms_single_stream_product_default": None if latency_default_ms is None else round(latency_default_ms, 4),
             "first_call_ms": first_call_ms,
             "first_call_new_constants_ms": first_call_new_constants_ms,   # the same structure, another radius: no compile (first_call.new_constants)
             "first_call": first,

@@ -228,3 +228,43 @@ def test_padded_rows_upload_download_round_trip(gpu, dims):
     N.check(L.sdfk_march(h, C.c_float(0.0), 1, C.byref(m)))
     assert_mesh_equal(Mesh._from_handle(m), O.march(vals, cols, mn, mx))
     L.sdfk_volume_free(h)
+
+
+def test_device_colours_of_a_w_only_mesh_are_zero_on_demand(gpu):
+    """A .W-only program's mesh colours are all zero (Voxels.cs:88-92) and k_vertices does not store them (12 bytes per vertex saved per
+    job): whoever asks for DEVICE colours -- sdfk_mesh_device_ptrs, sdfk_mesh_copy_device -- gets them zeroed then, whatever the buffer
+    held before (the pool hands out recycled blocks)."""
+    import torch
+    L = N.lib()
+    mn, mx, dims = [-1.5] * 3, [1.5] * 3, (96, 96, 96)
+    colored = S.CATALOGUE["sdf_with_color"]()[1]
+    plain = S.sphere_w(1.0)[1]
+    for rep in range(3):
+        # dirty the pool with a coloured mesh of a similar size first
+        h0 = _raw(colored, mn, mx, dims, False)
+        a0, b0 = C.c_int64(), C.c_int64()
+        N.check(L.sdfk_mesh_counts(h0, C.byref(a0), C.byref(b0)))
+        L.sdfk_mesh_free(h0)
+        h = _raw(plain, mn, mx, dims, False)
+        a, b = C.c_int64(), C.c_int64()
+        N.check(L.sdfk_mesh_counts(h, C.byref(a), C.byref(b)))
+        nv = a.value
+        assert nv > 1000
+        dst = torch.full((nv, 3), 5.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        N.check(L.sdfk_mesh_copy_device(h, None, C.c_void_p(dst.data_ptr()), None, None))
+        N.check(L.sdfk_synchronize())
+        assert not dst.cpu().numpy().any()
+        pv, pc = C.c_void_p(), C.c_void_p()
+        N.check(L.sdfk_mesh_device_ptrs(h, C.byref(pv), C.byref(pc), None, None))
+        N.check(L.sdfk_synchronize())
+        assert pc.value
+        # (the array behind that pointer is now valid: a second device copy takes it from there)
+        dst2 = torch.full((nv, 3), 3.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        N.check(L.sdfk_mesh_copy_device(h, None, C.c_void_p(dst2.data_ptr()), None, None))
+        N.check(L.sdfk_synchronize())
+        assert not dst2.cpu().numpy().any()
+        # the host copy agrees (it never reads the device colours of such a mesh)
+        m = Mesh._from_handle(h)
+        assert not m.Colors.any() and len(m.Vertices) == nv
