@@ -45,6 +45,11 @@ def test_sharded_bench_on_one_gpu(gpu, world):
         for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
             assert k in d
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1.2
+    # the pass that leaves the mesh sharded (exchange mode 3: only headers travel) ran after the headline and saw the same mesh
+    p3 = many["sharded"]["mesh_stays_sharded_pass"]
+    assert isinstance(p3, dict) and p3.get("counts_equal_the_headline_mesh") is True and p3["ms_per_step"] > 0, p3
+    assert many["sharded"]["speedup_ceiling_mesh_stays_sharded"] is None or many["sharded"]["speedup_ceiling_mesh_stays_sharded"] > 0
+    assert one["blocks"]["n"] >= 1 and one["blocks"]["ms_per_step_min"] <= one["ms_per_step"] <= one["blocks"]["ms_per_step_max"]
 
 
 @pytest.mark.parametrize("world", [2])
