@@ -180,16 +180,25 @@ class Sdf {
 public:
     Sdf(PointFn fn, bool writesColor) : st_(std::make_shared<State>()) { st_->fn = std::move(fn); st_->writesColor = writesColor; }
     bool WritesColor() const { return st_->writesColor; }
+    // the SDF as the flat op list the library compiles (what sdfk_program_create and sdfk_node_* take)
+    void Lower(std::vector<sdfk_op>& ops, int32_t out[4]) const
+    {
+        Builder b;
+        Vec3 p(Val(&b, b.emit(SDFK_OP_X)), Val(&b, b.emit(SDFK_OP_Y)), Val(&b, b.emit(SDFK_OP_Z)));
+        Vec4 o = st_->fn(p);
+        out[0] = out[1] = out[2] = -1;
+        out[3] = o.W.bind(&b);
+        if (st_->writesColor) { out[0] = o.X.bind(&b); out[1] = o.Y.bind(&b); out[2] = o.Z.bind(&b); }
+        ops = b.ops;
+    }
     sdfk_program* Program() const
     {
         if (!st_->prog) {
             EnsureInit();
-            Builder b;
-            Vec3 p(Val(&b, b.emit(SDFK_OP_X)), Val(&b, b.emit(SDFK_OP_Y)), Val(&b, b.emit(SDFK_OP_Z)));
-            Vec4 o = st_->fn(p);
-            int32_t out[4] = {-1, -1, -1, o.W.bind(&b)};
-            if (st_->writesColor) { out[0] = o.X.bind(&b); out[1] = o.Y.bind(&b); out[2] = o.Z.bind(&b); }
-            Check(sdfk_program_create(b.ops.data(), (int32_t)b.ops.size(), out, st_->writesColor ? 1 : 0, &st_->prog));
+            std::vector<sdfk_op> ops;
+            int32_t out[4];
+            Lower(ops, out);
+            Check(sdfk_program_create(ops.data(), (int32_t)ops.size(), out, st_->writesColor ? 1 : 0, &st_->prog));
         }
         return st_->prog;
     }
@@ -487,6 +496,44 @@ inline Mesh Sdf::ToMesh(Vector3 min, Vector3 max, int nx, int ny, int nz, int, i
     ReportProgress(progress, nz, step);
     return Mesh::FromHandle(m);
 }
+
+// ---------------------------------------------------------------------------------------
+// Node: SdfEx.ToMesh (Sdf.cs:59-63) over several GPUs from THIS process (sdfk_node_*)
+// ---------------------------------------------------------------------------------------
+// Every listed device gets a context and a rank thread of the library's own; ToMesh fills the caller's four exact-length arrays:
+// every GPU copies its own slab into its slice over its own PCIe link (the mesh stays sharded until it is on the host).
+class Node {
+public:
+    explicit Node(const std::vector<int32_t>& devices = {})
+    {
+        Check(sdfk_node_open(devices.empty() ? nullptr : devices.data(), (int32_t)devices.size(), &h_));
+        int32_t backend = 0;
+        Check(sdfk_node_info(h_, &world_, &backend));
+    }
+    ~Node() { if (h_) sdfk_node_close(h_); }
+    Node(const Node&) = delete;
+    Node& operator=(const Node&) = delete;
+    int World() const { return world_; }
+    Mesh ToMesh(const Sdf& sdf, Vector3 min, Vector3 max, int nx, int ny, int nz, bool clipToBounds = true, float isoValue = 0.0f) const
+    {
+        std::vector<sdfk_op> ops;
+        int32_t out[4];
+        sdf.Lower(ops, out);
+        int64_t nv = 0, ni = 0;
+        int32_t hasColors = 0;
+        Check(sdfk_node_mesh_begin(h_, ops.data(), (int32_t)ops.size(), out, sdf.WritesColor() ? 1 : 0, &min.X, &max.X, nx, ny, nz,
+                                   clipToBounds ? 1 : 0, isoValue, &nv, &ni, &hasColors));
+        Mesh m;
+        m.Vertices.resize(nv); m.Colors.resize(nv); m.Normals.resize(nv); m.Triangles.resize(ni);   // (value-initialised: zero colours already)
+        Check(sdfk_node_mesh_copy(h_, nv ? &m.Vertices.data()->X : nullptr, (nv && hasColors) ? &m.Colors.data()->X : nullptr,
+                                  nv ? &m.Normals.data()->X : nullptr, ni ? m.Triangles.data() : nullptr, &m.Min.X, &m.Max.X));
+        return m;
+    }
+
+private:
+    sdfk_node* h_ = nullptr;
+    int32_t world_ = 1;
+};
 
 // ---------------------------------------------------------------------------------------
 // RayMarcher (RayMarcher.cs) + the image containers it returns (VectorData.cs)

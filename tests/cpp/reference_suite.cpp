@@ -255,9 +255,27 @@ TEST(SdfSamplePoints)   // SdfEx.Sample (Sdf.cs:22-47): the value at the centre 
     IS_TRUE(out[3].W == 4.5f && out[3].X == 0.25f && out[3].Y == 0.5f && out[3].Z == 0.75f);
 }
 
+TEST(NodeOfTwoRanksSharingTheGpu)   // SdfEx.ToMesh (Sdf.cs:29-39: 1248 vertices) through sdfk_node_*: two rank threads of the library on GPU 0
+{
+    Node node({0, 0});
+    ARE_EQUAL(2, node.World());
+    for (int rep = 0; rep < 2; rep++) {
+        auto mesh = node.ToMesh(Sdfs::Sphere(0.5f), Vector3(-1, -1, -1), Vector3(1, 1, 1), 32, 32, 32);
+        ARE_EQUAL((size_t)1248, mesh.Vertices.size());
+        auto one = Sdfs::Sphere(0.5f).ToMesh(Vector3(-1, -1, -1), Vector3(1, 1, 1), 32, 32, 32);
+        ARE_EQUAL(one.Triangles.size(), mesh.Triangles.size());
+        bool same = one.Triangles == mesh.Triangles;
+        for (size_t i = 0; same && i < one.Vertices.size(); i++)
+            same = one.Vertices[i].X == mesh.Vertices[i].X && one.Vertices[i].Y == mesh.Vertices[i].Y && one.Vertices[i].Z == mesh.Vertices[i].Z &&
+                   one.Normals[i].X == mesh.Normals[i].X && one.Normals[i].Y == mesh.Normals[i].Y && one.Normals[i].Z == mesh.Normals[i].Z;
+        IS_TRUE(same);
+        IS_TRUE(one.Min.X == mesh.Min.X && one.Max.Z == mesh.Max.Z);
+    }
+}
+
 int main()
 {
-    run_MeshWriteObjFormat(); run_SdfSamplePoints();
+    run_MeshWriteObjFormat(); run_SdfSamplePoints(); run_NodeOfTwoRanksSharingTheGpu();
     run_RayMarcherSphereDepth(); run_RayMarcherBoxDepth(); run_RayMarcherCylinderDepth(); run_RayMarcherPlaneDepth(); run_RayMarcherSphereRepeat();
     run_ColoredSpheres(); run_Sphere5(); run_Sphere10(); run_UnclippedSphere10(); run_ClippedSphere10(); run_Box10();
     run_Cylinder50(); run_Sphere128Progress(); run_CreateVolumeSphere(); run_CreateMeshSphere(); run_SolidSphere();

@@ -32,4 +32,4 @@ def test_reference_suite_through_cpp_host_layer(tmp_path, gpu):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(p.stdout[-3000:], p.stderr[-2000:])
     assert p.returncode == 0, p.stdout[-3000:]
-    assert "21 tests, 0 failures" in p.stdout
+    assert "22 tests, 0 failures" in p.stdout
