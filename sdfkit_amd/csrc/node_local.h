@@ -68,6 +68,9 @@ struct sdfk_node {
     NodeBarrier bar;
     std::vector<const void*> send_ptrs;   // host transport: every rank's send buffer of the all-gather in progress
     std::mutex call_mu;                   // one sdfk_node_to_mesh at a time
+    // fault injection for the tests (SDFK_NODE_FAULT_RANK=k at sdfk_node_open): rank k fails the next command's rank-local
+    // part ONCE -- what an allocation failing on one device looks like to the others
+    std::atomic<int> fault_rank{-1};
 };
 
 namespace {
@@ -96,10 +99,30 @@ void node_worker_release(sdfk_node::Worker* w)
 // the rank's session for the scene of the current command (kept while the scene stays the same)
 int node_worker_session(sdfk_node::Worker* w);
 
+// Before the ranks enter a COLLECTIVE part of a command they agree that every one of them got there: a rank-local failure (an
+// allocation on ONE device) must fail the command on every rank -- the others would wait in the exchange for ever.  Returns the
+// first failing rank's status (the same on every rank), its message in t_err.
+int node_agree(sdfk_node::Worker* w, int mine)
+{
+    sdfk_node* n = w->node;
+    if (!mine && n->fault_rank.load() == w->rank) {
+        n->fault_rank.store(-1);
+        mine = fail(SDFK_ERR_NOMEM, "SDFK_NODE_FAULT_RANK: injected failure");
+    }
+    w->status = mine;
+    w->error = mine ? t_err : std::string();
+    n->bar.wait();
+    int r = SDFK_OK;
+    for (auto& q : n->workers)
+        if (q.status && !r) { r = q.status; if (&q != w) t_err = "rank " + std::to_string(q.rank) + " failed: " + q.error; }
+    n->bar.wait();   // (nobody changes its status before everybody has read it)
+    return r;
+}
+
 int node_worker_to_mesh(sdfk_node::Worker* w, sdfk_mesh** out)
 {
     *out = nullptr;
-    if (int r = node_worker_session(w)) return r;
+    if (int r = node_agree(w, node_worker_session(w))) return r;
     int r = sdfk_dist_submit(w->sess);
     if (!r) r = sdfk_dist_collect(w->sess, nullptr, nullptr);
     // (the node's sessions leave the mesh sharded -- exchange mode 3 --: asking for the WHOLE mesh gathers the payloads of this step,
@@ -115,7 +138,7 @@ int node_worker_to_mesh(sdfk_node::Worker* w, sdfk_mesh** out)
 int node_worker_begin(sdfk_node::Worker* w)
 {
     sdfk_node* n = w->node;
-    if (int r = node_worker_session(w)) return r;
+    if (int r = node_agree(w, node_worker_session(w))) return r;
     int r = sdfk_dist_submit(w->sess);
     if (!r) r = sdfk_dist_collect(w->sess, nullptr, nullptr);
     if (r || w->rank != 0) return r;
@@ -230,6 +253,8 @@ void node_worker_main(sdfk_node::Worker* w)
             node_worker_release(w);
             sdfk_dist_shutdown();
             sdfk_shutdown();          // (this thread's context: frees everything it holds and gives the context back)
+            context_unclaim(w->st);   // (also when the context never came up: sdfk_shutdown has nothing to do then)
+            t_state = nullptr;
         }
         {
             std::lock_guard<std::mutex> lk(n->mu);
@@ -296,6 +321,7 @@ extern "C" int sdfk_node_open(const int32_t* devices, int32_t n_devices, sdfk_no
     n->workers.resize(devs.size());
     n->send_ptrs.assign(devs.size(), nullptr);
     n->bar.n = n->world;
+    if (const char* f = getenv("SDFK_NODE_FAULT_RANK")) n->fault_rank.store(atoi(f));
     for (size_t i = 0; i < devs.size(); i++) {
         n->workers[i].node = n;
         n->workers[i].device = devs[i];

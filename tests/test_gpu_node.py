@@ -85,6 +85,28 @@ def test_node_errors_come_back_to_the_caller(gpu):
         assert_mesh_equal(node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False), _oracle(scene, mn, mx, dims, clip=False))
 
 
+def test_one_ranks_failure_fails_the_command_on_every_rank(gpu, monkeypatch):
+    """A rank-local failure (an allocation on ONE device) must not leave the other ranks waiting in the exchange: the ranks agree
+    that all of them reached the collective part before any enters it (node_local.h node_agree).  SDFK_NODE_FAULT_RANK injects
+    one such failure."""
+    L = N.lib()
+    mn, mx, dims = [-1.5] * 3, [1.5] * 3, (40, 40, 40)
+    scene, sdf = S.sphere_w(1.0)
+    ref = _oracle(scene, mn, mx, dims, clip=False)
+    for form in ("handle", "arrays"):
+        monkeypatch.setenv("SDFK_NODE_FAULT_RANK", "1")
+        with D.Node([0, 0, 0]) as node:
+            monkeypatch.delenv("SDFK_NODE_FAULT_RANK")
+            with pytest.raises(Exception, match="rank 1 failed.*injected"):
+                if form == "handle":
+                    node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False)
+                else:
+                    node.to_mesh_host(sdf, mn, mx, *dims, clipToBounds=False)
+            # the fault was for one command: the next one is served
+            assert_mesh_equal(node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False), ref)
+            assert_mesh_equal(node.to_mesh_host(sdf, mn, mx, *dims, clipToBounds=False), ref)
+
+
 def test_threads_have_their_own_current_context(gpu):
     """sdfk_init is per thread (like hipSetDevice): a second thread that initialises device 0 shares that device's context with the
     first; a thread that never called sdfk_init works in the process's first context; meshes made on one thread are read on another."""
