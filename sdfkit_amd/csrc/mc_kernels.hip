@@ -238,6 +238,52 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* s_
     return pre;
 }
 
+// Which chunk a workgroup starts with.  Workgroups are dealt round-robin over the eight XCDs (b and b + 8 share an L2), and a chunk's
+// second window in k_vertices is the first window of a chunk a few chunks further on (the next layer's cells): with G > 0 the q-th
+// workgroup of an XCD takes chunk ((q / G) * 8 + xcd) * G + q % G -- runs of G consecutive chunks per XCD -- so that the second
+// fetch of a window hits that XCD's L2.  G = 0: chunk b.  Measured at 512^3 (round 5, profiles/r05_ab_chunk_xcd_groups.txt):
+// k_vertices fetches 57.3 MB with G = 0, 51.3 (8), 41.6 (16), 36.7 (32), 34.3 (64) and takes 47.1 / 46.3 / 45.8-46.0 / 46.9 / 47.4 us
+// (long runs leave the XCDs unevenly loaded); k_resolve with the same dealing 15.8 -> 15.0 us; k_triangles reads nothing twice
+// and does not care.  (Round 2 had tried one contiguous EIGHTH of the chunks per XCD: 18 % slower.)
+#ifndef SDFK_KV_XCD_GROUP
+#define SDFK_KV_XCD_GROUP 16
+#endif
+#ifndef SDFK_KR_XCD_GROUP
+#define SDFK_KR_XCD_GROUP 16
+#endif
+#ifndef SDFK_KT_XCD_GROUP
+#define SDFK_KT_XCD_GROUP 0
+#endif
+template <uint32_t G>
+__device__ __forceinline__ uint32_t first_chunk_of_block()
+{
+    const uint32_t b = blockIdx.x;
+    if (G == 0) return b;
+    const uint32_t span = 8u * (G ? G : 1u), whole = (gridDim.x / span) * span;
+    if (b >= whole) return b;
+    const uint32_t xcd = b & 7u, q = b >> 3;
+    return ((q / (G ? G : 1u)) * 8u + xcd) * G + q % (G ? G : 1u);
+}
+
+// The compaction's logical blocks (layer, part) for the same dealing: a run of G workgroups of one XCD takes G consecutive LAYERS of one
+// part -- sign plane z + 1 of a layer is plane z of the next, so the run fetches G + 1 planes instead of 2 G (with block = workgroup
+// index the two fetches of a plane come from different XCDs: 34 MB through the fabric for a 16.8 MB array).  Layers beyond the last
+// whole group of G keep the plain order.  Returns layer * bpl + part.
+#ifndef SDFK_K2_XCD_GROUP
+#define SDFK_K2_XCD_GROUP 16
+#endif
+__device__ __forceinline__ int compact_block_of_workgroup(int nlay, int bpl)
+{
+    constexpr int G = SDFK_K2_XCD_GROUP;
+    if (G == 0) return (int)blockIdx.x;
+    const int v = (int)first_chunk_of_block<(uint32_t)G>();
+    const int GG = G ? G : 1, grouped = (nlay / GG) * GG * bpl;
+    if (v >= grouped) return v;
+    const int run = v / GG, k = v - run * GG;
+    const int lg = run / bpl, part = run - lg * bpl;
+    return (lg * GG + k) * bpl + part;
+}
+
 // ---------------------------------------------------------------------------
 // K2: ordered compaction of active cells
 // ---------------------------------------------------------------------------
@@ -296,7 +342,8 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
 {
     const int nlay = P.lay_list_end - P.lay_count_begin;
     const int nlog = nlay * P.bpl;                           // logical blocks: [layer][part]
-    const int part = (int)blockIdx.x % P.bpl, lay0 = ((int)blockIdx.x / P.bpl) * K2_LPB;
+    const int wg = K2_LPB == 1 ? compact_block_of_workgroup(nlay, P.bpl) : (int)blockIdx.x;   // (the workgroup's place in (layer group, part) order)
+    const int part = wg % P.bpl, lay0 = (wg / P.bpl) * K2_LPB;
     const int nl = min(K2_LPB, nlay - lay0);                 // layers of this workgroup
     const int b0 = lay0 * P.bpl + part;                      // logical block of its first layer; layer l: b0 + l * bpl
     const int nseg = P.ncy * P.nxw;
@@ -465,10 +512,10 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
 // 256 x 64 = 2^14 records) gives every segment its place in sweep order.
 __global__ __launch_bounds__(256) void k_compact_write(McParams P)
 {
-    const int b = (int)blockIdx.x;                 // logical block = (layer, part)
+    const int nlay = P.lay_list_end - P.lay_count_begin, nlog = nlay * P.bpl;
+    const int b = compact_block_of_workgroup(nlay, P.bpl);   // logical block = (layer, part)
     const int lay = b / P.bpl, part = b - lay * P.bpl;
     const int z = P.lay_count_begin + lay;
-    const int nlay = P.lay_list_end - P.lay_count_begin, nlog = nlay * P.bpl;
     const int nseg = P.ncy * P.nxw;
     const int s0 = part * 1024 + (int)threadIdx.x;
     // this lane's share of the counts of all blocks before b (in flight together with the sign words below)
@@ -802,7 +849,7 @@ __global__ __launch_bounds__(256, 5) void k_resolve(McParams P)
     const int nchunks = (int)((n + MC_CHUNK - 1u) / MC_CHUNK);
     float* col = s_v + threadIdx.x;
     int parity = 0;
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x, parity ^= 1) {
+    for (int c = (int)first_chunk_of_block<SDFK_KR_XCD_GROUP>(); c < nchunks; c += gridDim.x, parity ^= 1) {
         const uint32_t i = (uint32_t)c * MC_CHUNK + threadIdx.x;
         const bool mine_rec = threadIdx.x < MC_CHUNK && i < n;   // (lanes MC_CHUNK..255 idle here: see MC_CHUNK)
         uint32_t nown = 0, nt_emit = 0, nslots = 0, info = 0, dead = 0;
@@ -1026,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     if (blockIdx.x == 0) publish_totals(P);   // k_resolve has completed (stream order)
     uint64_t chunk_prefix = 0;
     uint32_t prefix_upto = 0;
-    for (uint32_t base = blockIdx.x * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
+    for (uint32_t base = first_chunk_of_block<SDFK_KV_XCD_GROUP>() * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
         const uint32_t cnt = min(MC_CHUNK, n - base);
         const uint32_t ci = base / MC_CHUNK;   // chunk index
         const uint32_t irec = base + threadIdx.x;
@@ -1392,7 +1439,7 @@ __global__ __launch_bounds__(256) void k_triangles(McParams P, McMeshOut M)
         }
     }
     __syncthreads();   // (s_rowoff is read below)
-    for (uint32_t base = blockIdx.x * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
+    for (uint32_t base = first_chunk_of_block<SDFK_KT_XCD_GROUP>() * MC_CHUNK; base < n; base += gridDim.x * MC_CHUNK) {
         const uint32_t irec = base + threadIdx.x;
         const uint32_t ci = base / MC_CHUNK;
         uint32_t my_ni = 0;
