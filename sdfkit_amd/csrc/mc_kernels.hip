@@ -337,6 +337,53 @@ __device__ __forceinline__ uint64_t segment_mask(uint64_t a, uint64_t an, uint64
 constexpr int K2_LPB = SDFK_COMPACT_LPB;
 static_assert(K2_LPB >= 1 && K2_LPB <= 8, "sign planes per workgroup are held in registers");
 
+// Totals of the compaction and the layer marks, from the count pass's blockcnt[] (one workgroup: the write pass's first block, or
+// k_blockscan).
+// (out of line, the few fields it needs by value: inlined into the write pass its registers cost every workgroup of that kernel a
+// wavefront of occupancy per SIMD -- 102 instead of 94 VGPRs --, and a reference to the kernel-argument block would force a scratch
+// copy of it at the call)
+__device__ __noinline__ void publish_compaction_impl(const uint64_t* blockcnt, McCounters* counters, uint32_t* rowstart_end, int gb, int ge, int nlog)
+{
+    uint64_t ghost = 0, upto_emit_end = 0, all13 = 0, all = 0;
+    const int nt = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < nlog; i0 += 4 * nt) {   // (four independent loads per trip)
+        uint64_t wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wv[k] = i0 + k * nt < nlog ? blockcnt[i0 + k * nt] : 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k * nt;
+            const uint64_t c = wv[k] & 0xffffffffull;
+            all += c;
+            if (i < gb) ghost += c;
+            if (i < ge) upto_emit_end += c;
+            all13 += wv[k] >> 32;
+        }
+    }
+    __shared__ uint64_t s_sum[4][16];
+    ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13); all = wave_sum_u64(all);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nt >> 6;
+    if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; s_sum[3][wave] = all; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t[4] = {0, 0, 0, 0};
+        for (int w = 0; w < nw; w++)
+            for (int q = 0; q < 4; q++) t[q] += s_sum[q][w];
+        const uint32_t nall = (uint32_t)t[3];
+        counters->n_active = nall;
+        counters->n_ghost_cells = (uint32_t)t[0];
+        counters->n_emit_cells = (uint32_t)(t[1] - t[0]);
+        counters->n_case13 = (uint32_t)t[2];
+        *rowstart_end = nall;   // sentinel after the last layer's rows
+    }
+}
+
+__device__ __forceinline__ void publish_compaction(const McParams& P, int nlay, int nlog)
+{
+    publish_compaction_impl(P.blockcnt, P.counters, P.rowstart + (size_t)nlay * P.ncy, (P.lay_emit_begin - P.lay_count_begin) * P.bpl,
+                            (P.lay_emit_end - P.lay_count_begin) * P.bpl, nlog);
+}
+
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_compact(McParams P)
 {
@@ -426,31 +473,7 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
             // The FIRST block publishes the totals and the layer marks: everything here follows from the count pass's blockcnt[], the
             // first block starts first and its extra work hides behind the rest of the launch (the last block, which did this in
             // rounds 1-3, starts last and was the launch's tail)
-            uint64_t ghost = 0, upto_emit_end = 0, all13 = 0, all = 0;
-            const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.bpl, ge = (P.lay_emit_end - P.lay_count_begin) * P.bpl;
-            for (int i = threadIdx.x; i < nlog; i += 256) {
-                const uint64_t wv = P.blockcnt[i];
-                const uint64_t c = wv & 0xffffffffull;
-                all += c;
-                if (i < gb) ghost += c;
-                if (i < ge) upto_emit_end += c;
-                all13 += wv >> 32;
-            }
-            __shared__ uint64_t s_sum[4][4];
-            ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13); all = wave_sum_u64(all);
-            const int lane = threadIdx.x & 63;
-            if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; s_sum[3][wave] = all; }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const uint64_t ng = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
-                const uint64_t ue = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
-                const uint32_t nall = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
-                P.counters->n_active = nall;
-                P.counters->n_ghost_cells = (uint32_t)ng;
-                P.counters->n_emit_cells = (uint32_t)(ue - ng);
-                P.counters->n_case13 = (uint32_t)(s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]);
-                P.rowstart[(size_t)nlay * P.ncy] = nall;   // sentinel after the last layer's rows
-            }
+            publish_compaction(P, nlay, nlog);
         }
         if (i0 < nseg) {
             uint32_t pos = base_acc + pre;
@@ -519,13 +542,18 @@ __global__ __launch_bounds__(256) void k_compact_write(McParams P)
     const int nseg = P.ncy * P.nxw;
     const int s0 = part * 1024 + (int)threadIdx.x;
     // this lane's share of the counts of all blocks before b (in flight together with the sign words below)
+    // (grids of many blocks: ONE word, left by k_blockscan -- summing 16 K predecessors per workgroup is 16 dependent round trips)
     uint32_t before = 0;
-    for (int i = threadIdx.x; i < b; i += 1024) {
-        const uint32_t c0 = (uint32_t)P.blockcnt[i];
-        const uint32_t c1 = i + 256 < b ? (uint32_t)P.blockcnt[i + 256] : 0u;
-        const uint32_t c2 = i + 512 < b ? (uint32_t)P.blockcnt[i + 512] : 0u;
-        const uint32_t c3 = i + 768 < b ? (uint32_t)P.blockcnt[i + 768] : 0u;
-        before += (c0 + c1) + (c2 + c3);
+    if (P.blockpre) {
+        if (threadIdx.x == 0) before = P.blockpre[b];
+    } else {
+        for (int i = threadIdx.x; i < b; i += 1024) {
+            const uint32_t c0 = (uint32_t)P.blockcnt[i];
+            const uint32_t c1 = i + 256 < b ? (uint32_t)P.blockcnt[i + 256] : 0u;
+            const uint32_t c2 = i + 512 < b ? (uint32_t)P.blockcnt[i + 512] : 0u;
+            const uint32_t c3 = i + 768 < b ? (uint32_t)P.blockcnt[i + 768] : 0u;
+            before += (c0 + c1) + (c2 + c3);
+        }
     }
     bool look[4];
 #pragma unroll
@@ -574,33 +602,9 @@ __global__ __launch_bounds__(256) void k_compact_write(McParams P)
     }
     __syncthreads();
     const uint32_t base = s_before[0] + s_before[1] + s_before[2] + s_before[3];
-    if (b == 0) {
+    if (b == 0 && !P.blockpre) {
         // the first block publishes the totals and the layer marks (everything follows from the count pass's blockcnt[])
-        uint64_t ghost = 0, upto_emit_end = 0, all13 = 0, all = 0;
-        const int gb = (P.lay_emit_begin - P.lay_count_begin) * P.bpl, ge = (P.lay_emit_end - P.lay_count_begin) * P.bpl;
-        for (int i = threadIdx.x; i < nlog; i += 256) {
-            const uint64_t wv = P.blockcnt[i];
-            const uint64_t c = wv & 0xffffffffull;
-            all += c;
-            if (i < gb) ghost += c;
-            if (i < ge) upto_emit_end += c;
-            all13 += wv >> 32;
-        }
-        __shared__ uint64_t s_sum[4][4];
-        ghost = wave_sum_u64(ghost); upto_emit_end = wave_sum_u64(upto_emit_end); all13 = wave_sum_u64(all13); all = wave_sum_u64(all);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) { s_sum[0][wave] = ghost; s_sum[1][wave] = upto_emit_end; s_sum[2][wave] = all13; s_sum[3][wave] = all; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint64_t ng = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
-            const uint64_t ue = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
-            const uint32_t nall = (uint32_t)(s_sum[3][0] + s_sum[3][1] + s_sum[3][2] + s_sum[3][3]);
-            P.counters->n_active = nall;
-            P.counters->n_ghost_cells = (uint32_t)ng;
-            P.counters->n_emit_cells = (uint32_t)(ue - ng);
-            P.counters->n_case13 = (uint32_t)(s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]);
-            P.rowstart[(size_t)nlay * P.ncy] = nall;   // sentinel after the last layer's rows
-        }
+        publish_compaction(P, nlay, nlog);
     }
     uint32_t* rowstart = P.rowstart + (size_t)lay * P.ncy;
     uint32_t qbase = base;
@@ -624,6 +628,61 @@ __global__ __launch_bounds__(256) void k_compact_write(McParams P)
         }
         qbase += (uint32_t)((total >> (16 * k)) & 0xffffull);
     }
+}
+
+// Grids of more than MC_SCAN_BLOCKS logical blocks (1024^3: 16 K): the exclusive prefix of the count pass's cell counts, ONE workgroup of
+// 1024 lanes between the two passes (each lane a run of consecutive blocks), and the totals the write pass's first block publishes
+// otherwise.  Below that size a write-pass workgroup sums its few predecessors itself, in flight with its sign words, and a launch
+// would only add its latency.
+// (both scans: a lane takes SCAN_PER consecutive entries, all loaded before the first is used -- 16 K entries are ONE trip of loads, one
+// workgroup scan and one trip of stores)
+constexpr int SCAN_PER = 16;
+template <class T>
+__device__ __forceinline__ T scan_1024(T sum, T* s_w /*[16]*/, T* tile_total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T n = __shfl_up(incl, o);
+        if (lane >= o) incl += n;
+    }
+    __syncthreads();   // (s_w of the previous tile has been read)
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    T pre = incl - sum, tile = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const T v = s_w[w];
+        if (w < wave) pre += v;
+        tile += v;
+    }
+    *tile_total = tile;
+    return pre;
+}
+
+__global__ __launch_bounds__(1024) void k_blockscan(McParams P)
+{
+    const int nlay = P.lay_list_end - P.lay_count_begin, nlog = nlay * P.bpl;
+    __shared__ uint32_t s_w[16];
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < nlog; t0 += 1024 * SCAN_PER) {
+        const int i = t0 + SCAN_PER * (int)threadIdx.x;
+        uint32_t c[SCAN_PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; k++) c[k] = i + k < nlog ? (uint32_t)P.blockcnt[i + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; k++) sum += c[k];
+        uint32_t tile;
+        uint32_t pre = carry + scan_1024(sum, s_w, &tile);
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; k++) {
+            if (i + k < nlog) P.blockpre[i + k] = pre;
+            pre += c[k];
+        }
+        carry += tile;
+    }
+    publish_compaction(P, nlay, nlog);
 }
 
 // Sum of the per-chunk (vertices << 31 | triangles) totals of chunks [from, to) over the
@@ -656,6 +715,12 @@ __device__ __forceinline__ uint64_t chunk_totals_sum(const uint64_t* chunktot, u
 {
     return chunk_totals_block(chunk_totals_lane(chunktot, from, to), s_part);
 }
+// This lane's share of the totals of chunks [0, to): summed from chunktot, or -- long lists, P.chunkscan -- the one word k_chunkscan left
+__device__ __forceinline__ uint64_t chunk_prefix_lane(const McParams& P, uint32_t to)
+{
+    if (P.chunkscan) return threadIdx.x == 0 ? P.chunkpre[to] : 0ull;
+    return chunk_totals_lane(P.chunktot, 0, to);
+}
 
 // Grand totals, the vertex count of the ghost layer, dead cells: published to the device
 // counters and to the host mirror by ONE workgroup after k_resolve has completed (workgroup 0
@@ -667,13 +732,15 @@ __device__ __forceinline__ void publish_totals(const McParams& P)
     // vertices numbered before the first emitted cell: chunk prefix + in-chunk prefix
     const uint32_t i0 = min(P.counters->n_ghost_cells, nrec);
     const uint32_t c0 = i0 / MC_CHUNK;
-    uint64_t all = 0, upto = 0, dead = 0;
-    for (uint32_t i = threadIdx.x; i < nch; i += 256u) {
-        const uint64_t v = P.chunktot[i];
-        all += v;
-        if (i < c0) upto += v;
-        dead += P.chunkdead[i];
-    }
+    uint64_t all = chunk_prefix_lane(P, nch), upto = chunk_prefix_lane(P, c0), dead = 0;
+    if (P.counters->n_case13 != 0)   // (k_resolve counts dead cells only in volumes that have such sign words at all)
+        for (uint32_t i = threadIdx.x; i < nch; i += 1024u) {
+            const uint32_t a = P.chunkdead[i];
+            const uint32_t b = i + 256u < nch ? P.chunkdead[i + 256u] : 0u;
+            const uint32_t c = i + 512u < nch ? P.chunkdead[i + 512u] : 0u;
+            const uint32_t d = i + 768u < nch ? P.chunkdead[i + 768u] : 0u;
+            dead += (uint64_t)(a + b) + (uint64_t)(c + d);
+        }
     all = wave_sum_u64(all); upto = wave_sum_u64(upto); dead = wave_sum_u64(dead);
     __shared__ uint64_t s_tot[3][4];
     if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_tot[0][w] = all; s_tot[1][w] = upto; s_tot[2][w] = dead; }
@@ -698,6 +765,32 @@ __device__ __forceinline__ void publish_totals(const McParams& P)
 }
 
 __global__ __launch_bounds__(256) void k_publish(McParams P) { publish_totals(P); }
+
+// Long record lists (capacities of more than MC_SCAN_CHUNKS chunks: 1024^3): the exclusive prefix of k_resolve's per-chunk totals, ONE
+// workgroup of 1024 lanes between k_resolve and k_vertices; chunkpre[number of chunks] = the grand total.
+__global__ __launch_bounds__(1024) void k_chunkscan(McParams P)
+{
+    const uint32_t nrec = min(P.counters->n_active, P.cap_active);
+    const uint32_t nch = (nrec + MC_CHUNK - 1u) / MC_CHUNK;
+    __shared__ uint64_t s_w[16];
+    uint64_t carry = 0;
+    for (uint32_t t0 = 0; t0 <= nch; t0 += 1024u * SCAN_PER) {   // (<=: the entry after the last chunk gets the total)
+        const uint32_t i = t0 + (uint32_t)SCAN_PER * threadIdx.x;
+        uint64_t c[SCAN_PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)SCAN_PER; k++) c[k] = i + k < nch ? P.chunktot[i + k] : 0ull;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; k++) sum += c[k];
+        uint64_t tile;
+        uint64_t pre = carry + scan_1024(sum, s_w, &tile);
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)SCAN_PER; k++) {
+            if (i + k <= nch) P.chunkpre[i + k] = pre;
+            pre += c[k];
+        }
+        carry += tile;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // shared helpers
@@ -1067,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
     {
         const uint32_t i0 = min(P.counters->n_ghost_cells, n);
         if (i0 > 0)   // (all records ghost: every chunk counts)
-            nghost = (uint32_t)(chunk_totals_sum(P.chunktot, 0, i0 < n ? i0 / MC_CHUNK : (n + MC_CHUNK - 1u) / MC_CHUNK, s_part) >> 31) +
+            nghost = (uint32_t)(chunk_totals_block(chunk_prefix_lane(P, i0 < n ? i0 / MC_CHUNK : (n + MC_CHUNK - 1u) / MC_CHUNK), s_part) >> 31) +
                      (i0 < n ? (P.rec_pre[i0] & 0xffffu) : 0u);
     }
     if (blockIdx.x == 0) publish_totals(P);   // k_resolve has completed (stream order)
@@ -1121,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 }
             }
             // (the totals of the chunks before this one ride in the same batch of loads)
-            prefix_lane = chunk_totals_lane(P.chunktot, prefix_upto, ci);
+            prefix_lane = P.chunkscan ? (threadIdx.x == 0 ? P.chunkpre[ci] : 0ull) : chunk_totals_lane(P.chunktot, prefix_upto, ci);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const uint32_t slot = threadIdx.x + 256u * k;
@@ -1134,11 +1227,14 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                 }
             }
         }
-        // chunk prefix = totals of all earlier chunks (advanced incrementally when a workgroup
-        // takes more than one chunk); left in chunkpre[] for k_triangles
-        chunk_prefix += chunk_totals_block(prefix_lane, s_part);
-        prefix_upto = ci;
-        if (threadIdx.x == 0) P.chunkpre[ci] = chunk_prefix;
+        // chunk prefix = totals of all earlier chunks (advanced incrementally when a workgroup takes more than one chunk); left in
+        // chunkpre[] for k_triangles (long lists: it comes from k_chunkscan, whole)
+        if (P.chunkscan) chunk_prefix = chunk_totals_block(prefix_lane, s_part);
+        else {
+            chunk_prefix += chunk_totals_block(prefix_lane, s_part);
+            prefix_upto = ci;
+            if (threadIdx.x == 0) P.chunkpre[ci] = chunk_prefix;
+        }
         s_pre[threadIdx.x] = threadIdx.x < cnt ? my_pre : total;
         if (threadIdx.x == 255) s_pre[256] = total;
         // vertex -> creator table (a cell creates at most 13): one LDS read per vertex instead of a search

@@ -16,6 +16,16 @@ namespace sdfk {
 constexpr uint32_t MC_CHUNK = MC_CHUNK_RECORDS;
 static_assert(MC_CHUNK >= 64 && MC_CHUNK <= 256, "one 256-thread workgroup per chunk");
 // vertex-id slots per chunk (rec_vid): a record references at most 13 distinct vertex ids (12 edges + the centre vertex)
+// logical compaction blocks / chunks of records above which ONE workgroup computes their prefix between two kernels of the chain
+// (k_blockscan, k_chunkscan) instead of every consumer workgroup summing its predecessors itself
+#ifndef SDFK_SCAN_BLOCKS
+#define SDFK_SCAN_BLOCKS 4096
+#endif
+#ifndef SDFK_SCAN_CHUNKS
+#define SDFK_SCAN_CHUNKS 4096
+#endif
+constexpr int MC_SCAN_BLOCKS = SDFK_SCAN_BLOCKS;
+constexpr uint32_t MC_SCAN_CHUNKS = SDFK_SCAN_CHUNKS;
 constexpr uint32_t MC_VSTRIDE = MC_CHUNK * 13u;
 static_assert(MC_VSTRIDE <= 4096, "the in-chunk slot prefix has 12 bits in rec_info");
 
@@ -51,8 +61,14 @@ struct McParams {
     int bpl;               // logical blocks of k_compact per layer: ceil(ncy * nxw / 1024)
     uint64_t* blockcnt;    // per logical block of k_compact: active cells | case-13 sign words << 32
     uint32_t* wavecnt;     // active cells per wavefront of the count pass ([block][4])
+    uint32_t* blockpre;    // non-null (grids of more than MC_SCAN_BLOCKS logical blocks): exclusive prefix of blockcnt's cell counts, by
+                           // k_blockscan between the two passes -- a write-pass workgroup that sums its predecessors itself reads
+                           // O(blocks) words, O(blocks^2) per launch: 16 K blocks at 1024^3
     uint64_t* chunktot;    // (vertices << 31 | triangles) per MC_CHUNK-record chunk (k_resolve)
-    uint64_t* chunkpre;    // exclusive prefix of chunktot, per chunk (k_vertices, read by k_triangles)
+    uint64_t* chunkpre;    // exclusive prefix of chunktot, per chunk (+ the total after the last): by k_vertices, read by k_triangles
+    int chunkscan;         // 1 (record capacities of more than MC_SCAN_CHUNKS chunks): chunkpre comes from k_chunkscan, one workgroup
+                           // between k_resolve and k_vertices -- a k_vertices workgroup that sums its predecessors' totals itself reads
+                           // O(chunks) words: 13 K chunks at 1024^3, 13 dependent round trips per workgroup
     // Active cells ("records") in serial-sweep order.  Everything the emit kernels read is
     // compact (tens of MB, L2/MALL resident): no per-voxel maps.
     uint32_t* rec_xy;      // x | y << xbits

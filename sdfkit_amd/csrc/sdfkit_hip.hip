@@ -2059,6 +2059,10 @@ void job_release(sdfk_march_job* j, bool kernels_may_be_queued)
     }
 }
 
+#ifndef SDFK_COMPACT_STRIDED
+#define SDFK_COMPACT_STRIDED 1   // the write pass with interleaved segments (k_compact_write, mc_kernels.hip)
+#endif
+
 int alloc_records(sdfk_march_job* j, size_t c)
 {
     McParams& P = j->P;
@@ -2082,6 +2086,7 @@ int alloc_records(sdfk_march_job* j, size_t c)
     rr = rr ? rr : job_alloc(j, &P.chunkwin, c / MC_CHUNK + 2);
     rr = rr ? rr : job_alloc(j, &P.chunkwin2, c / MC_CHUNK + 2);
     P.cap_active = (uint32_t)c;
+    P.chunkscan = c / MC_CHUNK + 1 > MC_SCAN_CHUNKS ? 1 : 0;   // (k_chunkscan: mc_kernels.hip)
     return rr;
 }
 
@@ -2110,9 +2115,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
         // (a workgroup takes the same 1024 segments of K2_LPB consecutive layers: mc_kernels.hip)
         const int nwg = ((P.lay_list_end - P.lay_count_begin + K2_LPB - 1) / K2_LPB) * P.bpl;
         hipLaunchKernelGGL(k_compact<false>, dim3(nwg), dim3(256), 0, g.stream, P);
-#ifndef SDFK_COMPACT_STRIDED
-#define SDFK_COMPACT_STRIDED 1
-#endif
+        if (P.blockpre) hipLaunchKernelGGL(k_blockscan, dim3(1), dim3(1024), 0, g.stream, P);   // (many blocks: their prefix in one pass)
         if (SDFK_COMPACT_STRIDED && K2_LPB == 1)   // (the write pass with interleaved segments: mc_kernels.hip)
             hipLaunchKernelGGL(k_compact_write, dim3((P.lay_list_end - P.lay_count_begin) * P.bpl), dim3(256), 0, g.stream, P);
         else
@@ -2137,6 +2140,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
         ProfScope ps("k_resolve");
         constexpr int cap = 256 * 12;
         hipLaunchKernelGGL(k_resolve, dim3(std::min(nchunks, cap)), dim3(256), 0, g.stream, P);
+        if (P.chunkscan) hipLaunchKernelGGL(k_chunkscan, dim3(1), dim3(1024), 0, g.stream, P);   // (long lists: the chunks' prefix in one pass)
         // totals for the host: workgroup 0 of k_vertices publishes them, unless the caller
         // needs the counts before (or without) emitting
         if (publish) hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, g.stream, P);
@@ -2248,6 +2252,9 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     }
     r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl + 1);
     r = r ? r : job_alloc(j, &P.wavecnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl * 4 + 4);
+    P.blockpre = nullptr;
+    if ((P.lay_list_end - P.lay_count_begin) * P.bpl > MC_SCAN_BLOCKS && SDFK_COMPACT_STRIDED && K2_LPB == 1)   // (k_blockscan: mc_kernels.hip)
+        r = r ? r : job_alloc(j, &P.blockpre, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl + 1);
     r = r ? r : job_alloc(j, &P.rowstart, (size_t)(P.lay_list_end - P.lay_count_begin) * P.ncy + 2);
     r = r ? r : job_alloc(j, &P.counters, 1);
     P.host_counters = &g.slots_dev[j->slot].c;
