@@ -353,7 +353,11 @@ extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_
 // has its place).  sdfk_eval_blocks: one WAVEFRONT per listed block, lane = x -- the 64-bit ballot of "value > iso" over the lanes
 // IS the sign word of a (y, z) row, sixteen evaluations and sixteen ballots a block.  Both write bits[z][y][xw] directly: this
 // path has no byte form and no k_bits_transpose.
-struct CullArgs { unsigned long long* bits; unsigned* worklist; unsigned* counter; int nbx, nby, nbz; };
+// The work list is kept in SDFK_CULL_LISTS sub-lists, each with a counter on a cache line of its own (workgroup w of the culling kernel
+// appends to sub-list w % SDFK_CULL_LISTS, region `region` words long): every append is one atomic, same-address atomics serialise at
+// ~10 ns each, and a thousand workgroups appending to ONE counter were 10 of the kernel's 16 us at 512^3.
+#define SDFK_CULL_LISTS 64
+struct CullArgs { unsigned long long* bits; unsigned* worklist; unsigned* counter; int nbx, nby, nbz; int cpw; unsigned region; };
 #if SDFK_KERNELS & 0x600
 __device__ __forceinline__ float sdfk_coord(float m, int i, float d) { return m + (float)i * d; }
 #endif
@@ -362,78 +366,146 @@ __device__ __forceinline__ float sdfk_coord(float m, int i, float d) { return m 
 // along x (the interval of mod(x, period) covers the whole period).  (Round 4 gave a block ONE lane that walked the eight sub-boxes
 // in a row: 131 072 lanes at 512^3, two wavefronts per SIMD, each a chain of eight interval evaluations -- 19 us of latency for 3 us
 // of vector work.)  The eight lanes combine their bytes with three butterfly steps; each then stores two of the block's sixteen rows.
-extern "C" __global__ __launch_bounds__(1024) void sdfk_cull_blocks(SampleArgs A, CullArgs C, SdfkK K)
+//
+// COARSE boxes first (round 5): a wavefront owns C.cpw (1..32) consecutive coarse boxes of 2 x 2 x 2 blocks (128 x 8 x 8 voxels).  Lane l
+// evaluates the program over the whole of coarse box l -- ONE interval evaluation per wavefront for all of them -- and a box whose
+// interval excludes the iso value gives its eight blocks their constant words without the 64 sub-box evaluations (sound for the
+// same reason: the interval contains every float a voxel of the box can produce; an unknown or straddling interval decides nothing).
+// Only the coarse boxes the surface may pass through take the per-sub-box pass: a fifth of them for the 512^3 sphere (3.9x fewer
+// interval evaluations), all of them for a scene that repeats along x with a period below 128 voxels (1 / cpw more).  C.cpw < 0: the
+// coarse pass is skipped (A/B: SDFK_CULL_COARSE=0), -C.cpw boxes per wavefront.
+extern "C" __global__ __launch_bounds__(256) void sdfk_cull_blocks(SampleArgs A, CullArgs C, SdfkK K)
 {
-    __shared__ unsigned s_cnt[16], s_base;
-    const int nb = C.nbx * C.nby * C.nbz;
-    const int gid = blockIdx.x * 1024 + threadIdx.x;
-    const int b = gid >> 3, sx = gid & 7;
-    int cls = -1;   // -1: not a block; 0 / 1: every voxel of this lane's sub-box is <= iso / > iso; 2: evaluate the block
-    int bx = 0, by = 0, bz = 0;
-    if (b < nb) {
-        bx = b % C.nbx;                      // (x words fastest: neighbouring blocks write neighbouring words of a (y, z) row)
-        const int t = b / C.nbx;
-        by = t % C.nby;
-        bz = t / C.nby;
-        const int x0 = bx * 64, y0 = by * 4, z0 = bz * 4;
-        cls = 2;
-        // only whole blocks away from the clipped faces are candidates (the others are O(n^2) few)
-        const bool whole = x0 + 64 <= A.nx && y0 + 4 <= A.ny && z0 + 4 <= A.nz;
-        const bool faces = A.clip && (x0 == 0 || x0 + 64 >= A.nx || y0 == 0 || y0 + 4 >= A.ny || A.z0 + z0 == 0 || A.z0 + z0 + 4 >= A.nz_global);
-        if (whole && !faces) {
-            const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0 + 8 * sx, A.dx), sdfk_coord(A.mx, x0 + 8 * sx + 7, A.dx));
-            const sdfk_iv Y = iv_make(sdfk_coord(A.my, y0, A.dy), sdfk_coord(A.my, y0 + 3, A.dy));
-            const sdfk_iv Z = iv_make(sdfk_coord(A.mz, A.z0 + z0, A.dz), sdfk_coord(A.mz, A.z0 + z0 + 3, A.dz));
+    __shared__ unsigned s_list[4][256];   // the blocks a wavefront lists (at most 8 per coarse box)
+    __shared__ unsigned s_cnt[4], s_base;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cpw = C.cpw < 0 ? -C.cpw : C.cpw;
+    const int ncx = (C.nbx + 1) >> 1, ncy = (C.nby + 1) >> 1, ncz = (C.nbz + 1) >> 1;
+    const int ncoarse = ncx * ncy * ncz;
+    const int c0 = (blockIdx.x * 4 + wave) * cpw;   // this wavefront's first coarse box
+    // phase 1: lane l decides coarse box c0 + l as a whole.  -1: no such box; 0 / 1: all its voxels <= iso / > iso; 2: look closer;
+    // + 4: every one of its eight blocks exists, is whole and away from the clipped faces (the loop below then needs no tests)
+    int ccls = -1, pbx = 0, pby = 0, pbz = 0;
+    if (lane < cpw && c0 + lane < ncoarse) {
+        const int c = c0 + lane;
+        pbx = c % ncx;
+        const int t = c / ncx;
+        pby = t % ncy;
+        pbz = t / ncy;
+        const int x0 = pbx * 128, y0 = pby * 8, z0 = pbz * 8;
+        const bool whole = x0 + 128 <= A.nx && y0 + 8 <= A.ny && z0 + 8 <= A.nz;
+        const bool faces = A.clip && (x0 == 0 || x0 + 128 >= A.nx || y0 == 0 || y0 + 8 >= A.ny || A.z0 + z0 == 0 || A.z0 + z0 + 8 >= A.nz_global);
+        ccls = 2;
+        if (C.cpw > 0) {
+            const int x1 = x0 + 127 < A.nx ? x0 + 127 : A.nx - 1, y1 = y0 + 7 < A.ny ? y0 + 7 : A.ny - 1, z1 = z0 + 7 < A.nz ? z0 + 7 : A.nz - 1;
+            const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0, A.dx), sdfk_coord(A.mx, x1, A.dx));
+            const sdfk_iv Y = iv_make(sdfk_coord(A.my, y0, A.dy), sdfk_coord(A.my, y1, A.dy));
+            const sdfk_iv Z = iv_make(sdfk_coord(A.mz, A.z0 + z0, A.dz), sdfk_coord(A.mz, A.z0 + z1, A.dz));
             const sdfk_iv W = sdf_interval(K, X, Y, Z);
-            // (decided only by an interval that is known as a whole: both comparisons are false for NaN)
-            if (W.lo > A.iso && W.hi >= W.lo) cls = 1;
-            else if (W.hi <= A.iso && W.lo <= W.hi) cls = 0;
+            if (W.lo > A.iso && W.hi >= W.lo) ccls = 1;
+            else if (W.hi <= A.iso && W.lo <= W.hi) ccls = 0;
         }
+        if (whole && !faces) ccls += 4;
     }
-    // the block's word (byte sx = 0xff where the sub-box lies above the iso value) and "some sub-box is undecided", over the 8 lanes of the block
-    unsigned lo = (cls == 1 && sx < 4) ? 0xffu << (8 * sx) : 0u, hi = (cls == 1 && sx >= 4) ? 0xffu << (8 * (sx - 4)) : 0u;
-    unsigned und = cls == 2 ? 1u : 0u;
-    // (ds_swizzle in bit mode: and 0x1f, or 0, xor 1 / 2 / 4 -- lanes 8 k .. 8 k + 7 exchange among themselves)
+    // phase 2: coarse box by coarse box, its eight blocks side by side (block j = lane / 8 at (j & 1, j / 2 & 1, j / 4), sub-box lane & 7;
+    // the lane stores rows 2 sx and 2 sx + 1 of its block's sixteen (zz, yy) rows: their place relative to the coarse box's first word)
+    const int j = lane >> 3, sx = lane & 7;
+    const int bi = j & 1, bj = (j >> 1) & 1, bk = j >> 2;
+    long off[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int row = 2 * sx + q, zz = row >> 2, yy = row & 3;
+        off[q] = ((long)(4 * bk + zz) * A.ny + (4 * bj + yy)) * C.nbx + bi;
+    }
+    unsigned nlisted = 0;
+    for (int k = 0; k < cpw; k++) {
+        const int cc = __builtin_amdgcn_readlane(ccls, k);   // (all uniform over the wavefront)
+        if (cc < 0) break;
+        const int cbx = __builtin_amdgcn_readlane(pbx, k), cby = __builtin_amdgcn_readlane(pby, k), cbz = __builtin_amdgcn_readlane(pbz, k);
+        unsigned long long* base = C.bits + ((long)(8 * cbz) * A.ny + 8 * cby) * C.nbx + 2 * cbx;
+        if (cc == 4 || cc == 5) {   // decided as a whole, nothing to test: 128 constant words
+            const unsigned long long word = cc == 5 ? ~0ull : 0ull;
+            base[off[0]] = word;
+            base[off[1]] = word;
+            continue;
+        }
+        const int bx = 2 * cbx + bi, by = 2 * cby + bj, bz = 2 * cbz + bk;
+        int cls = -1;   // -1: not a block; 0 / 1: every voxel of this lane's sub-box is <= iso / > iso; 2: evaluate the block
+        if (bx < C.nbx && by < C.nby && bz < C.nbz) {
+            const int x0 = bx * 64, y0 = by * 4, z0 = bz * 4;
+            cls = 2;
+            // only whole blocks away from the clipped faces are candidates (the others are O(n^2) few)
+            const bool whole = x0 + 64 <= A.nx && y0 + 4 <= A.ny && z0 + 4 <= A.nz;
+            const bool faces = A.clip && (x0 == 0 || x0 + 64 >= A.nx || y0 == 0 || y0 + 4 >= A.ny || A.z0 + z0 == 0 || A.z0 + z0 + 4 >= A.nz_global);
+            if (whole && !faces) {
+                if ((cc & 3) != 2) cls = cc & 3;   // decided with its coarse box
+                else {
+                    const sdfk_iv X = iv_make(sdfk_coord(A.mx, x0 + 8 * sx, A.dx), sdfk_coord(A.mx, x0 + 8 * sx + 7, A.dx));
+                    const sdfk_iv Y = iv_make(sdfk_coord(A.my, y0, A.dy), sdfk_coord(A.my, y0 + 3, A.dy));
+                    const sdfk_iv Z = iv_make(sdfk_coord(A.mz, A.z0 + z0, A.dz), sdfk_coord(A.mz, A.z0 + z0 + 3, A.dz));
+                    const sdfk_iv W = sdf_interval(K, X, Y, Z);
+                    // (decided only by an interval that is known as a whole: both comparisons are false for NaN)
+                    if (W.lo > A.iso && W.hi >= W.lo) cls = 1;
+                    else if (W.hi <= A.iso && W.lo <= W.hi) cls = 0;
+                }
+            }
+        }
+        // the block's word (byte sx = 0xff where the sub-box lies above the iso value) and "some sub-box is undecided", over the 8 lanes of the block
+        unsigned lo = (cls == 1 && sx < 4) ? 0xffu << (8 * sx) : 0u, hi = (cls == 1 && sx >= 4) ? 0xffu << (8 * (sx - 4)) : 0u;
+        unsigned und = cls == 2 ? 1u : 0u;
+        // (ds_swizzle in bit mode: and 0x1f, or 0, xor 1 / 2 / 4 -- lanes 8 k .. 8 k + 7 exchange among themselves)
 #define SDFK_OR8(v)                                                              \
     v |= (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (1 << 10) | 0x1f);        \
     v |= (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (2 << 10) | 0x1f);        \
     v |= (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);
-    SDFK_OR8(lo) SDFK_OR8(hi) SDFK_OR8(und)
+        SDFK_OR8(lo) SDFK_OR8(hi) SDFK_OR8(und)
 #undef SDFK_OR8
-    if (cls >= 0 && !und) {
-        const unsigned long long word = (unsigned long long)lo | ((unsigned long long)hi << 32);
-#pragma unroll
-        for (int q = 0; q < 2; q++) {        // rows 2 sx and 2 sx + 1 of the block's sixteen (zz, yy) rows
-            const int row = 2 * sx + q, zz = row >> 2, yy = row & 3;
-            C.bits[((long)(bz * 4 + zz) * A.ny + (by * 4 + yy)) * C.nbx + bx] = word;
+        if (cls >= 0 && !und) {
+            const unsigned long long word = (unsigned long long)lo | ((unsigned long long)hi << 32);
+            base[off[0]] = word;
+            base[off[1]] = word;
         }
+        const bool listed = cls >= 0 && und && sx == 0;
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(listed);
+        if (listed) s_list[wave][nlisted + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull))] = (unsigned)((bz * C.nby + by) * C.nbx + bx);
+        nlisted += (unsigned)__builtin_popcountll(need);
     }
-    // the undecided blocks of this WORKGROUP (128 blocks, their first lanes): ONE atomic for all of them -- every atomic goes to the
-    // same counter, and same-address atomics serialise (one per wavefront, 8 blocks each, made this kernel 73 us at 512^3)
-    const bool listed = cls >= 0 && und && sx == 0;
-    const unsigned long long need = __builtin_amdgcn_ballot_w64(listed);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wave] = (unsigned)__builtin_popcountll(need);
+    // the undecided blocks of this WORKGROUP: ONE atomic for all of them, to one of SDFK_CULL_LISTS counters (one atomic per wavefront
+    // of 8 blocks to one counter made this kernel 73 us at 512^3)
+    if (lane == 0) s_cnt[wave] = nlisted;
     __syncthreads();
     unsigned before = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
-        const unsigned c = s_cnt[w];
-        before += w < wave ? c : 0u;
-        total += c;
+    for (int w = 0; w < 4; w++) {
+        const unsigned n = s_cnt[w];
+        before += w < wave ? n : 0u;
+        total += n;
     }
-    if (threadIdx.x == 0 && total) s_base = atomicAdd(C.counter, total);
+    const unsigned sub = blockIdx.x % SDFK_CULL_LISTS;
+    if (threadIdx.x == 0 && total) s_base = atomicAdd(C.counter + 32u * sub, total);
     __syncthreads();
-    if (listed) C.worklist[s_base + before + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull))] = (unsigned)b;
+    for (unsigned i = (unsigned)lane; i < nlisted; i += 64u) C.worklist[(size_t)sub * C.region + s_base + before + i] = s_list[wave][i];
 }
 #endif
 #if SDFK_KERNELS & 0x400
 extern "C" __global__ __launch_bounds__(256) void sdfk_eval_blocks(SampleArgs A, CullArgs C, SdfkK K)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned count = *C.counter;
+    // the sub-lists' lengths, lane s that of sub-list s, and their running sum: item e of the whole is item e - (sum before s) of
+    // sub-list s = the number of running sums <= e
+    static_assert(SDFK_CULL_LISTS == 64, "one lane per sub-list");
+    const unsigned mine = C.counter[32 * lane];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned n = (unsigned)__shfl_up((int)incl, o);
+        if (lane >= o) incl += n;
+    }
+    const unsigned count = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     for (unsigned e = blockIdx.x * 4u + (unsigned)wave; e < count; e += gridDim.x * 4u) {
-        const int b = (int)C.worklist[e];
+        const int sub = __builtin_popcountll(__builtin_amdgcn_ballot_w64(incl <= e));
+        const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)(incl - mine), sub);
+        const int b = (int)C.worklist[(size_t)sub * C.region + (e - first)];
         const int bx = b % C.nbx, t = b / C.nbx, by = t % C.nby, bz = t / C.nby;
         const int ix = bx * 64 + lane;
         const float px = sdfk_coord(A.mx, ix, A.dx);

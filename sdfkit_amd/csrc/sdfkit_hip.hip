@@ -889,7 +889,7 @@ struct sdfk_volume {
     // (values == colors == nullptr): its sampler leaves the sign bits only, corners and vertex colours are re-evaluated.
     // elided_colors: the program writes colours (the mesh has a colour array although the volume has none).
     bool elided = false, elided_colors = false;
-    uint32_t* cull_list = nullptr;    // SDFK_OPT_ELIDE_VOLUME = 2: [0] = number of undecided blocks, [16..] = their indices (sdfk_cull_blocks)
+    uint32_t* cull_list = nullptr;    // SDFK_OPT_ELIDE_VOLUME = 2: 64 counters (128 B apart), then the 64 sub-lists of undecided blocks (sdfk_cull_blocks)
     // sign bits (value > bits_iso) packed along X, written by the fused sampling kernel;
     // valid until Values change (upload / ClipToBounds)
     uint64_t* bits = nullptr;
@@ -1912,22 +1912,38 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
                 // block culling: one lane per 64 x 4 x 4 block decides it by interval arithmetic (constant sign words) or lists it; the
                 // listed blocks -- those the surface passes through -- are evaluated voxel by voxel; both write the X-packed sign
                 // words themselves (sample_codegen.h): no byte form, no transposer
-                struct { unsigned long long* bits; unsigned* worklist; unsigned* counter; int nbx, nby, nbz; } Cargs;
+                struct { unsigned long long* bits; unsigned* worklist; unsigned* counter; int nbx, nby, nbz; int cpw; unsigned region; } Cargs;   // (= CullArgs of sample_codegen.h)
                 Cargs.bits = (unsigned long long*)v->bits;
                 Cargs.nbx = v->nxw(); Cargs.nby = (v->ny + 3) / 4; Cargs.nbz = (v->nz + 3) / 4;
                 const size_t nblocks = (size_t)Cargs.nbx * Cargs.nby * Cargs.nbz;
-                if (!v->cull_list) {
-                    if (int r = dev_alloc((void**)&v->cull_list, (nblocks + 16) * sizeof(uint32_t))) return r;
+                // 64 sub-lists (SDFK_CULL_LISTS), their counters 128 bytes apart in front: workgroup w appends to sub-list w % 64, whose region
+                // holds what its share of the workgroups can list (at most 1024 blocks each)
+                constexpr size_t kLists = 64, kHeader = kLists * 32;
+
+                // coarse boxes of 2 x 2 x 2 blocks, cpw of them per wavefront (its one coarse evaluation is the overhead when every box needs
+                // the closer look: 1 / cpw): as many as leave >= 4096 wavefronts to the launch, 4 at most.  Measured (sphere / README scene,
+                // us) at 512^3, 16 384 coarse boxes: cpw 1: 16.7 / 25.4, 2: 14.1 / 21.0, 4: 13.4 / 18.9, 16: 19.3 / 35.0, 32: 27.2 / 57.6 (few, long
+                // wavefronts), without the coarse pass 15.1 / 23.3 at cpw 1; at 1024^3: cpw 4: 44.8 / 59.0, 8: 57.6 / 79.3, 16: 59.1 / 77.4,
+                // without the coarse pass 89.3 / 119.1 at cpw 8
+                const size_t ncoarse = (size_t)((Cargs.nbx + 1) / 2) * ((Cargs.nby + 1) / 2) * ((Cargs.nbz + 1) / 2);
+                static const int cpw_env = [] { const char* e = getenv("SDFK_CULL_CPW"); return e ? atoi(e) : 0; }();   // (experiments)
+                Cargs.cpw = cpw_env > 0 ? std::min(cpw_env, 32) : (int)std::min<size_t>(4, std::max<size_t>(1, ncoarse / 4096));
+                static const bool coarse_off = [] { const char* e = getenv("SDFK_CULL_COARSE"); return e && atoi(e) == 0; }();
+                if (coarse_off) Cargs.cpw = -Cargs.cpw;
+                const size_t cull_wgs = (ncoarse + (size_t)std::abs(Cargs.cpw) * 4 - 1) / ((size_t)std::abs(Cargs.cpw) * 4);
+                Cargs.region = (unsigned)(((cull_wgs + kLists - 1) / kLists) * (size_t)std::abs(Cargs.cpw) * 32);   // (32 blocks per coarse box of a workgroup's four wavefronts)
+                if (!v->cull_list) {   // (a volume's dimensions never change: neither does the size of its regions)
+                    if (int r = dev_alloc((void**)&v->cull_list, (kHeader + kLists * (size_t)Cargs.region) * sizeof(uint32_t))) return r;
                 }
-                Cargs.counter = v->cull_list; Cargs.worklist = v->cull_list + 16;
+                Cargs.counter = v->cull_list; Cargs.worklist = v->cull_list + kHeader;
                 hipFunction_t fn_cull = nullptr, fn_eval = nullptr;
                 if (int r = program_fn(p, PK_CULL, &fn_cull)) return r;
                 if (int r = program_fn(p, PK_EVAL_BLOCKS, &fn_eval)) return r;
-                HIPCHK(hipMemsetAsync(v->cull_list, 0, sizeof(uint32_t), g.stream));
+                HIPCHK(hipMemsetAsync(v->cull_list, 0, kHeader * sizeof(uint32_t), g.stream));
                 void* cparams[] = {&A, &Cargs, p->kargs()};
                 {
                     ProfScope ps2("sdfk_cull_blocks");
-                    HIPCHK(hipModuleLaunchKernel(fn_cull, (unsigned)((nblocks * 8 + 1023) / 1024), 1, 1, 1024, 1, 1, 0, g.stream, cparams, nullptr));   // (eight lanes per block)
+                    HIPCHK(hipModuleLaunchKernel(fn_cull, (unsigned)cull_wgs, 1, 1, 256, 1, 1, 0, g.stream, cparams, nullptr));   // (a wavefront per cpw coarse boxes)
                 }
                 {
                     ProfScope ps2("sdfk_eval_blocks");
