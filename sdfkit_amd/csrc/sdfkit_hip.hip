@@ -1927,13 +1927,14 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
                 // without the coarse pass 89.3 / 119.1 at cpw 8
                 const size_t ncoarse = (size_t)((Cargs.nbx + 1) / 2) * ((Cargs.nby + 1) / 2) * ((Cargs.nbz + 1) / 2);
                 static const int cpw_env = [] { const char* e = getenv("SDFK_CULL_CPW"); return e ? atoi(e) : 0; }();   // (experiments)
-                Cargs.cpw = cpw_env > 0 ? std::min(cpw_env, 32) : (int)std::min<size_t>(4, std::max<size_t>(1, ncoarse / 4096));
+                Cargs.cpw = cpw_env > 0 ? std::min(cpw_env, 4) : (int)std::min<size_t>(4, std::max<size_t>(1, ncoarse / 4096));   // (<= 4: the kernel's list)
                 static const bool coarse_off = [] { const char* e = getenv("SDFK_CULL_COARSE"); return e && atoi(e) == 0; }();
                 if (coarse_off) Cargs.cpw = -Cargs.cpw;
                 const size_t cull_wgs = (ncoarse + (size_t)std::abs(Cargs.cpw) * 4 - 1) / ((size_t)std::abs(Cargs.cpw) * 4);
                 Cargs.region = (unsigned)(((cull_wgs + kLists - 1) / kLists) * (size_t)std::abs(Cargs.cpw) * 32);   // (32 blocks per coarse box of a workgroup's four wavefronts)
                 if (!v->cull_list) {   // (a volume's dimensions never change: neither does the size of its regions)
-                    if (int r = dev_alloc((void**)&v->cull_list, (kHeader + kLists * (size_t)Cargs.region) * sizeof(uint32_t))) return r;
+                    // (the blocks' sub-box masks, a byte each, behind the regions)
+                    if (int r = dev_alloc((void**)&v->cull_list, (kHeader + kLists * (size_t)Cargs.region) * sizeof(uint32_t) + kLists * (size_t)Cargs.region + 64)) return r;
                 }
                 Cargs.counter = v->cull_list; Cargs.worklist = v->cull_list + kHeader;
                 hipFunction_t fn_cull = nullptr, fn_eval = nullptr;
