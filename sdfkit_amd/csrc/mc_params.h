@@ -18,11 +18,13 @@ static_assert(MC_CHUNK >= 64 && MC_CHUNK <= 256, "one 256-thread workgroup per c
 // vertex-id slots per chunk (rec_vid): a record references at most 13 distinct vertex ids (12 edges + the centre vertex)
 // logical compaction blocks / chunks of records above which ONE workgroup computes their prefix between two kernels of the chain
 // (k_blockscan, k_chunkscan) instead of every consumer workgroup summing its predecessors itself
+// (8192: a one-workgroup launch costs a serial chain ~6 us; what it saves grows with the square of the count -- ~2 us at 5 000 chunks,
+// 14 us at 13 000, 30 us at 16 000 blocks: profiles/r05_ab_prefix_scans_1024.txt)
 #ifndef SDFK_SCAN_BLOCKS
-#define SDFK_SCAN_BLOCKS 4096
+#define SDFK_SCAN_BLOCKS 8192
 #endif
 #ifndef SDFK_SCAN_CHUNKS
-#define SDFK_SCAN_CHUNKS 4096
+#define SDFK_SCAN_CHUNKS 8192
 #endif
 constexpr int MC_SCAN_BLOCKS = SDFK_SCAN_BLOCKS;
 constexpr uint32_t MC_SCAN_CHUNKS = SDFK_SCAN_CHUNKS;

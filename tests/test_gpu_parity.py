@@ -350,21 +350,21 @@ def test_sparse_rows_volume(gpu):
 
 
 def test_many_layers_many_chunks(gpu):
-    """More than MC_SCAN_BLOCKS (4096) logical blocks in the compaction and more than MC_SCAN_CHUNKS (4096) chunks of records: their
+    """More than MC_SCAN_BLOCKS (8192) logical blocks in the compaction and more than MC_SCAN_CHUNKS (8192) chunks of records: their
     prefixes then come from k_blockscan / k_chunkscan (one workgroup between two kernels of the chain) instead of every consumer
-    workgroup summing its predecessors (mc_kernels.hip).  A tall grid of 6000 planes with a busy surface, as a host volume (first
+    workgroup summing its predecessors (mc_kernels.hip).  A tall grid of 8300 planes with a busy surface, as a host volume (first
     call: capacity too small, redone exactly; second call: speculative sizes) and as a sampled program (the volume-less default path)."""
-    shape = (24, 20, 6000)
+    shape = (32, 28, 8300)
     X, Y, Z = np.meshgrid(*[np.arange(n, dtype=np.float32) for n in shape], indexing="ij")
     v = (np.sin(0.9 * X) * np.cos(0.8 * Y) + 0.6 * np.sin(0.11 * Z) - 0.1).astype(np.float32)
     rng = np.random.default_rng(11)
     c = rng.uniform(0, 1, shape + (3,)).astype(np.float32)
     om = O.march(v, c, [-1] * 3, [1] * 3)
-    assert len(om.cells) > 4096 * 240
+    assert len(om.cells) > 8192 * 240
     for rep in range(2):
         assert_mesh_equal(MarchingCubes.CreateMesh(Voxels(v, c, [-1] * 3, [1] * 3)), om)
     scene, sdf = S.CATALOGUE["readme_repeat_xy"]()
-    mn, mx, dims = [-2.8125, -2.8125, -0.6], [2.8125, 2.8125, 0.6], (40, 36, 4300)
+    mn, mx, dims = [-2.8125, -2.8125, -0.6], [2.8125, 2.8125, 0.6], (40, 36, 8300)
     ov, oc = O.sample(scene, mn, mx, *dims)
     O.clip_to_bounds(ov, mn, mx)
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims, clipToBounds=True), O.march(ov, oc, mn, mx))
