@@ -500,6 +500,7 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
         }
     }
     if (!WRITE) {
+        if (P.zero_cull && blockIdx.x == 0 && threadIdx.x < 64) P.zero_cull[32 * threadIdx.x] = 0u;   // (read for the last time by the kernel before this one)
         // low 32 bits: active cells of the block; high 32 bits: its case-13 sign words (rare)
         __shared__ uint32_t s_cnt[K2_LPB][4], s_n13[K2_LPB];
         if (threadIdx.x < K2_LPB) s_n13[threadIdx.x] = 0;

@@ -60,6 +60,8 @@ struct McParams {
     int step;              // scale of cell coordinates in vertex positions (Cell.cs:345-347)
     // workspace
     const uint64_t* bits;  // [nz][ny][nxw]: bit b of word xw = (value(64*xw+b, y, z) > iso)
+    uint32_t* zero_cull;   // non-null (volume-less jobs): the 64 counters (32 words apart) of the culling kernel that made `bits`; the count
+                           // pass clears them, so that the next job of the lane needs no memset
     int bpl;               // logical blocks of k_compact per layer: ceil(ncy * nxw / 1024)
     uint64_t* blockcnt;    // per logical block of k_compact: active cells | case-13 sign words << 32
     uint32_t* wavecnt;     // active cells per wavefront of the count pass ([block][4])

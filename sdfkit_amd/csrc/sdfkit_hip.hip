@@ -115,7 +115,9 @@ struct Context {
     // The caching allocator is stream-ordered PER LANE: a block goes back to the pool of the
     // lane it was allocated on and is only handed out again to work queued on that lane.
     static constexpr int NSIDE = 4;
-    struct Lane { hipStream_t stream = nullptr; std::multimap<size_t, void*> free_blocks; };
+    // (clean_cull_headers: counter blocks of the culling kernel that are known to be all zero IN THIS LANE'S STREAM ORDER -- the count pass
+    // of the job that used one last cleared it --, so that a volume-less job needs no memset in front of its first kernel)
+    struct Lane { hipStream_t stream = nullptr; std::multimap<size_t, void*> free_blocks; std::vector<uint32_t*> clean_cull_headers; };
     Lane lanes[1 + NSIDE];
     // stream placement (place_streams): the streams the library made for its lanes and the exchange, the class -- set of
     // streams that must not be busy together -- each was measured to be in, and who uses which
@@ -889,7 +891,10 @@ struct sdfk_volume {
     // (values == colors == nullptr): its sampler leaves the sign bits only, corners and vertex colours are re-evaluated.
     // elided_colors: the program writes colours (the mesh has a colour array although the volume has none).
     bool elided = false, elided_colors = false;
-    uint32_t* cull_list = nullptr;    // SDFK_OPT_ELIDE_VOLUME = 2: 64 counters (128 B apart), then the 64 sub-lists of undecided blocks (sdfk_cull_blocks)
+    uint32_t* cull_list = nullptr;    // SDFK_OPT_ELIDE_VOLUME = 2: the 64 sub-lists of undecided blocks, then their sub-box masks (sdfk_cull_blocks)
+    uint32_t* cull_header = nullptr;  // ... and their 64 counters, 128 B apart (from the lane's clean blocks: Context::Lane)
+    mutable bool cull_header_clean = false;   // all zero again (the count pass of the meshing job has been queued behind the kernels that used it)
+    int cull_header_lane = 0;
     // sign bits (value > bits_iso) packed along X, written by the fused sampling kernel;
     // valid until Values change (upload / ClipToBounds)
     uint64_t* bits = nullptr;
@@ -965,6 +970,7 @@ struct sdfk_march_job {
     bool colors_elided = false;        // the volume has no colour storage although its program writes colours (SDFK_OPT_ELIDE_VOLUME)
     int slot = -1;                 // index of the pinned result slot (owned until job_release)
     int lane = 0;                  // lane the job's kernels are queued on
+    bool* cull_clean = nullptr;        // the source volume's "its culling counters are zero again": set when the count pass is queued
     float* bounds_partial = nullptr;   // per-workgroup AABB partials of k_vertices (allocated once per job: launch_emit is allocation-free after)
     int bounds_blocks = 0;
     uint2* vdesc = nullptr;        // (creator record, edge) per emitted vertex for sdfk_vertex_colors (same rule)
@@ -1149,6 +1155,7 @@ extern "C" void sdfk_shutdown(void)
     for (auto& lane : g.lanes) {
         for (auto& kv : lane.free_blocks) (void)hipFree(kv.second);
         lane.free_blocks.clear();
+        lane.clean_cull_headers.clear();   // (still among the live blocks: freed with them)
     }
     for (auto& kv : g.live_blocks) (void)hipFree(kv.first);
     g.live_blocks.clear();
@@ -1743,6 +1750,10 @@ extern "C" void sdfk_volume_free(sdfk_volume* v)
     dev_free(v->bits);
     dev_free(v->bits8);
     dev_free(v->cull_list);
+    if (v->cull_header) {   // (zero again, in its lane's order: the next volume-less job of that lane takes it as it is)
+        if (v->cull_header_clean) g.lanes[v->cull_header_lane].clean_cull_headers.push_back(v->cull_header);
+        else dev_free(v->cull_header);
+    }
     delete v;
 }
 
@@ -1934,13 +1945,25 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
                 Cargs.region = (unsigned)(((cull_wgs + kLists - 1) / kLists) * (size_t)std::abs(Cargs.cpw) * 32);   // (32 blocks per coarse box of a workgroup's four wavefronts)
                 if (!v->cull_list) {   // (a volume's dimensions never change: neither does the size of its regions)
                     // (the blocks' sub-box masks, a byte each, behind the regions)
-                    if (int r = dev_alloc((void**)&v->cull_list, (kHeader + kLists * (size_t)Cargs.region) * sizeof(uint32_t) + kLists * (size_t)Cargs.region + 64)) return r;
+                    if (int r = dev_alloc((void**)&v->cull_list, kLists * (size_t)Cargs.region * sizeof(uint32_t) + kLists * (size_t)Cargs.region + 64)) return r;
                 }
-                Cargs.counter = v->cull_list; Cargs.worklist = v->cull_list + kHeader;
+                if (!v->cull_header) {   // the counters: a block this lane knows to be zero, or a new one, cleared once
+                    auto& clean = g.lanes[g.cur_lane].clean_cull_headers;
+                    if (!clean.empty()) { v->cull_header = clean.back(); clean.pop_back(); }
+                    else {
+                        if (int r = dev_alloc((void**)&v->cull_header, kHeader * sizeof(uint32_t))) return r;
+                        HIPCHK(hipMemsetAsync(v->cull_header, 0, kHeader * sizeof(uint32_t), g.stream));
+                    }
+                    v->cull_header_lane = g.cur_lane;
+                } else if (!v->cull_header_clean || v->cull_header_lane != g.cur_lane) {
+                    HIPCHK(hipMemsetAsync(v->cull_header, 0, kHeader * sizeof(uint32_t), g.stream));
+                    v->cull_header_lane = g.cur_lane;
+                }
+                v->cull_header_clean = false;
+                Cargs.counter = v->cull_header; Cargs.worklist = v->cull_list;
                 hipFunction_t fn_cull = nullptr, fn_eval = nullptr;
                 if (int r = program_fn(p, PK_CULL, &fn_cull)) return r;
                 if (int r = program_fn(p, PK_EVAL_BLOCKS, &fn_eval)) return r;
-                HIPCHK(hipMemsetAsync(v->cull_list, 0, kHeader * sizeof(uint32_t), g.stream));
                 void* cparams[] = {&A, &Cargs, p->kargs()};
                 {
                     ProfScope ps2("sdfk_cull_blocks");
@@ -2132,6 +2155,7 @@ int launch_classify(sdfk_march_job* j, bool publish)
         // (a workgroup takes the same 1024 segments of K2_LPB consecutive layers: mc_kernels.hip)
         const int nwg = ((P.lay_list_end - P.lay_count_begin + K2_LPB - 1) / K2_LPB) * P.bpl;
         hipLaunchKernelGGL(k_compact<false>, dim3(nwg), dim3(256), 0, g.stream, P);
+        if (P.zero_cull && j->cull_clean) *j->cull_clean = true;   // (the count pass clears them)
         if (P.blockpre) hipLaunchKernelGGL(k_blockscan, dim3(1), dim3(1024), 0, g.stream, P);   // (many blocks: their prefix in one pass)
         if (SDFK_COMPACT_STRIDED && K2_LPB == 1)   // (the write pass with interleaved segments: mc_kernels.hip)
             hipLaunchKernelGGL(k_compact_write, dim3((P.lay_list_end - P.lay_count_begin) * P.bpl), dim3(256), 0, g.stream, P);
@@ -2211,6 +2235,8 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     memset(&P, 0, sizeof P);
     P.values = w->values; P.colors = w->colors;
     j->colors_elided = w->elided && w->elided_colors;
+    // (the counters of the culling kernel that made this volume's sign bits: the count pass clears them for the lane's next job)
+    if (w->elided && w->cull_header && w->cull_header_lane == g.cur_lane) { P.zero_cull = w->cull_header; j->cull_clean = &w->cull_header_clean; }
     if (w->elided && (step != 1 || !w->sampled_by || !g_cfg.corner_eval || (w->elided_colors && !g_cfg.vcolor_eval) || !w->bits_valid || w->bits_iso != iso)) {
         job_release(j); delete j;
         return fail(SDFK_ERR_INVALID, "internal: a volume without storage can only be meshed by the program that sampled it (step 1, same iso)");
