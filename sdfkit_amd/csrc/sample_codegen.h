@@ -162,13 +162,28 @@ static const char* const kSampleKernels = R"SRC(
 // X-packed words the marching-cubes classifier reads; the volume is never re-read densely.
 typedef float sdfk_f4 __attribute__((ext_vector_type(4)));
 // (rows of the volume are A.pitch8 floats long -- nz rounded up to a multiple of 4 -- so every 4-voxel group is 16-byte aligned)
-__device__ __forceinline__ void sdfk_store4_nt(float* p, float a, float b, float c, float d)
+// `base` is UNIFORM over the wavefront (a row / run start), `elem` this lane's first float in it.
+// SDFK_SAMPLE_NT = 2: the store leaves as "sc1 nt" -- written through and dropped from the XCD's L2 instead of kept there.  Measured
+// with tools/ubench/ub_store2.hip (512 MiB in this kernel's pattern, four buffers in rotation): nt 81.2-82.0 us, sc1 nt 78.5-79.2 us
+// (plain 84.0, sc1 81.3, sc0 sc1 81.5; as a linear fill: plain 79, nt 80, every sc1 form 76.0-76.6).  The compiler has no spelling for
+// it (a volatile store is "sc0 sc1" but flat and not nt; __builtin_nontemporal_store drops the volatile): inline assembly, in the
+// scalar-base form so that the address costs no vector instructions.
+template <bool COLOR = false>
+__device__ __forceinline__ void sdfk_store4_nt(float* base, int elem, float a, float b, float c, float d)
 {
     const sdfk_f4 t = {a, b, c, d};
-#if SDFK_SAMPLE_NT
-    __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(p));
+#if SDFK_SAMPLE_NT == 3   // (values sc1 nt, colours nt)
+    if (COLOR) { __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(base + elem)); return; }
+#endif
+#if SDFK_SAMPLE_NT >= 2
+    // (s_nop 1: a store of more than 64 bits needs two wait states before a vector instruction may overwrite its data registers on
+    // gfx940+, and the compiler's hazard recogniser does not look inside an asm statement -- without it the next row's values landed
+    // in this row's store)
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" : : "v"((unsigned)elem * 4u), "v"(t), "s"(base) : "memory");
+#elif SDFK_SAMPLE_NT
+    __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(base + elem));
 #else
-    *reinterpret_cast<sdfk_f4*>(p) = t;
+    *reinterpret_cast<sdfk_f4*>(base + elem) = t;
 #endif
 }
 #ifndef SDFK_SAMPLE_RPW
@@ -259,8 +274,9 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
                 sdf_eval(K, px, py, pz[k], cr[k], cg[k], cb[k], w[k]);
                 if ((CLIP || (!STORE && A.clip)) && (edge_xy || edge_z[k])) w[k] = A.outside;
             }
-            const long o = MODE == SDFK_FLAT ? (long)ix * plane + (f0 + 4 * lane) : ((long)ix * A.ny + iy) * P + z;
-            if (STORE) sdfk_store4_nt(A.values + o, w[0], w[1], w[2], w[3]);
+            // (the wavefront's run of the row starts at a uniform address: voxel f0 of the x row's plane, or z tile blockIdx.x of row (ix, y))
+            const long o0 = MODE == SDFK_FLAT ? (long)ix * plane + f0 : ((long)ix * A.ny + (int)blockIdx.y) * P + (int)blockIdx.x * 256;
+            if (STORE) sdfk_store4_nt(A.values + o0, 4 * lane, w[0], w[1], w[2], w[3]);
 #if SDFK_WRITES_COLOR
             if (STORE && A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
                 sdfk_f4* mine = reinterpret_cast<sdfk_f4*>(cbuf[wave] + 12 * lane);
@@ -297,7 +313,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
             for (int q = 0; q < 3; q++) {
                 const sdfk_f4 t = q == 0 ? t0 : (q == 1 ? t1 : t2);
                 const int e = 256 * q + 4 * lane;   // first float of this lane's piece
-                if (e + 3 < run) sdfk_store4_nt(c + e, t.x, t.y, t.z, t.w);
+                if (e + 3 < run) sdfk_store4_nt<true>(c, e, t.x, t.y, t.z, t.w);
                 else {           // the run ends inside the piece
                     if (e < run) c[e] = t.x;
                     if (e + 1 < run) c[e + 1] = t.y;
