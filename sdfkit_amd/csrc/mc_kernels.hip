@@ -47,16 +47,19 @@ namespace sdfk {
 //         layer's part of every such chunk) took the global path; with ncy + 100 or more none do.  1152 covers ncy <= ~1050.
 //   slots: rows near a horizontal tangent hold long runs of records, so the next layer's rows can hold far more than the
 //         chunk's own (README scene: 1.4 % of the vertices outside 640 slots, 0.5 % outside 752).
-// 52.8 KB of LDS per workgroup in all: three workgroups per CU, as the 162 VGPRs allow anyway.
+// Round 5: 576 slots and 1024 row starts (16-bit, relative to their window) = 40.6 KB of LDS, and the register allocation held to 128
+// VGPRs (one spill): FOUR workgroups per CU instead of three -- the kernel is bound by what is resident.  Same box, us: 752 slots /
+// 1152 rows / 3 per CU: sphere 46.1, README scene 83.8, 8-primitive union at 1024^3 261; 576 / 384 / 4 per CU: 42.0 / 83.4 / 246 (576 /
+// 384 at 3 per CU: 46.3 / 92.8 -- the smaller windows alone cost the README scene 9 us, the fourth workgroup gives them back).
 #ifndef SDFK_K4_WMAX
-#define SDFK_K4_WMAX 752
+#define SDFK_K4_WMAX 576
 #endif
 #ifndef SDFK_K4_RMAX
-#define SDFK_K4_RMAX 1152
+#define SDFK_K4_RMAX 1024
 #endif
 constexpr int K4_WMAX = SDFK_K4_WMAX;   // k_vertices: record-window slots staged in LDS (both windows together)
 constexpr int K4_RMAX = SDFK_K4_RMAX;   // k_vertices: rowstart entries staged per window
-static_assert(K4_WMAX <= 768 && K4_WMAX >= 512, "k_vertices stages the windows in three rounds of 256 slots");
+static_assert(K4_WMAX <= 768 && K4_WMAX > 512, "k_vertices stages the windows in three rounds of 256 slots");
 // k_triangles stages the chunk's block of vertex ids (rec_vid, MC_VSTRIDE slots at most) in LDS: a smooth surface uses 3.5 slots per
 // record (840 per chunk), 1536 cover 6.4 per record; what a noisier chunk has beyond that is read from global memory (19.4 KB of
 // LDS in all: eight workgroups per CU)
@@ -1126,12 +1129,15 @@ __device__ __forceinline__ void add_sharer_gradients(const V& vs, int es, int oc
     }
 }
 
+#ifndef SDFK_KV_MINWAVES
+#define SDFK_KV_MINWAVES 4   // (wavefronts per SIMD the register allocation leaves room for: four workgroups per CU, see K4_WMAX)
+#endif
 template <bool ISO0>   // ISO0: P.iso == +0.0 (CornersLdsT, mc_device.h)
-__global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
+__global__ __launch_bounds__(256, SDFK_KV_MINWAVES) void k_vertices(McParams P, McMeshOut M)
 {
     __shared__ float s_wc[8 * K4_WMAX];          // window corner values: [corner][slot]
     __shared__ uint32_t s_wxy[K4_WMAX], s_winfo[K4_WMAX];
-    __shared__ uint32_t s_rs[2][K4_RMAX];
+    __shared__ uint16_t s_rs[2][K4_RMAX];   // row starts RELATIVE to their window: 0 = before it, 1 + i = its record i, count + 2 = beyond
     __shared__ uint64_t s_occ[MCLUT_NROWS];
     __shared__ uint32_t s_pre[257];
     __shared__ uint64_t s_own[256];
@@ -1196,7 +1202,13 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
         }
         for (int i = threadIdx.x; i < 2 * nrs; i += 256) {
             const int w = i >= nrs, k = w ? i - nrs : i;
-            s_rs[w][k] = min(P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)], n);   // never past the stored records
+            const uint32_t rs = min(P.rowstart[min(r_f + (w ? P.ncy : 0) + k, nrows_total)], n);   // never past the stored records
+            const uint32_t ws = w ? w2_start : w1_start, wc = w ? w2_cnt : w1_cnt;
+            // 0 = before the window, 1 + i = its record i, count + 2 = beyond.  (In 64-bit signed arithmetic on purpose: hipcc 7.0 -O3
+            // compiles "rs < ws ? 0u : min(rs - ws, wc + 1u) + 1u" for gfx950 WITHOUT the comparison -- the wrapped difference, clamped:
+            // "beyond" for a row that starts before the window.  tools/ubench/ub_sel.hip reproduces it in twenty lines.)
+            const long long d = (long long)rs + 1 - (long long)ws;
+            s_rs[w][k] = (uint16_t)max(0ll, min(d, (long long)wc + 2));
         }
         uint64_t prefix_lane = 0;
         {
@@ -1352,15 +1364,15 @@ __global__ __launch_bounds__(256) void k_vertices(McParams P, McMeshOut M)
                         else if (row >= r_f + P.ncy && row - r_f - P.ncy + 1 < nrs) { w = 1; k = row - r_f - P.ncy; }
                         bool in_window = false;
                         if (w >= 0) {
-                            const uint32_t ra = s_rs[w][k], rb = s_rs[w][k + 1];
-                            const uint32_t ws = w ? w2_start : w1_start, wc = w ? w2_cnt : w1_cnt, off = w ? w1_cnt : 0u;
+                            const uint32_t ra = s_rs[w][k], rb = s_rs[w][k + 1];   // (relative: see s_rs)
+                            const uint32_t wc = w ? w2_cnt : w1_cnt, off = w ? w1_cnt : 0u;
                             // (W1 begins at the chunk's first record, usually in the MIDDLE of row r_f: the only sharers looked
                             // up in that row are the +x neighbours of the chunk's own cells, which lie after them -- the part of
                             // the row before the window cannot hold the cell.  Sending these to the global-memory path cost two
                             // slow wave-iterations per chunk: 6 % of all sharer iterations of the 512^3 sphere.)
-                            if ((ra >= ws || w == 0) && rb <= ws + wc) {
+                            if ((ra >= 1u || w == 0) && rb >= 1u && rb <= wc + 1u) {
                                 in_window = true;
-                                uint32_t lo = max(ra, ws) - ws + off, hi = rb - ws + off;
+                                uint32_t lo = (ra >= 1u ? ra - 1u : 0u) + off, hi = rb - 1u + off;
                                 while (hi - lo > 4u) {
                                     const uint32_t mid = (lo + hi) >> 1;
                                     if ((int)(s_wxy[mid] & P.xmask) <= cx) lo = mid; else hi = mid;
