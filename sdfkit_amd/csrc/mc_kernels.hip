@@ -465,7 +465,16 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
                 if (++xk == P.nxw) xk = 0;
             }
         }
-        if (!WRITE) { cnts[l] = cnt; n13s[l] = n13; continue; }
+        if (!WRITE) {
+            cnts[l] = cnt; n13s[l] = n13;
+            // (the masks of a wavefront that found something, for the write pass: its lane t holds segments 4 t .. 4 t + 3 of the block)
+            if (P.segmask && __builtin_amdgcn_ballot_w64(cnt != 0u) != 0ull) {
+                uint64_t* q = P.segmask + ((size_t)(b0 + l * P.bpl) * 1024u + 4u * threadIdx.x);
+                *reinterpret_cast<u64x2u*>(q) = u64x2u{m[0], m[1]};
+                *reinterpret_cast<u64x2u*>(q + 2) = u64x2u{m[2], m[3]};
+            }
+            continue;
+        }
         // exclusive prefix of this block = sum of the counts of all earlier blocks (a few thousand
         // words, read cooperatively: cheaper than a separate scan launch)
         uint32_t total, red = before[l];
@@ -537,7 +546,11 @@ __global__ __launch_bounds__(256) void k_compact(McParams P)
 // waiting for the slowest).  Quarter k of the block is exactly what wavefront k of the COUNT pass covered, so "nothing there" is a
 // wave-uniform test per quarter.  One 64-bit workgroup scan of the four packed per-quarter counts (a quarter holds at most
 // 256 x 64 = 2^14 records) gives every segment its place in sweep order.
-__global__ __launch_bounds__(256) void k_compact_write(McParams P)
+#ifndef SDFK_KW_MINWAVES
+#define SDFK_KW_MINWAVES 1
+#endif
+template <bool MASKS>   // MASKS: P.segmask holds the count pass's activity masks
+__global__ __launch_bounds__(256, MASKS ? SDFK_KW_MINWAVES : 1) void k_compact_write(McParams P)
 {
     const int nlay = P.lay_list_end - P.lay_count_begin, nlog = nlay * P.bpl;
     const int b = compact_block_of_workgroup(nlay, P.bpl);   // logical block = (layer, part)
@@ -564,7 +577,19 @@ __global__ __launch_bounds__(256) void k_compact_write(McParams P)
     for (int k = 0; k < 4; k++) look[k] = P.wavecnt[b * 4 + k] != 0;   // (uniform over the workgroup)
     uint64_t m[4] = {0, 0, 0, 0};
     int ys[4] = {0, 0, 0, 0}, xws[4] = {0, 0, 0, 0};
-    {
+    if (MASKS) {
+        // the count pass left the masks of the quarters that hold something: one 8-byte load per segment (512 contiguous bytes per
+        // wavefront instruction) instead of four 16-byte loads and the activity logic again -- 40 instead of 96 VGPRs
+        const uint64_t* q = P.segmask + (size_t)b * 1024u + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (look[k] && s0 + 256 * k < nseg) m[k] = q[256 * k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = s0 + 256 * k;
+            if (s < nseg) { ys[k] = s / P.nxw; xws[k] = s - ys[k] * P.nxw; }
+        }
+    } else {
         const size_t plane = (size_t)P.ny * P.nxw;
         const uint64_t* f0 = P.bits + (size_t)z * plane;
         u64x2u wa[4], wb[4], wc[4], wd[4];

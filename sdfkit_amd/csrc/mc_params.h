@@ -65,6 +65,8 @@ struct McParams {
     int bpl;               // logical blocks of k_compact per layer: ceil(ncy * nxw / 1024)
     uint64_t* blockcnt;    // per logical block of k_compact: active cells | case-13 sign words << 32
     uint32_t* wavecnt;     // active cells per wavefront of the count pass ([block][4])
+    uint64_t* segmask;     // non-null: the count pass leaves the activity masks of the wavefronts that found something ([block][1024 segments],
+                           // a bit per cell); the write pass loads ONE word per segment instead of sixteen sign words and recomputes nothing
     uint32_t* blockpre;    // non-null (grids of more than MC_SCAN_BLOCKS logical blocks): exclusive prefix of blockcnt's cell counts, by
                            // k_blockscan between the two passes -- a write-pass workgroup that sums its predecessors itself reads
                            // O(blocks) words, O(blocks^2) per launch: 16 K blocks at 1024^3

@@ -2099,6 +2099,9 @@ void job_release(sdfk_march_job* j, bool kernels_may_be_queued)
     }
 }
 
+#ifndef SDFK_COMPACT_MASKS
+#define SDFK_COMPACT_MASKS 1   // the count pass leaves its activity masks for the write pass (McParams::segmask)
+#endif
 #ifndef SDFK_COMPACT_STRIDED
 #define SDFK_COMPACT_STRIDED 1   // the write pass with interleaved segments (k_compact_write, mc_kernels.hip)
 #endif
@@ -2158,7 +2161,8 @@ int launch_classify(sdfk_march_job* j, bool publish)
         if (P.zero_cull && j->cull_clean) *j->cull_clean = true;   // (the count pass clears them)
         if (P.blockpre) hipLaunchKernelGGL(k_blockscan, dim3(1), dim3(1024), 0, g.stream, P);   // (many blocks: their prefix in one pass)
         if (SDFK_COMPACT_STRIDED && K2_LPB == 1)   // (the write pass with interleaved segments: mc_kernels.hip)
-            hipLaunchKernelGGL(k_compact_write, dim3((P.lay_list_end - P.lay_count_begin) * P.bpl), dim3(256), 0, g.stream, P);
+            if (P.segmask) hipLaunchKernelGGL(k_compact_write<true>, dim3((P.lay_list_end - P.lay_count_begin) * P.bpl), dim3(256), 0, g.stream, P);
+            else hipLaunchKernelGGL(k_compact_write<false>, dim3((P.lay_list_end - P.lay_count_begin) * P.bpl), dim3(256), 0, g.stream, P);
         else
             hipLaunchKernelGGL(k_compact<true>, dim3(nwg), dim3(256), 0, g.stream, P);
         HIPCHK(hipGetLastError());
@@ -2295,6 +2299,9 @@ int setup_job(const sdfk_volume* v, float iso, int step, int layer_begin, int la
     }
     r = r ? r : job_alloc(j, &P.blockcnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl + 1);
     r = r ? r : job_alloc(j, &P.wavecnt, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl * 4 + 4);
+    P.segmask = nullptr;
+    if (SDFK_COMPACT_STRIDED && K2_LPB == 1 && SDFK_COMPACT_MASKS)   // (the write pass reads the count pass's masks: mc_kernels.hip)
+        r = r ? r : job_alloc(j, &P.segmask, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl * 1024 + 4);
     P.blockpre = nullptr;
     if ((P.lay_list_end - P.lay_count_begin) * P.bpl > MC_SCAN_BLOCKS && SDFK_COMPACT_STRIDED && K2_LPB == 1)   // (k_blockscan: mc_kernels.hip)
         r = r ? r : job_alloc(j, &P.blockpre, (size_t)(P.lay_list_end - P.lay_count_begin) * P.bpl + 1);
