@@ -365,10 +365,12 @@ extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_
 // its sign bits written as constants.  No assumption about the SDF (no Lipschitz bound): the intervals contain every float
 // the per-voxel evaluation can produce, NaN = unknown = evaluate.
 // A block = 64 x (ONE word of the X-packed sign array the marching-cubes classifier reads) x 4 y x 4 z = 1024 voxels, 16 words.
-// sdfk_cull_blocks: eight LANES per block decide it (16 constant words) or append it to a work list (order irrelevant: every word
-// has its place).  sdfk_eval_blocks: one WAVEFRONT per listed block, lane = x -- the 64-bit ballot of "value > iso" over the lanes
-// IS the sign word of a (y, z) row, sixteen evaluations and sixteen ballots a block.  Both write bits[z][y][xw] directly: this
-// path has no byte form and no k_bits_transpose.
+// sdfk_cull_blocks: coarse boxes of 2 x 2 x 2 blocks first (one interval evaluation decides eight blocks), then eight LANES per block,
+// one per 8-x sub-box = one byte of the block's word: the words go out with the bytes of the decided sub-boxes, and a block with
+// undecided ones is appended to a work list with their mask (order irrelevant: every word has its place).  sdfk_eval_blocks: one
+// WAVEFRONT per listed block evaluates its undecided sub-boxes voxel by voxel -- the ballot of "value > iso" holds a sub-box's bytes of
+// eight sign words (all eight undecided: lane = x, the ballot IS the word).  Both write bits[z][y][xw] directly: this path has no byte
+// form and no k_bits_transpose.
 // The work list is kept in SDFK_CULL_LISTS sub-lists, each with a counter on a cache line of its own (workgroup w of the culling kernel
 // appends to sub-list w % SDFK_CULL_LISTS, region `region` words long): every append is one atomic, same-address atomics serialise at
 // ~10 ns each, and a thousand workgroups appending to ONE counter were 10 of the kernel's 16 us at 512^3.
