@@ -118,6 +118,14 @@ def attempt_limit_s():
     return float(os.environ.get("SDFK_BENCH_RANKS_TIMEOUT_S", "300"))   # (a hung collective must not eat the caller's whole budget)
 
 
+def _content_mismatch(line):
+    """True when a bench line says that a sharded mesh differs from the single-GPU mesh (sharded.every_mesh_equals_single_gpu)"""
+    try:
+        return json.loads(line).get("sharded", {}).get("every_mesh_equals_single_gpu") is False
+    except (ValueError, AttributeError):
+        return False
+
+
 def supervise_rank(argv):
     """One rank of a multi-rank run as its launcher started it (`torch.distributed.run ... bench.py --gpus N`: RANK /
     WORLD_SIZE in the environment).  This process is a SUPERVISOR: it never touches HIP.  The measuring process is a child
@@ -179,11 +187,15 @@ def supervise_rank(argv):
         failed = torch.tensor([0 if ok else 1])
         dist.all_reduce(failed, op=dist.ReduceOp.MAX)
         if int(failed.item()) == 0:
+            # a run whose sharded mesh DIFFERS from the single-GPU mesh of the same grid is reported -- the line says where -- and fails:
+            # every rank leaves with exit code 4 (no retry: a more conservative exchange would hide a wrong mesh, not fix it)
+            mismatch = torch.tensor([1 if (rank == 0 and _content_mismatch(line)) else 0])
+            dist.broadcast(mismatch, src=0)
             if rank == 0:
                 sys.stdout.write(line + "\n")
                 sys.stdout.flush()
             dist.destroy_process_group()
-            return 0
+            return 4 if int(mismatch.item()) else 0
         sys.stderr.write(out)
         rc = rc or 1
     dist.destroy_process_group()
@@ -209,10 +221,11 @@ def launch_ranks(argv, n):
     if rc == 124:
         print(f"bench.py: the ranks did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
     lines = [l for l in out.splitlines() if l.startswith("{")]
-    if rc == 0 and lines:
+    wrong_mesh = any(_content_mismatch(l) for l in lines)
+    if (rc == 0 or wrong_mesh) and lines:
         sys.stdout.write(out)
         sys.stdout.flush()
-        return 0
+        return 4 if wrong_mesh else 0     # (the line is on stdout either way; a wrong sharded mesh is an error of the run)
     sys.stderr.write(out)
     return rc or 1
 
@@ -320,6 +333,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--minimal", action="store_true", help="timed loop + per-kernel pass only (for rocprofv3 counter passes: no cold-call, "
                     "latency, host-copy or host-Values legs, whose launches would mix into the per-kernel means)")
+    ap.add_argument("--elide", action="store_true", help="PROFILING ONLY (with --minimal): the timed loop runs the product default -- the volume is not "
+                    "stored (SDFK_OPT_ELIDE_VOLUME = 2) -- so that a rocprofv3 pass sees the volume-less step's kernels; such a line is not the contract's step")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -372,7 +387,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     N.init(local_rank)
     L = N.lib()
-    N.set_option(N.OPT_ELIDE_VOLUME, 0)   # the contract's step STORES the volume, whatever the environment's default; the elided form has a leg of its own
+    N.set_option(N.OPT_ELIDE_VOLUME, 2 if (args.elide and args.minimal) else 0)   # the contract's step STORES the volume, whatever the environment's default; the elided form has a leg of its own
     # torch events (the roofline pass) and the library's lane 0 on one explicit stream.  NOT for a sharded run: it uses no
     # torch GPU work at all, and one more stream in the process changes which of them share a hardware queue (a sharded step
     # on a small slab: 94 us with the extra stream, 39 us without -- tools/slab_step_trace.py)
@@ -475,7 +490,7 @@ def main():
 
     prog0, mn0, mx0, clip0 = prog, mn, mx, clip   # (the headline scene: defaults of single_gpu_stepper)
 
-    def single_gpu_stepper(depth_n, prog=None, mn=None, mx=None, clip=None):
+    def single_gpu_stepper(depth_n, prog=None, mn=None, mx=None, clip=None, n=n):
         prog = prog if prog is not None else prog0
         mn, mx, clip = (mn0 if mn is None else mn), (mx0 if mx is None else mx), (clip0 if clip is None else clip)
         # sdfk_sample_march returns its mesh handle while the kernels are still queued (the
@@ -610,10 +625,66 @@ def main():
         nv, ni = sum(p[0] for p in per_rank), sum(p[1] for p in per_rank)
     ms_step = dt / args.steps * 1e3   # (each block already is the max over ranks)
 
+    # ---- CONTENT of a sharded mesh (not just its counts): rank 0 meshes the same grid on ONE GPU through the ordinary single-GPU call
+    # and compares SHA-256 digests of Vertices / Colors / Normals / Triangles with the mesh the sharded step left (sdfk_dist_mesh: the
+    # gathered slabs concatenated; collective with exchange mode 3, where it runs the payload exchange of that step on demand), and
+    # every rank's OWN slab (sdfk_dist_slab_mesh, global indices) with its slice of the single-GPU mesh.  First contact with a node
+    # of several GPUs then yields correctness evidence, not just a time: `mesh_equals_single_gpu: false` makes the run exit non-zero.
+    def mesh_digest(V, Cc, Nn, T):
+        import hashlib
+        return {name: hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes() if a.size else b"").hexdigest()
+                for name, a in (("Vertices", V), ("Colors", Cc), ("Normals", Nn), ("Triangles", T))}
+
+    def content_check(ses, sdf_x, mn_x, mx_x, clip_x, nn):
+        mode_x = ses.stats()["exchange_mode"]
+        counts_x = ses.counts()
+        own = ses.slab_mesh()            # (first: with exchange mode 3 no payload has moved yet)
+        own_d = mesh_digest(own.Vertices, own.Colors, own.Normals, own.Triangles)
+        own_n = (len(own.Vertices), len(own.Triangles))
+        del own
+        whole = None
+        if mode_x == 3 or rank == 0:     # (mode 3: collective -- the payload exchange of this step happens here; mode 2: only rank 0 holds it)
+            whole = ses.mesh()
+        slabs = [None] * world
+        if world > 1:
+            dist.all_gather_object(slabs, (own_d, own_n))
+        else:
+            slabs = [(own_d, own_n)]
+        res = None
+        if rank == 0:
+            with N.option(N.OPT_ELIDE_VOLUME, 0):
+                single = sdf_x.ToMesh(mn_x, mx_x, nn, nn, nn, clipToBounds=clip_x)
+            T_g = whole.Triangles
+            if os.environ.get("SDFK_BENCH_FAULT_FLIP_INDEX") == "1" and len(T_g):   # (tests: one flipped index must turn the check false)
+                T_g = T_g.copy()
+                T_g[len(T_g) // 2] ^= 1
+            d_g = mesh_digest(whole.Vertices, whole.Colors, whole.Normals, T_g)
+            d_s = mesh_digest(single.Vertices, single.Colors, single.Normals, single.Triangles)
+            slab_ok, vb, ib = True, 0, 0
+            for q in range(world):
+                nvq, niq = counts_x[q]
+                want = mesh_digest(single.Vertices[vb:vb + nvq], single.Colors[vb:vb + nvq], single.Normals[vb:vb + nvq], single.Triangles[ib:ib + niq])
+                slab_ok = slab_ok and slabs[q][1] == (nvq, niq) and slabs[q][0] == want
+                vb, ib = vb + nvq, ib + niq
+            slab_ok = slab_ok and (vb, ib) == (len(single.Vertices), len(single.Triangles))
+            res = {"mesh_equals_single_gpu": bool(d_g == d_s and len(whole.Vertices) == len(single.Vertices)),
+                   "every_ranks_slab_equals_its_slice": bool(slab_ok),
+                   "vertices": len(single.Vertices), "indices": len(single.Triangles), "sha256_single_gpu": d_s,
+                   "sha256_sharded": d_g if d_g != d_s else "identical",
+                   "what": "SHA-256 of Vertices / Colors / Normals / Triangles: the mesh of the sharded step collected last (sdfk_dist_mesh) against "
+                           "sdf.ToMesh of the same grid on rank 0's GPU alone; every rank's own slab (sdfk_dist_slab_mesh) against its slice"}
+            del single
+        del whole
+        if world > 1:
+            dist.barrier()
+        return res
+
     # ---- the sharded step without its exchange: this rank's slab kernels alone, queued back to back
     # (what "kernel-only" means at N > 1); max over ranks
     dist_extra = {}
+    headline_content = None
     if sharded:
+        headline_content = content_check(worker, sdf, mn, mx, clip, n)   # (before enqueue_only reuses slot 0's send buffer)
         st = worker.stats()
         for _ in range(3):
             worker.enqueue_only()
@@ -682,7 +753,9 @@ def main():
                       "speedup_ceiling_mesh_stays_sharded": None if not (single_ms and tk) else round(single_ms / (tk / args.steps * 1e3), 2),
                       "single_gpu_ms_per_step": None if single_ms is None else round(single_ms, 4),
                       "speedup_measured": None if not single_ms else round(single_ms / ms_step, 3),
-                      "steps_redone_on_the_exact_path": st["redone"], "stride_regrowths": st["regrown"]}
+                      "steps_redone_on_the_exact_path": st["redone"], "stride_regrowths": st["regrown"],
+                      "mesh_equals_single_gpu": None if headline_content is None else headline_content["mesh_equals_single_gpu"],
+                      "content_check": headline_content}
         if os.environ.get("SDFK_BENCH_NOTE"):
             dist_extra["note"] = os.environ["SDFK_BENCH_NOTE"]
 
@@ -783,68 +856,179 @@ def main():
             return (time.perf_counter() - t0) / k
 
     elided_ms = elided1_ms = None
+    elided_kern = None
     if not sharded and not args.minimal and n ** 3 > (1 << 24) and os.environ.get("SDFK_BENCH_NO_ELIDED") != "1":
         elided1_ms = timed_elided(step, drain, args.steps, 1) * 1e3     # every voxel evaluated, nothing stored
         elided_ms = timed_elided(step, drain, args.steps, 2) * 1e3      # + blocks decided by interval arithmetic
+        # the volume-less step's kernels, one in-order stream, event pairs per launch (like `kernels_us` for the stored step)
+        with N.option(N.OPT_ELIDE_VOLUME, 2):
+            lanes_b = N.get_option(N.OPT_LANES)
+            N.set_option(N.OPT_LANES, 0)
+            for _ in range(4):
+                step()
+            drain()
+            N.check(L.sdfk_profile_reset())
+            N.check(L.sdfk_profile_enable(1))
+            for _ in range(args.steps):
+                step()
+            drain()
+            torch.cuda.synchronize()
+            N.check(L.sdfk_profile_enable(0))
+            elided_kern = {k: {"avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "launches": v[1]} for k, v in N.profile_snapshot().items() if v[1]}
+            N.check(L.sdfk_profile_reset())
+            N.set_option(N.OPT_LANES, lanes_b)
 
-    # ---- BASELINE config C3 ("HBM roofline run": the README's RepeatXY scene with colours, 512^3, clipToBounds,
-    # /root/reference README.md:24-30) timed in THIS run, next to the headline -- never as `value`: 10 pipelined steps bracketed by
-    # synchronisation, and its sampling kernel alone, back to back (16 B/voxel stored + 1/8 B/voxel of sign bits)
-    c3 = None
-    if not sharded and not args.minimal and args.scene == "sphere" and n == 512 and os.environ.get("SDFK_BENCH_NO_C3") != "1":
+    # ---- the other BASELINE configs that fit one GPU, timed in THIS run next to the headline -- never as `value`: C2 (256^3 sphere,
+    # launch-bound), C3 ("HBM roofline run": the README's RepeatXY scene with colours, 512^3, clipToBounds, /root/reference
+    # README.md:24-30) and C4 (1024^3 union of 8 primitives, the grid BASELINE shards over 8 GPUs, here whole on one).  Each: k pipelined
+    # steps bracketed by synchronisation with the volume STORED, the same with the product default (volume-less above 2^24 voxels),
+    # and its sampling kernel alone, back to back ((4 | 16) B/voxel stored + 1/8 B/voxel of sign bits).
+    def side_config(scene_name, n_side, k_side, depth_side, label, sampler_launches=None):
         from sdfkit_amd.api import Voxels
-        sdf3, mn3, mx3, clip3 = scene_for("repeatxy")
-        step3, drain3, _ = single_gpu_stepper(5, sdf3.program(), mn3, mx3, clip3)
-        for _ in range(8):
-            nv3, ni3 = step3()
-        nv3, ni3 = drain3()
+        sdf_s, mn_s, mx_s, clip_s = scene_for(scene_name)
+        t0 = time.perf_counter()
+        prog_s = sdf_s.program()
+        step_s_, drain_s, _ = single_gpu_stepper(depth_side, prog_s, mn_s, mx_s, clip_s, n_side)
+        nv_s, ni_s = step_s_()
+        nv_s, ni_s = drain_s()
+        first_ms = (time.perf_counter() - t0) * 1e3          # program creation + the first sample -> mesh of this scene and shape
+        for _ in range(7):
+            step_s_()
+        nv_s, ni_s = drain_s()
         t_w = time.perf_counter()
         while (time.perf_counter() - t_w) * 1e3 < warm_ms:      # sustained clocks, as for the headline
-            for _ in range(8):
-                step3()
-            drain3()
+            for _ in range(depth_side + 3):
+                step_s_()
+            drain_s()
         torch.cuda.synchronize()
-        k3 = 10
         t0 = time.perf_counter()
-        for _ in range(k3):
-            nv3, ni3 = step3()
-        nv3, ni3 = drain3()
+        for _ in range(k_side):
+            nv_s, ni_s = step_s_()
+        nv_s, ni_s = drain_s()
         torch.cuda.synchronize()
-        s3 = (time.perf_counter() - t0) / k3
-        vols = [Voxels(mn3, mx3, n, n, n) for _ in range(2)]
+        s_stored = (time.perf_counter() - t0) / k_side
+        colors_s = bool(sdf_s.writes_color)
+        bpv = 16 if colors_s else 4
+        ks = sampler_launches or k_side
+        vols = [Voxels(mn_s, mx_s, n_side, n_side, n_side) for _ in range(2)]
         for k in range(4):
-            vols[k % 2]._sample(sdf3, clip=clip3)
+            vols[k % 2]._sample(sdf_s, clip=clip_s)
         N.check(L.sdfk_profile_enable(2))            # the sampling kernel alone
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for k in range(k3):
-            vols[k % 2]._sample(sdf3, clip=clip3)
+        for k in range(ks):
+            vols[k % 2]._sample(sdf_s, clip=clip_s)
         e1.record(stream)
         torch.cuda.synchronize()
         N.check(L.sdfk_profile_enable(0))
-        samp3_us = e0.elapsed_time(e1) * 1e3 / k3
+        samp_us = e0.elapsed_time(e1) * 1e3 / ks
         for vol in vols:
             vol._free()
-        e3 = e31 = None
-        if os.environ.get("SDFK_BENCH_NO_ELIDED") != "1":
-            e31 = timed_elided(step3, drain3, k3, 1)
-            e3 = timed_elided(step3, drain3, k3, 2)
-        bytes3 = n ** 3 * 16 + n ** 3 // 8
-        meas3 = load_pmc_traffic("pipeline_step", "repeatxy", n)
-        c3 = {"workload": WORKLOADS["repeatxy"] + f", {n}^3", "steps": k3, "ms_per_step": round(s3 * 1e3, 4),
-              "mvoxels_per_s": round(n ** 3 / s3 / 1e6, 1), "vertices": nv3, "triangles": ni3 // 3,
-              "frac_design_bytes": round((bytes3 + 36 * nv3 + 4 * ni3) / s3 / 1e9 / HBM_PEAK_GBS, 4),
-              "frac_measured_bytes": None if not meas3 else round(meas3 / s3 / 1e9 / HBM_PEAK_GBS, 4),
-              "elided_volume_ms_per_step": None if e3 is None else round(e3 * 1e3, 4),
-              "elided_volume_no_culling_ms_per_step": None if e31 is None else round(e31 * 1e3, 4),
-              "sampler_us_back_to_back": round(samp3_us, 1),
-              "sampler_frac": round(n ** 3 * 16 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),            # algorithmic: 16 B/voxel stored
-              "sampler_frac_design_bytes": round(bytes3 / (samp3_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),   # + 1/8 B/voxel of sign bytes
-              "what": "BASELINE config C3 in this run: pipelined sample -> mesh of the README scene (colours: 16 B/voxel stored), then its sampling "
-                      "kernel alone, launched back to back into two resident volumes; fractions = bytes / time / 8 TB/s (design: 16 + 1/8 B per "
-                      "voxel + the mesh; measured: profiles/pmc_traffic.json)"}
-        del sdf3
+        e2 = e1_ = None
+        elidable = n_side ** 3 > (1 << 24)           # (grids up to the captured-graph limit are never elided: DESIGN.md section 5)
+        if os.environ.get("SDFK_BENCH_NO_ELIDED") != "1" and elidable:
+            e1_ = timed_elided(step_s_, drain_s, k_side, 1)
+            e2 = timed_elided(step_s_, drain_s, k_side, 2)
+        nvox = n_side ** 3
+        bytes_s = nvox * bpv + nvox // 8
+        meas = load_pmc_traffic("pipeline_step", scene_name, n_side)
+        mesh_b = 36 * nv_s + 4 * ni_s
+        out_s = {"workload": WORKLOADS[scene_name] + f", {n_side}^3", "config": label, "steps": k_side, "ms_per_step": round(s_stored * 1e3, 4),
+                 "mvoxels_per_s": round(nvox / s_stored / 1e6, 1), "mtris_per_s": round(ni_s / 3 / s_stored / 1e6, 2),
+                 "vertices": nv_s, "triangles": ni_s // 3,
+                 "first_call_ms": round(first_ms, 1),
+                 "frac_design_bytes": round((bytes_s + mesh_b) / s_stored / 1e9 / HBM_PEAK_GBS, 4),
+                 "frac_contract_bytes": None if colors_s else round((nvox * 8 + mesh_b) / s_stored / 1e9 / HBM_PEAK_GBS, 4),
+                 "frac_measured_bytes": None if not meas else round(meas / s_stored / 1e9 / HBM_PEAK_GBS, 4),
+                 # the PRODUCT DEFAULT (SDFK_OPT_ELIDE_VOLUME = 2): the temporary volume of SdfEx.ToMesh is not stored
+                 "product_default_ms_per_step": round((e2 if e2 is not None else s_stored) * 1e3, 4),
+                 "product_default_is": "volume-less (cull + eval of the blocks the surface passes through)" if e2 is not None else
+                                       ("the stored step: grids of at most 2^24 voxels are one captured graph launch and are never elided" if not elidable else "not measured"),
+                 "elided_volume_ms_per_step": None if e2 is None else round(e2 * 1e3, 4),
+                 "elided_volume_no_culling_ms_per_step": None if e1_ is None else round(e1_ * 1e3, 4),
+                 "sampler_us_back_to_back": round(samp_us, 1),
+                 "sampler_frac": round(nvox * bpv / (samp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),            # algorithmic: (4 | 16) B/voxel stored
+                 "sampler_frac_design_bytes": round(bytes_s / (samp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),   # + 1/8 B/voxel of sign bytes
+                 "what": f"BASELINE config {label} in this run: {k_side} pipelined sample -> mesh steps ({depth_side} in flight, volume stored: {bpv} B/voxel), "
+                         f"the same with the product default, then its sampling kernel alone ({ks} launches back to back into two resident volumes); "
+                         "fractions = bytes / time / 8 TB/s (design: (4 | 16) + 1/8 B per voxel + the mesh; contract: SURVEY 8(d)'s 8 B/voxel for a "
+                         "distance-only volume; measured: profiles/pmc_traffic.json)"}
+        del sdf_s
+        return out_s
+
+    side_ok = not sharded and not args.minimal and args.scene == "sphere" and n == 512
+    c3 = c2 = c4 = None
+    if side_ok and os.environ.get("SDFK_BENCH_NO_C3") != "1":
+        c3 = side_config("repeatxy", 512, 10, 5, "C3")
+    if side_ok and os.environ.get("SDFK_BENCH_NO_C2") != "1":
+        c2 = side_config("sphere", 256, 40, 5, "C2")
+    if side_ok and os.environ.get("SDFK_BENCH_NO_C4") != "1":
+        c4 = side_config("union8", 1024, 5, 3, "C4 (the whole 1024^3 grid on ONE GPU; the 8-GPU Z-slab form is `bench.py --gpus N`'s c4_union8_1024 leg)", sampler_launches=4)
+
+    # ---- a CONTROL for the colour sampler (C3 / C4 run at ~0.70 of peak where the distance-only sampler reaches 0.82): (a) a plain
+    # fill of the same bytes and duration -- one launch writes 2 GiB and lasts ~350 us, where hbm_measured's fill writes 512 MiB in
+    # 80 us -- and (b) the SAME sampling kernel with next to no arithmetic (a sphere with a constant colour: one square root per voxel,
+    # 16 B/voxel stored).  If both drop to the colour sampler's rate, long launches at this store rate are what the part sustains
+    # (clock / power management) and nothing is left in the kernel; if they hold the short fill's rate, the SDF's arithmetic is.
+    long_fill = None
+    if side_ok and c3 is not None and os.environ.get("SDFK_BENCH_NO_CONTROL") != "1":
+        from sdfkit_amd import SdfFuncs
+        from sdfkit_amd.api import Voxels
+        bufs = [torch.empty(2 << 30, dtype=torch.uint8, device=dev) for _ in range(2)]
+        for b_ in bufs:
+            b_.fill_(1)
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - t_w) * 1e3 < warm_ms:
+            bufs[k % 2].fill_(0)
+            k += 1
+            if k % 16 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(10):
+            bufs[k % 2].fill_(0)
+        e1.record()
+        torch.cuda.synchronize()
+        fill_us = e0.elapsed_time(e1) * 1e3 / 10
+        fill_gbs = (2 << 30) / (fill_us * 1e-6) / 1e9
+        del bufs
+        triv = SdfFuncs.Sphere(0.5).WithColor(1.0, 0.2, 0.3).ToSdf()
+        mn3, mx3 = [-2.8125] * 3, [2.8125] * 3
+        vols = [Voxels(mn3, mx3, 512, 512, 512) for _ in range(2)]
+        for k in range(4):
+            vols[k % 2]._sample(triv, clip=True)
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - t_w) * 1e3 < warm_ms:
+            vols[k % 2]._sample(triv, clip=True)
+            k += 1
+            if k % 16 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(10):
+            vols[k % 2]._sample(triv, clip=True)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        triv_us = e0.elapsed_time(e1) * 1e3 / 10
+        for vol in vols:
+            vol._free()
+        triv_gbs = 512 ** 3 * 16 / (triv_us * 1e-6) / 1e9
+        c3_gbs = 512 ** 3 * 16 / (c3["sampler_us_back_to_back"] * 1e-6) / 1e9
+        long_fill = {"fill_2gib_us": round(fill_us, 1), "fill_2gib_gbs": round(fill_gbs, 1), "fill_2gib_frac_of_peak": round(fill_gbs / HBM_PEAK_GBS, 4),
+                     "trivial_colour_sampler_us": round(triv_us, 1), "trivial_colour_sampler_gbs": round(triv_gbs, 1),
+                     "trivial_colour_sampler_frac_of_peak": round(triv_gbs / HBM_PEAK_GBS, 4),
+                     "what": "controls for the colour sampler: torch fill_ of 2 GiB (two buffers in turn, 10 launches after the clock warm-up: a plain "
+                             "fill as LONG as the colour sampler's launch) and sdfk_sample_bits_clip on a sphere with a constant colour (the same "
+                             "kernel shape and 16 B/voxel of stores, one square root of arithmetic), 512^3, 10 launches back to back"}
+        c3["sampler_frac_of_long_fill"] = round(c3_gbs / fill_gbs, 4)
+        c3["sampler_frac_of_trivial_colour_sampler"] = round(c3_gbs / triv_gbs, 4)
 
     # ---- BASELINE config C5 (stretch: RayMarcher.Render, RayMarcher.cs:45-211) in THIS run: 1920 x 1080, 256 depth iterations, the README
     # scene, camera (-2, 2, 4) -> origin (Perf/Program.cs:54-58), images device-resident; never `value`.  ALU-bound (no HBM traffic to
@@ -1042,6 +1226,17 @@ def main():
             # arrays are fresh managed memory; the pooled figure -- the opt-in Mesh.Recycle(), not in the reference -- has its own key)
             extra["one_step_incl_mesh_d2h_ms"] = d2h["managed"]["median_ms"]
             extra["one_step_incl_mesh_d2h_pooled_ms"] = d2h["pooled"]["median_ms"]
+            # ... and the same calls as a host that changes NOTHING gets them: the product default (SDFK_OPT_ELIDE_VOLUME = 2, the
+            # temporary volume of SdfEx.ToMesh is not stored) -- the figures above keep the contract's stored volume like `value`
+            if n ** 3 > (1 << 24):
+                with N.option(N.OPT_ELIDE_VOLUME, 2):
+                    for kind in ("pooled", "managed"):
+                        ts = [one_call(kind) for _ in range(8)]
+                        d2h[kind + "_product_default"] = {"median_ms": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "all_ms": [round(t, 3) for t in ts]}
+                    pipelined_handoff(3)
+                    extra["pipelined_handoff_product_default_ms_per_mesh"] = round(pipelined_handoff(10), 3)
+                extra["one_step_incl_mesh_d2h_product_default_ms"] = d2h["managed_product_default"]["median_ms"]
+                extra["one_step_incl_mesh_d2h_product_default_pooled_ms"] = d2h["pooled_product_default"]["median_ms"]
             extra["one_step_incl_mesh_d2h"] = {
                 "what": "sdfk_sample_march + sdfk_mesh_counts + sdfk_mesh_copy of V/C/N/T to the host + sdfk_mesh_bounds, one call at a time; "
                         "median of 7 calls after a warm-up call (the second copy into an address is still slow -- the runtime maps the pages "
@@ -1099,6 +1294,39 @@ def main():
             return None if not nbytes or not seconds else round(nbytes / seconds / 1e9 / HBM_PEAK_GBS, 4)
 
         lat_s = None if latency_ms is None else latency_ms * 1e-3
+        # ---- the PRODUCT DEFAULT path (volume-less) with a bound of its own: its longest kernel is k_vertices, which neither moves many
+        # bytes nor waits for them -- it is bound by VECTOR ISSUE (fp64 cell math the reference dictates); the fraction is the share of
+        # the SIMDs' cycles in which a vector instruction was in flight, from the committed SQ counter pass of the volume-less run
+        # (profiles/pmc_traffic.json, tools/gpu_elided_counters.sh), over the kernel's event-timed duration in THIS run
+        elided_obj = None
+        if elided_ms is not None and elided_kern:
+            chain = [k for k in elided_kern if not k.startswith(("sdfk_cull", "sdfk_eval_blocks"))]
+            kv = next((k for k in elided_kern if k.startswith("k_vertices")), None)
+            act = load_pmc_traffic("k_vertices<true>:SQ_ACTIVE_INST_VALU", args.scene + "_elided", n)
+            ins = load_pmc_traffic("k_vertices<true>:SQ_INSTS_VALU", args.scene + "_elided", n)
+            busy = load_pmc_traffic("k_vertices<true>:SQ_BUSY_CYCLES", args.scene + "_elided", n)
+            meas_e = load_pmc_traffic("pipeline_step", args.scene + "_elided", n)
+            kv_s = None if not kv else elided_kern[kv]["avg_us"] * 1e-6
+            serial_us = sum(v["avg_us"] for v in elided_kern.values())
+            elided_obj = {
+                "ms_per_step": round(elided_ms, 4), "mvoxels_per_s": round(n ** 3 / (elided_ms * 1e-3) / 1e6, 1),
+                "latency_ms_single_call": None if latency_default_ms is None else round(latency_default_ms, 4),
+                "kernels_us": elided_kern, "kernels_serial_sum_us": round(serial_us, 1),
+                "chain_serial_us": round(sum(elided_kern[k]["avg_us"] for k in chain), 1),
+                "measured_hbm_bytes": meas_e,
+                "frac_measured_bytes": None if not meas_e else round(meas_e / (elided_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "roofline": None if not (kv and act) else {
+                    "bound": "valu", "kernel": kv, "avg_launch_us": elided_kern[kv]["avg_us"],
+                    # wavefront quad-cycles with a vector instruction in flight x 4 / (1024 SIMDs x 2.4 GHz x the launch): the share of
+                    # the vector ALUs' time this kernel keeps busy (fp64 instructions occupy the pipe twice as long as fp32 ones)
+                    "frac": round(act * 4 / 1024 / 2.4e9 / kv_s, 4),
+                    "achieved": round(act * 4 / 1024 / kv_s / 1e9, 3), "peak": 2.4, "unit": "G busy SIMD-cycles/s per SIMD",
+                    "valu_insts_per_launch": ins, "sq_busy_cycles_per_launch": busy,
+                    "source": "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of k_vertices in a volume-less run (committed: profiles/pmc_traffic.json, "
+                              "`...@sphere_elided@512`), duration event-timed in this run on one in-order stream"},
+                "what": "the product default (SDFK_OPT_ELIDE_VOLUME = 2) on the headline grid: pipelined ms/step, one synchronous call, every kernel of "
+                        "the volume-less step on one in-order stream (cull + eval of the surface blocks, then the meshing chain), and the bound of its "
+                        "longest kernel.  The step as a whole is LATENCY-bound: seven dependent launches of 7-40 us each, ~50 MB of algorithmic bytes"}
         out = {
             "metric": "Mvoxels/s, 512^3 sphere SDF sample->mesh" if (n == 512 and args.scene == "sphere")
                       else f"Mvoxels/s, {n}^3 {args.scene} SDF sample->mesh",
@@ -1109,6 +1337,7 @@ def main():
             "value_cold_clocks": round(n ** 3 / (dt_cold / args.steps) / 1e6, 1),
             "ms_per_step_cold_clocks": round(dt_cold / args.steps * 1e3, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            **({"NOT_THE_CONTRACT_STEP": "--elide: the volume is not stored (a profiling run of the product default)"} if (args.elide and args.minimal) else {}),
             "ms_per_step": round(ms_step, 4),
             "blocks": {"n": len(block_dts), "ms_per_step_median": round(ms_step, 4),
                        "ms_per_step_min": round(min(block_dts) / args.steps * 1e3, 4), "ms_per_step_max": round(max(block_dts) / args.steps * 1e3, 4),
@@ -1159,10 +1388,14 @@ def main():
             "pipeline_measured_hbm_gbs": None if not measured_hbm else round(measured_hbm / step_s / 1e9, 1),
             "kernels_us": kern,
             "roofline": roof,
+            "c2_sphere_256": c2,
             "c3_repeatxy": c3,
+            "c4_union8_1024": c4,
+            "colour_sampler_control": long_fill,
             "c5_raymarch": c5,
             "elided_volume_ms_per_step": None if elided_ms is None else round(elided_ms, 4),
             "elided_volume_no_culling_ms_per_step": None if elided1_ms is None else round(elided1_ms, 4),
+            "elided": elided_obj,
             "elided_volume_is": "SDFK_OPT_ELIDE_VOLUME (opt-in): the same K pipelined steps with a volume that is never stored -- the sampler "
                                 "leaves sign bits only, corners and vertex colours are re-evaluated; meshes bit-identical.  = 2 (the first figure): "
                                 "64 x 4 x 4 blocks whose values provably lie on one side of the iso value -- the program evaluated in interval "
@@ -1175,29 +1408,195 @@ def main():
             out["sharded"] = dist_extra
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_n or n, max(args.cpu_passes, 1))
-    # ---- tuned pass (N > 1 over RCCL).  The headline above used the plainest exchange.  The line is now SAFE: rank 0 leaves it
-    # in the file its supervisor named, every rank leaves a marker -- a worker that dies or hangs from here on still counts as a
-    # finished headline attempt (supervise_rank) -- and only then do the ranks try what has never run between two GPUs on the
-    # development boxes: the tuner (ncclAllGather against direct grouped sends, int32 against 16-bit indices, 20 pipelined steps
-    # each) and K timed steps in the configuration it keeps.  A watchdog ends a rank whose tuned pass does not finish in time.
+    # ---- after the headline (N > 1).  The headline above used the plainest exchange.  The line is now SAFE: rank 0 leaves it in the file
+    # its supervisor named, every rank leaves a marker -- a worker that dies or hangs from here on still counts as a finished headline
+    # attempt (supervise_rank) -- and rank 0 rewrites the file after every further pass, so that whatever finished is reported.  Order =
+    # least new ground first: (1) BASELINE C4 (1024^3 union of 8 primitives, the config that can scale) with the SAME exchange as the
+    # headline; (2) the passes that leave the mesh sharded (exchange mode 3: headers only), headline grid and C4; (3) last, the tuner, which
+    # tries the exchanges that have never run between two GPUs.  Every pass has a watchdog of its own.
     result_base = os.environ.get("SDFK_BENCH_RESULT_BASE")
-    tune_it = sharded and world > 1 and D.info()[2] == 1 and os.environ.get("SDFK_BENCH_NO_TUNE") != "1"
-    if sharded and world > 1 and result_base:
-        if rank == 0:
+    multi = sharded and world > 1
+    after_on = multi and os.environ.get("SDFK_BENCH_NO_TUNE") != "1"
+    tune_it = after_on and D.info()[2] == 1
+
+    def save_line():
+        if multi and result_base and rank == 0:
             with open(result_base + ".json.tmp", "w") as f:
-                out["sharded"]["tuned_pass"] = "did not finish (the headline pass above is unaffected)" if tune_it else "off (SDFK_BENCH_NO_TUNE / host transport)"
                 f.write(json.dumps(out) + "\n")
             os.replace(result_base + ".json.tmp", result_base + ".json")
-        open(f"{result_base}.rank{rank}.done", "w").close()
-    tuned_pass = None
-    if tune_it:
-        import threading
-        limit_b = float(os.environ.get("SDFK_BENCH_TUNE_TIMEOUT_S", "90"))
-        dog = threading.Timer(limit_b, lambda: (print(f"bench.py: rank {rank}: the tuned pass did not finish within {limit_b:.0f} s "
-                                                      f"(exchange mode {worker.stats()['exchange_mode']}, stride {worker.stats()['stride_bytes']} bytes)",
-                                                      file=sys.stderr, flush=True), os._exit(3)))
+
+    if multi:
+        if rank == 0:
+            out["sharded"]["tuned_pass"] = "did not finish (the headline pass above is unaffected)" if tune_it else "off (SDFK_BENCH_NO_TUNE / host transport)"
+            out["sharded"]["mesh_stays_sharded_pass"] = "did not finish" if after_on else "off"
+            out["sharded"]["c4_union8_1024"] = "did not finish" if after_on else "off"
+        save_line()
+        if result_base:
+            open(f"{result_base}.rank{rank}.done", "w").close()
+
+    import threading
+
+    def watchdog(what, seconds):
+        dog = threading.Timer(seconds, lambda: (print(f"bench.py: rank {rank}: {what} did not finish within {seconds:.0f} s", file=sys.stderr, flush=True), os._exit(3)))
         dog.daemon = True
         dog.start()
+        return dog
+
+    def timed_session_steps(ses, k):
+        """W + 8 untimed steps, then EXACTLY k steps bracketed by barrier + synchronize, max over ranks (seconds)"""
+        def step_():
+            if ses.in_flight == ses.depth:
+                ses.collect()
+            ses.submit()
+        for _ in range(max(args.warmup, 1) + 8):
+            step_()
+        ses.drain()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step_()
+        ses.drain()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # ---- (1) + (2b) BASELINE config C4 sharded: the only configuration of BASELINE.json where Z slabs can approach the >= 6x target --
+    # a 1024^3 step is 3.7 ms on one GPU (0.97 with the product default), its slab meshes ~150 MB: the slabs' compute dominates the
+    # exchange (DESIGN.md section 6).  Grid: 1024 beside the 512^3 headline (SDFK_BENCH_C4_GRID overrides; 2 x --grid otherwise).
+    c4_grid = int(os.environ.get("SDFK_BENCH_C4_GRID", "0")) or (1024 if n == 512 else 2 * n)
+    c4_leg = None
+    c4_state = {}
+
+    def c4_pass(mode_key, mode):
+        """K_c timed steps of the C4 grid in one exchange mode, its counts, stats and content check -> dict (rank 0; None elsewhere)"""
+        k_c = int(os.environ.get("SDFK_BENCH_C4_STEPS", "10"))
+        if "scene" not in c4_state:
+            c4_state["scene"] = scene_for("union8")
+        sdf_c, mn_c, mx_c, clip_c = c4_state["scene"]
+        with N.option(N.OPT_DIST_EXCHANGE, mode):
+            ses = D.SlabSession(sdf_c, mn_c, mx_c, c4_grid, c4_grid, c4_grid, clip_c, 0.0, depth=min(depth_env or 4, 3))
+        try:
+            dt_c = timed_session_steps(ses, k_c)
+            ses.submit()
+            ses.collect()
+            counts_c = [list(c) for c in ses.counts()]
+            st_c = ses.stats()
+            chk = content_check(ses, sdf_c, mn_c, mx_c, clip_c, c4_grid)
+            # rank 0's single-GPU step of the SAME grid (stored volume, like the sharded step, and the product default), measured here
+            # while the other ranks wait: the numerator of speedup_measured
+            if "single_ms" not in c4_state and os.environ.get("SDFK_BENCH_NO_SINGLE") != "1":
+                single = [None, None]
+                if rank == 0:
+                    s_step, s_drain, _ = single_gpu_stepper(3, sdf_c.program(), mn_c, mx_c, clip_c, c4_grid)
+                    for which, mode_e in ((0, 0), (1, 2)):
+                        with N.option(N.OPT_ELIDE_VOLUME, mode_e):
+                            for _ in range(6):
+                                s_step()
+                            s_drain()
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(k_c):
+                                s_step()
+                            s_drain()
+                            torch.cuda.synchronize()
+                            single[which] = (time.perf_counter() - t0) / k_c * 1e3
+                barrier()
+                c4_state["single_ms"] = single
+        finally:
+            ses.close()
+        if rank != 0:
+            return None
+        single = c4_state.get("single_ms", [None, None])
+        ms_c = dt_c / k_c * 1e3
+        return {"exchange": {-1: "host transport", 0: "ncclAllGather (in place)", 1: "grouped ncclSend / ncclRecv to every peer",
+                             2: "gather to rank 0", 3: "headers only: the mesh stays sharded (payloads on demand)"}[st_c["exchange_mode"]] +
+                            (" -- mesh stays sharded (SDFK_OPT_DIST_EXCHANGE = 3)" if mode == 3 and st_c["exchange_mode"] == -1 else ""),
+                "steps": k_c, "ms_per_step": round(ms_c, 4), "mvoxels_per_s": round(c4_grid ** 3 / (ms_c * 1e-3) / 1e6, 1),
+                "vertices": sum(c[0] for c in counts_c), "triangles": sum(c[1] for c in counts_c) // 3, "per_rank_vertices_indices": counts_c,
+                "gather_stride_bytes_per_rank": int(st_c["stride_bytes"]),
+                "bytes_received_per_rank": int((world - 1) * (st_c["stride_bytes"] if mode != 3 else 64)),
+                "steps_redone": st_c["redone"], "stride_regrowths": st_c["regrown"],
+                "single_gpu_ms_per_step": None if single[0] is None else round(single[0], 4),
+                "single_gpu_product_default_ms_per_step": None if single[1] is None else round(single[1], 4),
+                "speedup_measured": None if single[0] is None else round(single[0] / ms_c, 3),
+                "speedup_vs_single_gpu_product_default": None if single[1] is None else round(single[1] / ms_c, 3),
+                "mesh_equals_single_gpu": None if chk is None else chk["mesh_equals_single_gpu"], "content_check": chk}
+
+    if after_on and os.environ.get("SDFK_BENCH_NO_C4") != "1":
+        dog = watchdog("the C4 pass (default exchange)", float(os.environ.get("SDFK_BENCH_C4_TIMEOUT_S", "150")))
+        try:
+            barrier()
+            leg = c4_pass("all_gather", N.get_option(N.OPT_DIST_EXCHANGE))
+            if rank == 0:
+                c4_leg = {"workload": WORKLOADS["union8"] + f", {c4_grid}^3, z-slab x{world}", "grid": c4_grid, "all_gather": leg,
+                          "mesh_stays_sharded": "did not finish",
+                          "what": "BASELINE config C4 sharded like the headline: K timed steps (same barriers, max over ranks) with the default "
+                                  "exchange, then with exchange mode 3; speedup_measured = rank 0's single-GPU step of the same grid (volume "
+                                  "stored, as in the slabs) / the sharded step; reported here only, never as `value`"}
+                out["sharded"]["c4_union8_1024"] = c4_leg
+        except BaseException as e:   # noqa: B902 -- reported; the headline is already safe
+            if rank == 0:
+                out["sharded"]["c4_union8_1024"] = {"failed": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: rank {rank} (device {local_rank}): C4 pass failed: {e}", file=sys.stderr, flush=True)
+        dog.cancel()
+        save_line()
+
+    # ---- (2) "the mesh stays sharded" pass: the same K steps with SDFK_OPT_DIST_EXCHANGE = 3 -- a step moves the 64-byte headers
+    # only, the slab meshes stay on their GPUs (sdfk_dist_slab_mesh / sdfk_dist_mesh fetch payloads on demand).  NOT the contract's step
+    # (which all-gathers the slab meshes): reported beside it, after the headline is safe, under a watchdog of its own.
+    sharded_result_pass = None
+    if after_on and os.environ.get("SDFK_BENCH_NO_SHARDED_RESULT") != "1":
+        dog = watchdog("the sharded-result pass", float(os.environ.get("SDFK_BENCH_TUNE_TIMEOUT_S", "90")))
+        w3 = None
+        try:
+            barrier()
+            with N.option(N.OPT_DIST_EXCHANGE, 3):
+                w3 = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 4)
+            dt_c = timed_session_steps(w3, args.steps)
+            w3.submit()
+            w3.collect()
+            c3_counts = [list(c) for c in w3.counts()]
+            ok3 = (sum(c[0] for c in c3_counts), sum(c[1] for c in c3_counts)) == (nv, ni)
+            chk3 = content_check(w3, sdf, mn, mx, clip, n)
+            sharded_result_pass = {"exchange": "headers only (SDFK_OPT_DIST_EXCHANGE = 3): the mesh stays sharded, payloads on demand",
+                                   "ms_per_step": round(dt_c / args.steps * 1e3, 4), "value": round(n ** 3 / (dt_c / args.steps) / 1e6, 1),
+                                   "counts_equal_the_headline_mesh": ok3,
+                                   "mesh_equals_single_gpu": None if chk3 is None else chk3["mesh_equals_single_gpu"], "content_check": chk3,
+                                   "speedup_measured": None if not dist_extra.get("single_gpu_ms_per_step") else
+                                   round(dist_extra["single_gpu_ms_per_step"] / (dt_c / args.steps * 1e3), 3),
+                                   "what": "K timed steps (same barriers, max over ranks) in which every rank meshes its slab and only the 64-byte "
+                                           "headers cross the fabric; reported here only, never as `value`"}
+        except BaseException as e:   # noqa: B902 -- reported; the headline is already safe
+            sharded_result_pass = {"failed": f"{type(e).__name__}: {e}"}
+            print(f"bench.py: rank {rank} (device {local_rank}): sharded-result pass failed: {e}", file=sys.stderr, flush=True)
+        dog.cancel()
+        try:
+            if w3 is not None:
+                w3.close()
+        except BaseException:   # noqa: B902
+            pass
+        if rank == 0:
+            out["sharded"]["mesh_stays_sharded_pass"] = sharded_result_pass
+        save_line()
+        if os.environ.get("SDFK_BENCH_NO_C4") != "1" and (rank != 0 or isinstance(c4_leg, dict)):
+            dog = watchdog("the C4 pass (mesh stays sharded)", float(os.environ.get("SDFK_BENCH_C4_TIMEOUT_S", "150")))
+            try:
+                barrier()
+                leg3 = c4_pass("mesh_stays_sharded", 3)
+                if rank == 0:
+                    c4_leg["mesh_stays_sharded"] = leg3
+            except BaseException as e:   # noqa: B902
+                if rank == 0:
+                    c4_leg["mesh_stays_sharded"] = {"failed": f"{type(e).__name__}: {e}"}
+                print(f"bench.py: rank {rank} (device {local_rank}): C4 pass (mode 3) failed: {e}", file=sys.stderr, flush=True)
+            dog.cancel()
+            save_line()
+
+    # ---- (3) tuned pass (N > 1 over RCCL): the tuner (ncclAllGather against direct grouped sends, int32 against 16-bit indices, 20
+    # pipelined steps each) and K timed steps in the configuration it keeps.
+    tuned_pass = None
+    if tune_it:
+        dog = watchdog(f"the tuned pass (exchange mode {worker.stats()['exchange_mode']}, stride {worker.stats()['stride_bytes']} bytes)",
+                       float(os.environ.get("SDFK_BENCH_TUNE_TIMEOUT_S", "90")))
         try:
             barrier()
             tuned = {f"mode{m}_{'compact' if c else 'plain'}": ns for (m, c), ns in worker.tune(20).items()}
@@ -1213,80 +1612,49 @@ def main():
             barrier()
             dt_b = max_over_ranks(time.perf_counter() - t0)
             st_b = worker.stats()
+            step()
+            drain()
+            chk_b = content_check(worker, sdf, mn, mx, clip, n)
             tuned_pass = {"tuner_ns_per_20_steps": tuned,
                           "exchange": {0: "ncclAllGather (in place)", 1: "grouped ncclSend / ncclRecv to every peer", 2: "gather to rank 0"}[st_b["exchange_mode"]],
                           "payload": "compact (16-bit index offsets)" if st_b["index16"] else "plain (int32 indices)",
                           "ms_per_step": round(dt_b / args.steps * 1e3, 4), "value": round(n ** 3 / (dt_b / args.steps) / 1e6, 1),
                           "gather_stride_bytes_per_rank": int(st_b["stride_bytes"]),
+                          "mesh_equals_single_gpu": None if chk_b is None else chk_b["mesh_equals_single_gpu"],
                           "what": "K timed steps (same barriers, max over ranks) in the exchange / payload form sdfk_dist_tune kept; reported "
                                   "here only, never as `value`"}
         except BaseException as e:   # noqa: B902 -- reported; the headline is already safe
             tuned_pass = {"failed": f"{type(e).__name__}: {e}"}
             print(f"bench.py: rank {rank} (device {local_rank}): tuned pass failed: {e}", file=sys.stderr, flush=True)
         dog.cancel()
-    # ---- "the mesh stays sharded" pass (N > 1): the same K steps with SDFK_OPT_DIST_EXCHANGE = 3 -- a step moves the 64-byte headers
-    # only, the slab meshes stay on their GPUs (sdfk_dist_slab_mesh / sdfk_dist_mesh fetch payloads on demand).  NOT the contract's step
-    # (which all-gathers the slab meshes): reported beside it, after the headline is safe, under a watchdog of its own.
-    sharded_result_pass = None
-    if sharded and world > 1 and os.environ.get("SDFK_BENCH_NO_SHARDED_RESULT") != "1" and os.environ.get("SDFK_BENCH_NO_TUNE") != "1":
-        import threading
-        limit_c = float(os.environ.get("SDFK_BENCH_TUNE_TIMEOUT_S", "90"))
-        dog = threading.Timer(limit_c, lambda: (print(f"bench.py: rank {rank}: the sharded-result pass did not finish within {limit_c:.0f} s",
-                                                      file=sys.stderr, flush=True), os._exit(3)))
-        dog.daemon = True
-        dog.start()
-        w3 = None
-        try:
-            barrier()
-            with N.option(N.OPT_DIST_EXCHANGE, 3):
-                w3 = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 4)
-
-            def step3():
-                if w3.in_flight == w3.depth:
-                    w3.collect()
-                w3.submit()
-
-            def drain3():
-                while w3.in_flight:
-                    w3.collect()
-            for _ in range(max(args.warmup, 1) + 8):
-                step3()
-            drain3()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step3()
-            drain3()
-            barrier()
-            dt_c = max_over_ranks(time.perf_counter() - t0)
-            c3_counts = [list(c) for c in w3.counts()]
-            ok3 = (sum(c[0] for c in c3_counts), sum(c[1] for c in c3_counts)) == (nv, ni)
-            sharded_result_pass = {"exchange": "headers only (SDFK_OPT_DIST_EXCHANGE = 3): the mesh stays sharded, payloads on demand",
-                                   "ms_per_step": round(dt_c / args.steps * 1e3, 4), "value": round(n ** 3 / (dt_c / args.steps) / 1e6, 1),
-                                   "counts_equal_the_headline_mesh": ok3,
-                                   "speedup_measured": None if not dist_extra.get("single_gpu_ms_per_step") else
-                                   round(dist_extra["single_gpu_ms_per_step"] / (dt_c / args.steps * 1e3), 3),
-                                   "what": "K timed steps (same barriers, max over ranks) in which every rank meshes its slab and only the 64-byte "
-                                           "headers cross the fabric; reported here only, never as `value`"}
-        except BaseException as e:   # noqa: B902 -- reported; the headline is already safe
-            sharded_result_pass = {"failed": f"{type(e).__name__}: {e}"}
-            print(f"bench.py: rank {rank} (device {local_rank}): sharded-result pass failed: {e}", file=sys.stderr, flush=True)
-        dog.cancel()
-        try:
-            if w3 is not None:
-                w3.close()
-        except BaseException:   # noqa: B902
-            pass
+        if rank == 0:
+            out["sharded"]["tuned_pass"] = tuned_pass
+        save_line()
+    content_ok = True
     if rank == 0:
-        if sharded and world > 1:
-            out["sharded"]["tuned_pass"] = tuned_pass if tuned_pass is not None else "off (SDFK_BENCH_NO_TUNE / host transport)"
-            out["sharded"]["mesh_stays_sharded_pass"] = sharded_result_pass if sharded_result_pass is not None else "off"
+        if sharded:
+            # every content check of this run: the headline's, the C4 passes', the mesh-stays-sharded pass's, the tuned pass's
+            checks = {"headline": out["sharded"].get("mesh_equals_single_gpu")}
+            for key in ("mesh_stays_sharded_pass", "tuned_pass"):
+                if isinstance(out["sharded"].get(key), dict):
+                    checks[key] = out["sharded"][key].get("mesh_equals_single_gpu")
+            if isinstance(out["sharded"].get("c4_union8_1024"), dict):
+                for key in ("all_gather", "mesh_stays_sharded"):
+                    if isinstance(out["sharded"]["c4_union8_1024"].get(key), dict):
+                        checks["c4_" + key] = out["sharded"]["c4_union8_1024"][key].get("mesh_equals_single_gpu")
+            out["sharded"]["content_checks"] = checks
+            content_ok = all(v is not False for v in checks.values())
+            out["sharded"]["every_mesh_equals_single_gpu"] = content_ok
+            save_line()
         print(json.dumps(out), flush=True)
     if sharded:
         worker.close()
         dist.barrier()
         D.shutdown()
         dist.destroy_process_group()
+    if not content_ok:
+        print("bench.py: a sharded mesh DIFFERS from the single-GPU mesh of the same grid (sharded.content_checks)", file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 def _worker_post_mortem(e):

@@ -376,7 +376,8 @@ int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out);
  * copied over its own PCIe link to the offsets sdfk_dist_counts gives (vertices: sum of nv of the ranks before; likewise indices). */
 int sdfk_dist_slab_mesh(sdfk_dist_session* s, sdfk_mesh** out);
 /* The raw gather buffer of the step collected last: world payloads of stride_bytes each (header + sections, indices
- * rebased), device memory owned by the session. */
+ * rebased), device memory owned by the session.  SDFK_ERR_UNSUPPORTED on a rank that received the headers only (exchange mode 3;
+ * mode 2 on a rank other than 0): the foreign sections would be a fresh header followed by stale bytes. */
 int sdfk_dist_gathered(const sdfk_dist_session* s, void** device_ptr, int64_t* stride_bytes);
 /* stats[8] = { stride_bytes, steps submitted, steps redone on the exact path, stride regrowths, exchange mode used,
  *              host nanoseconds spent inside sdfk_dist_submit (total), inside sdfk_dist_collect (total),
@@ -387,7 +388,9 @@ int sdfk_dist_stats(const sdfk_dist_session* s, int64_t stats[8]);
  * fewer bytes per peer, an encode and a decode pass more), takes the slowest rank's time for each -- the same numbers on every
  * rank -- and keeps the fastest configuration for this session (a change of the payload form agrees the stride again).
  * Collective, nothing in flight; ns_per_config[4] (may be NULL): the agreed times, index = mode + 2 * (compact), -1 = the scene
- * does not fit the compact form; all 0 with the host transport, which has one exchange only. */
+ * does not fit the compact form; all 0 with the host transport, which has one exchange only.  SDFK_ERR_UNSUPPORTED for a session
+ * whose exchange mode is 2 or 3: who holds the mesh is that session's contract, not a candidate (the mode is left alone; after any
+ * failure the session keeps the mode it had). */
 int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int64_t* ns_per_config);
 /* This rank's slab step WITHOUT the exchange, queued like a step (measurement: "kernel-only" time of a sharded step). */
 int sdfk_dist_enqueue_only(sdfk_dist_session* s);

@@ -100,6 +100,8 @@ void dist_release()
     gd.rank = 0;
     gd.host_fn = nullptr;
     gd.host_ctx = nullptr;
+    gd.consensus_fn = nullptr;
+    gd.consensus_ctx = nullptr;
 }
 
 // The whole mesh out of a gather buffer: the sections of slab r go to the vertex / index offsets the headers give
@@ -242,7 +244,10 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         int32_t* decoded = nullptr;       // idx16: the whole mesh's int32 indices, decoded by the step (k_slabs_decode16)
         int64_t decoded_cap = 0;
         bool ready_valid = false, read_valid = false;
-        bool payloads_gathered = false;   // the last exchange of this slot moved the slab payloads (false: headers only, exchange mode 3)
+        bool payloads_gathered = false;   // the last exchange of this slot brought THIS rank the other ranks' slab payloads (false: headers
+                                          // only -- exchange mode 3, or a rank other than 0 under gather-to-root); set once the exchange is queued
+        bool own_rebased = false;         // this rank's own section holds GLOBAL indices: the rebase kernel ran over it (never with headers
+                                          // only, never in the compact form) -- what sdfk_dist_slab_mesh must know to bias or not
         sdfk_mesh* exact = nullptr;       // mesh of run_exact until pack_exact
     };
     std::vector<Slot> slots;
@@ -277,6 +282,15 @@ struct sdfk_dist_session final : sdfk::SlabOps {
     int world() const override { return gd.world; }
     int rank() const override { return gd.rank; }
     const char* last_error() const override { return err.c_str(); }
+    // (slab_protocol.h: before a collective, after the rank-local part.  Only a node's rank threads have an agreement that costs nothing.)
+    int consensus(int mine) override
+    {
+        if (!gd.consensus_fn) return mine;
+        if (mine && err.empty()) err = t_err;
+        const int r = gd.consensus_fn(gd.consensus_ctx, mine);
+        if (r && !mine) err = t_err;   // (another rank's failure, named by the hook)
+        return r;
+    }
 
     int run_exact(int k, int64_t* nv, int64_t* ni, int64_t* need) override
     {
@@ -431,7 +445,13 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         if (int r = have_buffers(s, "exchange")) return r;
         const int w = gd.world, me = gd.rank;
         hipStream_t cs = gd.stream;
-        s.payloads_gathered = mode != 3 || w == 1;
+        // what THIS rank receives: headers only in mode 3, and under gather-to-root (mode 2) on every rank but 0 -- with either transport
+        const bool headers_only = w > 1 && ((mode == 2 && me != 0) || mode == 3);
+        // (host bookkeeping of device-side effects: both flags are set at the END, once everything of this exchange is queued -- a
+        // failed on-demand payload exchange must not look done to the next sdfk_dist_mesh, and an own section nobody rebased must
+        // not be handed out as global)
+        s.payloads_gathered = false;
+        s.own_rebased = false;
         if (gd.backend == 2) {
             // host transport: device -> pinned, the host's own all-gather, pinned -> device (synchronous: a test / bring-up path)
             char* hs = gd.stage;
@@ -442,9 +462,10 @@ struct sdfk_dist_session final : sdfk::SlabOps {
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
             if (e != hipSuccess) return keep(fail(SDFK_ERR_HIP, "host transport: %s", hipGetErrorString(e)));
             if (gd.host_fn(gd.host_ctx, hs, hr, piece) != 0) return keep(fail(SDFK_ERR_HIP, "the host transport's all-gather failed"));
-            if (mode == 3) {   // header q -> the head of section q (this rank's own section keeps its payload)
+            if (headers_only) {   // header q -> the head of section q (this rank's own section keeps its payload); mode 2: like RCCL's
+                                  // gather-to-root, only rank 0 takes the payloads (the host's all-gather moved them anyway: a test path)
                 for (int q = 0; q < w && e == hipSuccess; q++)
-                    if (q != me) e = hipMemcpyAsync(s.gathered + (size_t)q * stride, hr + (size_t)q * piece, (size_t)piece, hipMemcpyHostToDevice, cs);
+                    if (q != me) e = hipMemcpyAsync(s.gathered + (size_t)q * stride, hr + (size_t)q * piece, (size_t)SDFK_SLAB_HEADER_BYTES, hipMemcpyHostToDevice, cs);
             } else
                 e = hipMemcpyAsync(s.gathered, hr, (size_t)w * (size_t)stride, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipStreamSynchronize(cs);   // (the staging block is reused by the next exchange)
@@ -476,7 +497,6 @@ struct sdfk_dist_session final : sdfk::SlabOps {
         }
         // indices of slab r += vertices of slabs 0..r-1; the headers land in pinned host memory (one event, no copy).
         // (mode 2 on a rank other than 0: there are no foreign payloads to rebase -- the kernel sees header-only slabs)
-        const bool headers_only = w > 1 && ((mode == 2 && me != 0 && gd.backend == 1) || mode == 3);
         if (idx16 && !headers_only)   // compact slabs: decode into the whole mesh's int32 index array (+ the header mirror)
             hipLaunchKernelGGL(sdfk::k_slabs_decode16, dim3(64, w), dim3(256), 0, cs, (const char*)s.gathered, w, stride, (sdfk::SlabHeader*)s.hdr_dev,
                                s.decoded, s.decoded_cap);
@@ -485,6 +505,8 @@ struct sdfk_dist_session final : sdfk::SlabOps {
                                headers_only ? 1 : 0);
         if (hipGetLastError() != hipSuccess || hipEventRecord(s.ready, cs) != hipSuccess) return keep(fail(SDFK_ERR_HIP, "rebase launch failed"));
         s.ready_valid = true;
+        s.payloads_gathered = !headers_only;
+        s.own_rebased = !headers_only && !idx16;   // (k_slabs_rebase returns early for mirror_only and leaves 16-bit sections alone)
         return SDFK_OK;
     }
 
@@ -527,12 +549,20 @@ extern "C" int sdfk_dist_unique_id(void* id_out)
     return SDFK_OK;
 }
 
-extern "C" int sdfk_dist_init(int32_t world, int32_t rank, const void* id)
+// sdfk_dist_init in its two halves: everything that can fail on ONE rank (the library, the exchange stream, the agreement buffers) ...
+static int dist_prepare_rccl(int32_t world, int32_t rank)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!id) return fail(SDFK_ERR_INVALID, "sdfk_dist_init: null id");
     if (int r = rccl_load()) return r;
-    if (int r = dist_common_init(world, rank)) return r;
+    return dist_common_init(world, rank);
+}
+
+// ... and the collective ncclCommInitRank, which returns when EVERY rank has made the call: ranks that can (a node's threads) agree
+// between the two that all of them are prepared, so that nobody waits for a rank that never joins
+static int dist_join_rccl(const void* id)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    const int world = gd.world, rank = gd.rank;
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     const ncclResult_t nr = gd.nccl.CommInitRank(&gd.comm, world, uid, rank);
@@ -544,6 +574,14 @@ extern "C" int sdfk_dist_init(int32_t world, int32_t rank, const void* id)
     }
     gd.backend = 1;
     return SDFK_OK;
+}
+
+extern "C" int sdfk_dist_init(int32_t world, int32_t rank, const void* id)
+{
+    if (!id) return fail(SDFK_ERR_INVALID, "sdfk_dist_init: null id");
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (int r = dist_prepare_rccl(world, rank)) return r;
+    return dist_join_rccl(id);
 }
 
 extern "C" int sdfk_dist_init_host(int32_t world, int32_t rank, sdfk_allgather_fn allgather, void* ctx)
@@ -693,6 +731,11 @@ extern "C" int sdfk_dist_gathered(const sdfk_dist_session* s, void** device_ptr,
     if (!s) return fail(SDFK_ERR_INVALID, "sdfk_dist_gathered: null session");
     const int k = s->proto.last_slot();
     if (k < 0) return fail(SDFK_ERR_INVALID, "sdfk_dist_gathered: no collected step (or its slot has been resubmitted)");
+    // headers only (mode 3; mode 2 on a rank other than 0): the foreign sections hold this step's 64-byte header followed by stale
+    // bytes -- a consumer that decoded them would get a wrong mesh without noticing
+    if (!s->slots[k].payloads_gathered)
+        return fail(SDFK_ERR_UNSUPPORTED, "sdfk_dist_gathered: this rank received the headers only (SDFK_OPT_DIST_EXCHANGE = %d): "
+                                          "sdfk_dist_slab_mesh gives its own slab, sdfk_dist_mesh gathers the payloads on demand", s->exchange_mode);
     if (device_ptr) *device_ptr = s->slots[k].gathered;
     if (stride_bytes) *stride_bytes = s->stride;
     return SDFK_OK;
@@ -730,6 +773,12 @@ extern "C" int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int6
     if (s->proto.in_flight() != 0) return fail(SDFK_ERR_INVALID, "sdfk_dist_tune: collect every queued step first");
     if (ns_per_config) for (int k = 0; k < 4; k++) ns_per_config[k] = 0;
     if (gd.backend != 1) return SDFK_OK;   // the host transport has one exchange only
+    // the tuner chooses between exchanges that leave the WHOLE mesh on every rank (0 and 1); a session that keeps the mesh sharded
+    // (3) or gathers it to rank 0 (2) has another contract, which a measurement must not replace behind the caller's back
+    if (s->exchange_mode >= 2)
+        return fail(SDFK_ERR_UNSUPPORTED, "sdfk_dist_tune: the session's exchange mode %d is a contract (who holds the mesh), not a candidate: "
+                                          "tune a session created with SDFK_OPT_DIST_EXCHANGE = 0 or 1", s->exchange_mode);
+    const int mode_before = s->exchange_mode;
     auto run = [&](int n) {
         for (int i = 0; i < n; i++) {
             if (s->proto.in_flight() == s->proto.depth())
@@ -748,7 +797,7 @@ extern "C" int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int6
     const int64_t kNever = INT64_MAX;
     int64_t agreed[4] = {kNever, kNever, kNever, kNever};   // index = mode + 2 * (16-bit indices)
     for (int idx = 0; idx < 2; idx++) {
-        if (int r = set_form(idx != 0)) return dist_fail(s, r);
+        if (int r = set_form(idx != 0)) { s->exchange_mode = mode_before; return dist_fail(s, r); }
         for (int mode = 1; mode >= 0; mode--) {
             s->exchange_mode = mode;
             int r = run(2 * s->proto.depth() + 2);   // (captured step graphs of every slot and lane exist after this)
@@ -757,8 +806,8 @@ extern "C" int sdfk_dist_tune(sdfk_dist_session* s, int32_t steps_per_mode, int6
             if (!r) r = run(steps_per_mode);
             if (!r) r = s->quiesce();
             const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            if (r) return dist_fail(s, r);
-            if (int r2 = s->agree_max(ns, &agreed[mode + 2 * idx])) { t_err = s->err; return r2; }
+            if (r) { s->exchange_mode = mode_before; return dist_fail(s, r); }
+            if (int r2 = s->agree_max(ns, &agreed[mode + 2 * idx])) { s->exchange_mode = mode_before; t_err = s->err; return r2; }
             // (a slab that does not fit 16-bit offsets sent the session back to int32 indices -- on every rank, seen in the
             // same step's headers: the compact form is not a candidate for this scene)
             if (idx && !s->idx16) agreed[mode + 2 * idx] = kNever;
@@ -782,7 +831,7 @@ extern "C" int sdfk_dist_mesh(sdfk_dist_session* s, sdfk_mesh** out)
     const int k = s->proto.last_slot();
     const int64_t* h = s->proto.last_headers();
     if (k < 0 || !h) return fail(SDFK_ERR_INVALID, "sdfk_dist_mesh: no collected step (or its slot has been resubmitted)");
-    if (s->exchange_mode == 2 && gd.rank != 0 && gd.backend == 1 && gd.world > 1)
+    if (s->exchange_mode == 2 && gd.rank != 0 && gd.world > 1)
         return fail(SDFK_ERR_UNSUPPORTED, "sdfk_dist_mesh: with SDFK_OPT_DIST_EXCHANGE = 2 only rank 0 holds the mesh");
     int64_t nv = 0, ni = 0;
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
@@ -855,8 +904,9 @@ extern "C" int sdfk_dist_slab_mesh(sdfk_dist_session* s, sdfk_mesh** out)
     sdfk_mesh* m = nullptr;
     if (int r = alloc_mesh(&m, (size_t)nv, (size_t)ni)) return r;
     sdfk_dist_session::Slot& sl = s->slots[k];
-    // (indices in this rank's section: still slab-local after a headers-only step or in the compact form, rebased in place otherwise)
-    const bool local_ids = !sl.payloads_gathered || s->idx16;
+    // (indices in this rank's section: still slab-local after a headers-only step -- mode 3, or mode 2 on a rank other than 0 -- and
+    // in the compact form; rebased in place otherwise: the slot remembers whether the rebase kernel ran over THIS section)
+    const bool local_ids = !sl.own_rebased;
     SlabExtractArgs A{s->send_buf(sl), m->vertices, m->colors, m->normals, m->triangles, m->bounds, local_ids ? (int32_t)vbase : 0};
     const int64_t words = 9 * nv + ni;
     hipLaunchKernelGGL(k_slab_extract, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((words + 1023) / 1024, 1024))), dim3(256), 0, g.stream, A);

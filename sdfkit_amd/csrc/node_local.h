@@ -14,17 +14,35 @@
 #include <thread>
 
 namespace {
+// A barrier that can be ABORTED: a rank thread whose command failed in a rank-local spot never reaches the next rendezvous of that
+// command; it aborts the barrier, which releases everybody who waits there (and everybody who arrives later) with `false` -- they
+// fail the command too instead of waiting for ever.  The poster re-arms it before the next command, when every worker is idle.
 struct NodeBarrier {
     std::mutex m;
     std::condition_variable cv;
     int n = 1, count = 0;
     uint64_t gen = 0;
-    void wait()
+    bool aborted = false;
+    bool wait()
     {
         std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
         const uint64_t my = gen;
-        if (++count == n) { count = 0; gen++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != my; });
+        if (++count == n) { count = 0; gen++; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return gen != my || aborted; });
+        return gen != my;   // (released by the last arrival, not by an abort)
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = true;
+        cv.notify_all();
+    }
+    void rearm()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        aborted = false;
+        count = 0;
     }
 };
 }  // namespace
@@ -41,6 +59,7 @@ struct sdfk_node {
         sdfk_dist_session* sess = nullptr;
         int status = SDFK_OK;
         std::string error;
+        bool released = false;   // the status is "another rank failed and released me": the caller is told about THAT rank first
     };
     int world = 1;
     bool host_transport = false;
@@ -69,8 +88,12 @@ struct sdfk_node {
     std::vector<const void*> send_ptrs;   // host transport: every rank's send buffer of the all-gather in progress
     std::mutex call_mu;                   // one sdfk_node_to_mesh at a time
     // fault injection for the tests (SDFK_NODE_FAULT_RANK=k at sdfk_node_open): rank k fails the next command's rank-local
-    // part ONCE -- what an allocation failing on one device looks like to the others
+    // part ONCE -- what an allocation failing on one device looks like to the others.  SDFK_NODE_FAULT_STAGE says where:
+    // 0 (default) while it makes its session, 1 in the rank-local part of the step (the protocol's consensus point between
+    // enqueue / run_exact and the first collective), 2 inside the exchange of the host transport, between two rendezvous of the
+    // ranks (nobody can agree there: the failed rank aborts the barrier and the others are released)
     std::atomic<int> fault_rank{-1};
+    int fault_stage = 0;
 };
 
 namespace {
@@ -80,10 +103,15 @@ int node_allgather(void* ctx, const void* send, void* recv, int64_t bytes)
 {
     sdfk_node::Worker* w = (sdfk_node::Worker*)ctx;
     sdfk_node* n = w->node;
+    if (n->fault_stage == 2 && n->fault_rank.load() == w->rank) {   // (injected: this rank never reaches the rendezvous)
+        n->fault_rank.store(-1);
+        fail(SDFK_ERR_NOMEM, "SDFK_NODE_FAULT_RANK: injected failure inside the exchange");
+        return -1;
+    }
     n->send_ptrs[(size_t)w->rank] = send;
-    n->bar.wait();
+    if (!n->bar.wait()) return -1;   // (aborted: a rank failed elsewhere in this command)
     for (int q = 0; q < n->world; q++) memcpy((char*)recv + (size_t)q * (size_t)bytes, n->send_ptrs[(size_t)q], (size_t)bytes);
-    n->bar.wait();   // (nobody overwrites its send buffer before everybody has read it)
+    if (!n->bar.wait()) return -1;   // (nobody overwrites its send buffer before everybody has read it)
     return 0;
 }
 
@@ -102,22 +130,30 @@ int node_worker_session(sdfk_node::Worker* w);
 // Before the ranks enter a COLLECTIVE part of a command they agree that every one of them got there: a rank-local failure (an
 // allocation on ONE device) must fail the command on every rank -- the others would wait in the exchange for ever.  Returns the
 // first failing rank's status (the same on every rank), its message in t_err.
-int node_agree(sdfk_node::Worker* w, int mine)
+int node_agree(sdfk_node::Worker* w, int mine, int stage = 0)
 {
     sdfk_node* n = w->node;
-    if (!mine && n->fault_rank.load() == w->rank) {
+    if (!mine && n->fault_stage == stage && n->fault_rank.load() == w->rank) {
         n->fault_rank.store(-1);
-        mine = fail(SDFK_ERR_NOMEM, "SDFK_NODE_FAULT_RANK: injected failure");
+        mine = fail(SDFK_ERR_NOMEM, "SDFK_NODE_FAULT_RANK: injected failure%s", stage ? " in the rank-local part of the step" : "");
     }
     w->status = mine;
     w->error = mine ? t_err : std::string();
-    n->bar.wait();
+    w->released = false;
+    auto released = [&] {   // the barrier was aborted: some rank left this command in a spot where nobody could agree
+        w->released = !mine;
+        return mine ? mine : fail(SDFK_ERR_HIP, "another rank failed and left the command");
+    };
+    if (!n->bar.wait()) return released();
     int r = SDFK_OK;
     for (auto& q : n->workers)
-        if (q.status && !r) { r = q.status; if (&q != w) t_err = "rank " + std::to_string(q.rank) + " failed: " + q.error; }
-    n->bar.wait();   // (nobody changes its status before everybody has read it)
+        if (q.status && !r) { r = q.status; if (&q != w) { t_err = "rank " + std::to_string(q.rank) + " failed: " + q.error; w->released = true; } }
+    if (!n->bar.wait()) return released();   // (nobody changes its status before everybody has read it)
     return r;
 }
+
+// SlabOps::consensus of a node's rank (dist_rccl.h): the agreement between the rank-local part of a step and its first collective
+int node_consensus(void* ctx, int mine) { return node_agree((sdfk_node::Worker*)ctx, mine, 1); }
 
 int node_worker_to_mesh(sdfk_node::Worker* w, sdfk_mesh** out)
 {
@@ -221,11 +257,31 @@ void node_worker_main(sdfk_node::Worker* w)
     n->bar.wait();                                   // (2) the id is there
     ok = true;
     for (auto& q : n->workers) ok = ok && q.status == SDFK_OK;
+    // the rank-local half of sdfk_dist_init first (the library, the exchange stream, the agreement buffers) ...
+    bool prepared = false;
     if (ok) {
-        w->status = n->host_transport ? sdfk_dist_init_host(n->world, w->rank, node_allgather, w) : sdfk_dist_init(n->world, w->rank, n->uid);
+        w->status = n->host_transport ? sdfk_dist_init_host(n->world, w->rank, node_allgather, w) : dist_prepare_rccl(n->world, w->rank);
         if (w->status) w->error = t_err;
+        prepared = !w->status;
+        if (!w->status && n->fault_stage == 3 && n->fault_rank.load() == w->rank) {   // (injected: this rank's preparation fails)
+            n->fault_rank.store(-1);
+            w->status = fail(SDFK_ERR_NOMEM, "SDFK_NODE_FAULT_RANK: injected failure before ncclCommInitRank");
+            w->error = t_err;
+        }
     }
-    n->bar.wait();                                   // (3) the communicator is up (or somebody failed: the opener reads the statuses)
+    n->bar.wait();                                   // (3) every rank is prepared (or has failed)
+    ok = true;
+    for (auto& q : n->workers) ok = ok && q.status == SDFK_OK;
+    // ... and only when EVERY rank got that far the collective half: ncclCommInitRank returns when all ranks have made the call
+    if (ok && !n->host_transport) {
+        w->status = dist_join_rccl(n->uid);
+        if (w->status) w->error = t_err;
+    } else if (!ok && prepared) {
+        std::lock_guard<std::recursive_mutex> lk(g_mu);
+        dist_release();                              // (prepared, but the node will not come up)
+    }
+    if (ok && !w->status) { gd.consensus_fn = node_consensus; gd.consensus_ctx = w; }
+    n->bar.wait();                                   // (4) the communicator is up (or somebody failed: the opener reads the statuses)
     ok = true;
     for (auto& q : n->workers) ok = ok && q.status == SDFK_OK;
     // ---- commands
@@ -240,20 +296,33 @@ void node_worker_main(sdfk_node::Worker* w)
         }
         if (cmd == 1 && ok) {
             sdfk_mesh* m = nullptr;
+            w->released = false;
             w->status = node_worker_to_mesh(w, &m);
             w->error = w->status ? t_err : std::string();
             if (w->rank == 0) n->mesh0 = m;
             else if (m) sdfk_mesh_free(m);
         }
         if ((cmd == 3 || cmd == 4) && ok) {
+            w->released = false;
             w->status = cmd == 3 ? node_worker_begin(w) : node_worker_copy(w);
             w->error = w->status ? t_err : std::string();
+        }
+        // a rank that leaves a collective command with an error may have left it between two rendezvous: whoever waits for it there
+        // (the host transport's all-gather, an agreement) is released and fails the command too
+        if ((cmd == 1 || cmd == 3) && ok && w->status) {
+            n->bar.abort();
+            // (the session's protocol state no longer matches the other ranks': the next command makes a new one on every rank --
+            // the ranks that were released drop theirs as well)
+            node_worker_release(w);
         }
         if (cmd == 2) {
             node_worker_release(w);
             sdfk_dist_shutdown();
-            sdfk_shutdown();          // (this thread's context: frees everything it holds and gives the context back)
-            context_unclaim(w->st);   // (also when the context never came up: sdfk_shutdown has nothing to do then)
+            bool up;
+            { std::lock_guard<std::recursive_mutex> lk(w->st->mu); up = w->st->ctx.inited; }
+            if (up) sdfk_shutdown();        // (this thread's context: frees everything it holds and gives the context back -- ONCE: a second
+                                            // unclaim could hit a context some other thread has claimed in between)
+            else context_unclaim(w->st);    // (the context never came up: sdfk_shutdown has nothing to do, the claim is still ours)
             t_state = nullptr;
         }
         {
@@ -267,6 +336,7 @@ void node_worker_main(sdfk_node::Worker* w)
 int node_post(sdfk_node* n, int cmd)
 {
     std::unique_lock<std::mutex> lk(n->mu);
+    if (cmd != 0) n->bar.rearm();   // (every worker is idle between commands; the start-up rendezvous -- command 0 -- is under way)
     n->cmd = cmd;
     n->done = 0;
     n->cmd_gen++;
@@ -290,8 +360,10 @@ void node_set_scene(sdfk_node* n, const sdfk_op* ops, int32_t n_ops, const int32
 }
 int node_first_error(sdfk_node* n, const char* what)
 {
-    for (auto& w : n->workers)
-        if (w.status) return fail(w.status, "%s: rank %d (device %d): %s", what, w.rank, w.device, w.error.c_str());
+    // the rank that failed by itself first; a rank that only reports "another rank failed" when nobody else has anything better
+    for (int pass = 0; pass < 2; pass++)
+        for (auto& w : n->workers)
+            if (w.status && (pass || !w.released)) return fail(w.status, "%s: rank %d (device %d): %s", what, w.rank, w.device, w.error.c_str());
     return SDFK_OK;
 }
 }  // namespace
@@ -322,6 +394,7 @@ extern "C" int sdfk_node_open(const int32_t* devices, int32_t n_devices, sdfk_no
     n->send_ptrs.assign(devs.size(), nullptr);
     n->bar.n = n->world;
     if (const char* f = getenv("SDFK_NODE_FAULT_RANK")) n->fault_rank.store(atoi(f));
+    if (const char* f = getenv("SDFK_NODE_FAULT_STAGE")) n->fault_stage = atoi(f);
     for (size_t i = 0; i < devs.size(); i++) {
         n->workers[i].node = n;
         n->workers[i].device = devs[i];
@@ -362,12 +435,11 @@ extern "C" int sdfk_node_to_mesh(sdfk_node* n, const sdfk_op* ops, int32_t n_ops
     n->mesh0 = nullptr;
     n->step_open = false;
     node_post(n, 1);
-    for (auto& w : n->workers)
-        if (w.status) {
-            if (n->mesh0) sdfk_mesh_free(n->mesh0);
-            n->mesh0 = nullptr;
-            return fail(w.status, "sdfk_node_to_mesh: rank %d (device %d): %s", w.rank, w.device, w.error.c_str());
-        }
+    if (int r = node_first_error(n, "sdfk_node_to_mesh")) {
+        if (n->mesh0) sdfk_mesh_free(n->mesh0);
+        n->mesh0 = nullptr;
+        return r;
+    }
     *out = n->mesh0;
     n->mesh0 = nullptr;
     return SDFK_OK;

@@ -208,6 +208,9 @@ struct DistContext {
     char* stage = nullptr;               // host transport: pinned staging, (1 + world) x stage_stride
     int64_t stage_stride = 0;
     int sessions = 0;
+    // ranks that are threads of ONE process (node_local.h) can agree on a status for the price of a thread barrier: SlabOps::consensus
+    int (*consensus_fn)(void* ctx, int mine) = nullptr;
+    void* consensus_ctx = nullptr;
 };
 
 // ---- device contexts --------------------------------------------------------------------------------------------------------
@@ -229,11 +232,12 @@ struct DeviceState {
     bool listed = true;        // found by sdfk_init(device) (false: the private context of a local node's virtual rank)
 };
 DeviceState g_state0;                                   // the first device's context (storage; `inited` says whether it is in use)
-DeviceState* g_default_state = &g_state0;               // current context of threads that never chose one
-std::mutex g_registry_mu;                               // guards g_states / g_default_state / process-wide settings
+std::atomic<DeviceState*> g_default_state{&g_state0};   // current context of threads that never chose one (written under g_registry_mu,
+                                                        // read without it by every call of such a thread: atomic)
+std::mutex g_registry_mu;                               // guards g_states / writes of g_default_state / process-wide settings
 std::vector<DeviceState*> g_states{&g_state0};          // the contexts sdfk_init made, by device (a local node's private ones are not listed)
 thread_local DeviceState* t_state = nullptr;
-inline DeviceState& cur_state() { return *(t_state ? t_state : g_default_state); }
+inline DeviceState& cur_state() { return *(t_state ? t_state : g_default_state.load(std::memory_order_acquire)); }
 // (the names the rest of this file has always used for "the" context, its lock and its sharding state)
 #define g (cur_state().ctx)
 #define g_mu (cur_state().mu)
@@ -1090,16 +1094,20 @@ DeviceState* context_claim(int device, bool listed)
     if (listed)
         for (DeviceState* q : g_states)
             if (q->listed && q->claimed_device == device) st = q;
+    // (a node rank's PRIVATE context never is the object the threads that never chose a context fall back to: they would silently
+    // work inside rank 0's context -- they get the uninitialised default instead and fail loudly until somebody calls sdfk_init)
+    DeviceState* const dflt = g_default_state.load(std::memory_order_relaxed);
     if (!st)
         for (DeviceState* q : g_states)
-            if (q->claimed_device < 0) { st = q; break; }
+            if (q->claimed_device < 0 && (listed || q != dflt)) { st = q; break; }
     if (!st) {
         st = new DeviceState();
         g_states.push_back(st);
     }
     st->claimed_device = device;
     st->listed = listed;
-    if (listed && g_default_state->claimed_device < 0) g_default_state = st;   // (the first context in use serves the threads that never chose)
+    // the first LISTED context in use serves the threads that never chose (also when the default so far was free, or never came up)
+    if (listed && (dflt->claimed_device < 0 || !dflt->listed)) g_default_state.store(st, std::memory_order_release);
     return st;
 }
 
@@ -1108,9 +1116,9 @@ void context_unclaim(DeviceState* st)
     std::lock_guard<std::mutex> rl(g_registry_mu);
     st->claimed_device = -1;
     st->listed = true;
-    if (g_default_state == st)
+    if (g_default_state.load(std::memory_order_relaxed) == st)
         for (DeviceState* q : g_states)
-            if (q->listed && q->claimed_device >= 0) { g_default_state = q; break; }
+            if (q->listed && q->claimed_device >= 0) { g_default_state.store(q, std::memory_order_release); break; }
 }
 }  // namespace
 
@@ -2158,7 +2166,11 @@ int launch_classify(sdfk_march_job* j, bool publish)
         // (a workgroup takes the same 1024 segments of K2_LPB consecutive layers: mc_kernels.hip)
         const int nwg = ((P.lay_list_end - P.lay_count_begin + K2_LPB - 1) / K2_LPB) * P.bpl;
         hipLaunchKernelGGL(k_compact<false>, dim3(nwg), dim3(256), 0, g.stream, P);
-        if (P.zero_cull && j->cull_clean) *j->cull_clean = true;   // (the count pass clears them)
+        // (the count pass clears the culling kernel's counters: host bookkeeping of a device-side effect, so only once the launch is
+        // known to be queued and to have workgroups -- a counter block recorded as clean that is not would make the next volume-less
+        // job walk stale work lists)
+        HIPCHK(hipGetLastError());
+        if (P.zero_cull && j->cull_clean && nwg > 0) *j->cull_clean = true;
         if (P.blockpre) hipLaunchKernelGGL(k_blockscan, dim3(1), dim3(1024), 0, g.stream, P);   // (many blocks: their prefix in one pass)
         if (SDFK_COMPACT_STRIDED && K2_LPB == 1)   // (the write pass with interleaved segments: mc_kernels.hip)
             if (P.segmask) hipLaunchKernelGGL(k_compact_write<true>, dim3((P.lay_list_end - P.lay_count_begin) * P.bpl), dim3(256), 0, g.stream, P);

@@ -48,6 +48,13 @@ struct SlabOps {
     // Waits for everything this rank has queued.
     virtual int quiesce() = 0;
     virtual const char* last_error() const = 0;
+    // A rank-local operation (run_exact, resize, pack_exact, enqueue: allocations, launches) has returned `mine` and a COLLECTIVE
+    // comes next.  A rank that failed returns from the step; the others would wait in the collective for ever.  A backend that can
+    // agree cheaply (ranks that are threads of one process: dist_rccl.h + node_local.h) makes every rank return the first failing
+    // rank's status here, so that all leave the step together; the default -- one process per GPU, where an agreement would be a
+    // host-synchronising collective in every pipelined step and a dead rank is the launcher's business -- is no agreement.
+    // Called by every rank at the same points of the protocol, in the same order.
+    virtual int consensus(int mine) { return mine; }
     // Bytes the payload described by one gathered header needs (the protocol compares it with the stride).  Default: the
     // plain layout, header + vertex_bytes per vertex + 4 bytes per index; a backend with another encoding overrides it.
     virtual int64_t payload_bytes(const int64_t* hdr) const
@@ -83,7 +90,7 @@ public:
             queue_.push_back(e);
             return 0;
         }
-        if (int r = ops_->enqueue(slot)) return ops_fail(r);
+        if (int r = ops_->consensus(ops_->enqueue(slot))) return ops_fail(r);
         if (int r = ops_->exchange(slot)) return ops_fail(r);
         queue_.push_back(Entry{slot, false, 0, 0});
         return 0;
@@ -168,7 +175,7 @@ private:
     int exact_step_once(int slot, int64_t* nv, int64_t* ni)
     {
         int64_t need = 0, mx = 0;
-        if (int r = ops_->run_exact(slot, nv, ni, &need)) return ops_fail(r);
+        if (int r = ops_->consensus(ops_->run_exact(slot, nv, ni, &need))) return ops_fail(r);
         if (int r = ops_->agree_max(need, &mx)) return ops_fail(r);
         if (mx > stride_) {
             // every rank sends `stride` bytes in every step, used or not: keep the head-room modest
@@ -182,7 +189,8 @@ private:
                 last_slot_ = -1;
                 last_hdr_ = nullptr;
             }
-            if (int r = ops_->resize(want)) {
+            if (int r = ops_->consensus(ops_->resize(want))) {   // (a rank whose own resize succeeded drops its buffers with the others:
+                // the next bootstrap allocates them again)
                 // no buffers any more (the backend has released what it had): nothing queued can complete into them, and the
                 // next submit() must bootstrap -- never enqueue into buffers that do not exist
                 stride_ = 0;
@@ -198,11 +206,11 @@ private:
             if (regrow)
                 for (auto& q : queue_) {
                     q.exact = false;
-                    if (int r = ops_->enqueue(q.slot)) return ops_fail(r);
+                    if (int r = ops_->consensus(ops_->enqueue(q.slot))) return ops_fail(r);
                     if (int r = ops_->exchange(q.slot)) return ops_fail(r);
                 }
         }
-        if (int r = ops_->pack_exact(slot)) return ops_fail(r);
+        if (int r = ops_->consensus(ops_->pack_exact(slot))) return ops_fail(r);
         if (int r = ops_->exchange(slot)) return ops_fail(r);
         const int64_t* hdr = nullptr;
         if (int r = ops_->headers(slot, &hdr)) return ops_fail(r);   // (the exact path is synchronous)

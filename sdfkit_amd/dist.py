@@ -160,6 +160,13 @@ class SlabSession:
         """This rank's slab kernels without the exchange (measurement)."""
         N.check(self.L.sdfk_dist_enqueue_only(self.h))
 
+    def gathered(self):
+        """(device pointer, stride in bytes) of the gather buffer of the step collected last (sdfk_dist_gathered): `world` self-describing
+        slab payloads.  Refused (SDFK_ERR_UNSUPPORTED) on a rank that received headers only -- exchange mode 3, mode 2 off rank 0."""
+        ptr, stride = C.c_void_p(), C.c_int64()
+        N.check(self.L.sdfk_dist_gathered(self.h, C.byref(ptr), C.byref(stride)))
+        return ptr.value, stride.value
+
     def slab_mesh(self):
         """Host copy of THIS rank's slab of the step collected last, indices global (sdfk_dist_slab_mesh: no payload exchange --
         with SDFK_OPT_DIST_EXCHANGE = 3 the whole mesh is the ranks' slabs in rank order)."""

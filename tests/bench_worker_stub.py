@@ -38,6 +38,10 @@ if first and mode == "tune_hang":      # (one rank hangs in the tuner's collecti
     time.sleep(3600)
 if first and mode == "tune_die":       # (rank 0 waits for the dead rank in the next collective and fails)
     dist.barrier()
+if mode == "wrong_mesh":               # (the real worker's content check found a sharded mesh that differs from the single-GPU one)
+    line["sharded"] = {"every_mesh_equals_single_gpu": False, "content_checks": {"headline": False}}
 if rank == 0:
     print(json.dumps(dict(line, tuned_pass="done")), flush=True)
 dist.destroy_process_group()
+if mode == "wrong_mesh":
+    sys.exit(4)

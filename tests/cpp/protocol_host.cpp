@@ -22,6 +22,7 @@ struct proto_callbacks {
     int (*exchange)(void* ctx, int32_t slot);
     int (*headers)(void* ctx, int32_t slot, const int64_t** hdr);
     int (*quiesce)(void* ctx);
+    int (*consensus)(void* ctx, int32_t mine);   // may be NULL: SlabOps's default (no agreement)
 };
 
 }  // extern "C"
@@ -41,6 +42,7 @@ struct CallbackOps final : sdfk::SlabOps {
     int exchange(int k) override { return cb.exchange(cb.ctx, k); }
     int headers(int k, const int64_t** h) override { return cb.headers(cb.ctx, k, h); }
     int quiesce() override { return cb.quiesce(cb.ctx); }
+    int consensus(int mine) override { return cb.consensus ? cb.consensus(cb.ctx, mine) : mine; }
     const char* last_error() const override { return err.c_str(); }
 };
 

@@ -35,8 +35,9 @@ if REAL:
     D.init(device=DEVICE)
 else:
     D.init_host(device=0)
-MODE = N.get_option(N.OPT_DIST_EXCHANGE) if REAL else -1      # (the host transport reports -1; SDFK_DIST_EXCHANGE=3 still means "headers only")
-HOLDS_MESH = not (REAL and MODE == 2 and dist.get_rank() != 0)   # gather-to-root: only rank 0 holds the whole mesh
+OPT_MODE = N.get_option(N.OPT_DIST_EXCHANGE)
+MODE = OPT_MODE if REAL else -1      # (the host transport reports -1; SDFK_DIST_EXCHANGE = 2 / 3 still mean "to rank 0 only" / "headers only")
+HOLDS_MESH = not (OPT_MODE == 2 and dist.get_rank() != 0)   # gather-to-root: only rank 0 holds the whole mesh (with either transport)
 graphs_on = N.get_option(N.OPT_GRAPHS) != 0 and N.get_option(N.OPT_DIST_LANES) != 0
 
 
@@ -51,7 +52,7 @@ def same(m, full=True):
 ok = True
 if HOLDS_MESH:
     ok = same(D.sharded_to_mesh(sdf, mn, mx, *dims))      # the one-off form first (sdfk_dist_to_mesh)
-elif REAL:   # (collective: every rank makes the call; the ranks that hold no mesh get SDFK_ERR_UNSUPPORTED from the extraction)
+else:   # (collective: every rank makes the call; the ranks that hold no mesh get SDFK_ERR_UNSUPPORTED from the extraction)
     try:
         D.sharded_to_mesh(sdf, mn, mx, *dims)
         ok = False
@@ -73,6 +74,16 @@ for it in range(16):
         ses.collect()
         if it % 3 == 0:
             ok &= own_slab_is_its_slice(ses)      # (before the whole mesh is asked for: exchange mode 3 has moved no payload yet)
+            # a rank that received headers only (mode 3; mode 2 on a rank other than 0) must not hand out the gather buffer: the
+            # foreign sections hold a fresh header followed by stale bytes
+            if dist.get_world_size() > 1 and (OPT_MODE == 3 or not HOLDS_MESH):
+                try:
+                    ses.gathered()
+                    ok = False
+                except N.SdfKitNativeError as e:
+                    ok &= "headers only" in str(e)
+            elif dist.get_world_size() > 1:
+                ok &= ses.gathered()[1] == ses.stats()["stride_bytes"]
         if HOLDS_MESH:
             ok &= same(ses.mesh())
         if it % 3 == 1:

@@ -24,7 +24,8 @@ class Callbacks(C.Structure):
                 ("enqueue", C.CFUNCTYPE(C.c_int, C.c_void_p, _i32)),
                 ("exchange", C.CFUNCTYPE(C.c_int, C.c_void_p, _i32)),
                 ("headers", C.CFUNCTYPE(C.c_int, C.c_void_p, _i32, C.POINTER(_p64))),
-                ("quiesce", C.CFUNCTYPE(C.c_int, C.c_void_p))]
+                ("quiesce", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+                ("consensus", C.CFUNCTYPE(C.c_int, C.c_void_p, _i32))]
 
 
 def lib():
@@ -96,7 +97,7 @@ class ProtoSession:
     """sdfk::SlabProtocol over `make_worker(slot)` workers (run_local() -> (nv, ni); pack_self_describing(buf);
     enqueue(buf); vertex_bytes) and the default process group's all_gather."""
 
-    def __init__(self, make_worker, depth, group=None, headroom=0.125):
+    def __init__(self, make_worker, depth, group=None, headroom=0.125, agree_on_failures=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -158,11 +159,21 @@ class ProtoSession:
         def quiesce(ctx):
             pass
 
+        def consensus(ctx, mine):
+            # SlabOps::consensus with a backend that CAN agree (what a node's rank threads do with a thread barrier): the
+            # largest status over the ranks, so that a rank-local failure takes every rank out of the step before the collective
+            t = torch.tensor([mine], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            self.log.append(("consensus", int(mine), int(t.item())))
+            return int(t.item())
+
         self.cb = Callbacks()
         self.cb.ctx, self.cb.world, self.cb.rank = None, self.world, self.rank
         fns = dict(run_exact=run_exact, agree_max=agree_max, resize=resize, pack_exact=pack_exact, enqueue=enqueue,
-                   exchange=exchange, headers=headers, quiesce=quiesce)
+                   exchange=exchange, headers=headers, quiesce=quiesce, consensus=consensus)
         for name, ftype in Callbacks._fields_[3:]:
+            if name == "consensus" and not agree_on_failures:
+                continue                      # (NULL: the protocol's default, no agreement)
             setattr(self.cb, name, ftype(guard(fns[name])))
         self.L = lib()
         self.h = C.c_void_p(self.L.proto_create(C.byref(self.cb), depth, headroom))

@@ -91,6 +91,21 @@ def test_a_failed_tuned_pass_does_not_cost_the_headline(first_attempt):
     assert "reporting the headline pass" in p.stderr and "multi-rank run failed" not in p.stderr
 
 
+def test_a_wrong_sharded_mesh_fails_the_run_but_keeps_the_line():
+    """`sharded.every_mesh_equals_single_gpu: false` (bench.py's content check: SHA-256 of the gathered mesh against the same grid meshed on
+    one GPU): the line still reaches stdout -- it says which pass differed -- but the run exits non-zero, on every rank and in the
+    launcher, and nobody retries with a more conservative exchange (that would hide a wrong mesh, not fix it)."""
+    import json
+    p = _launch_with_stub("wrong_mesh", 120)
+    assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["sharded"]["every_mesh_equals_single_gpu"] is False and d["note"] == ""      # the first attempt's line: no retry
+    assert bench._content_mismatch(lines[0]) and not bench._content_mismatch('{"sharded": {"every_mesh_equals_single_gpu": true}}')
+    assert not bench._content_mismatch('{"metric": "x"}') and not bench._content_mismatch("not json")
+
+
 def test_plain_python_with_gpus_gt_1_launches_before_touching_torch():
     """`python bench.py --gpus 2` must reach the launcher without importing torch in the parent: run it
     with a poisoned `torch` on the path of the PARENT only -- the launcher hands the children the same

@@ -283,6 +283,65 @@ def test_reset_bootstraps_again_on_every_rank(world):
     assert all(len(set(strides)) == 1 and strides[0] > 0 and redone == 0 and grown == 0 for _, _, strides, redone, grown in res), res
 
 
+class _BreaksAt(FixtureSessionWorker):
+    """A worker whose `at`-th enqueue fails for real on this rank (an allocation that fails on ONE device): an exception, which the
+    harness turns into a non-zero status of the callback."""
+
+    def __init__(self, *a, at=None, **k):
+        super().__init__(*a, **k)
+        self.at = at
+
+    def enqueue(self, buf):
+        if self.at is not None and self.calls + 1 == self.at:
+            self.calls += 1
+            raise MemoryError("injected: this rank could not queue its step")
+        super().enqueue(buf)
+
+
+def _rank_local_failure_worker(rank, world, port, dims, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from tests import proto_host as P
+        from tests import scenes as S
+        ref = _reference(S.union8, dims)
+        # the LAST rank cannot queue the 2nd speculative step of slot 0 (the 5th submit with two slots: the first is the bootstrap's
+        # exact step): with an agreement between the rank-local
+        # part and the exchange every rank's submit() fails there -- nobody is left waiting in the all-gather
+        ses = P.ProtoSession(lambda slot: _BreaksAt(ref, *dims, rank, world, at=(2 if (rank == world - 1 and slot == 0) else None)),
+                             depth=2, agree_on_failures=True)
+        done, failed_at = 0, None
+        for it in range(6):
+            try:
+                if ses.in_flight == ses.depth:
+                    ses.collect()
+                    done += 1
+                ses.submit()
+            except RuntimeError:
+                failed_at = it
+                break
+        agreed = [e for e in ses.log if e[0] == "consensus" and e[2] != 0]
+        out_q.put((rank, failed_at, done, len(agreed), agreed[0][1] if agreed else None))
+        ses.h = None      # (no drain: the step that failed is not in the queue, and the ranks stop here together)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_local_failure_takes_every_rank_out_of_the_step(world):
+    """SlabOps::consensus (slab_protocol.h): between the rank-local part of a step (enqueue / run_exact / resize / pack_exact) and
+    the collective that follows, ranks that can agree cheaply do -- a rank that could not queue its step must not leave the
+    others in the exchange for ever (the round-5 advisor's finding for sdfk_node_*, whose ranks are threads).  Here the agreement
+    is a gloo all-reduce; every rank's submit() fails at the SAME step and no rank hangs."""
+    res = _spawn(_rank_local_failure_worker, world, ((22, 20, 19),))
+    assert {f for _, f, *_ in res} == {4}, res                       # the fifth submit, on every rank
+    assert all(n == 1 for *_, n, _ in res), res                      # exactly one agreement came back non-zero
+    own = {r: mine for r, _, _, _, mine in res}
+    assert own[world - 1] != 0 and all(own[r] == 0 for r in range(world - 1)), res   # ... and only the last rank had failed itself
+
+
 def test_slab_partition_covers_all_layers():
     from tests import proto_host as P
     for n_layers in (0, 1, 7, 8, 511, 1023):

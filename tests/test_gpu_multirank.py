@@ -37,7 +37,8 @@ def test_sharded_bench_on_one_gpu(gpu, world):
     args = ["--steps", "6", "--warmup", "2", "--no-cpu", "--scene", "repeatxy", "--grid", "160"]
     one = _bench([sys.executable, "bench.py"] + args)
     many = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                   "--master-port", str(_free_port()), "bench.py", "--gpus", str(world)] + args, {"SDFK_BENCH_ONE_GPU": "1"})
+                   "--master-port", str(_free_port()), "bench.py", "--gpus", str(world)] + args,
+                  {"SDFK_BENCH_ONE_GPU": "1", "SDFK_BENCH_C4_GRID": "96", "SDFK_BENCH_C4_STEPS": "4"})
     assert many["n_gpus"] == world and one["n_gpus"] == 1
     assert many["config"]["vertices"] == one["config"]["vertices"] > 10000
     assert many["config"]["triangles"] == one["config"]["triangles"]
@@ -49,7 +50,47 @@ def test_sharded_bench_on_one_gpu(gpu, world):
     p3 = many["sharded"]["mesh_stays_sharded_pass"]
     assert isinstance(p3, dict) and p3.get("counts_equal_the_headline_mesh") is True and p3["ms_per_step"] > 0, p3
     assert many["sharded"]["speedup_ceiling_mesh_stays_sharded"] is None or many["sharded"]["speedup_ceiling_mesh_stays_sharded"] > 0
+    # CONTENT, not just counts: rank 0 meshed the same grid on one GPU and compared SHA-256 digests of the four arrays with the gathered
+    # mesh -- for the headline, for the pass that leaves the mesh sharded (payloads gathered on demand) -- and every rank's own slab
+    # with its slice
+    sh = many["sharded"]
+    assert sh["mesh_equals_single_gpu"] is True and sh["content_check"]["every_ranks_slab_equals_its_slice"] is True, sh["content_check"]
+    assert sh["content_check"]["vertices"] == many["config"]["vertices"] and len(sh["content_check"]["sha256_single_gpu"]["Triangles"]) == 64
+    assert p3["mesh_equals_single_gpu"] is True and p3["content_check"]["every_ranks_slab_equals_its_slice"] is True, p3
+    # BASELINE config C4 (union of 8 primitives; here on a reduced grid) sharded in the same run, with the default exchange and with
+    # the mesh left sharded: times, what every rank receives, the single-GPU step of the same grid, and the same content check
+    c4 = sh["c4_union8_1024"]
+    assert isinstance(c4, dict) and c4["grid"] == 96, c4
+    for key, per_rank_bytes in (("all_gather", None), ("mesh_stays_sharded", (world - 1) * 64)):
+        leg = c4[key]
+        assert isinstance(leg, dict) and leg["ms_per_step"] > 0 and leg["steps"] == 4 and leg["vertices"] > 1000, leg
+        assert leg["mesh_equals_single_gpu"] is True and leg["content_check"]["every_ranks_slab_equals_its_slice"] is True, leg
+        assert leg["steps_redone"] == 0 and len(leg["per_rank_vertices_indices"]) == world
+        assert leg["bytes_received_per_rank"] == (per_rank_bytes if per_rank_bytes is not None else (world - 1) * leg["gather_stride_bytes_per_rank"])
+        assert leg["single_gpu_ms_per_step"] > 0 and leg["speedup_measured"] > 0 and leg["single_gpu_product_default_ms_per_step"] > 0
+    assert c4["all_gather"]["vertices"] == c4["mesh_stays_sharded"]["vertices"]
+    assert sh["every_mesh_equals_single_gpu"] is True and all(v is True for v in sh["content_checks"].values()), sh["content_checks"]
+    assert {"headline", "mesh_stays_sharded_pass", "c4_all_gather", "c4_mesh_stays_sharded"} <= set(sh["content_checks"])
     assert one["blocks"]["n"] >= 1 and one["blocks"]["ms_per_step_min"] <= one["ms_per_step"] <= one["blocks"]["ms_per_step_max"]
+
+
+def test_a_flipped_index_turns_the_content_check_false_and_fails_the_run(gpu):
+    """Fault injection for the check itself: SDFK_BENCH_FAULT_FLIP_INDEX=1 flips ONE index of the gathered mesh on rank 0 before it is
+    hashed.  The line must say `mesh_equals_single_gpu: false` and the run must exit non-zero (4) -- on a node of real GPUs that is what
+    a wrong exchange or a wrong rebase would look like."""
+    args = ["--steps", "4", "--warmup", "1", "--no-cpu", "--grid", "96"]
+    e = dict(os.environ)
+    e.update({"SDFK_BENCH_ONE_GPU": "1", "SDFK_BENCH_FAULT_FLIP_INDEX": "1", "SDFK_BENCH_C4_GRID": "64", "SDFK_BENCH_C4_STEPS": "2"})
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode != 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
+    sh = json.loads(lines[0])["sharded"]
+    assert sh["mesh_equals_single_gpu"] is False and sh["every_mesh_equals_single_gpu"] is False
+    assert sh["content_check"]["sha256_sharded"] != "identical" and sh["content_check"]["sha256_sharded"]["Triangles"] != sh["content_check"]["sha256_single_gpu"]["Triangles"]
+    assert sh["content_check"]["sha256_sharded"]["Vertices"] == sh["content_check"]["sha256_single_gpu"]["Vertices"]      # only the flipped array differs
+    assert sh["content_check"]["every_ranks_slab_equals_its_slice"] is True          # (the slabs themselves were right: the fault is in the gathered copy)
+    assert "DIFFERS from the single-GPU mesh" in out.stderr
 
 
 @pytest.mark.parametrize("world", [2])
@@ -59,6 +100,7 @@ def test_bench_gpus_n_started_as_plain_python(gpu, world):
     args = ["--steps", "6", "--warmup", "2", "--no-cpu", "--grid", "128"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["SDFK_BENCH_ONE_GPU"] = "1"
+    env.update({"SDFK_BENCH_C4_GRID": "64", "SDFK_BENCH_C4_STEPS": "2"})
     out = subprocess.run([sys.executable, "bench.py", "--gpus", str(world)] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -265,18 +307,25 @@ def test_sharded_step_host_cost_world_one(gpu):
     d = _bench([sys.executable, "bench.py", "--steps", "40", "--warmup", "4", "--no-cpu", "--grid", "128", "--minimal"], {"SDFK_BENCH_FORCE_DIST": "1"})
     sh = d["sharded"]
     assert sh["world"] == 1 and sh["backend"].startswith("RCCL") and sh["steps_redone_on_the_exact_path"] == 0
+    # the content check over REAL RCCL (world 1): the mesh the session leaves == sdf.ToMesh of the same grid, SHA-256 of all four arrays
+    assert sh["mesh_equals_single_gpu"] is True and sh["content_check"]["every_ranks_slab_equals_its_slice"] is True, sh["content_check"]
+    assert sh["every_mesh_equals_single_gpu"] is True
     assert 0 < sh["host_us_per_step"]["submit"] < 200 and sh["host_us_per_step"]["collect"] >= 0
     assert d["config"]["vertices"] > 10000
 
 
 @pytest.mark.parametrize("world,name,dims,idx16,exchange", [(2, "readme_repeat_xy", (40, 36, 44), 0, 0), (3, "union8", (36, 40, 50), 0, 0), (4, "sphere_w", (64, 64, 64), 0, 0),
                                                             (3, "readme_repeat_xy", (40, 36, 44), 1, 0), (2, "sphere_w", (64, 64, 64), 1, 0),
-                                                            (3, "readme_repeat_xy", (40, 36, 44), 0, 3), (2, "union8", (36, 40, 50), 1, 3), (4, "sphere_w", (64, 64, 64), 0, 3)])
+                                                            (3, "readme_repeat_xy", (40, 36, 44), 0, 3), (2, "union8", (36, 40, 50), 1, 3), (4, "sphere_w", (64, 64, 64), 0, 3),
+                                                            (3, "readme_repeat_xy", (40, 36, 44), 0, 2), (2, "union8", (36, 40, 50), 1, 2)])
 def test_pipelined_session_full_parity_multi_rank(gpu, world, name, dims, idx16, exchange):
     """2-4 ranks (one GPU, the library's host transport over gloo), real kernels: every rank's whole mesh == the oracle's, bit
     for bit -- with int32 indices rebased by the step, and with the compact 16-bit index payloads decoded by sdfk_dist_mesh.
     exchange 3 = the mesh stays sharded: a step moves the 64-byte headers only; every rank's OWN slab (sdfk_dist_slab_mesh, global
-    indices) is its slice of the oracle's mesh, and sdfk_dist_mesh gathers the payloads of that step on demand."""
+    indices) is its slice of the oracle's mesh, and sdfk_dist_mesh gathers the payloads of that step on demand.
+    exchange 2 = gather to rank 0: the other ranks receive headers only, their own sections are never rebased -- their
+    sdfk_dist_slab_mesh must still come out with GLOBAL indices (round-5 advisor finding: it did not over RCCL; the host transport
+    now has the same who-receives-what as RCCL so that one GPU reaches the path)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join("tests", "multirank_worker.py"), name] + [str(d) for d in dims]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, SDFK_DIST_INDEX16=str(idx16), SDFK_DIST_EXCHANGE=str(exchange)))
@@ -298,3 +347,28 @@ def test_bench_contract_fields(gpu):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - 256 ** 3 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-2
+
+
+def test_default_line_carries_every_baseline_config(gpu):
+    """The driver's N = 1 run (default flags; here without the CPU baseline): beside the 512^3 headline the line carries BASELINE's C2
+    (256^3 sphere), C3 (512^3 RepeatXY with colours), C4 (1024^3 union of 8 primitives, whole on one GPU) and C5 (ray marcher), the
+    product-default (volume-less) path with a bound of its own, and the controls for the colour sampler."""
+    d = _bench([sys.executable, "bench.py", "--no-cpu", "--steps", "10", "--warmup", "2"], {"SDFK_BENCH_BLOCKS": "3"})
+    assert d["config"]["vertices"] == 549144 and d["roofline"]["kernel"] == "sdfk_sample_bits"
+    c2, c3, c4 = d["c2_sphere_256"], d["c3_repeatxy"], d["c4_union8_1024"]
+    assert c2["vertices"] == 137232 and c2["elided_volume_ms_per_step"] is None and c2["product_default_ms_per_step"] == c2["ms_per_step"]
+    assert c3["vertices"] > 900000 and 0 < c3["product_default_ms_per_step"] < c3["ms_per_step"]
+    assert c4["vertices"] == 3148104 and c4["triangles"] == 6296176 and 0 < c4["product_default_ms_per_step"] < c4["ms_per_step"]
+    for c in (c2, c3, c4):
+        assert c["ms_per_step"] > 0 and 0.2 < c["sampler_frac"] < 1.0 and c["sampler_us_back_to_back"] > 0 and c["mtris_per_s"] > 0
+    ctl = d["colour_sampler_control"]
+    assert ctl["fill_2gib_us"] > 100 and 0.3 < ctl["fill_2gib_frac_of_peak"] < 1.0 and 0.3 < ctl["trivial_colour_sampler_frac_of_peak"] < 1.0
+    assert 0.5 < c3["sampler_frac_of_long_fill"] < 1.5 and 0.5 < c3["sampler_frac_of_trivial_colour_sampler"] < 1.5
+    el = d["elided"]
+    assert el["ms_per_step"] == d["elided_volume_ms_per_step"] and el["kernels_us"]["k_vertices"]["avg_us"] > 0 and el["chain_serial_us"] > 0
+    assert "sdfk_cull_blocks" in el["kernels_us"] and "sdfk_eval_blocks" in el["kernels_us"] and "sdfk_sample_bits" not in el["kernels_us"]
+    if el["roofline"] is not None:          # (needs the committed SQ counter pass: profiles/pmc_traffic.json)
+        assert el["roofline"]["bound"] == "valu" and el["roofline"]["kernel"].startswith("k_vertices") and 0.1 < el["roofline"]["frac"] < 1.0
+    assert d["c5_raymarch"]["ms_per_frame"] > 0
+    assert 0 < d["one_step_incl_mesh_d2h_product_default_pooled_ms"] <= d["one_step_incl_mesh_d2h_product_default_ms"] * 1.5
+    assert d["pipelined_handoff_product_default_ms_per_mesh"] > 0

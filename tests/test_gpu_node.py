@@ -85,26 +85,52 @@ def test_node_errors_come_back_to_the_caller(gpu):
         assert_mesh_equal(node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False), _oracle(scene, mn, mx, dims, clip=False))
 
 
-def test_one_ranks_failure_fails_the_command_on_every_rank(gpu, monkeypatch):
-    """A rank-local failure (an allocation on ONE device) must not leave the other ranks waiting in the exchange: the ranks agree
-    that all of them reached the collective part before any enters it (node_local.h node_agree).  SDFK_NODE_FAULT_RANK injects
-    one such failure."""
-    L = N.lib()
+@pytest.mark.parametrize("stage,what", [(0, "injected failure$"), (1, "rank-local part of the step"), (2, "inside the exchange")])
+def test_one_ranks_failure_fails_the_command_on_every_rank(gpu, monkeypatch, stage, what):
+    """A rank-local failure (an allocation on ONE device) must not leave the other ranks waiting in a collective -- wherever it
+    happens.  SDFK_NODE_FAULT_RANK injects one such failure on rank 1, SDFK_NODE_FAULT_STAGE says where:
+      0  while the rank makes its session: the ranks agree before any of them enters the step (node_agree);
+      1  in the rank-local part of the step, after the session stage (the round-5 advisor's finding): the protocol's consensus point
+         between enqueue / run_exact and the first collective (SlabOps::consensus = a thread barrier for a node's ranks);
+      2  INSIDE the exchange, between two rendezvous of the ranks, where nobody can agree: the failed rank aborts the node's
+         barrier, which releases the ranks that wait for it there.
+    In every case the caller gets the failing rank's own message, the node is not stuck (the call returns, and so does
+    sdfk_node_close), and the next command is served."""
     mn, mx, dims = [-1.5] * 3, [1.5] * 3, (40, 40, 40)
     scene, sdf = S.sphere_w(1.0)
     ref = _oracle(scene, mn, mx, dims, clip=False)
     for form in ("handle", "arrays"):
         monkeypatch.setenv("SDFK_NODE_FAULT_RANK", "1")
+        monkeypatch.setenv("SDFK_NODE_FAULT_STAGE", str(stage))
         with D.Node([0, 0, 0]) as node:
             monkeypatch.delenv("SDFK_NODE_FAULT_RANK")
-            with pytest.raises(Exception, match="rank 1 failed.*injected"):
+            monkeypatch.delenv("SDFK_NODE_FAULT_STAGE")
+            with pytest.raises(Exception, match="rank 1 .*injected failure") as ei:
                 if form == "handle":
                     node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False)
                 else:
                     node.to_mesh_host(sdf, mn, mx, *dims, clipToBounds=False)
+            import re
+            assert re.search(what, str(ei.value)), str(ei.value)
             # the fault was for one command: the next one is served
             assert_mesh_equal(node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False), ref)
             assert_mesh_equal(node.to_mesh_host(sdf, mn, mx, *dims, clipToBounds=False), ref)
+
+
+def test_a_rank_that_cannot_prepare_fails_the_opening_of_the_node(gpu, monkeypatch):
+    """Start-up has the same shape: ncclCommInitRank returns when EVERY rank has called it, so the ranks first do the rank-local half
+    of sdfk_dist_init (library, exchange stream, agreement buffers), agree that all of them are prepared, and only then join.
+    SDFK_NODE_FAULT_STAGE=3 fails rank 1's preparation: sdfk_node_open returns its message, nothing hangs, the next node opens."""
+    monkeypatch.setenv("SDFK_NODE_FAULT_RANK", "1")
+    monkeypatch.setenv("SDFK_NODE_FAULT_STAGE", "3")
+    with pytest.raises(Exception, match="rank 1 .*injected failure before ncclCommInitRank"):
+        D.Node([0, 0])
+    monkeypatch.delenv("SDFK_NODE_FAULT_RANK")
+    monkeypatch.delenv("SDFK_NODE_FAULT_STAGE")
+    mn, mx, dims = [-1.5] * 3, [1.5] * 3, (40, 40, 40)
+    scene, sdf = S.sphere_w(1.0)
+    with D.Node([0, 0]) as node:
+        assert_mesh_equal(node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False), _oracle(scene, mn, mx, dims, clip=False))
 
 
 def test_threads_have_their_own_current_context(gpu):
@@ -136,3 +162,50 @@ def test_threads_have_their_own_current_context(gpu):
     n = C.c_int()
     assert N.lib().sdfk_init(63) == N.ERR_INVALID
     assert_mesh_equal(sdf.ToMesh(mn, mx, *dims, clipToBounds=False), ref)
+
+
+_NODE_BEFORE_INIT = r"""
+import ctypes as C, sys, threading
+sys.path.insert(0, %r)
+from sdfkit_amd import _native as N
+from sdfkit_amd import dist as D
+from tests import scenes as S
+L = N.lib()
+mn, mx, dims = [-1.5] * 3, [1.5] * 3, (40, 40, 40)
+_, sdf = S.sphere_w(1.0)
+node = D.Node([0])                          # a node BEFORE any sdfk_init of the process
+ref = node.to_mesh(sdf, mn, mx, *dims, clipToBounds=False)
+out = {}
+def never_chose():                          # a thread that never called sdfk_init: must not fall into rank 0's private context
+    v = C.c_void_p()
+    out["status"] = L.sdfk_volume_create(8, 8, 8, N.f3(mn), N.f3(mx), 0, C.byref(v))
+    out["msg"] = L.sdfk_last_error().decode()
+t = threading.Thread(target=never_chose); t.start(); t.join()
+assert out["status"] == N.ERR_NO_DEVICE and "sdfk_init" in out["msg"], out
+N.init(0)                                   # now a listed context exists: it becomes the default of the threads that never chose
+def after_init():
+    v = C.c_void_p()
+    out["status2"] = L.sdfk_volume_create(8, 8, 8, N.f3(mn), N.f3(mx), 0, C.byref(v))
+    if v.value: L.sdfk_volume_free(v)
+t = threading.Thread(target=after_init); t.start(); t.join()
+assert out["status2"] == 0, out
+mine = sdf.ToMesh(mn, mx, *dims, clipToBounds=False)
+import numpy as np
+assert np.array_equal(mine.Vertices, ref.Vertices) and np.array_equal(mine.Triangles, ref.Triangles)
+node.close()
+again = sdf.ToMesh(mn, mx, *dims, clipToBounds=False)      # the listed context survives the node's private ones
+assert np.array_equal(again.Vertices, ref.Vertices)
+print("node-before-init ok")
+"""
+
+
+def test_a_node_opened_before_sdfk_init_keeps_its_contexts_private():
+    """Round-5 advisor: a node opened before any sdfk_init took the process's DEFAULT context object for rank 0, and threads that never
+    called sdfk_init then silently worked inside rank 0's private context.  An unlisted claim never takes the default's object: such a
+    thread fails loudly (SDFK_ERR_NO_DEVICE) until somebody calls sdfk_init, whose context then becomes the default."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _NODE_BEFORE_INIT % root], capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode == 0 and "node-before-init ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
