@@ -348,6 +348,11 @@ def main():
         # a rank as the launcher (the driver's torch.distributed.run, or launch_ranks above) started it: supervise a worker
         sys.exit(supervise_rank(sys.argv[1:]))
 
+    # SDFK_BENCH_STACKS_AFTER_S=t: every thread's Python stack goes to stderr t seconds from now (and every t seconds after) -- where a
+    # rank sits when a pass hangs on first contact with a node (the supervisor's time limit only says THAT it hung)
+    if os.environ.get("SDFK_BENCH_STACKS_AFTER_S"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SDFK_BENCH_STACKS_AFTER_S"]), repeat=True, file=sys.stderr)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -540,6 +545,7 @@ def main():
         # sets the form of the headline pass (default: plain)
         idx16_env = os.environ.get("SDFK_BENCH_INDEX16")
         N.set_option(N.OPT_DIST_INDEX16, int(idx16_env) if idx16_env is not None else 0)
+        headline_mode = N.get_option(N.OPT_DIST_EXCHANGE)
         worker = D.SlabSession(sdf, mn, mx, n, n, n, clip, 0.0, depth=depth_env or 4)
         last = [0, 0]
         tuned = None
@@ -635,8 +641,8 @@ def main():
         return {name: hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes() if a.size else b"").hexdigest()
                 for name, a in (("Vertices", V), ("Colors", Cc), ("Normals", Nn), ("Triangles", T))}
 
-    def content_check(ses, sdf_x, mn_x, mx_x, clip_x, nn):
-        mode_x = ses.stats()["exchange_mode"]
+    def content_check(ses, sdf_x, mn_x, mx_x, clip_x, nn, mode_x):
+        # (mode_x: the SDFK_OPT_DIST_EXCHANGE the session was created with -- its stats report -1 for the host transport, whatever the mode)
         counts_x = ses.counts()
         own = ses.slab_mesh()            # (first: with exchange mode 3 no payload has moved yet)
         own_d = mesh_digest(own.Vertices, own.Colors, own.Normals, own.Triangles)
@@ -652,8 +658,12 @@ def main():
             slabs = [(own_d, own_n)]
         res = None
         if rank == 0:
+            # (sdfk_sample_march itself: in a process that has joined a sharding context sdf.ToMesh IS the sharded, collective call)
+            from sdfkit_amd.api import Mesh as HostMesh
             with N.option(N.OPT_ELIDE_VOLUME, 0):
-                single = sdf_x.ToMesh(mn_x, mx_x, nn, nn, nn, clipToBounds=clip_x)
+                h1 = C.c_void_p()
+                N.check(L.sdfk_sample_march(sdf_x.program(), N.f3(mn_x), N.f3(mx_x), nn, nn, nn, 1 if clip_x else 0, C.c_float(0.0), 1, C.byref(h1)))
+                single = HostMesh._from_handle(h1)
             T_g = whole.Triangles
             if os.environ.get("SDFK_BENCH_FAULT_FLIP_INDEX") == "1" and len(T_g):   # (tests: one flipped index must turn the check false)
                 T_g = T_g.copy()
@@ -672,7 +682,7 @@ def main():
                    "vertices": len(single.Vertices), "indices": len(single.Triangles), "sha256_single_gpu": d_s,
                    "sha256_sharded": d_g if d_g != d_s else "identical",
                    "what": "SHA-256 of Vertices / Colors / Normals / Triangles: the mesh of the sharded step collected last (sdfk_dist_mesh) against "
-                           "sdf.ToMesh of the same grid on rank 0's GPU alone; every rank's own slab (sdfk_dist_slab_mesh) against its slice"}
+                           "sdfk_sample_march of the same grid on rank 0's GPU alone; every rank's own slab (sdfk_dist_slab_mesh) against its slice"}
             del single
         del whole
         if world > 1:
@@ -684,7 +694,7 @@ def main():
     dist_extra = {}
     headline_content = None
     if sharded:
-        headline_content = content_check(worker, sdf, mn, mx, clip, n)   # (before enqueue_only reuses slot 0's send buffer)
+        headline_content = content_check(worker, sdf, mn, mx, clip, n, headline_mode)   # (before enqueue_only reuses slot 0's send buffer)
         st = worker.stats()
         for _ in range(3):
             worker.enqueue_only()
@@ -1480,7 +1490,7 @@ def main():
             ses.collect()
             counts_c = [list(c) for c in ses.counts()]
             st_c = ses.stats()
-            chk = content_check(ses, sdf_c, mn_c, mx_c, clip_c, c4_grid)
+            chk = content_check(ses, sdf_c, mn_c, mx_c, clip_c, c4_grid, mode)
             # rank 0's single-GPU step of the SAME grid (stored volume, like the sharded step, and the product default), measured here
             # while the other ranks wait: the numerator of speedup_measured
             if "single_ms" not in c4_state and os.environ.get("SDFK_BENCH_NO_SINGLE") != "1":
@@ -1556,7 +1566,7 @@ def main():
             w3.collect()
             c3_counts = [list(c) for c in w3.counts()]
             ok3 = (sum(c[0] for c in c3_counts), sum(c[1] for c in c3_counts)) == (nv, ni)
-            chk3 = content_check(w3, sdf, mn, mx, clip, n)
+            chk3 = content_check(w3, sdf, mn, mx, clip, n, 3)
             sharded_result_pass = {"exchange": "headers only (SDFK_OPT_DIST_EXCHANGE = 3): the mesh stays sharded, payloads on demand",
                                    "ms_per_step": round(dt_c / args.steps * 1e3, 4), "value": round(n ** 3 / (dt_c / args.steps) / 1e6, 1),
                                    "counts_equal_the_headline_mesh": ok3,
@@ -1614,7 +1624,7 @@ def main():
             st_b = worker.stats()
             step()
             drain()
-            chk_b = content_check(worker, sdf, mn, mx, clip, n)
+            chk_b = content_check(worker, sdf, mn, mx, clip, n, st_b["exchange_mode"])
             tuned_pass = {"tuner_ns_per_20_steps": tuned,
                           "exchange": {0: "ncclAllGather (in place)", 1: "grouped ncclSend / ncclRecv to every peer", 2: "gather to rank 0"}[st_b["exchange_mode"]],
                           "payload": "compact (16-bit index offsets)" if st_b["index16"] else "plain (int32 indices)",

@@ -60,6 +60,7 @@ struct sdfk_node {
         int status = SDFK_OK;
         std::string error;
         bool released = false;   // the status is "another rank failed and released me": the caller is told about THAT rank first
+        std::string transport_error;   // what the host transport between the rank threads had to say (its caller only knows "it failed")
     };
     int world = 1;
     bool host_transport = false;
@@ -105,13 +106,18 @@ int node_allgather(void* ctx, const void* send, void* recv, int64_t bytes)
     sdfk_node* n = w->node;
     if (n->fault_stage == 2 && n->fault_rank.load() == w->rank) {   // (injected: this rank never reaches the rendezvous)
         n->fault_rank.store(-1);
-        fail(SDFK_ERR_NOMEM, "SDFK_NODE_FAULT_RANK: injected failure inside the exchange");
+        w->transport_error = "SDFK_NODE_FAULT_RANK: injected failure inside the exchange";
         return -1;
     }
+    auto released = [&] {   // the barrier was aborted: a rank failed elsewhere in this command and will never arrive
+        w->released = true;
+        w->transport_error = "another rank failed and left the command";
+        return -1;
+    };
     n->send_ptrs[(size_t)w->rank] = send;
-    if (!n->bar.wait()) return -1;   // (aborted: a rank failed elsewhere in this command)
+    if (!n->bar.wait()) return released();
     for (int q = 0; q < n->world; q++) memcpy((char*)recv + (size_t)q * (size_t)bytes, n->send_ptrs[(size_t)q], (size_t)bytes);
-    if (!n->bar.wait()) return -1;   // (nobody overwrites its send buffer before everybody has read it)
+    if (!n->bar.wait()) return released();   // (nobody overwrites its send buffer before everybody has read it)
     return 0;
 }
 
@@ -297,6 +303,7 @@ void node_worker_main(sdfk_node::Worker* w)
         if (cmd == 1 && ok) {
             sdfk_mesh* m = nullptr;
             w->released = false;
+            w->transport_error.clear();
             w->status = node_worker_to_mesh(w, &m);
             w->error = w->status ? t_err : std::string();
             if (w->rank == 0) n->mesh0 = m;
@@ -304,9 +311,11 @@ void node_worker_main(sdfk_node::Worker* w)
         }
         if ((cmd == 3 || cmd == 4) && ok) {
             w->released = false;
+            w->transport_error.clear();
             w->status = cmd == 3 ? node_worker_begin(w) : node_worker_copy(w);
             w->error = w->status ? t_err : std::string();
         }
+        if (w->status && !w->transport_error.empty()) w->error += ": " + w->transport_error;
         // a rank that leaves a collective command with an error may have left it between two rendezvous: whoever waits for it there
         // (the host transport's all-gather, an agreement) is released and fails the command too
         if ((cmd == 1 || cmd == 3) && ok && w->status) {

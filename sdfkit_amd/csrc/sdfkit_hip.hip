@@ -235,6 +235,7 @@ DeviceState g_state0;                                   // the first device's co
 std::atomic<DeviceState*> g_default_state{&g_state0};   // current context of threads that never chose one (written under g_registry_mu,
                                                         // read without it by every call of such a thread: atomic)
 std::mutex g_registry_mu;                               // guards g_states / writes of g_default_state / process-wide settings
+std::atomic<int> g_contexts_up{0};                      // initialised contexts of the process, listed or private (a node's ranks)
 std::vector<DeviceState*> g_states{&g_state0};          // the contexts sdfk_init made, by device (a local node's private ones are not listed)
 thread_local DeviceState* t_state = nullptr;
 inline DeviceState& cur_state() { return *(t_state ? t_state : g_default_state.load(std::memory_order_acquire)); }
@@ -1083,6 +1084,7 @@ int context_init(int device)
     g.device = device;
     t_bound_device = device;
     g.inited = true;
+    g_contexts_up.fetch_add(1);
     return SDFK_OK;
 }
 
@@ -1214,6 +1216,7 @@ extern "C" void sdfk_shutdown(void)
     g.own_stream = nullptr;
     g.stream = g.user_stream = nullptr;
     g.inited = false;
+    g_contexts_up.fetch_sub(1);
     g.device = -1;
     context_unclaim(&cur_state());   // (the context object stays, free for the next sdfk_init)
 }
@@ -3432,7 +3435,9 @@ extern "C" int sdfk_host_alloc(int64_t n_bytes, void** out)
 {
     if (!out || n_bytes < 0) return fail(SDFK_ERR_INVALID, "sdfk_host_alloc: bad argument");
     *out = nullptr;
-    {
+    // (the arena is process-wide and pinned memory belongs to no device context: ANY initialised context of the process will do --
+    // also a node's private ones, for a host whose only use of the library is sdfk_node_* and that never called sdfk_init itself)
+    if (g_contexts_up.load() <= 0) {
         std::lock_guard<std::recursive_mutex> lk(g_mu);
         if (int r = require_init()) return r;
     }
