@@ -252,6 +252,13 @@ def scene_for(name, other_constants=False):
         for q in prims[1:]:
             prod = SdfExprs.Union(prod, q)
         return prod.ToSdf(), [-2.0] * 3, [2.0] * 3, True
+    if name == "sphere_color":   # (probes only: the colour sampler's kernel shape with next to no arithmetic -- one primitive, a constant colour)
+        from sdfkit_amd import SdfFuncs
+        return SdfFuncs.Sphere(0.5 + dr).WithColor(1.0, 0.2, 0.3).ToSdf(), [-2.8125] * 3, [2.8125] * 3, True
+    if name == "two_spheres_color":   # (probes only: MarchingCubesTests.ColoredSpheres' scene -- two primitives with constant colours, one Union)
+        from sdfkit_amd import SdfFuncs
+        return SdfFuncs.Union(SdfFuncs.Sphere(0.4).WithColor(1.0, 0.2, 0.3).Translate(-1, 0, 0),
+                              SdfFuncs.Sphere(0.2 + dr).WithColor(0.1, 1.0, 0.3).Translate(1, 0, 0)).ToSdf(), [-3.0] * 3, [3.0] * 3, False
     raise SystemExit(f"unknown scene {name}")
 
 
@@ -1278,6 +1285,13 @@ def main():
         if dom:
             own = roof_us is not None
             us = roof_us if own else kern[dom]["avg_us"]
+            if "sdfk_sample_colors" in kern and dom.startswith("sdfk_sample_bits_nc"):
+                # a colour volume sampled in two passes (SDFK_OPT_COLOR_PASSES): the pair of kernels writes the 16 B/voxel between them
+                if not own:
+                    us += kern["sdfk_sample_colors"]["avg_us"]
+                cands[dom + " + sdfk_sample_colors"] = cands.pop(dom)
+                design[dom + " + sdfk_sample_colors"] = design.pop(dom)
+                dom = dom + " + sdfk_sample_colors"
             ach = cands[dom] / (us * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": load_pmc_traffic(dom, args.scene, n),

@@ -173,7 +173,13 @@ typedef enum sdfk_option {
                                    Never elided: a volume the caller can see (sdfk_sample / sdfk_sample_march_slab / Voxels.SampleSdf:
                                    those always store), step > 1, a NaN iso value, a program one of whose volumes had case-13 sign words
                                    (the dead-cell test of the meshing reads voxels: that job is redone on a stored volume) */
-    SDFK_OPT_COUNT_ = 17
+    SDFK_OPT_COLOR_PASSES = 17, /* How Voxels.SampleSdf writes a COLOUR volume (16 B per voxel into two arrays: Voxels.cs:112-120).  One fused pass
+                                 * from workgroups that own 8 x rows runs at 0.70-0.75 of the HBM peak even without arithmetic; values (+ sign
+                                 * bytes) by that kernel and then the colour array as one linear stream by a second kernel reaches 0.78-0.84
+                                 * -- when the program is cheap enough to be evaluated a second time, one voxel per lane.  0 (default): two
+                                 * passes for programs of at most 24 operations (one primitive with a constant colour) on grids of at least
+                                 * 2^21 voxels, one pass otherwise; 1: always one pass; 2: always two.  Bit-identical results either way. */
+    SDFK_OPT_COUNT_ = 18
 } sdfk_option;
 int sdfk_set_option(int32_t key, int64_t value);
 int sdfk_get_option(int32_t key, int64_t* value);

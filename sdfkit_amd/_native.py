@@ -136,6 +136,7 @@ OPT_LANES, OPT_TOKENS, OPT_GRAPHS, OPT_COPY_MODE, OPT_CORNER_EVAL, OPT_VCOLOR_EV
 OPT_DIST_EXCHANGE, OPT_DIST_LANES, OPT_HW_QUEUES, OPT_CODE_CACHE, OPT_PREFAULT_HUGE, OPT_DIST_INDEX16, OPT_STREAM_PLACEMENT, OPT_IDLE_LANE = 7, 8, 9, 10, 11, 12, 13, 14
 OPT_IDLE_PROGRAMS = 15
 OPT_ELIDE_VOLUME = 16
+OPT_COLOR_PASSES = 17
 
 
 def library_path():

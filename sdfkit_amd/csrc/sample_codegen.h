@@ -207,7 +207,9 @@ __device__ __forceinline__ void sdfk_store4_nt(float* base, int elem, float a, f
 // cells re-evaluated (sdfk_corners_eval) and the vertex colours re-evaluated (sdfk_vertex_colors) the meshing chain never reads
 // it, so the 4 (16) bytes per voxel need not be written at all; the colour arithmetic is dead code the compiler removes.
 // ClipToBounds is then a run-time flag (A.clip) instead of a second instantiation.
-template <bool CLIP, int MODE, bool STORE = true>
+// COLS = false (sdfk_sample_bits_nc*): a colour program's VALUES and sign bytes only -- the first of two passes, the colours follow in
+// sdfk_sample_colors below (its colour arithmetic is dead code here).  Why two passes can be faster than one: see sdfk_sample_colors.
+template <bool CLIP, int MODE, bool STORE = true, bool COLS = true>
 __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const SdfkK& K)
 {
     constexpr int RPW = SDFK_SAMPLE_RPW;
@@ -221,7 +223,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
     asm volatile("" ::: "v" SDFK_S1_(SDFK_SAMPLE_VREG));
 #endif
 #if SDFK_WRITES_COLOR
-    __shared__ __attribute__((aligned(16))) float cbuf[STORE ? 8 / RPW : 1][STORE ? 768 : 1];   // colour staging, one slice per wavefront
+    __shared__ __attribute__((aligned(16))) float cbuf[STORE && COLS ? 8 / RPW : 1][STORE && COLS ? 768 : 1];   // colour staging, one slice per wavefront
 #endif
     // (a program that only assigns .W has no staging buffer: 0.5 instead of 12.5 KB of LDS per workgroup -- at 8 wavefronts
     // per SIMD the sampler would otherwise hold 100 of a CU's 160 KB, and the marching-cubes kernels of the job before it
@@ -278,7 +280,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
             const long o0 = MODE == SDFK_FLAT ? (long)ix * plane + f0 : ((long)ix * A.ny + (int)blockIdx.y) * P + (int)blockIdx.x * 256;
             if (STORE) sdfk_store4_nt(A.values + o0, 4 * lane, w[0], w[1], w[2], w[3]);
 #if SDFK_WRITES_COLOR
-            if (STORE && A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
+            if (STORE && COLS && A.colors) {   // rgb of the lane's 4 voxels -> the wavefront's LDS slice (stored below)
                 sdfk_f4* mine = reinterpret_cast<sdfk_f4*>(cbuf[wave] + 12 * lane);
                 mine[0] = sdfk_f4{cr[0], cg[0], cb[0], cr[1]};
                 mine[1] = sdfk_f4{cg[1], cb[1], cr[2], cg[2]};
@@ -289,7 +291,7 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
             if (MODE == SDFK_FLAT && z + 3 >= A.nz) n &= z < A.nz ? (1u << (A.nz - z)) - 1u : 0u;   // row padding: 0 bits
         }
         nib[r][lane] = (unsigned char)n;
-        if (STORE && A.colors && ix < A.nx) {
+        if (STORE && COLS && A.colors && ix < A.nx) {
             // A lane produced 48 contiguous bytes (4 voxels x rgb) of the wavefront's 3 KiB run.
             // Stored as they are, every instruction would touch a third of every line; through
             // the LDS slice they become three full 1 KiB nontemporal stores (lane L writes
@@ -335,9 +337,10 @@ __device__ __forceinline__ void sdfk_sample_bits_body(const SampleArgs& A, const
 }
 // SDFK_KERNELS: bit mask of the entry points this module contains (the host compiles a program's kernels on demand:
 // bit 0 / 1 = the two instantiations without ClipToBounds, 3 / 4 = with it, 5 = sdfk_vertex_colors, 6 = sdfk_corners_eval, 7 = sdfk_raymarch,
-// 2 / 8 = the sign-bits-only samplers of SDFK_OPT_ELIDE_VOLUME, 9 / 10 = its block culling: sdfk_cull_blocks / sdfk_eval_blocks, 11 = sdfk_eval_points)
+// 2 / 8 = the sign-bits-only samplers of SDFK_OPT_ELIDE_VOLUME, 9 / 10 = its block culling: sdfk_cull_blocks / sdfk_eval_blocks, 11 = sdfk_eval_points,
+// 12..15 = the four fused samplers without their colour half (sdfk_sample_bits_nc*), 16 = sdfk_sample_colors: two-pass sampling of colour volumes)
 #ifndef SDFK_KERNELS
-#define SDFK_KERNELS 0xfff
+#define SDFK_KERNELS 0x1ffff
 #endif
 #if SDFK_KERNELS & 0x04
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_signs(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_ROWS, false>(A, K); }
@@ -356,6 +359,63 @@ extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_
 #endif
 #if SDFK_KERNELS & 0x10
 extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_clip_flat(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<true, SDFK_FLAT>(A, K); }
+#endif
+
+// ---- two-pass sampling of a COLOUR volume (SDFK_OPT_COLOR_PASSES) -------------------------------------------------------------------
+// One pass writes 16 B per voxel into TWO arrays (values, colours) from workgroups that own 8 x rows each: 16 address streams per
+// workgroup, four 1-KiB stores per lane and row.  That pattern runs at 0.72-0.75 of the HBM peak WITHOUT any arithmetic, and no
+// re-mapping inside one kernel gets past 0.81 (tools/ubench/ub_mixstore.hip, round 6: the tile 0.72-0.75, one mixed-address store per
+// lane in a linear mapping 0.78-0.81, padded planes / longer runs: no gain) -- while the values alone go out at 0.81-0.82 in this
+// very tile (the distance-only sampler) and the colour array alone, written as ONE linear stream with one full-KiB store per
+// wavefront, at 0.85-0.86: 0.84-0.85 for the two launches together.  So a program whose arithmetic is cheap enough to be done twice
+// samples in two passes: sdfk_sample_bits_nc* = the kernel above without its colour half, then sdfk_sample_colors = the colour array
+// as a plain fill -- a workgroup evaluates 256 consecutive voxels of the volume (one per lane; the volume [nx][ny][pitch] is one
+// contiguous run), leaves r, g, b in LDS, and three of its four wavefronts store one contiguous KiB each.  Same sdf_eval, same
+// coordinates: bit-identical colours (tests/test_gpu_color_passes.py).  ClipToBounds touches values only (Voxels.cs:133-167).
+#if SDFK_KERNELS & 0x1000
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_nc(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_ROWS, true, false>(A, K); }
+#endif
+#if SDFK_KERNELS & 0x2000
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_nc_flat(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<false, SDFK_FLAT, true, false>(A, K); }
+#endif
+#if SDFK_KERNELS & 0x4000
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_nc_clip(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<true, SDFK_ROWS, true, false>(A, K); }
+#endif
+#if SDFK_KERNELS & 0x8000
+extern "C" __global__ __launch_bounds__(512 / SDFK_SAMPLE_RPW) void sdfk_sample_bits_nc_clip_flat(SampleArgs A, SdfkK K) { sdfk_sample_bits_body<true, SDFK_FLAT, true, false>(A, K); }
+#endif
+#if SDFK_KERNELS & 0x10000
+extern "C" __global__ __launch_bounds__(256) void sdfk_sample_colors(SampleArgs A, SdfkK K)
+{
+#if SDFK_WRITES_COLOR
+    __shared__ __attribute__((aligned(16))) float cb[768];
+    const unsigned tid = threadIdx.x;
+    const unsigned P = (unsigned)A.pitch8, plane = (unsigned)A.ny * P;   // floats per row / per x row (the padded layout of the volume)
+    const unsigned long long total = (unsigned long long)A.nx * plane;    // voxels of the padded volume (< 2^32)
+    const unsigned long long chunk0 = (unsigned long long)blockIdx.x * 256ull;   // (uniform; at most 2^24 chunks: nx ny nz < 2^31, Voxels.cs:82)
+    const unsigned long long me = chunk0 + tid;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    if (me < total) {
+        // (the chunk's first voxel: uniform divisions; a lane then wraps at most once per level unless rows / planes are shorter than 256)
+        unsigned ix = (unsigned)(chunk0 / plane);
+        unsigned q = (unsigned)(chunk0 - (unsigned long long)ix * plane) + tid;
+        if (q >= plane) { const unsigned k = q / plane; q -= k * plane; ix += k; }
+        const unsigned iy = q / P, z = q - iy * P;
+        const float px = A.mx + (float)(int)ix * A.dx, py = A.my + (float)(int)iy * A.dy, pz = A.mz + (float)(A.z0 + (int)z) * A.dz;
+        float w;
+        sdf_eval(K, px, py, pz, r, g, b, w);
+    }
+    cb[3 * tid] = r; cb[3 * tid + 1] = g; cb[3 * tid + 2] = b;
+    __syncthreads();
+    if (tid < 192) {   // three wavefronts, one contiguous KiB each (total and chunk0 are multiples of 4 voxels: no piece straddles the end)
+        const unsigned long long e = chunk0 * 3ull + 4ull * tid;
+        if (e + 3 < total * 3ull) {
+            const sdfk_f4 t = *reinterpret_cast<const sdfk_f4*>(cb + 4 * tid);
+            __builtin_nontemporal_store(t, reinterpret_cast<sdfk_f4*>(A.colors + e));
+        }
+    }
+#endif
+}
 #endif
 
 // ---- SDFK_OPT_ELIDE_VOLUME = 2, block culling: the sign bits without evaluating most voxels ---------------------------------

@@ -22,6 +22,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -60,6 +61,7 @@ struct Config {
     int dist_index16 = 0;     // SDFK_OPT_DIST_INDEX16
     int code_cache = 1;       // SDFK_OPT_CODE_CACHE
     int idle_programs = 32;   // SDFK_OPT_IDLE_PROGRAMS
+    int color_passes = 0;     // SDFK_OPT_COLOR_PASSES: 0 = by the program's size and the grid's (default), 1 = always one pass, 2 = always two
     int elide_volume = 2;     // SDFK_OPT_ELIDE_VOLUME (default: the temporary volume of sdfk_sample_march is not stored, blocks are culled)
     int prefault_huge = 0;    // SDFK_OPT_PREFAULT_HUGE
     int place_streams = 1;    // SDFK_OPT_STREAM_PLACEMENT
@@ -857,9 +859,19 @@ int copy_to_host(const std::vector<CopyPiece>& pieces, const std::function<void(
 // opaque objects
 // ---------------------------------------------------------------------------
 // Kernels of a program (bit k of SDFK_KERNELS in the generated source, csrc/sample_codegen.h)
+// SDFK_OPT_COLOR_PASSES = 0: a colour volume is sampled in two passes when its program has at most kTwoPassMaxOps operations -- ONE primitive
+// with a constant colour (Sdfs.Cylinder: 16, a sphere .WithColor: ~20) -- and the grid at least kTwoPassMinVoxels voxels.  The second pass
+// evaluates one voxel per lane (one store per lane is what makes it a plain fill), without the fused kernel's sharing of everything
+// that depends on x and y only among a lane's four z: measured at 512^3 (profiles/r06_ab_color_passes.txt, us per sampling, one / two
+// passes): sphere with a constant colour 383 / 345, two coloured spheres under a Union (43 operations) 382 / 396, the README scene (64)
+// 384 / 480, the 8-primitive union of BASELINE C4 (213) 389 / 578.
+constexpr int kTwoPassMaxOps = 24;
+constexpr size_t kTwoPassMinVoxels = size_t(1) << 21;
 enum ProgKernel { PK_BITS = 0, PK_BITS_FLAT = 1, PK_SIGNS = 2, PK_BITS_CLIP = 3, PK_BITS_CLIP_FLAT = 4, PK_VCOLORS = 5, PK_CORNERS = 6, PK_RAYMARCH = 7,
-                  PK_SIGNS_FLAT = 8, PK_CULL = 9, PK_EVAL_BLOCKS = 10, PK_POINTS = 11, PK_COUNT = 12 };
-static bool pk_is_sampler(int k) { return k <= PK_BITS_CLIP_FLAT || k == PK_SIGNS_FLAT || k == PK_CULL || k == PK_EVAL_BLOCKS; }
+                  PK_SIGNS_FLAT = 8, PK_CULL = 9, PK_EVAL_BLOCKS = 10, PK_POINTS = 11,
+                  // two-pass sampling of a colour volume (SDFK_OPT_COLOR_PASSES): the fused samplers without their colour half, then the colours
+                  PK_BITS_NC = 12, PK_BITS_NC_FLAT = 13, PK_BITS_NC_CLIP = 14, PK_BITS_NC_CLIP_FLAT = 15, PK_COLORS = 16, PK_COUNT = 17 };
+static bool pk_is_sampler(int k) { return k <= PK_BITS_CLIP_FLAT || k == PK_SIGNS_FLAT || k == PK_CULL || k == PK_EVAL_BLOCKS || (k >= PK_BITS_NC && k <= PK_BITS_NC_CLIP_FLAT); }
 
 // The compiled kernels of one program STRUCTURE (opcodes, operand ids, outputs -- the generated source; a program's
 // constants are kernel arguments, csrc/sample_codegen.h): shared by every program of that structure, so that a scene whose
@@ -880,6 +892,7 @@ struct sdfk_program {
     ProgCode* code = nullptr;
     std::vector<float> params;   // the constants, in the order of the K.k[] slots of the generated source (never empty)
     int writes_color = 0;
+    int n_ops = 0;  // operations of the program (SDFK_OPT_COLOR_PASSES = 0 decides by it whether evaluating twice is cheap enough)
     int refs = 1;   // the caller's handle + volumes it has sampled + queued jobs that launch from its module
     bool orphaned = false;   // the caller's handle is gone (sdfk_program_destroy): captured jobs keyed on it can never be asked for again
     bool no_elide = false;   // a volume of this program had case-13 sign words (the dead-cell test reads voxels): its volumes are stored from then on
@@ -1034,6 +1047,7 @@ static void config_from_env_once()
     g_cfg.code_cache = geti("SDFK_NO_CACHE", 0) ? 0 : 1;
     g_cfg.idle_programs = ranged("SDFK_IDLE_PROGRAMS", 32, 0, 1024);
     g_cfg.elide_volume = ranged("SDFK_ELIDE_VOLUME", 2, 0, 2);
+    g_cfg.color_passes = ranged("SDFK_COLOR_PASSES", 0, 0, 2);
     g_cfg.prefault_huge = geti("SDFK_PREFAULT_HUGE", 0) ? 1 : 0;
     g_cfg.place_streams = geti("SDFK_STREAM_PLACEMENT", 1) ? 1 : 0;
     g_cfg.idle_lane = geti("SDFK_IDLE_LANE", 1) ? 1 : 0;
@@ -1302,6 +1316,7 @@ extern "C" int sdfk_set_option(int32_t key, int64_t value)
     case SDFK_OPT_CODE_CACHE: if (!in(0, 1)) break; g_cfg.code_cache = (int)value; return SDFK_OK;
     case SDFK_OPT_IDLE_PROGRAMS: if (!in(0, 1024)) break; g_cfg.idle_programs = (int)value; codes_trim(); return SDFK_OK;
     case SDFK_OPT_ELIDE_VOLUME: if (!in(0, 2)) break; g_cfg.elide_volume = (int)value; return SDFK_OK;
+    case SDFK_OPT_COLOR_PASSES: if (!in(0, 2)) break; g_cfg.color_passes = (int)value; return SDFK_OK;
     case SDFK_OPT_PREFAULT_HUGE: if (!in(0, 1)) break; g_cfg.prefault_huge = (int)value; return SDFK_OK;
     case SDFK_OPT_HW_QUEUES: return fail(SDFK_ERR_INVALID, "SDFK_OPT_HW_QUEUES is read-only");
     default: return fail(SDFK_ERR_INVALID, "sdfk_set_option: unknown option %d", key);
@@ -1329,6 +1344,7 @@ extern "C" int sdfk_get_option(int32_t key, int64_t* value)
     case SDFK_OPT_CODE_CACHE: *value = g_cfg.code_cache; break;
     case SDFK_OPT_IDLE_PROGRAMS: *value = g_cfg.idle_programs; break;
     case SDFK_OPT_ELIDE_VOLUME: *value = g_cfg.elide_volume; break;
+    case SDFK_OPT_COLOR_PASSES: *value = g_cfg.color_passes; break;
     case SDFK_OPT_PREFAULT_HUGE: *value = g_cfg.prefault_huge; break;
     case SDFK_OPT_HW_QUEUES: *value = g_cfg.hw_queues; break;
     default: return fail(SDFK_ERR_INVALID, "sdfk_get_option: unknown option %d", key);
@@ -1577,7 +1593,7 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::vector<char> code;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
     config_from_env();
-    return compile_source(src, 0xfffu, code, false);   // every kernel, a real compile: this IS the check
+    return compile_source(src, (1u << PK_COUNT) - 1u, code, false);   // every kernel, a real compile: this IS the check
 }
 
 extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4],
@@ -1591,6 +1607,7 @@ extern "C" int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int3
     std::string src;
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src, &p->params)) { delete p; return r; }   // validates the op list
     p->writes_color = writes_color;
+    p->n_ops = n_ops;
     p->code = code_acquire(std::move(src));
     *out = p;
     return SDFK_OK;
@@ -1606,8 +1623,11 @@ int program_fn(const sdfk_program* cp, int k, hipFunction_t* fn)
     if (!p->fn[k]) {
         static const char* const names[PK_COUNT] = {"sdfk_sample_bits", "sdfk_sample_bits_flat", "sdfk_sample_signs", "sdfk_sample_bits_clip",
                                                     "sdfk_sample_bits_clip_flat", "sdfk_vertex_colors", "sdfk_corners_eval", "sdfk_raymarch",
-                                                    "sdfk_sample_signs_flat", "sdfk_cull_blocks", "sdfk_eval_blocks", "sdfk_eval_points"};
+                                                    "sdfk_sample_signs_flat", "sdfk_cull_blocks", "sdfk_eval_blocks", "sdfk_eval_points",
+                                                    "sdfk_sample_bits_nc", "sdfk_sample_bits_nc_flat", "sdfk_sample_bits_nc_clip", "sdfk_sample_bits_nc_clip_flat",
+                                                    "sdfk_sample_colors"};
         unsigned mask = 1u << k;
+        if (k >= PK_BITS_NC && k <= PK_BITS_NC_CLIP_FLAT && !p->fn[PK_COLORS]) mask |= 1u << PK_COLORS;   // (the second pass: same module)
         if (k == PK_CULL || k == PK_EVAL_BLOCKS) mask |= (1u << PK_CULL) | (1u << PK_EVAL_BLOCKS);   // (a pair)
         if (pk_is_sampler(k) && !p->fn[PK_CORNERS]) {   // (and, for a program that writes colours, sdfk_vertex_colors)
             mask |= 1u << PK_CORNERS;
@@ -1921,13 +1941,24 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
             if (force == 0 && (v->nz & 3) == 0) mode = 0;
             if (force == 1 || v->ny > 65535 || v->nx8() > 65535) mode = 1;   // (the row-tiled form has y and x/8 in 16-bit grid dimensions)
             static const char* const names[2][2] = {{"sdfk_sample_bits", "sdfk_sample_bits_flat"}, {"sdfk_sample_bits_clip", "sdfk_sample_bits_clip_flat"}};
-            hipFunction_t fn = nullptr;   // (compiled on first use)
-            const int pk = v->elided ? (mode ? PK_SIGNS_FLAT : PK_SIGNS) : (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode;
+            hipFunction_t fn = nullptr, fn_colors = nullptr;   // (compiled on first use)
+            // Two passes for a colour volume (sample_codegen.h, "two-pass sampling"): values + sign bytes with this tile's kernel, then the
+            // colour array as ONE linear stream.  Worth it when the program is cheap enough to evaluate twice and the grid is large enough
+            // for the store rate to matter; SDFK_OPT_COLOR_PASSES = 1 / 2 force one / two passes at any size.
+            const bool two_pass = !v->elided && p->writes_color && v->colors &&
+                                  (g_cfg.color_passes == 2 || (g_cfg.color_passes == 0 && p->n_ops <= kTwoPassMaxOps && v->nvox() >= kTwoPassMinVoxels));
+            const int pk = v->elided ? (mode ? PK_SIGNS_FLAT : PK_SIGNS)
+                         : two_pass ? (clip_to_bounds ? PK_BITS_NC_CLIP : PK_BITS_NC) + mode
+                                    : (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode;
+            if (two_pass)
+                if (int r = program_fn(p, PK_COLORS, &fn_colors)) return r;
             if (!(v->elided && g_cfg.elide_volume >= 2))
                 if (int r = program_fn(p, pk, &fn)) return r;
             const bool cull = v->elided && g_cfg.elide_volume >= 2;
             // (the name rocprofv3 shows for the entry point launched; the two culling kernels have scopes of their own)
-            ProfScope ps(cull ? nullptr : (v->elided ? (mode ? "sdfk_sample_signs_flat" : "sdfk_sample_signs") : names[clip_to_bounds ? 1 : 0][mode]));
+            static const char* const names_nc[2][2] = {{"sdfk_sample_bits_nc", "sdfk_sample_bits_nc_flat"}, {"sdfk_sample_bits_nc_clip", "sdfk_sample_bits_nc_clip_flat"}};
+            std::unique_ptr<ProfScope> ps(new ProfScope(cull ? nullptr : (v->elided ? (mode ? "sdfk_sample_signs_flat" : "sdfk_sample_signs")
+                                                                                      : (two_pass ? names_nc : names)[clip_to_bounds ? 1 : 0][mode])));
             const size_t plane = (size_t)v->ny * v->pitch();
             phase_token_wait(0);
             if (cull) {
@@ -1991,6 +2022,12 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
             else
                 HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((v->nz + 255) / 256), (unsigned)v->ny,
                                              (unsigned)v->nx8(), tpb, 1, 1, 0, g.stream, params, nullptr));
+            ps.reset();
+            if (two_pass) {   // the colours: 256 consecutive voxels of the padded volume per workgroup, three contiguous KiB each
+                ProfScope ps2("sdfk_sample_colors");
+                const size_t total = (size_t)v->nx * plane;
+                HIPCHK(hipModuleLaunchKernel(fn_colors, (unsigned)((total + 255) / 256), 1, 1, 256, 1, 1, 0, g.stream, params, nullptr));
+            }
         }
         phase_token_pass(0);
         if (g.sampler_only) {   // measurement mode (sdfk_profile_enable(2)): the sampling kernel alone, back to back

@@ -95,7 +95,7 @@ namespace SdfKit.Hip
 
         /// <summary>enum sdfk_option</summary>
         public const int OptLanes = 1, OptTokens = 2, OptGraphs = 3, OptCopyMode = 4, OptCornerEval = 5, OptVcolorEval = 6,
-                         OptDistExchange = 7, OptDistLanes = 8, OptHwQueues = 9, OptCodeCache = 10, OptPrefaultHuge = 11, OptDistIndex16 = 12, OptStreamPlacement = 13, OptIdleLane = 14, OptIdlePrograms = 15, OptElideVolume = 16;
+                         OptDistExchange = 7, OptDistLanes = 8, OptHwQueues = 9, OptCodeCache = 10, OptPrefaultHuge = 11, OptDistIndex16 = 12, OptStreamPlacement = 13, OptIdleLane = 14, OptIdlePrograms = 15, OptElideVolume = 16, OptColorPasses = 17;
 
         // libc's own setenv: on Unix Environment.SetEnvironmentVariable only edits the runtime's managed copy of the environment,
         // which the getenv of native code -- the HIP runtime's -- never sees

@@ -13,7 +13,8 @@ def test_options_round_trip_and_ranges():
     for key, good, bad in ((N.OPT_LANES, (0, 2, 3, 4), (-1, 5)), (N.OPT_TOKENS, (-1, 0, 1, 3), (-2, 4)), (N.OPT_GRAPHS, (0, 1, 2), (3,)),
                            (N.OPT_COPY_MODE, (0, 1, 2), (3, -1)), (N.OPT_CORNER_EVAL, (0, 1), (2,)), (N.OPT_VCOLOR_EVAL, (0, 1), (2,)),
                            (N.OPT_DIST_EXCHANGE, (0, 1, 2, 3), (4, -1)), (N.OPT_DIST_LANES, (0, 2, 3), (4, -1)), (N.OPT_CODE_CACHE, (0, 1), (2,)),
-                           (N.OPT_PREFAULT_HUGE, (0, 1), (2,)), (N.OPT_DIST_INDEX16, (0, 1), (2,)), (N.OPT_STREAM_PLACEMENT, (0, 1), (2, -1)), (N.OPT_IDLE_LANE, (0, 1), (2,)), (N.OPT_IDLE_PROGRAMS, (0, 32), (-1, 1025)), (N.OPT_ELIDE_VOLUME, (1, 2, 0), (3, -1))):
+                           (N.OPT_PREFAULT_HUGE, (0, 1), (2,)), (N.OPT_DIST_INDEX16, (0, 1), (2,)), (N.OPT_STREAM_PLACEMENT, (0, 1), (2, -1)), (N.OPT_IDLE_LANE, (0, 1), (2,)), (N.OPT_IDLE_PROGRAMS, (0, 32), (-1, 1025)), (N.OPT_ELIDE_VOLUME, (1, 2, 0), (3, -1)),
+                           (N.OPT_COLOR_PASSES, (1, 2, 0), (3, -1))):
         before = N.get_option(key)
         try:
             for v in good:

@@ -82,6 +82,73 @@ __global__ __launch_bounds__(512 / RPW) void k_tile_vc(float* v, float* c)
         for (int q = 0; q < 3; q++) st<F>(c + o * 3 + 256 * q + 4 * lane, vf4{(float)q, 2.f, 3.f, 4.f});
     }
 }
+// the sampler's tile with the x rows' planes PADDED: row ix starts at ix * (N * N + pad) voxels -- does the power-of-two stride between
+// the 8 rows of a workgroup (1 MiB for the values, 3 MiB for the colours at 512^3: the same channel for all of them?) cost the rate?
+template <int RPW, int F>
+__global__ __launch_bounds__(512 / RPW) void k_tile_vc_pad(float* v, float* c, size_t pad)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int rr = 0; rr < RPW; rr++) {
+        const int ix = blockIdx.z * 8 + wave * RPW + rr;
+        const size_t o = (size_t)ix * ((size_t)N * N + pad) + (size_t)blockIdx.y * N + blockIdx.x * 256;
+        st<F>(v + o + 4 * lane, vf4{1.f, 2.f, 3.f, 4.f});
+        for (int q = 0; q < 3; q++) st<F>(c + o * 3 + 256 * q + 4 * lane, vf4{(float)q, 2.f, 3.f, 4.f});
+    }
+}
+// values only, the tile, padded planes
+template <int F>
+__global__ __launch_bounds__(256) void k_tile_v_pad(float* v, size_t pad)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int rr = 0; rr < 2; rr++) {
+        const int ix = blockIdx.z * 8 + wave * 2 + rr;
+        const size_t o = (size_t)ix * ((size_t)N * N + pad) + (size_t)blockIdx.y * N + blockIdx.x * 256;
+        st<F>(v + o + 4 * lane, vf4{1.f, 2.f, 3.f, 4.f});
+    }
+}
+// the tile with LONG runs: a workgroup = 8 x rows x (256 * ZL) z; per row ZL KiB of values and 3 ZL KiB of colours, contiguous
+template <int ZL, int F>
+__global__ __launch_bounds__(256) void k_tile_vc_long(float* v, float* c)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blockIdx.x: run of 256 * ZL voxels within the (y, z) plane of the rows (N * N / 256 / ZL of them), blockIdx.z: x / 8
+    for (int zi = 0; zi < ZL; zi++)
+        for (int rr = 0; rr < 2; rr++) {
+            const int ix = blockIdx.z * 8 + wave * 2 + rr;
+            const size_t o = (size_t)ix * N * N + ((size_t)blockIdx.x * ZL + zi) * 256;
+            st<F>(v + o + 4 * lane, vf4{1.f, 2.f, 3.f, 4.f});
+            for (int q = 0; q < 3; q++) st<F>(c + o * 3 + 256 * q + 4 * lane, vf4{(float)q, 2.f, 3.f, 4.f});
+        }
+}
+// MIXED store in the tile with padded planes (1024 threads: 8 rows x 128 z)
+template <int F>
+__global__ __launch_bounds__(1024) void k_mix1_tile_pad(float* v, float* c, size_t pad)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = wave / 2, zc = wave % 2;
+    const int ix = blockIdx.z * 8 + r;
+    const size_t vox0 = (size_t)ix * ((size_t)N * N + pad) + (size_t)blockIdx.y * N + (size_t)blockIdx.x * 128 + zc * 64;
+    float* p = lane < 16 ? v + vox0 + 4 * lane : c + vox0 * 3 + 4 * (lane - 16);
+    st<F>(p, vf4{(float)lane, 2.f, 3.f, 4.f});
+}
+
+// COLOURS ONLY, one voxel per lane: a wavefront = 64 consecutive voxels = 768 B of colours = lanes 0..47 store 16 B each (T threads / workgroup)
+template <int T, int F>
+__global__ __launch_bounds__(T) void k_c48(float* c)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t vox0 = ((size_t)blockIdx.x * (T / 64) + wave) * 64;
+    if (lane < 48) st<F>(c + vox0 * 3 + 4 * lane, vf4{(float)lane, 2.f, 3.f, 4.f});
+}
+// COLOURS ONLY, four voxels per lane: a wavefront = 256 voxels = three full-KiB stores per lane (the colour part of the sampler today), linear
+template <int F>
+__global__ __launch_bounds__(256) void k_c3k(float* c)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t w = (size_t)blockIdx.x * 4 + wave;
+    for (int q = 0; q < 3; q++) st<F>(c + w * 768 + 256 * q + 4 * lane, vf4{(float)q, 2.f, 3.f, 4.f});
+}
+
 // two-kernel split: values by one launch, colours by another (each one store per lane) -- what "a second pass" would cost in stores alone
 template <int F>
 __global__ __launch_bounds__(256) void k_one(float* a)
@@ -109,8 +176,9 @@ int main()
 {
     const size_t nvox = (size_t)N * N * N;
     float *v[2], *c[2];
-    for (auto& p : v) CK(hipMalloc(&p, nvox * 4));
-    for (auto& p : c) CK(hipMalloc(&p, nvox * 12));
+    const size_t maxpad = 8192;   // voxels
+    for (auto& p : v) CK(hipMalloc(&p, (nvox + N * maxpad) * 4));
+    for (auto& p : c) CK(hipMalloc(&p, (nvox + N * maxpad) * 12));
     const size_t B = nvox * 16;
     for (int rep = 0; rep < 2; rep++) {
         timeit("plain fill of the colour array (1.61 GB), 1 store / lane, nt", [&](int i) { hipLaunchKernelGGL((k_fill<1, 0>), dim3(nvox * 12 / 4096), dim3(256), 0, 0, c[i & 1]); }, nvox * 12);
@@ -127,6 +195,27 @@ int main()
         timeit("MIXED store, tile 8 x rows x 64 z (512 threads), nt", [&](int i) { hipLaunchKernelGGL((k_mix1_tile<512, 0>), dim3(N / 64, N, N / 8), dim3(512), 0, 0, v[i & 1], c[i & 1]); }, B);
         timeit("MIXED store, tile 8 x rows x 128 z (1024 threads), nt", [&](int i) { hipLaunchKernelGGL((k_mix1_tile<1024, 0>), dim3(N / 128, N, N / 8), dim3(1024), 0, 0, v[i & 1], c[i & 1]); }, B);
         timeit("MIXED store, tile 8 x rows x 128 z (1024 threads), sc1 nt", [&](int i) { hipLaunchKernelGGL((k_mix1_tile<1024, 1>), dim3(N / 128, N, N / 8), dim3(1024), 0, 0, v[i & 1], c[i & 1]); }, B);
+        timeit("COLOURS ONLY, 1 voxel / lane, lanes 0..47 store (256 threads), nt", [&](int i) { hipLaunchKernelGGL((k_c48<256, 0>), dim3(nvox / 256), dim3(256), 0, 0, c[i & 1]); }, nvox * 12);
+        timeit("COLOURS ONLY, 1 voxel / lane, lanes 0..47 store (1024 threads), nt", [&](int i) { hipLaunchKernelGGL((k_c48<1024, 0>), dim3(nvox / 1024), dim3(1024), 0, 0, c[i & 1]); }, nvox * 12);
+        timeit("COLOURS ONLY, 1 voxel / lane, lanes 0..47 store (256 threads), sc1 nt", [&](int i) { hipLaunchKernelGGL((k_c48<256, 1>), dim3(nvox / 256), dim3(256), 0, 0, c[i & 1]); }, nvox * 12);
+        timeit("COLOURS ONLY, 4 voxels / lane, 3 full-KiB stores / lane, linear, nt", [&](int i) { hipLaunchKernelGGL((k_c3k<0>), dim3(nvox / 1024), dim3(256), 0, 0, c[i & 1]); }, nvox * 12);
+        timeit("COLOURS ONLY, 4 voxels / lane, 3 full-KiB stores / lane, linear, sc1 nt", [&](int i) { hipLaunchKernelGGL((k_c3k<1>), dim3(nvox / 1024), dim3(256), 0, 0, c[i & 1]); }, nvox * 12);
+        if (rep == 0)
+        for (size_t pad : {(size_t)0, (size_t)64, (size_t)1024, (size_t)1088, (size_t)4160}) {
+            char nm[160];
+            snprintf(nm, sizeof nm, "sampler tile, x planes padded by %zu voxels, 2 rows / wavefront, nt", pad);
+            timeit(nm, [&](int i) { hipLaunchKernelGGL((k_tile_vc_pad<2, 0>), dim3(N / 256, N, N / 8), dim3(256), 0, 0, v[i & 1], c[i & 1], pad); }, B);
+            snprintf(nm, sizeof nm, "  the same, sc1 nt (pad %zu)", pad);
+            timeit(nm, [&](int i) { hipLaunchKernelGGL((k_tile_vc_pad<2, 1>), dim3(N / 256, N, N / 8), dim3(256), 0, 0, v[i & 1], c[i & 1], pad); }, B);
+            snprintf(nm, sizeof nm, "  MIXED tile 8 x 128 z, sc1 nt (pad %zu)", pad);
+            timeit(nm, [&](int i) { hipLaunchKernelGGL((k_mix1_tile_pad<1>), dim3(N / 128, N, N / 8), dim3(1024), 0, 0, v[i & 1], c[i & 1], pad); }, B);
+            snprintf(nm, sizeof nm, "  VALUES ONLY tile, nt (pad %zu)", pad);
+            timeit(nm, [&](int i) { hipLaunchKernelGGL((k_tile_v_pad<0>), dim3(N / 256, N, N / 8), dim3(256), 0, 0, v[i & 1], pad); }, nvox * 4);
+        }
+        timeit("VALUES ONLY linear fill, 1 store / lane, nt", [&](int i) { hipLaunchKernelGGL((k_fill<1, 0>), dim3(nvox * 4 / 4096), dim3(256), 0, 0, v[i & 1]); }, nvox * 4);
+        timeit("sampler tile with runs of 1024 voxels per row and workgroup, nt", [&](int i) { hipLaunchKernelGGL((k_tile_vc_long<4, 0>), dim3(N * N / 256 / 4, 1, N / 8), dim3(256), 0, 0, v[i & 1], c[i & 1]); }, B);
+        timeit("sampler tile with runs of 4096 voxels per row and workgroup, nt", [&](int i) { hipLaunchKernelGGL((k_tile_vc_long<16, 0>), dim3(N * N / 256 / 16, 1, N / 8), dim3(256), 0, 0, v[i & 1], c[i & 1]); }, B);
+        timeit("sampler tile with runs of 4096 voxels per row and workgroup, sc1 nt", [&](int i) { hipLaunchKernelGGL((k_tile_vc_long<16, 1>), dim3(N * N / 256 / 16, 1, N / 8), dim3(256), 0, 0, v[i & 1], c[i & 1]); }, B);
         timeit("MIXED store, 2 runs of 64 voxels per wavefront (2 stores / lane), nt", [&](int i) { hipLaunchKernelGGL((k_mixR<2, 0>), dim3(nvox / 512), dim3(256), 0, 0, v[i & 1], c[i & 1]); }, B);
         timeit("MIXED store, 4 runs of 64 voxels per wavefront (4 stores / lane), nt", [&](int i) { hipLaunchKernelGGL((k_mixR<4, 0>), dim3(nvox / 1024), dim3(256), 0, 0, v[i & 1], c[i & 1]); }, B);
     }
