@@ -140,7 +140,7 @@ typedef enum sdfk_option {
                                    8-rank slab of 512^3 takes 82 / 46 / 35 us with 1 / 2 / 3; a fourth shares a hardware queue: 98 us) */
     SDFK_OPT_HW_QUEUES = 9,     /* read-only: GPU_MAX_HW_QUEUES as the process had it when the library came up (0 = unset).  The
                                    HIP runtime maps all streams of a process onto that many in-order hardware queues (default 4);
-                                   the library's streams want 8 (sdfk_init in sdfkit_hip.hip says why), and the variable only
+                                   the library's streams want 8 (sdfk_init in csrc/lib_context.hip says why), and the variable only
                                    counts if it is set before the process's FIRST HIP call: host bindings export it, the
                                    library itself never edits the environment */
     SDFK_OPT_CODE_CACHE = 10,   /* 1 (default): compiled code objects are kept on disk (sdfk_set_cache_dir); 0: off */
@@ -198,7 +198,7 @@ int sdfk_program_create(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgb
 int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color);
 /* the generated HIP source of the program's STRUCTURE (constants appear as K.k[i]) */
 const char* sdfk_program_source(const sdfk_program* p);
-/* JIT bookkeeping of this process.  Compiled code objects are kept on disk (see sdfkit_hip.hip,
+/* JIT bookkeeping of this process.  Compiled code objects are kept on disk (see csrc/lib_jit.hip,
  * "on-disk cache": $SDFK_CACHE_DIR | $XDG_CACHE_HOME/sdfkit_hip | ~/.cache/sdfkit_hip; SDFK_NO_CACHE=1
  * switches it off), so only the first process that sees a program pays for hiprtc -- the counterpart
  * of SdfExprCompiler.Compile (SdfExpr.cs:234-238) paying the expression JIT once per delegate. */

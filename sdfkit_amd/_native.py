@@ -10,7 +10,7 @@ import sys
 
 from . import build as _build
 
-# Streams that wait for events must not share hardware queues with the library's lanes (sdfk_init, sdfkit_hip.hip, says
+# Streams that wait for events must not share hardware queues with the library's lanes (sdfk_init, csrc/lib_context.hip, says
 # why): the HIP runtime reads this when it initialises -- with torch in the process that is the first CUDA call, not the
 # import -- so it is set as early as this module is imported, unless the user chose a value.  The library itself never
 # edits the environment (a host binding's job: this module, shim/SdfKit.Hip/Native.cs, include/SdfKit.hpp);

@@ -1,5 +1,5 @@
 // dist_rccl.h -- the Z-slab sharded step behind the C ABI (include/sdfkit_hip.h, "Z-slab sharding"): the GPU backend of
-// the protocol in slab_protocol.h.  Included by sdfkit_hip.hip (it uses the library's context, lanes, allocator and the
+// the protocol in slab_protocol.h.  Included by lib_dist.hip (it uses the library's context, lanes, allocator and the
 // slab form of the captured step graphs).
 //
 // Streams of a sharded rank: the library's own stream (exact steps, mesh extraction), lanes 1..3 (the steps' kernel
@@ -18,9 +18,9 @@
 
 #include "slab_protocol.h"
 
-namespace {
 
-// (struct RcclApi, struct DistContext and the per-context `gd`: sdfkit_hip.hip, "device contexts")
+
+// (struct RcclApi, struct DistContext and the per-context `gd`: lib_internal.h, "device contexts")
 
 int rccl_load()
 {
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_slab_extract(SlabExtractArgs A)
     if (blockIdx.x == 0 && threadIdx.x < 6) A.bounds[threadIdx.x] = nv > 0 ? (threadIdx.x < 3 ? h->bmin[threadIdx.x] : h->bmax[threadIdx.x - 3]) : 0.0f;
 }
 
-}  // namespace
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the session: SlabOps on HIP + RCCL (or the host transport)
@@ -550,7 +550,7 @@ extern "C" int sdfk_dist_unique_id(void* id_out)
 }
 
 // sdfk_dist_init in its two halves: everything that can fail on ONE rank (the library, the exchange stream, the agreement buffers) ...
-static int dist_prepare_rccl(int32_t world, int32_t rank)
+int dist_prepare_rccl(int32_t world, int32_t rank)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (int r = rccl_load()) return r;
@@ -559,7 +559,7 @@ static int dist_prepare_rccl(int32_t world, int32_t rank)
 
 // ... and the collective ncclCommInitRank, which returns when EVERY rank has made the call: ranks that can (a node's threads) agree
 // between the two that all of them are prepared, so that nobody waits for a rank that never joins
-static int dist_join_rccl(const void* id)
+int dist_join_rccl(const void* id)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     const int world = gd.world, rank = gd.rank;
@@ -683,7 +683,7 @@ extern "C" int sdfk_dist_session_create(const sdfk_program* p, const float min[3
     return SDFK_OK;
 }
 
-static int dist_fail(sdfk_dist_session* s, int r)
+int dist_fail(sdfk_dist_session* s, int r)
 {
     t_err = s->proto.error().empty() ? s->err : s->proto.error();
     return r == 1 ? SDFK_ERR_INVALID : r;   // (1: a misuse the protocol itself reports)

@@ -34,7 +34,7 @@
 #include <limits.h>
 #include <stdint.h>
 #include "mc_device.h"
-#include "mc_params.h"
+#include "mc_kernels.h"
 
 namespace sdfk {
 
@@ -334,11 +334,6 @@ __device__ __forceinline__ uint64_t segment_mask(uint64_t a, uint64_t an, uint64
 // with 1, 30.1 with 2 and 41.3 with 4 layers per workgroup -- a quarter of the workgroups, each lane four layers in a row with a
 // workgroup scan per layer -- and the pipelined step does not move (0.1399 / 0.1391 / 0.1449 ms): the fabric serves the second
 // fetch at no visible cost, the longer workgroups cost what they cost.
-#ifndef SDFK_COMPACT_LPB
-#define SDFK_COMPACT_LPB 1
-#endif
-constexpr int K2_LPB = SDFK_COMPACT_LPB;
-static_assert(K2_LPB >= 1 && K2_LPB <= 8, "sign planes per workgroup are held in registers");
 
 // Totals of the compaction and the layer marks, from the count pass's blockcnt[] (one workgroup: the write pass's first block, or
 // k_blockscan).
@@ -1482,7 +1477,7 @@ __global__ __launch_bounds__(256, SDFK_KV_MINWAVES) void k_vertices(McParams P, 
 }
 
 // A kernel that does nothing for `ticks` of the 100 MHz wall clock: the probe of the stream-placement measurement
-// (sdfkit_hip.hip, "stream placement").
+// (lib_context.hip, "stream placement").
 __global__ __launch_bounds__(64) void k_spin(int ticks, int* sink)
 {
     const long long t0 = wall_clock64();
@@ -1534,9 +1529,6 @@ __device__ __forceinline__ void reduce_bounds(const McMeshOut& M, float* s_bound
 // idx_bits: 0 (or 32) = Triangles as int32; 16 = the compact form k_payload_compact writes (uint16 offsets against one int32
 // base per block of 1024 indices, the bases after the offsets).  flags bit 0: the 16-bit form did not fit (some block of
 // indices spans more than 65535 ids): the step is redone, the session goes back to int32 indices.
-struct SlabHeader { int64_t nv, ni; float bmin[3], bmax[3]; int32_t vbytes; int32_t cap_v; int32_t idx_bits; int32_t flags; float pad[2]; };
-constexpr int SLAB_IDX_BLOCK = 1024;
-static_assert(sizeof(SlabHeader) == 64, "SDFK_SLAB_HEADER_BYTES");
 
 // ---------------------------------------------------------------------------
 // K5: triangles
@@ -1688,19 +1680,6 @@ __global__ void k_slab_header(SlabHeader* dst, int64_t nv, int64_t ni, const flo
 // arrays are written by the device from the job's counters.  A speculative job whose buffers
 // turned out too small leaves nv = ni = -1 in the header (the host redoes that step); a
 // payload that does not fit `capacity` leaves the header only.
-struct PackArgs {
-    const McCounters* counters;   // of the queued job
-    uint32_t cap_active, cap_v;
-    uint64_t cap_i;
-    const float* vertices;
-    const float* colors;
-    const float* normals;
-    const int32_t* triangles;
-    const float* bounds;          // device float[6], written by k_triangles
-    char* dst;
-    int64_t capacity;
-    int vbytes;                   // 36, or 24 = colours left out
-};
 
 __global__ __launch_bounds__(256) void k_pack_pending(PackArgs A)
 {
@@ -1838,13 +1817,6 @@ __global__ __launch_bounds__(256) void k_slabs_rebase(char* __restrict__ gathere
 // with the normal matrix the HOST derived (Matrix4x4.Invert / Transpose are BCL calls of the reference: the shim makes them
 // with the BCL itself) + Vector3.Normalize for the normals; per-workgroup AABB partials for Mesh.Measure.  Row-vector
 // convention, products summed left to right, no contraction.
-struct XformArgs {
-    float* vertices;
-    float* normals;
-    int64_t n;
-    float m[16], nm[16];
-    float* partial;   // [grid][6]
-};
 
 __global__ __launch_bounds__(256) void k_mesh_transform(XformArgs A)
 {
@@ -1977,5 +1949,17 @@ __global__ __launch_bounds__(256) void k_repitch(const float* __restrict__ src, 
         else dst[i] = src[r * pw + c];
     }
 }
+
+// ---- explicit instantiations of the template kernels (declared in mc_kernels.h; launched from lib_*.hip) ---------------------------
+template __global__ void k_signbits8<true>(const float* __restrict__ values, uint8_t* __restrict__ bits8, int nx, int ny, int nz, int nx8, int pitch, float iso);
+template __global__ void k_signbits8<false>(const float* __restrict__ values, uint8_t* __restrict__ bits8, int nx, int ny, int nz, int nx8, int pitch, float iso);
+template __global__ void k_compact<true>(McParams P);
+template __global__ void k_compact<false>(McParams P);
+template __global__ void k_compact_write<true>(McParams P);
+template __global__ void k_compact_write<false>(McParams P);
+template __global__ void k_vertices<true>(McParams P, McMeshOut M);
+template __global__ void k_vertices<false>(McParams P, McMeshOut M);
+template __global__ void k_repitch<true>(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int w, int pw);
+template __global__ void k_repitch<false>(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int w, int pw);
 
 }  // namespace sdfk

@@ -1,19 +1,19 @@
 // node_local.h -- several GPUs from ONE process (include/sdfkit_hip.h, "one process, several GPUs"): sdfk_node_*.
 //
 // The reference is a library that a single .NET process calls (Sdf.cs:59-63: `sdf.ToMesh(...)`); the Z-slab sharded step of
-// dist_rccl.h wants one RANK per GPU.  A node gives every GPU a device context of its own (sdfkit_hip.hip, "device contexts") and a
+// dist_rccl.h wants one RANK per GPU.  A node gives every GPU a device context of its own (lib_internal.h, "device contexts") and a
 // host THREAD of the library's own that is the rank: the threads join one RCCL communicator per device (ncclCommInitRank on a shared
 // id, exactly what one process per GPU does) and run the very same sharded step -- sdfk_dist_session_* -- side by side; the calling
 // thread posts a command and gets rank 0's whole mesh back as an ordinary sdfk_mesh (its accessors work from any thread: the mesh
 // remembers its context).  Nothing else is new: partition, exchange, rebase and extraction are dist_rccl.h's.
 // Ranks that share a device (a device listed twice: tests on a one-GPU box, RCCL refuses two ranks on one device) exchange through
 // host memory between the threads (the library's host transport, sdfk_dist_init_host).
-// Included by sdfkit_hip.hip after dist_rccl.h.
+// Included by lib_dist.hip after dist_rccl.h.
 #pragma once
 #include <condition_variable>
 #include <thread>
 
-namespace {
+
 // A barrier that can be ABORTED: a rank thread whose command failed in a rank-local spot never reaches the next rendezvous of that
 // command; it aborts the barrier, which releases everybody who waits there (and everybody who arrives later) with `false` -- they
 // fail the command too instead of waiting for ever.  The poster re-arms it before the next command, when every worker is idle.
@@ -45,7 +45,7 @@ struct NodeBarrier {
         count = 0;
     }
 };
-}  // namespace
+
 
 struct sdfk_node {
     struct Worker {
@@ -97,7 +97,7 @@ struct sdfk_node {
     int fault_stage = 0;
 };
 
-namespace {
+
 
 // the host transport between the threads of a node: everybody publishes its send buffer, then copies everybody's
 int node_allgather(void* ctx, const void* send, void* recv, int64_t bytes)
@@ -354,9 +354,9 @@ int node_post(sdfk_node* n, int cmd)
     return SDFK_OK;
 }
 
-}  // namespace
 
-namespace {
+
+
 void node_set_scene(sdfk_node* n, const sdfk_op* ops, int32_t n_ops, const int32_t out_rgbw[4], int32_t writes_color, const float min[3],
                     const float max[3], int32_t nx, int32_t ny, int32_t nz, int32_t clip_to_bounds, float iso_value)
 {
@@ -375,7 +375,7 @@ int node_first_error(sdfk_node* n, const char* what)
             if (w.status && (pass || !w.released)) return fail(w.status, "%s: rank %d (device %d): %s", what, w.rank, w.device, w.error.c_str());
     return SDFK_OK;
 }
-}  // namespace
+
 
 extern "C" int sdfk_node_open(const int32_t* devices, int32_t n_devices, sdfk_node** out)
 {

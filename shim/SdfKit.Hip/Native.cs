@@ -102,7 +102,7 @@ namespace SdfKit.Hip
         [DllImport("libc", EntryPoint = "setenv")] static extern int libc_setenv(string name, string value, int overwrite);
 
         /// <summary>The HIP runtime maps all streams of a process onto GPU_MAX_HW_QUEUES in-order hardware queues (default 4) and reads
-        /// the variable when IT initialises; the library's streams want 8 (sdfk_init in sdfkit_hip.hip says why).  A library must not
+        /// the variable when IT initialises; the library's streams want 8 (sdfk_init in csrc/lib_context.hip says why).  A library must not
         /// edit the environment of its process; this binding does, once, before its first native call -- which is this
         /// process's first HIP call unless the host used HIP before (then the host's launcher exports the variable itself).  It has to
         /// be the NATIVE environment: setenv(3) through P/Invoke (overwrite = 0: a value the launcher exported stands).</summary>

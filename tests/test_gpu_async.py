@@ -61,7 +61,7 @@ def test_many_queued_meshes_read_late_and_out_of_order(gpu):
 
 
 def test_phase_tokens_do_not_change_results(gpu):
-    """SDFK_OPT_TOKENS (sdfkit_hip.hip, phase_token_wait/pass): the sampling kernels / k_vertices of consecutive jobs on the
+    """SDFK_OPT_TOKENS (csrc/lib_context.hip, phase_token_wait/pass): the sampling kernels / k_vertices of consecutive jobs on the
     lanes wait for each other's events.  Forced on for small grids here (the default applies them from 2^27 voxels up),
     graphs off so that every job takes the ordinary path: many jobs in flight, two scenes, read late."""
     with N.option(N.OPT_GRAPHS, 0):
@@ -286,7 +286,7 @@ def test_held_mesh_survives_many_other_jobs(gpu):
 
 
 def test_stream_placement_keeps_the_lanes_apart(gpu):
-    """sdfk_init measured which of its streams run side by side (csrc/sdfkit_hip.hip, "stream placement"): lanes 1-3 sit in three
+    """sdfk_init measured which of its streams run side by side (csrc/lib_context.hip, "stream placement"): lanes 1-3 sit in three
     different classes, none of them lane 0's; the stream kept for a sharded rank's exchange is in lane 0's class."""
     from sdfkit_amd import _native as N
     p = N.stream_placement()

@@ -1,4 +1,4 @@
-"""Captured launch graphs behind sdfk_sample_march (sdfkit_hip.hip, "captured launch graphs"): the repeat job of a
+"""Captured launch graphs behind sdfk_sample_march (csrc/lib_march.hip, "captured launch graphs"): the repeat job of a
 (program, bounds, grid, clip, iso) is one hipGraphLaunch into buffers the library keeps.  Results must be the ordinary
 path's, bit for bit, whatever the callers do with the handles: hold many, drop them unread, change scene on the same
 grid, outgrow the captured capacities.  All through the C ABI."""

@@ -3,7 +3,7 @@
 set -e
 T=$(mktemp -d)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math --cuda-device-only -c \
-    "$(dirname "$0")/../sdfkit_amd/csrc/sdfkit_hip.hip" -o $T/dev.o
+    "$(dirname "$0")/../sdfkit_amd/csrc/mc_kernels.hip" -o $T/dev.o
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=$T/dev.o \
     --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/k.co
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $T/k.co | \

@@ -8,8 +8,7 @@ D=sdfkit_amd/_ablate
 if [ "$1" = build ]; then
     shift; mkdir -p $D
     while [ $# -ge 2 ]; do
-        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fno-fast-math -fvisibility=hidden -Wl,--version-script=sdfkit_amd/csrc/exports.map \
-            -Wno-unused-function $2 -o $D/$1.so sdfkit_amd/csrc/sdfkit_hip.hip -lhiprtc -ldl &
+        python3 -m sdfkit_amd.build $R/$D/$1.so $2 &    # (the same translation units with the extra flags, objects of their own)
         shift 2
     done
     wait; ls -la $D
