@@ -1016,24 +1016,34 @@ def main():
         triv = SdfFuncs.Sphere(0.5).WithColor(1.0, 0.2, 0.3).ToSdf()
         mn3, mx3 = [-2.8125] * 3, [2.8125] * 3
         vols = [Voxels(mn3, mx3, 512, 512, 512) for _ in range(2)]
-        for k in range(4):
-            vols[k % 2]._sample(triv, clip=True)
-        torch.cuda.synchronize()
-        t_w = time.perf_counter()
-        k = 0
-        while (time.perf_counter() - t_w) * 1e3 < warm_ms:
-            vols[k % 2]._sample(triv, clip=True)
-            k += 1
-            if k % 16 == 0:
+
+        def triv_sampler_us(passes):
+            # (SDFK_OPT_COLOR_PASSES: 1 = the ONE fused kernel whose shape this controls for; 2 = values + sign bytes, then the colour array as one
+            # linear stream -- what the library does by default for programs this small)
+            with N.option(N.OPT_COLOR_PASSES, passes):
+                for k in range(4):
+                    vols[k % 2]._sample(triv, clip=True)
                 torch.cuda.synchronize()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for k in range(10):
-            vols[k % 2]._sample(triv, clip=True)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        triv_us = e0.elapsed_time(e1) * 1e3 / 10
+                t_w = time.perf_counter()
+                k = 0
+                while (time.perf_counter() - t_w) * 1e3 < warm_ms:
+                    vols[k % 2]._sample(triv, clip=True)
+                    k += 1
+                    if k % 16 == 0:
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for k in range(10):
+                    vols[k % 2]._sample(triv, clip=True)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / 10
+
+        N.check(L.sdfk_profile_enable(2))            # (the sampling kernels alone: no transposer behind them)
+        triv_us = triv_sampler_us(1)
+        triv2_us = triv_sampler_us(2)
+        N.check(L.sdfk_profile_enable(0))
         for vol in vols:
             vol._free()
         triv_gbs = 512 ** 3 * 16 / (triv_us * 1e-6) / 1e9
@@ -1041,9 +1051,13 @@ def main():
         long_fill = {"fill_2gib_us": round(fill_us, 1), "fill_2gib_gbs": round(fill_gbs, 1), "fill_2gib_frac_of_peak": round(fill_gbs / HBM_PEAK_GBS, 4),
                      "trivial_colour_sampler_us": round(triv_us, 1), "trivial_colour_sampler_gbs": round(triv_gbs, 1),
                      "trivial_colour_sampler_frac_of_peak": round(triv_gbs / HBM_PEAK_GBS, 4),
+                     "trivial_colour_sampler_two_passes_us": round(triv2_us, 1),
+                     "trivial_colour_sampler_two_passes_frac_of_peak": round(512 ** 3 * 16 / (triv2_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                      "what": "controls for the colour sampler: torch fill_ of 2 GiB (two buffers in turn, 10 launches after the clock warm-up: a plain "
                              "fill as LONG as the colour sampler's launch) and sdfk_sample_bits_clip on a sphere with a constant colour (the same "
-                             "kernel shape and 16 B/voxel of stores, one square root of arithmetic), 512^3, 10 launches back to back"}
+                             "kernel shape and 16 B/voxel of stores, one square root of arithmetic; SDFK_OPT_COLOR_PASSES = 1), 512^3, 10 launches back to back; "
+                             "two_passes = the same program as the library samples it by default (values + sign bytes, then the colour array as one linear "
+                             "stream: profiles/r06_ab_color_passes.txt)"}
         c3["sampler_frac_of_long_fill"] = round(c3_gbs / fill_gbs, 4)
         c3["sampler_frac_of_trivial_colour_sampler"] = round(c3_gbs / triv_gbs, 4)
 

@@ -225,6 +225,22 @@ for name, dims in (("readme_repeat_xy", (40, 36, 44)), ("sphere_w", (64, 64, 64)
         assert ses.stats()["redone"] == 0 and ses.stats()["index16_fallbacks"] == 0
         ses.close()
     N.set_option(N.OPT_DIST_INDEX16, 0)
+    # a session whose exchange mode is a CONTRACT (2: rank 0 holds the mesh, 3: the mesh stays sharded) is not the tuner's to change
+    for mode in (2, 3):
+        N.set_option(N.OPT_DIST_EXCHANGE, mode)
+        ses = D.SlabSession(sdf, mn, mx, *dims, True, 0.0, depth=2)
+        ses.submit()
+        ses.collect()
+        try:
+            ses.tune(4)
+            raise SystemExit("sdfk_dist_tune accepted exchange mode %%d" %% mode)
+        except N.SdfKitNativeError as e:
+            assert e.status == N.ERR_UNSUPPORTED and "contract" in str(e), e
+        assert ses.stats()["exchange_mode"] == mode
+        ses.submit()
+        ses.collect()
+        assert_mesh_equal(ses.mesh(), om)
+        ses.close()
     N.set_option(N.OPT_DIST_EXCHANGE, 0)
 D.shutdown()
 print("rccl world 1 ok")

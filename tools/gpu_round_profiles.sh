@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: everything profiles/ needs for a round.  usage: tools/gpu_round_profiles.sh r04
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; export TMPDIR=/tmp
 O=gpurun_out/profiles_$tag; mkdir -p $O
@@ -43,3 +43,9 @@ grep "^{" $O/bench_c4_1024.json | cut -c1-300
 head -4 $O/pmc_hbm_traffic_repeatxy.txt
 # instruction / wait counters per kernel (two more PMC passes)
 bash tools/gpu_pmc.sh 2>&1 | grep -v "^W2026\|^E2026" > $O/pmc_sq_counters.txt
+# the volume-less (product default) step: kernel stats, SQ and HBM counters (-> profiles/pmc_traffic.json `...@sphere_elided@512`)
+bash tools/gpu_elided_counters.sh $tag > $O/elided_counters.log 2>&1
+cp gpurun_out/elided_$tag/*.csv gpurun_out/elided_$tag/*.txt $O/ 2>/dev/null
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+# the default line once more, now with the counters of THIS box behind roofline.traffic / elided.roofline
+python3 bench.py --no-cpu > $O/bench_no_cpu_with_fresh_counters.json 2>/dev/null
