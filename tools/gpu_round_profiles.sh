@@ -7,10 +7,10 @@ O=gpurun_out/profiles_$tag; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 # (the kernel statistics of the HEADLINE workload only: without the C3 and elided-volume legs of the default line, whose launches
 # -- another scene, another sampler -- would mix into the per-kernel means)
-export SDFK_BENCH_NO_C3=1 SDFK_BENCH_NO_ELIDED=1
+export SDFK_BENCH_NO_C3=1 SDFK_BENCH_NO_C2=1 SDFK_BENCH_NO_C4=1 SDFK_BENCH_NO_C5=1 SDFK_BENCH_NO_ELIDED=1
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_under_rocprof.json 2>/dev/null
 SDFK_LANES=0 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/stats_serial -o s --output-format csv -- python3 bench.py --no-cpu > $O/bench_serial_under_rocprof.json 2>/dev/null
-unset SDFK_BENCH_NO_C3 SDFK_BENCH_NO_ELIDED
+unset SDFK_BENCH_NO_C3 SDFK_BENCH_NO_C2 SDFK_BENCH_NO_C4 SDFK_BENCH_NO_C5 SDFK_BENCH_NO_ELIDED
 SDFK_LANES=0 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_w -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal > /dev/null 2>&1
 SDFK_LANES=0 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_f -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --minimal > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_w/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv > $O/pmc_hbm_traffic.txt
