@@ -231,8 +231,8 @@ extern "C" int sdfk_program_check(const sdfk_op* ops, int32_t n_ops, const int32
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     std::string src;
     std::vector<char> code;
+    config_from_env();   // (first: SDFK_DUMP_SOURCE is honoured by generate_source)
     if (int r = generate_source(ops, n_ops, out_rgbw, writes_color, src)) return r;
-    config_from_env();
     return compile_source(src, (1u << PK_COUNT) - 1u, code, false);   // every kernel, a real compile: this IS the check
 }
 
