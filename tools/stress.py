@@ -64,7 +64,7 @@ while time.time() - t0 < secs:
         assert np.array_equal(got[:64, 3].view(np.uint32), want[:, 3].view(np.uint32)), ("points", case["name"])
     elif k == 8:                                   # a large grid under a random volume-elision mode, mesh arrays recycled
         big = BIG[int(rng.integers(0, len(BIG)))]
-        with N.option(N.OPT_ELIDE_VOLUME, int(rng.integers(0, 3))):
+        with N.option(N.OPT_ELIDE_VOLUME, int(rng.integers(0, 3))), N.option(N.OPT_COLOR_PASSES, int(rng.integers(0, 3))):
             mesh = big["sdf"].ToMesh(MN, MX, *big["dims"])
         assert same(mesh, big["m"]), ("big", big["name"], N.get_option(N.OPT_ELIDE_VOLUME))
         mesh.Recycle()
@@ -88,8 +88,12 @@ while time.time() - t0 < secs:
         assert same(Mesh._from_handle(h), case2["m"]), ("late read", case2["name"], case2["dims"])
     elif k == 4 and held:                        # drop one unread
         L.sdfk_mesh_free(held.pop(int(rng.integers(0, len(held))))[1])
-    elif k == 5:                                 # two-stage: sample, explicit clip, mesh; then another iso
-        vol = Voxels.SampleSdf(case["sdf"], MN, MX, *case["dims"])
+    elif k == 5:                                 # two-stage: sample (colour volumes in one pass or two, at random), explicit clip, mesh; then another iso
+        with N.option(N.OPT_COLOR_PASSES, int(rng.integers(0, 3))):
+            vol = Voxels.SampleSdf(case["sdf"], MN, MX, *case["dims"])
+            if rng.random() < 0.25:              # and the volume itself, Values and Colors, against the oracle's (before the explicit clip)
+                v0, c0 = O.sample(case["scene"], MN, MX, *case["dims"])
+                assert np.array_equal(vol.Values, v0) and np.array_equal(vol.Colors, c0), ("volume", case["name"], case["dims"], N.get_option(N.OPT_COLOR_PASSES))
         vol.ClipToBounds()
         assert same(MarchingCubes.CreateMesh(vol), case["m"]), ("two-stage", case["name"], case["dims"])
         if case["m25"] is None:
