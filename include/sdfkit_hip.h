@@ -25,10 +25,13 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SDFK_ABI_VERSION 5   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint;
+#define SDFK_ABI_VERSION 6   /* 2: sdfk_jit_stats, sdfk_host_alloc, sdfk_host_free; 3: sdfk_graph_stats; 4: sdfk_set_option, sdfk_dist_*, sdfk_mesh_transform, sdfk_mesh_size_hint;
                                 5: SDFK_OPT_ELIDE_VOLUME defaults to 2 (the temporary volume of sdfk_sample_march is not stored); sdfk_init makes a
                                    context per device and per-thread current; sdfk_node_* (several GPUs from one process); sdfk_dist_slab_mesh and exchange
-                                   mode 3 (the mesh stays sharded); sdfk_eval_points (SdfEx.Sample) */
+                                   mode 3 (the mesh stays sharded); sdfk_eval_points (SdfEx.Sample);
+                                6: SDFK_OPT_COLOR_PASSES; sdfk_dist_gathered refuses a step that brought this rank headers only and sdfk_dist_tune
+                                   a session whose exchange mode is 2 or 3 (SDFK_ERR_UNSUPPORTED); gather-to-root has the same who-receives-what on
+                                   the host transport as over RCCL; sdfk_host_alloc works in a process whose only contexts are a node's */
 
 typedef enum sdfk_status {
     SDFK_OK = 0,

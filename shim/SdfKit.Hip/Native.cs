@@ -120,7 +120,7 @@ namespace SdfKit.Hip
             lock (initLock) {
                 if (inited) return;
                 // (the entry points this shim binds -- sdfk_set_option, sdfk_dist_*, sdfk_mesh_size_hint -- are ABI 4; ABI 5 changed a default)
-                if (sdfk_abi_version() != 5) throw new InvalidOperationException("libsdfkit_hip.so does not have the ABI version (5) this shim was written for");
+                if (sdfk_abi_version() != 6) throw new InvalidOperationException("libsdfkit_hip.so does not have the ABI version (6) this shim was written for");
                 int device = int.TryParse(Environment.GetEnvironmentVariable("LOCAL_RANK"), out var r) ? r : 0;
                 Check(sdfk_init(device));
                 // what the library saw when it came up (0 = unset): with fewer than 8 hardware queues its lanes share queues --

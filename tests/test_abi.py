@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     rows = [l.split() for l in out.splitlines() if l.strip()]
     assert all(len(r) == 3 and r[1] == "T" for r in rows), [r for r in rows if len(r) != 3 or r[1] != "T"]
     assert sorted(r[2] for r in rows) == syms
-    assert lib.sdfk_abi_version() == 5
+    assert lib.sdfk_abi_version() == 6
 
 
 def test_graft_entry_version_check_follows_the_header():
