@@ -650,47 +650,65 @@ def main():
 
     def content_check(ses, sdf_x, mn_x, mx_x, clip_x, nn, mode_x):
         # (mode_x: the SDFK_OPT_DIST_EXCHANGE the session was created with -- its stats report -1 for the host transport, whatever the mode)
-        counts_x = ses.counts()
-        own = ses.slab_mesh()            # (first: with exchange mode 3 no payload has moved yet)
-        own_d = mesh_digest(own.Vertices, own.Colors, own.Normals, own.Triangles)
-        own_n = (len(own.Vertices), len(own.Triangles))
-        del own
+        # A failure of the CHECK on one rank (an allocation, a copy) must cost neither the line nor the other ranks: rank-local parts are
+        # guarded, the collectives (the on-demand payload exchange of mode 3, the gathering of the digests, the barrier) are always entered.
+        problems = []
+
+        def guarded(what, fn):
+            try:
+                return fn()
+            except BaseException as e:   # noqa: B902 -- reported on the line
+                problems.append(f"rank {rank}: {what}: {type(e).__name__}: {e}")
+                return None
+
+        counts_x = guarded("counts", ses.counts)
+
+        def own_slab():                  # (first: with exchange mode 3 no payload has moved yet)
+            own = ses.slab_mesh()
+            return mesh_digest(own.Vertices, own.Colors, own.Normals, own.Triangles), (len(own.Vertices), len(own.Triangles))
+        own_dn = guarded("sdfk_dist_slab_mesh", own_slab)
         whole = None
         if mode_x == 3 or rank == 0:     # (mode 3: collective -- the payload exchange of this step happens here; mode 2: only rank 0 holds it)
-            whole = ses.mesh()
+            whole = guarded("sdfk_dist_mesh", ses.mesh)
         slabs = [None] * world
         if world > 1:
-            dist.all_gather_object(slabs, (own_d, own_n))
+            dist.all_gather_object(slabs, (own_dn, list(problems)))
         else:
-            slabs = [(own_d, own_n)]
+            slabs = [(own_dn, list(problems))]
         res = None
         if rank == 0:
-            # (sdfk_sample_march itself: in a process that has joined a sharding context sdf.ToMesh IS the sharded, collective call)
-            from sdfkit_amd.api import Mesh as HostMesh
-            with N.option(N.OPT_ELIDE_VOLUME, 0):
-                h1 = C.c_void_p()
-                N.check(L.sdfk_sample_march(sdf_x.program(), N.f3(mn_x), N.f3(mx_x), nn, nn, nn, 1 if clip_x else 0, C.c_float(0.0), 1, C.byref(h1)))
-                single = HostMesh._from_handle(h1)
-            T_g = whole.Triangles
-            if os.environ.get("SDFK_BENCH_FAULT_FLIP_INDEX") == "1" and len(T_g):   # (tests: one flipped index must turn the check false)
-                T_g = T_g.copy()
-                T_g[len(T_g) // 2] ^= 1
-            d_g = mesh_digest(whole.Vertices, whole.Colors, whole.Normals, T_g)
-            d_s = mesh_digest(single.Vertices, single.Colors, single.Normals, single.Triangles)
-            slab_ok, vb, ib = True, 0, 0
-            for q in range(world):
-                nvq, niq = counts_x[q]
-                want = mesh_digest(single.Vertices[vb:vb + nvq], single.Colors[vb:vb + nvq], single.Normals[vb:vb + nvq], single.Triangles[ib:ib + niq])
-                slab_ok = slab_ok and slabs[q][1] == (nvq, niq) and slabs[q][0] == want
-                vb, ib = vb + nvq, ib + niq
-            slab_ok = slab_ok and (vb, ib) == (len(single.Vertices), len(single.Triangles))
-            res = {"mesh_equals_single_gpu": bool(d_g == d_s and len(whole.Vertices) == len(single.Vertices)),
-                   "every_ranks_slab_equals_its_slice": bool(slab_ok),
-                   "vertices": len(single.Vertices), "indices": len(single.Triangles), "sha256_single_gpu": d_s,
-                   "sha256_sharded": d_g if d_g != d_s else "identical",
-                   "what": "SHA-256 of Vertices / Colors / Normals / Triangles: the mesh of the sharded step collected last (sdfk_dist_mesh) against "
-                           "sdfk_sample_march of the same grid on rank 0's GPU alone; every rank's own slab (sdfk_dist_slab_mesh) against its slice"}
-            del single
+            def compare():
+                # (sdfk_sample_march itself: in a process that has joined a sharding context sdf.ToMesh IS the sharded, collective call)
+                from sdfkit_amd.api import Mesh as HostMesh
+                with N.option(N.OPT_ELIDE_VOLUME, 0):
+                    h1 = C.c_void_p()
+                    N.check(L.sdfk_sample_march(sdf_x.program(), N.f3(mn_x), N.f3(mx_x), nn, nn, nn, 1 if clip_x else 0, C.c_float(0.0), 1, C.byref(h1)))
+                    single = HostMesh._from_handle(h1)
+                T_g = whole.Triangles
+                if os.environ.get("SDFK_BENCH_FAULT_FLIP_INDEX") == "1" and len(T_g):   # (tests: one flipped index must turn the check false)
+                    T_g = T_g.copy()
+                    T_g[len(T_g) // 2] ^= 1
+                d_g = mesh_digest(whole.Vertices, whole.Colors, whole.Normals, T_g)
+                d_s = mesh_digest(single.Vertices, single.Colors, single.Normals, single.Triangles)
+                slab_ok, vb, ib = True, 0, 0
+                for q in range(world):
+                    nvq, niq = counts_x[q]
+                    want = mesh_digest(single.Vertices[vb:vb + nvq], single.Colors[vb:vb + nvq], single.Normals[vb:vb + nvq], single.Triangles[ib:ib + niq])
+                    slab_ok = slab_ok and slabs[q][0] is not None and tuple(slabs[q][0][1]) == (nvq, niq) and slabs[q][0][0] == want
+                    vb, ib = vb + nvq, ib + niq
+                slab_ok = slab_ok and (vb, ib) == (len(single.Vertices), len(single.Triangles))
+                return {"mesh_equals_single_gpu": bool(d_g == d_s and len(whole.Vertices) == len(single.Vertices)),
+                        "every_ranks_slab_equals_its_slice": bool(slab_ok),
+                        "vertices": len(single.Vertices), "indices": len(single.Triangles), "sha256_single_gpu": d_s,
+                        "sha256_sharded": d_g if d_g != d_s else "identical"}
+            everybody = [p for q in range(world) for p in (slabs[q][1] if slabs[q] else [f"rank {q}: nothing gathered"])]
+            res = (guarded("comparison", compare) if (whole is not None and counts_x is not None) else None) or \
+                {"mesh_equals_single_gpu": None, "every_ranks_slab_equals_its_slice": None}
+            everybody += [p for p in problems if p not in everybody]
+            if everybody:      # the check itself could not be completed: neither true nor false, and said so
+                res["check_failed"] = everybody
+            res["what"] = ("SHA-256 of Vertices / Colors / Normals / Triangles: the mesh of the sharded step collected last (sdfk_dist_mesh) against "
+                           "sdfk_sample_march of the same grid on rank 0's GPU alone; every rank's own slab (sdfk_dist_slab_mesh) against its slice")
         del whole
         if world > 1:
             dist.barrier()
