@@ -274,10 +274,10 @@ int sample_impl(const sdfk_program* p, sdfk_volume* v, int32_t clip_to_bounds, f
             const int pk = v->elided ? (mode ? PK_SIGNS_FLAT : PK_SIGNS)
                          : two_pass ? (clip_to_bounds ? PK_BITS_NC_CLIP : PK_BITS_NC) + mode
                                     : (clip_to_bounds ? PK_BITS_CLIP : PK_BITS) + mode;
-            if (two_pass)
-                if (int r = program_fn(p, PK_COLORS, &fn_colors)) return r;
             if (!(v->elided && g_cfg.elide_volume >= 2))
                 if (int r = program_fn(p, pk, &fn)) return r;
+            if (two_pass)   // (after the first pass's kernel, whose module brings sdfk_sample_colors along: one compile, not two)
+                if (int r = program_fn(p, PK_COLORS, &fn_colors)) return r;
             const bool cull = v->elided && g_cfg.elide_volume >= 2;
             // (the name rocprofv3 shows for the entry point launched; the two culling kernels have scopes of their own)
             static const char* const names_nc[2][2] = {{"sdfk_sample_bits_nc", "sdfk_sample_bits_nc_flat"}, {"sdfk_sample_bits_nc_clip", "sdfk_sample_bits_nc_clip_flat"}};

@@ -66,6 +66,9 @@ def test_sharded_bench_on_one_gpu(gpu, world):
         assert isinstance(leg, dict) and leg["ms_per_step"] > 0 and leg["steps"] == 4 and leg["vertices"] > 1000, leg
         assert leg["mesh_equals_single_gpu"] is True and leg["content_check"]["every_ranks_slab_equals_its_slice"] is True, leg
         assert leg["steps_redone"] == 0 and len(leg["per_rank_vertices_indices"]) == world
+        # (the "all_gather" leg runs with the process's DEFAULT exchange: headers only when the suite runs under SDFK_DIST_EXCHANGE=3)
+        if per_rank_bytes is None and os.environ.get("SDFK_DIST_EXCHANGE") == "3":
+            per_rank_bytes = (world - 1) * 64
         assert leg["bytes_received_per_rank"] == (per_rank_bytes if per_rank_bytes is not None else (world - 1) * leg["gather_stride_bytes_per_rank"])
         assert leg["single_gpu_ms_per_step"] > 0 and leg["speedup_measured"] > 0 and leg["single_gpu_product_default_ms_per_step"] > 0
     assert c4["all_gather"]["vertices"] == c4["mesh_stays_sharded"]["vertices"]
@@ -372,9 +375,12 @@ def test_default_line_carries_every_baseline_config(gpu):
     d = _bench([sys.executable, "bench.py", "--no-cpu", "--steps", "10", "--warmup", "2"], {"SDFK_BENCH_BLOCKS": "3"})
     assert d["config"]["vertices"] == 549144 and d["roofline"]["kernel"] == "sdfk_sample_bits"
     c2, c3, c4 = d["c2_sphere_256"], d["c3_repeatxy"], d["c4_union8_1024"]
+    # (the volume-less path needs re-evaluated corners and vertex colours: under SDFK_NO_CORNER_EVAL / SDFK_NO_VCOLOR_EVAL the "product default"
+    # legs store the volume like the headline -- tools/gpu_alt_configs.sh runs the suite that way)
+    volume_less = not (os.environ.get("SDFK_NO_CORNER_EVAL") or os.environ.get("SDFK_NO_VCOLOR_EVAL"))
     assert c2["vertices"] == 137232 and c2["elided_volume_ms_per_step"] is None and c2["product_default_ms_per_step"] == c2["ms_per_step"]
-    assert c3["vertices"] > 900000 and 0 < c3["product_default_ms_per_step"] < c3["ms_per_step"]
-    assert c4["vertices"] == 3148104 and c4["triangles"] == 6296176 and 0 < c4["product_default_ms_per_step"] < c4["ms_per_step"]
+    assert c3["vertices"] > 900000 and 0 < c3["product_default_ms_per_step"] < c3["ms_per_step"] * (1.0 if volume_less else 1.3)
+    assert c4["vertices"] == 3148104 and c4["triangles"] == 6296176 and 0 < c4["product_default_ms_per_step"] < c4["ms_per_step"] * (1.0 if volume_less else 1.3)
     for c in (c2, c3, c4):
         assert c["ms_per_step"] > 0 and 0.2 < c["sampler_frac"] < 1.0 and c["sampler_us_back_to_back"] > 0 and c["mtris_per_s"] > 0
     ctl = d["colour_sampler_control"]
@@ -382,7 +388,8 @@ def test_default_line_carries_every_baseline_config(gpu):
     assert 0.5 < c3["sampler_frac_of_long_fill"] < 1.5 and 0.5 < c3["sampler_frac_of_trivial_colour_sampler"] < 1.5
     el = d["elided"]
     assert el["ms_per_step"] == d["elided_volume_ms_per_step"] and el["kernels_us"]["k_vertices"]["avg_us"] > 0 and el["chain_serial_us"] > 0
-    assert "sdfk_cull_blocks" in el["kernels_us"] and "sdfk_eval_blocks" in el["kernels_us"] and "sdfk_sample_bits" not in el["kernels_us"]
+    if volume_less:
+        assert "sdfk_cull_blocks" in el["kernels_us"] and "sdfk_eval_blocks" in el["kernels_us"] and "sdfk_sample_bits" not in el["kernels_us"]
     if el["roofline"] is not None:          # (needs the committed SQ counter pass: profiles/pmc_traffic.json)
         assert el["roofline"]["bound"] == "valu" and el["roofline"]["kernel"].startswith("k_vertices") and 0.1 < el["roofline"]["frac"] < 1.0
     assert d["c5_raymarch"]["ms_per_frame"] > 0
