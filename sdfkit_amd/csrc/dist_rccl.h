@@ -14,6 +14,9 @@
 // payloads (SDFK_OPT_DIST_INDEX16) and the tuner that measures them against each other (sdfk_dist_tune) exist -- as explicit
 // opt-ins: none of them has run between two GPUs yet (one GPU per development box).
 #pragma once
+#ifndef SDFK_LIB_DIST_TU
+#error "dist_rccl.h holds definitions: it is part of lib_dist.hip, not a header to include elsewhere (declarations: lib_internal.h)"
+#endif
 #include <dlfcn.h>
 
 #include "slab_protocol.h"

@@ -2,6 +2,7 @@
 // from one process (node_local.h).
 #include "lib_internal.h"
 
+#define SDFK_LIB_DIST_TU 1
 #include "dist_rccl.h"
 #include "node_local.h"
 

@@ -10,6 +10,9 @@
 // host memory between the threads (the library's host transport, sdfk_dist_init_host).
 // Included by lib_dist.hip after dist_rccl.h.
 #pragma once
+#ifndef SDFK_LIB_DIST_TU
+#error "node_local.h holds definitions: it is part of lib_dist.hip, not a header to include elsewhere (declarations: lib_internal.h)"
+#endif
 #include <condition_variable>
 #include <thread>
 
