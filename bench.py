@@ -20,6 +20,15 @@ before anything in this process has touched the GPU, and relays rank 0's JSON li
 Every rank a launcher starts is a SUPERVISOR that never touches HIP: the measuring process is its child, with a time
 limit; the supervisors agree (gloo) whether all workers finished and otherwise ALL start the next, more conservative
 configuration (RANK_TRIES) -- a collective that hangs on first contact with a node costs one time limit, not the run.
+
+Beside the headline, on the same JSON line (never as `value`):
+  N = 1   BASELINE's other configs -- c2_sphere_256, c3_repeatxy, c4_union8_1024 (the whole 1024^3 grid on one GPU), c5_raymarch --, the
+          product default (`elided`: the temporary volume of SdfEx.ToMesh is not stored) with a bound of its own, the controls for the
+          colour sampler, the host hand-off figures, the CPU baseline (oracle/, the reference algorithm restated in C).
+  N > 1   after the headline is safe with the supervisor, under watchdogs of their own: BASELINE C4 (1024^3 union of 8 primitives)
+          sharded, with the default exchange and with the mesh left sharded; the CONTENT of every sharded mesh (SHA-256 of the four
+          arrays against the same grid meshed on rank 0's GPU alone -- a mismatch fails the run with exit code 4, line on stdout);
+          last, the tuner.  SDFK_BENCH_STACKS_AFTER_S=t: every rank dumps its Python stacks after t seconds (where a hung pass sits).
 """
 import argparse
 import ctypes as C
