@@ -333,6 +333,38 @@ def load_pmc_traffic(kernel, scene, n):
         return None
 
 
+def mesh_digest(V, Cc, Nn, T):
+    """SHA-256 of the bytes of a mesh's four arrays (numpy): what the sharded content check compares"""
+    import hashlib
+    import numpy as np
+    return {name: hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes() if a.size else b"").hexdigest()
+            for name, a in (("Vertices", V), ("Colors", Cc), ("Normals", Nn), ("Triangles", T))}
+
+
+def compare_sharded_with_single(single, whole, slab_digests, counts, flip_one_index=False):
+    """The comparison of the sharded content check, pure: `single` / `whole` = meshes (.Vertices / .Colors / .Normals / .Triangles numpy arrays) of
+    the same grid from one GPU / gathered from the ranks; slab_digests[q] = (mesh_digest of rank q's own slab, (vertices, indices)) or None;
+    counts[q] = (vertices, indices) of slab q from the gathered headers.  flip_one_index: fault injection -- one index of the gathered mesh
+    is flipped before it is hashed (the check must then say false).  tests/test_bench_host.py exercises it without a GPU."""
+    T_g = whole.Triangles
+    if flip_one_index and len(T_g):
+        T_g = T_g.copy()
+        T_g[len(T_g) // 2] ^= 1
+    d_g = mesh_digest(whole.Vertices, whole.Colors, whole.Normals, T_g)
+    d_s = mesh_digest(single.Vertices, single.Colors, single.Normals, single.Triangles)
+    slab_ok, vb, ib = True, 0, 0
+    for q, (nvq, niq) in enumerate(counts):
+        want = mesh_digest(single.Vertices[vb:vb + nvq], single.Colors[vb:vb + nvq], single.Normals[vb:vb + nvq], single.Triangles[ib:ib + niq])
+        got = slab_digests[q] if q < len(slab_digests) else None
+        slab_ok = slab_ok and got is not None and tuple(got[1]) == (nvq, niq) and got[0] == want
+        vb, ib = vb + nvq, ib + niq
+    slab_ok = slab_ok and (vb, ib) == (len(single.Vertices), len(single.Triangles))
+    return {"mesh_equals_single_gpu": bool(d_g == d_s and len(whole.Vertices) == len(single.Vertices)),
+            "every_ranks_slab_equals_its_slice": bool(slab_ok),
+            "vertices": len(single.Vertices), "indices": len(single.Triangles), "sha256_single_gpu": d_s,
+            "sha256_sharded": d_g if d_g != d_s else "identical"}
+
+
 XGMI_LINKS = 7
 XGMI_LINK_GBS_PER_DIRECTION = 76.8   # 153.6 GB/s per link, both directions together
 
@@ -652,11 +684,6 @@ def main():
     # gathered slabs concatenated; collective with exchange mode 3, where it runs the payload exchange of that step on demand), and
     # every rank's OWN slab (sdfk_dist_slab_mesh, global indices) with its slice of the single-GPU mesh.  First contact with a node
     # of several GPUs then yields correctness evidence, not just a time: `mesh_equals_single_gpu: false` makes the run exit non-zero.
-    def mesh_digest(V, Cc, Nn, T):
-        import hashlib
-        return {name: hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes() if a.size else b"").hexdigest()
-                for name, a in (("Vertices", V), ("Colors", Cc), ("Normals", Nn), ("Triangles", T))}
-
     def content_check(ses, sdf_x, mn_x, mx_x, clip_x, nn, mode_x):
         # (mode_x: the SDFK_OPT_DIST_EXCHANGE the session was created with -- its stats report -1 for the host transport, whatever the mode)
         # A failure of the CHECK on one rank (an allocation, a copy) must cost neither the line nor the other ranks: rank-local parts are
@@ -693,23 +720,9 @@ def main():
                     h1 = C.c_void_p()
                     N.check(L.sdfk_sample_march(sdf_x.program(), N.f3(mn_x), N.f3(mx_x), nn, nn, nn, 1 if clip_x else 0, C.c_float(0.0), 1, C.byref(h1)))
                     single = HostMesh._from_handle(h1)
-                T_g = whole.Triangles
-                if os.environ.get("SDFK_BENCH_FAULT_FLIP_INDEX") == "1" and len(T_g):   # (tests: one flipped index must turn the check false)
-                    T_g = T_g.copy()
-                    T_g[len(T_g) // 2] ^= 1
-                d_g = mesh_digest(whole.Vertices, whole.Colors, whole.Normals, T_g)
-                d_s = mesh_digest(single.Vertices, single.Colors, single.Normals, single.Triangles)
-                slab_ok, vb, ib = True, 0, 0
-                for q in range(world):
-                    nvq, niq = counts_x[q]
-                    want = mesh_digest(single.Vertices[vb:vb + nvq], single.Colors[vb:vb + nvq], single.Normals[vb:vb + nvq], single.Triangles[ib:ib + niq])
-                    slab_ok = slab_ok and slabs[q][0] is not None and tuple(slabs[q][0][1]) == (nvq, niq) and slabs[q][0][0] == want
-                    vb, ib = vb + nvq, ib + niq
-                slab_ok = slab_ok and (vb, ib) == (len(single.Vertices), len(single.Triangles))
-                return {"mesh_equals_single_gpu": bool(d_g == d_s and len(whole.Vertices) == len(single.Vertices)),
-                        "every_ranks_slab_equals_its_slice": bool(slab_ok),
-                        "vertices": len(single.Vertices), "indices": len(single.Triangles), "sha256_single_gpu": d_s,
-                        "sha256_sharded": d_g if d_g != d_s else "identical"}
+                # (SDFK_BENCH_FAULT_FLIP_INDEX=1, tests: one flipped index must turn the check false)
+                return compare_sharded_with_single(single, whole, [sl[0] if sl else None for sl in slabs], counts_x,
+                                                   flip_one_index=os.environ.get("SDFK_BENCH_FAULT_FLIP_INDEX") == "1")
             everybody = [p for q in range(world) for p in (slabs[q][1] if slabs[q] else [f"rank {q}: nothing gathered"])]
             res = (guarded("comparison", compare) if (whole is not None and counts_x is not None) else None) or \
                 {"mesh_equals_single_gpu": None, "every_ranks_slab_equals_its_slice": None}
