@@ -72,9 +72,18 @@ namespace SdfKit.Hip
                 Native.Check(Native.sdfk_dist_collect(h, out var nv, out var ni));
                 return (nv, ni);
             }
-            /// <summary>Measures both exchanges, with plain and with compact payloads, on this node's fabric and keeps the fastest configuration (collective, nothing in flight).</summary>
+            /// <summary>Measures both exchanges, with plain and with compact payloads, on this node's fabric and keeps the fastest configuration (collective, nothing in flight).
+            /// A session whose exchange mode is 2 (only rank 0 holds the mesh) or 3 (the mesh stays sharded) is refused -- InvalidOperationException --: who holds the
+            /// mesh is that session's contract, not a candidate (ABI 6).</summary>
             public void Tune(int stepsPerMode = 20) => Native.Check(Native.sdfk_dist_tune(h, stepsPerMode, null));
-            /// <summary>The whole mesh of the step collected last.</summary>
+            /// <summary>THIS rank's own slab of the step collected last, indices global (no payload exchange, not collective): with exchange mode 3 the whole mesh is the
+            /// ranks' slabs in rank order.</summary>
+            public Mesh SlabMesh()
+            {
+                Native.Check(Native.sdfk_dist_slab_mesh(h, out var mesh));
+                try { return SdfKit.Mesh.FromNative(mesh, writesColor); } finally { Native.sdfk_mesh_free(mesh); }
+            }
+            /// <summary>The whole mesh of the step collected last (exchange mode 3: collective -- the payloads of that step are gathered here; mode 2: rank 0 only).</summary>
             public Mesh Mesh()
             {
                 Native.Check(Native.sdfk_dist_mesh(h, out var mesh));
