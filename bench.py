@@ -1475,6 +1475,8 @@ def main():
             "stream_placement": N.stream_placement(),   # classes of lanes 0..4 / the exchange stream as measured at sdfk_init
             "pipeline_algorithmic_gbs": round(model_bytes / step_s / 1e9, 1),
             "pipeline_frac_of_hbm_peak": frac(model_bytes, step_s),
+            # (N > 1: the same bytes of the WHOLE grid over the step time, against the N GPUs' HBM together -- BASELINE: "as fraction of the HBM roofline")
+            "pipeline_frac_of_aggregate_hbm_peak": None if not frac(model_bytes, step_s) else round(frac(model_bytes, step_s) / world, 4),
             "pipeline_frac_is": ("contract model: 8 B/voxel (4 stored by sampling + 4 loaded by meshing) + 36 B/vertex + 4 B/index, divided by the step "
                                  "time and by 8 TB/s -- the fused path never re-reads the volume, so this is NOT achieved bandwidth: see "
                                  "frac_design_bytes / frac_measured_bytes" if not colors else
