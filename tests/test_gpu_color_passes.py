@@ -97,3 +97,25 @@ def test_sharded_slab_steps_with_two_passes(gpu):
     for extra in ({}, {"SDFK_NO_VCOLOR_EVAL": "1"}):
         out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, SDFK_COLOR_PASSES="2", **extra))
         assert out.returncode == 0 and out.stdout.count("identical") == 2, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_two_passes_on_random_compositions(gpu, seed):
+    """Random compositions of the per-point catalogue (tests/scenes.py random_scene: primitives, Translate, RepeatX / Y / XY with and without the
+    README colour lambda, WithColor, Union): the volume of two passes == the volume of one pass == the oracle's, on a row-tiled and a
+    plane-chunk shape."""
+    scene, sdf = S.random_scene(seed)
+    if not sdf.writes_color:
+        pytest.skip("this composition assigns no colour")
+    mn, mx = [-2.8125, -2.5, -2.25], [2.8125, 2.75, 2.5]
+    for dims, clip in (((12, 10, 256), True), ((11, 13, 37), False)):
+        ov, oc = O.sample(scene, mn, mx, *dims)
+        if clip:
+            O.clip_to_bounds(ov, mn, mx)
+        vols = []
+        for passes in (1, 2):
+            with N.option(N.OPT_COLOR_PASSES, passes):
+                v = sdf.ToVoxels(mn, mx, *dims, clipToBounds=clip)
+                vols.append((v.Values.copy(), v.Colors.copy()))
+                assert np.array_equal(v.Values, ov) and np.array_equal(v.Colors, oc), (seed, dims, passes)
+        assert np.array_equal(vols[0][0], vols[1][0]) and np.array_equal(vols[0][1], vols[1][1])
